@@ -1,0 +1,109 @@
+/*
+ * sigkernel_amd.h -- C ABI of libsigkernel_amd.so, the MI355X (gfx950) engine for the
+ * signature-PDE-kernel hot path of crispitagorico/sigkernel.
+ *
+ * The reference has no FFI: its boundary is the Python signature of the solver
+ * back-ends called from sigkernel/sigkernel.py.  Each entry point below names
+ * the reference call it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - P independent problems ("pairs"): P = A for compute_kernel, P = A*B for
+ *     compute_Gram with pair (a,b) at index a*B+b.
+ *   - M, N   : number of points of the two paths; Mc = M-1, Nc = N-1 coarse cells.
+ *   - dyadic : dyadic_order d; the fine grid has MM = Mc<<d by NN = Nc<<d cells.
+ *     Dyadic refinement is index arithmetic inside the kernels
+ *     (fine increment (i,j) = inc_c[i>>d][j>>d] / 4^d); the refined matrix that
+ *     the reference materialises with tile() (sigkernel.py:218, :364) never exists.
+ *   - all arrays are dense row-major device pointers owned by the caller; the
+ *     library keeps no reference after return and allocates nothing.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it -- no hidden synchronisation.
+ *   - return value: SK_OK or an sk_status error code (see sk_status_string).
+ *   - f32 entry points read/write float but carry the PDE state in double.
+ */
+#ifndef SIGKERNEL_AMD_H
+#define SIGKERNEL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sk_status {
+    SK_OK = 0,
+    SK_ERR_BAD_ARG = 1,      /* null pointer, non-positive size, unknown scheme/flag     */
+    SK_ERR_UNSUPPORTED = 2,  /* shape outside what the kernels implement (see message)  */
+    SK_ERR_LAUNCH = 3,       /* hipGetLastError() after the launch was not hipSuccess   */
+    SK_ERR_WORKSPACE = 4,    /* workspace pointer null or too small                     */
+    SK_ERR_NO_DEVICE = 5     /* no HIP device visible                                   */
+} sk_status;
+
+/* scheme: which finite-difference stencil (sigkernel/cython_backend.pyx:114-116,
+ * sigkernel/cuda_backend.py:150-156). */
+#define SK_SCHEME_DEFAULT 0 /* (k10+k01)(1+g/2+g^2/12) - k00(1-g^2/12)  -- _naive_solver=False */
+#define SK_SCHEME_NAIVE 1   /* (k10+k01)(1+g/2) - k00                    -- _naive_solver=True  */
+
+/* flags (bit-or) */
+#define SK_FLAG_NONE 0
+#define SK_FLAG_EXACT 1  /* FMA-free arithmetic in the reference's operand order: results are
+                            bit-identical to the reference's Cython CPU solver (slower path)   */
+#define SK_FLAG_SIMPLE 2 /* force the simple one-wavefront-per-pair anti-diagonal kernels       */
+
+int sk_version(void);
+const char *sk_status_string(int status);
+/* Number of HIP devices visible, or a negative sk_status. */
+int sk_device_count(void);
+
+/* ---- increments ---------------------------------------------------------------------------
+ * inc_c[p][i][j] = G[p][i+1][j+1] + G[p][i][j] - G[p][i+1][j] - G[p][i][j+1]
+ * Replaces the 4-corner difference at sigkernel.py:217 (paired) and :363 (Gram); recomputed in
+ * backward at :264 and :421.   G [P,M,N] -> inc_c [P,M-1,N-1]. */
+int sk_increments_f64(const double *G, int64_t P, int M, int N, double *inc_c, void *stream);
+int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, void *stream);
+
+/* Transpose of the above, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
+ * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
+ * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference
+ * differentiates the increments numerically with h = 1e-9; here dL/dG_static is formed
+ * exactly and the static kernel is differentiated by the caller).
+ * W [P,M-1,N-1], scale [P] -> dG [P,M,N]. */
+int sk_increments_adjoint_f64(const double *W, const double *scale, int64_t P, int M, int N, double *dG, void *stream);
+int sk_increments_adjoint_f32(const float *W, const float *scale, int64_t P, int M, int N, float *dG, void *stream);
+
+/* ---- forward solve ------------------------------------------------------------------------
+ * Solves the Goursat PDE for every pair and returns K[MM][NN].
+ * Replaces sigkernel_cuda[A,T](...) (sigkernel.py:231; kernel cuda_backend.py:6-49),
+ * sigkernel_Gram_cuda[(A,B),T](...) (sigkernel.py:378; cuda_backend.py:121-160) and their CPU
+ * twins sigkernel_cython / sigkernel_Gram_cython (sigkernel.py:246, :395;
+ * cython_backend.pyx:7-33, :64-119).  Unlike the reference there is no 1024-thread limit
+ * (sigkernel.py:222, :368) and no out-of-bounds extra row/column.
+ *   inc_c     [P,Mc,Nc]  coarse increments
+ *   out_final [P]        K[MM][NN]
+ *   out_grid  nullable   [P,MM+1,NN+1] full solution grid (what the reference returns)
+ *   out_edges nullable   [P,MM+NN+2]: K[MM][0..NN] followed by K[0..MM][NN] -- the terminal
+ *                        row and column, the only forward state the adjoint needs. */
+int sk_solve_fwd_f64(const double *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     double *out_final, double *out_grid, double *out_edges, void *stream);
+int sk_solve_fwd_f32(const float *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     float *out_final, float *out_grid, double *out_edges, void *stream);
+
+/* ---- adjoint solve ------------------------------------------------------------------------
+ * W[p][a][b] = d K_p[MM][NN] / d inc_c[p][a][b] by the reference's variation-of-parameters
+ * formula:  W = 4^-d * sum over the fine cells (i,j) of coarse cell (a,b) of
+ * K[i][j] * Krev[MM-1-i][NN-1-j], Krev = solution on the doubly flipped increments.
+ * Replaces the second solver launch and the KK product at sigkernel.py:282-311 (_SigKernel.backward)
+ * and :438-470 (prep_backward).
+ *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch (may be 0 -> NULL allowed).
+ *   out_final nullable [P]; W [P,Mc,Nc]. */
+size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size);
+int sk_solve_adj_f64(const double *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     double *out_final, double *W, void *workspace, size_t workspace_bytes, void *stream);
+int sk_solve_adj_f32(const float *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     float *out_final, float *W, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGKERNEL_AMD_H */

@@ -1,0 +1,11 @@
+"""sigkernel_amd -- MI355X-native signature-PDE-kernel engine.
+
+Drop-in for the ``SigKernel.compute_kernel / compute_Gram / compute_mmd`` path of
+crispitagorico/sigkernel: Python host code on PyTorch-ROCm calling hand-written HIP kernels
+(gfx950) through the C ABI in ``include/sigkernel_amd.h``.
+"""
+from .static_kernels import LinearKernel, RBFKernel
+from .sigkernel import SigKernel, _SigKernel, _SigKernelGram
+
+__all__ = ["SigKernel", "LinearKernel", "RBFKernel", "_SigKernel", "_SigKernelGram"]
+__version__ = "0.1.0"

@@ -1,0 +1,178 @@
+"""ctypes binding of libsigkernel_amd.so (C ABI: include/sigkernel_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not on a HIP
+device, the calls raise.  torch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsigkernel_amd.so")
+
+SK_OK = 0
+SCHEME_DEFAULT = 0
+SCHEME_NAIVE = 1
+FLAG_EXACT = 1
+FLAG_SIMPLE = 2
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/sigkernel_amd.h one to one
+SIGNATURES = {
+    "sk_version": (_int, []),
+    "sk_status_string": (ctypes.c_char_p, [_int]),
+    "sk_device_count": (_int, []),
+    "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_adjoint_f64": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_adjoint_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_f64": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_solve_fwd_f32": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
+    "sk_solve_adj_f64": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sk_solve_adj_f32": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class SigKernelLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SigKernelLibraryError(
+                "%s not found: build it with `python -m sigkernel_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(status, what):
+    if status != SK_OK:
+        msg = load().sk_status_string(status).decode()
+        exc = ValueError if status in (1, 2) else RuntimeError
+        raise exc("%s: %s (sk_status %d)" % (what, msg, status))
+
+
+def _suffix(t):
+    if t.dtype == torch.float64:
+        return "f64"
+    if t.dtype == torch.float32:
+        return "f32"
+    raise TypeError("sigkernel_amd supports float64 and float32 tensors, got %s" % t.dtype)
+
+
+def _dev(t, name):
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            "sigkernel_amd runs on MI355X only: tensor `%s` is on %s; move it to a HIP device "
+            "('cuda' in PyTorch-ROCm). There is no CPU fallback." % (name, t.device))
+    if not t.is_contiguous():
+        raise ValueError("tensor `%s` must be contiguous" % name)
+    return t
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    """The product back-end: every method enqueues HIP kernels on the current stream."""
+
+    name = "hip"
+
+    def increments(self, G):
+        """G [..., M, N] -> inc_c [..., M-1, N-1] (sigkernel.py:217, :363)."""
+        _dev(G, "G")
+        M, N = G.shape[-2:]
+        P = G.numel() // (M * N)
+        out = torch.empty(G.shape[:-2] + (M - 1, N - 1), dtype=G.dtype, device=G.device)
+        with torch.cuda.device(G.device):
+            fn = getattr(load(), "sk_increments_" + _suffix(G))
+            _check(fn(_ptr(G), P, M, N, _ptr(out), _stream(G)), "sk_increments")
+        return out
+
+    def increments_adjoint(self, W, scale=None):
+        """W [..., M-1, N-1] (+ per-pair scale [...]) -> dG [..., M, N]."""
+        _dev(W, "W")
+        Mc, Nc = W.shape[-2:]
+        P = W.numel() // (Mc * Nc)
+        if scale is not None:
+            _dev(scale, "scale")
+            if scale.dtype != W.dtype or scale.numel() != P:
+                raise ValueError("scale must have one entry per pair and W's dtype")
+        out = torch.empty(W.shape[:-2] + (Mc + 1, Nc + 1), dtype=W.dtype, device=W.device)
+        with torch.cuda.device(W.device):
+            fn = getattr(load(), "sk_increments_adjoint_" + _suffix(W))
+            _check(fn(_ptr(W), _ptr(scale), P, Mc + 1, Nc + 1, _ptr(out), _stream(W)), "sk_increments_adjoint")
+        return out
+
+    def solve_fwd(self, inc_c, dyadic, naive=False, flags=0, want_grid=False, want_edges=False):
+        """inc_c [..., Mc, Nc] -> final [...]; optionally (grid [..., MM+1, NN+1], edges [..., MM+NN+2])."""
+        _dev(inc_c, "inc_c")
+        Mc, Nc = inc_c.shape[-2:]
+        batch = inc_c.shape[:-2]
+        P = inc_c.numel() // (Mc * Nc)
+        MM, NN = Mc << dyadic, Nc << dyadic
+        out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
+        grid = torch.empty(batch + (MM + 1, NN + 1), dtype=inc_c.dtype, device=inc_c.device) if want_grid else None
+        edges = torch.empty(batch + (MM + NN + 2,), dtype=torch.float64, device=inc_c.device) if want_edges else None
+        with torch.cuda.device(inc_c.device):
+            fn = getattr(load(), "sk_solve_fwd_" + _suffix(inc_c))
+            _check(fn(_ptr(inc_c), P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
+                      _ptr(out), _ptr(grid), _ptr(edges), _stream(inc_c)), "sk_solve_fwd")
+        if want_grid or want_edges:
+            return out, grid, edges
+        return out
+
+    def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
+        """inc_c [..., Mc, Nc] -> (final [...], W [..., Mc, Nc] = d final / d inc_c)."""
+        _dev(inc_c, "inc_c")
+        Mc, Nc = inc_c.shape[-2:]
+        batch = inc_c.shape[:-2]
+        P = inc_c.numel() // (Mc * Nc)
+        out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
+        W = torch.empty_like(inc_c)
+        lib = load()
+        nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=inc_c.device)
+        with torch.cuda.device(inc_c.device):
+            fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
+            _check(fn(_ptr(inc_c), P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
+                      _ptr(out), _ptr(W), _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
+        # the caching allocator keeps `ws` alive for later work queued on this same stream
+        return out, W
+
+
+_backend = HipBackend()
+
+
+def get_backend():
+    return _backend
+
+
+def set_backend(b):
+    """Swap the solver back-end (test seam: tests/ install an oracle-backed fake to exercise the
+    host logic without a GPU). Returns the previous back-end."""
+    global _backend
+    prev, _backend = _backend, b
+    return prev

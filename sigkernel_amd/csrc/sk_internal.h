@@ -1,0 +1,43 @@
+// sk_internal.h -- declarations shared by the translation units of libsigkernel_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sigkernel_amd.h"
+
+namespace sk {
+
+// Geometry of one solve call; MM/NN are fine-grid cell counts.
+struct Geom {
+    int64_t P;
+    int Mc, Nc, dyadic;
+    int MM, NN;
+    int naive;
+};
+
+inline Geom make_geom(int64_t P, int Mc, int Nc, int dyadic, int scheme) {
+    Geom g;
+    g.P = P; g.Mc = Mc; g.Nc = Nc; g.dyadic = dyadic;
+    g.MM = Mc << dyadic; g.NN = Nc << dyadic;
+    g.naive = (scheme == SK_SCHEME_NAIVE);
+    return g;
+}
+
+// ---- sk_simple.hip: one wavefront per pair, anti-diagonal sweep, FMA-free arithmetic -------
+template <typename T>
+int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, double *out_edges, hipStream_t s);
+template <typename T>
+int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *ws, size_t ws_bytes, hipStream_t s);
+size_t adj_simple_workspace_bytes(const Geom &g);
+size_t simple_lds_bytes(const Geom &g);
+
+// ---- sk_increments.hip ------------------------------------------------------------------
+template <typename T>
+int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, hipStream_t s);
+template <typename T>
+int launch_increments_adjoint(const T *W, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
+
+inline int check_launch() {
+    return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;
+}
+
+}  // namespace sk

@@ -1,0 +1,211 @@
+"""SigKernel API and autograd surface, mirroring the reference's sigkernel/sigkernel.py:15-416.
+
+Host code only: static kernels stay torch ops (rocBLAS under PyTorch-ROCm); increments, the
+Goursat PDE solve and the adjoint PDE run in the HIP kernels of libsigkernel_amd.so through
+:mod:`sigkernel_amd._lib`.  Differences from the reference that are not observable in results:
+
+* the refined increment tensor of ``tile()`` (sigkernel.py:218, :364) is never built;
+* the adjoint is solved lazily in ``backward`` for both Functions (the reference does it eagerly in
+  ``_SigKernelGram.forward``, sigkernel.py:397-399) and contracted with the *analytic* derivative
+  of the static kernel instead of the h = 1e-9 finite difference (sigkernel.py:313-341, :472-500);
+* big batches are tiled by an HBM budget (``SigKernel.workspace_bytes``), not by ``max_batch``:
+  results never depended on ``max_batch`` (sigkernel.py:31-39, :102-127) and still do not.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["SigKernel", "_SigKernel", "_SigKernelGram"]
+
+_DEFAULT_WORKSPACE = 48 << 30  # bytes of transient HBM one call may use (288 GB part)
+
+
+def _budget(device, requested):
+    if requested is not None:
+        return int(requested)
+    if device.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(device)
+        return int(min(_DEFAULT_WORKSPACE, 0.5 * free))
+    return _DEFAULT_WORKSPACE
+
+
+def _tiles(n_rows, bytes_per_row, budget):
+    rows = int(max(1, min(n_rows, budget // max(1, bytes_per_row))))
+    return [(a, min(a + rows, n_rows)) for a in range(0, n_rows, rows)]
+
+
+def _check_inputs(X, Y, paired):
+    if X.dim() != 3 or Y.dim() != 3:
+        raise ValueError("X and Y must have shape (batch, length, dim)")
+    if X.shape[2] != Y.shape[2]:
+        raise ValueError("X and Y must have the same path dimension")
+    if paired and X.shape[0] != Y.shape[0]:
+        raise ValueError("compute_kernel needs the same batch size for X and Y")
+    if X.dtype != Y.dtype or X.device != Y.device:
+        raise ValueError("X and Y must share dtype and device")
+
+
+class _SigKernel(torch.autograd.Function):
+    """k_sig(x_i, y_i) for paired batches -- the reference's ``_SigKernel`` (sigkernel.py:201-343)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, static_kernel, dyadic_order, _naive_solver=False, workspace_bytes=None):
+        _check_inputs(X, Y, paired=True)
+        be = _lib.get_backend()
+        A, M, N = X.shape[0], X.shape[1], Y.shape[1]
+        ctx.save_for_backward(X, Y)
+        ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver = static_kernel, dyadic_order, _naive_solver
+        ctx.workspace_bytes = workspace_bytes
+        if M < 2 or N < 2:  # a single point: the grid is its boundary, k = 1 (sigkernel.py:212-253 with MM = 0)
+            return torch.ones(A, dtype=X.dtype, device=X.device)
+        Xd, Yd = X.detach(), Y.detach()
+        K = torch.empty(A, dtype=X.dtype, device=X.device)
+        per_row = 2 * M * N * X.element_size()
+        for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
+            G = static_kernel.batch_kernel(Xd[a0:a1], Yd[a0:a1]).contiguous()  # sigkernel.py:216
+            inc = be.increments(G)                                           # :217 (and :218 by index)
+            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)         # :231 / :246
+        return K
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        X, Y = ctx.saved_tensors
+        sk, d, naive = ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver
+        be = _lib.get_backend()
+        A, M, N = X.shape[0], X.shape[1], Y.shape[1]
+        grad_X = torch.zeros_like(X)
+        if M >= 2 and N >= 2:
+            Yd = Y.detach()
+            per_row = 8 * M * N * X.element_size()
+            go = grad_output.to(X.dtype).contiguous()
+            for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
+                Xt = X.detach()[a0:a1].clone().requires_grad_(True)
+                with torch.enable_grad():
+                    G = sk.batch_kernel(Xt, Yd[a0:a1])
+                inc = be.increments(G.detach().contiguous())
+                _, W = be.solve_adj(inc, d, naive)                            # sigkernel.py:282-311
+                dG = be.increments_adjoint(W, go[a0:a1].contiguous())         # replaces :313-341
+                (g,) = torch.autograd.grad(G, Xt, dG)
+                grad_X[a0:a1] = g
+        return grad_X, None, None, None, None, None
+
+
+class _SigKernelGram(torch.autograd.Function):
+    """Gram matrix k_sig(x_i, y_j) -- the reference's ``_SigKernelGram`` (sigkernel.py:347-416)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, static_kernel, dyadic_order, sym=False, _naive_solver=False, workspace_bytes=None):
+        _check_inputs(X, Y, paired=False)
+        be = _lib.get_backend()
+        A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
+        ctx.save_for_backward(X, Y)
+        ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver = static_kernel, dyadic_order, _naive_solver
+        ctx.workspace_bytes = workspace_bytes
+        if M < 2 or N < 2:
+            return torch.ones(A, B, dtype=X.dtype, device=X.device)
+        Xd, Yd = X.detach(), Y.detach()
+        K = torch.empty(A, B, dtype=X.dtype, device=X.device)
+        per_row = 2 * B * M * N * X.element_size()
+        # `sym` is accepted and, like the reference's GPU path (sigkernel.py:366-382), not needed:
+        # every pair is solved; the result equals the sym=False one.
+        for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
+            G = static_kernel.Gram_matrix(Xd[a0:a1], Yd).contiguous()         # sigkernel.py:362
+            inc = be.increments(G)                                           # :363 (and :364 by index)
+            del G
+            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)         # :378 / :395
+        return K
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        X, Y = ctx.saved_tensors
+        sk, d, naive = ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver
+        be = _lib.get_backend()
+        A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
+        grad_X = torch.zeros_like(X)
+        if M >= 2 and N >= 2:
+            Yd = Y.detach()
+            go = grad_output.to(X.dtype).contiguous()
+            per_row = 8 * B * M * N * X.element_size()
+            for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
+                Xt = X.detach()[a0:a1].clone().requires_grad_(True)
+                with torch.enable_grad():
+                    G = sk.Gram_matrix(Xt, Yd)
+                inc = be.increments(G.detach().contiguous())
+                _, W = be.solve_adj(inc, d, naive)                            # sigkernel.py:438-470
+                del inc
+                dG = be.increments_adjoint(W, go[a0:a1].contiguous())         # replaces :472-500 and :410-416
+                del W
+                (g,) = torch.autograd.grad(G, Xt, dG)
+                grad_X[a0:a1] = g
+        # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
+        # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
+        if ctx.needs_input_grad[1]:
+            grad_X = 2 * grad_X
+        return grad_X, None, None, None, None, None, None
+
+
+class SigKernel:
+    """Signature kernel k_sig(x, y) = <S(f(x)), S(f(y))> for a static kernel k(x, y) = <f(x), f(y)>.
+
+    Drop-in for the reference's ``SigKernel`` (sigkernel.py:15-197): same constructor, same methods,
+    same shapes / dtypes / devices.  Tensors must live on a HIP device (``'cuda'`` in PyTorch-ROCm).
+
+    Extra, optional: ``workspace_bytes`` bounds the transient HBM a call may use (default: half of
+    the free memory, at most 48 GiB); ``process_group`` shards ``compute_Gram`` rows over the ranks
+    of a ``torch.distributed`` group (see :mod:`sigkernel_amd.distributed`).
+    """
+
+    def __init__(self, static_kernel, dyadic_order, _naive_solver=False, workspace_bytes=None, process_group=None):
+        self.static_kernel = static_kernel
+        self.dyadic_order = dyadic_order
+        self._naive_solver = _naive_solver
+        self.workspace_bytes = workspace_bytes
+        self.process_group = process_group
+
+    def compute_kernel(self, X, Y, max_batch=100):
+        """X (batch, len_x, dim), Y (batch, len_y, dim) -> (batch,) vector k(X^i_T, Y^i_T).
+
+        ``max_batch`` is kept for signature compatibility (sigkernel.py:23); tiling is by HBM budget."""
+        return _SigKernel.apply(X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)
+
+    def compute_Gram(self, X, Y, sym=False, max_batch=100):
+        """X (batch_X, len_x, dim), Y (batch_Y, len_y, dim) -> (batch_X, batch_Y) matrix k(X^i_T, Y^j_T)."""
+        if self.process_group is not None:
+            from .distributed import sharded_gram
+            return sharded_gram(self, X, Y, sym, self.process_group)
+        return _SigKernelGram.apply(X, Y, self.static_kernel, self.dyadic_order, sym, self._naive_solver,
+                                    self.workspace_bytes)
+
+    def compute_distance(self, X, Y, max_batch=100):
+        """(batch,) paired squared distances reduced to their mean, as the reference does (sigkernel.py:130-144)."""
+        assert not Y.requires_grad, "the second input should not require grad"
+        K_XX = self.compute_kernel(X, X, max_batch)
+        K_YY = self.compute_kernel(Y, Y, max_batch)
+        K_XY = self.compute_kernel(X, Y, max_batch)
+        return torch.mean(K_XX) + torch.mean(K_YY) - 2. * torch.mean(K_XY)
+
+    def compute_scoring_rule(self, X, y, max_batch=100):
+        """S(X, y) = E[k(X, X)] - 2 E[k(X, y)] with y of shape (1, len_y, dim) (sigkernel.py:146-161)."""
+        assert not y.requires_grad, "the second input should not require grad"
+        K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
+        K_Xy = self.compute_Gram(X, y, sym=False, max_batch=max_batch)
+        K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
+        return K_XX_m - 2. * torch.mean(K_Xy)
+
+    def compute_expected_scoring_rule(self, X, Y, max_batch=100):
+        """S(X, Y) = E_Y[S(X, y)] (sigkernel.py:163-178)."""
+        assert not Y.requires_grad, "the second input should not require grad"
+        K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
+        K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
+        K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
+        return K_XX_m - 2. * torch.mean(K_XY)
+
+    def compute_mmd(self, X, Y, max_batch=100):
+        """Unbiased MMD^2 between the samples X and Y (sigkernel.py:180-197)."""
+        assert not Y.requires_grad, "the second input should not require grad"
+        K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
+        K_YY = self.compute_Gram(Y, Y, sym=True, max_batch=max_batch)
+        K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
+        K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
+        K_YY_m = (torch.sum(K_YY) - torch.sum(torch.diag(K_YY))) / (K_YY.shape[0] * (K_YY.shape[0] - 1.))
+        return K_XX_m + K_YY_m - 2. * torch.mean(K_XY)

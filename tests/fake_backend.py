@@ -1,0 +1,35 @@
+"""Oracle-backed stand-in for sigkernel_amd._lib.HipBackend -- TESTS ONLY.
+
+Lets the `-m "not gpu"` suite exercise the host logic (autograd wiring, tiling, MMD formula,
+row sharding over gloo) on CPU tensors.  The product never imports this.
+"""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+class OracleBackend:
+    name = "oracle-fake"
+
+    def increments(self, G):
+        return torch.from_numpy(O.increments(G.detach().double().numpy())).to(G.dtype)
+
+    def increments_adjoint(self, W, scale=None):
+        dG = torch.from_numpy(O.increments_adjoint(W.detach().double().numpy())).to(W.dtype)
+        if scale is not None:
+            dG = dG * scale.reshape(scale.shape + (1, 1))
+        return dG
+
+    def solve_fwd(self, inc_c, dyadic, naive=False, flags=0, want_grid=False, want_edges=False):
+        a = inc_c.detach().double().numpy()
+        if want_grid or want_edges:
+            out, grid = O.solve_coarse(a, dyadic, naive, want_grid=True)
+            edges = np.concatenate([grid[..., -1, :], grid[..., :, -1]], axis=-1)
+            return (torch.from_numpy(out).to(inc_c.dtype), torch.from_numpy(grid).to(inc_c.dtype) if want_grid else None,
+                    torch.from_numpy(edges) if want_edges else None)
+        return torch.from_numpy(O.solve_coarse(a, dyadic, naive)).to(inc_c.dtype)
+
+    def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
+        out, W = O.adjoint_coarse(inc_c.detach().double().numpy(), dyadic, naive)
+        return torch.from_numpy(out).to(inc_c.dtype), torch.from_numpy(W).to(inc_c.dtype)

@@ -1,0 +1,67 @@
+"""The C-ABI library builds, loads and exports every symbol include/sigkernel_amd.h declares.
+No compute calls: this runs without a GPU."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "sigkernel_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_symbols()
+    for n in ("sk_solve_fwd_f64", "sk_solve_fwd_f32", "sk_solve_adj_f64", "sk_solve_adj_f32", "sk_increments_f64",
+              "sk_increments_adjoint_f64", "sk_adj_workspace_bytes", "sk_version", "sk_status_string"):
+        assert n in names
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from sigkernel_amd import build, _lib
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    for name in declared_symbols():
+        assert hasattr(lib, name), "missing export: " + name
+    # the ctypes signature table covers the header one to one
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert _lib.load().sk_version() >= 100
+    assert _lib.load().sk_status_string(1).decode().startswith("bad argument")
+
+
+def test_argument_errors_are_reported_without_a_device():
+    from sigkernel_amd import _lib
+    lib = _lib.load()
+    # null pointers / bad sizes are rejected before any HIP call
+    assert lib.sk_solve_fwd_f64(None, 1, 4, 4, 0, 0, 0, None, None, None, None) == 1
+    assert lib.sk_solve_fwd_f64(ctypes.c_void_p(16), 1, 0, 4, 0, 0, 0, ctypes.c_void_p(16), None, None, None) == 1
+    assert lib.sk_solve_fwd_f64(ctypes.c_void_p(16), 1, 4, 4, 0, 7, 0, ctypes.c_void_p(16), None, None, None) == 1
+    assert lib.sk_increments_f64(None, 1, 4, 4, None, None) == 1
+    assert lib.sk_solve_adj_f64(ctypes.c_void_p(16), 1, 4, 4, 0, 0, 0, None, None, None, 0, None) == 1
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    import pytest
+    import torch
+    import sigkernel_amd
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 0)
+    X = torch.rand(2, 4, 2, dtype=torch.float64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sk.compute_Gram(X, X)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sk.compute_kernel(X, X)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sigkernel_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libsk_oracle" not in src, f

@@ -1,0 +1,141 @@
+"""Pins the CPU oracle (oracle/sigkernel_oracle.c) to the golden vectors produced by the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import scipy.special
+import torch
+
+from conftest import golden, golden_gram_cases, make_kernel, rel_err
+from oracle import oracle as O
+
+FWD_TOL = 1e-13   # the oracle is the same arithmetic as the reference: expect exactly 0
+# The reference differentiates the static kernel by forward differences with h = 1e-9 in fp64
+# (sigkernel.py:472-487): its own gradients carry rounding noise of 1e-7..7e-6 (max-norm relative;
+# largest on the rough RBF cases).  test_adjoint_vs_noise_free_reference_formula shows the noise is the
+# reference's, not ours: against the same formula evaluated in extended precision we agree to 1e-8.
+GRAD_TOL = 2e-5
+
+
+def test_solver_grids_bit_identical():
+    g = golden("solver_grids")
+    for naive in (0, 1):
+        assert np.array_equal(O.solve_fine(g["inc3"], naive), g["grid3_naive%d" % naive])
+        assert np.array_equal(O.solve_fine(g["inc4"], naive), g["grid4_naive%d" % naive])
+        assert np.array_equal(O.gram_sym_fine(g["incs"], naive), g["grids_sym_naive%d" % naive])
+
+
+def test_coarse_solver_equals_fine_solver():
+    rng = np.random.default_rng(0)
+    inc_c = rng.normal(scale=0.2, size=(4, 5, 7))
+    for d in (0, 1, 2, 3):
+        r = 1 << d
+        fine = np.repeat(np.repeat(inc_c, r, axis=1) / r, r, axis=2) / r   # tile(tile(.)/r)/r, sigkernel.py:218
+        for naive in (0, 1):
+            grid = O.solve_fine(fine, naive)
+            out, grid_c = O.solve_coarse(inc_c, d, naive, want_grid=True)
+            assert np.array_equal(grid, grid_c)
+            assert np.array_equal(out, grid[:, -1, -1])
+            assert np.array_equal(O.solve_coarse(inc_c, d, naive, nthreads=4), out)
+
+
+@pytest.mark.parametrize("name", golden_gram_cases())
+def test_gram_forward_matches_reference(name):
+    c = golden(name)
+    X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
+    K = O.gram_forward(X, Y, make_kernel(c), int(c["dyadic"]), bool(c["naive"]))
+    assert rel_err(K, c["gram"]) <= FWD_TOL
+    assert rel_err(c["gram_tiled"], c["gram"]) <= FWD_TOL   # reference property: max_batch does not change results
+    n = c["paired"].shape[0]
+    assert rel_err(np.diag(K[:n, :n]), c["paired"]) <= 1e-12
+
+
+@pytest.mark.parametrize("name", golden_gram_cases())
+def test_adjoint_matches_reference_gradients(name):
+    c = golden(name)
+    X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
+    gp = O.gram_grad_points(X, Y, make_kernel(c), int(c["dyadic"]), bool(c["naive"]))   # (A,B,M,D)
+    grad = np.einsum("ab,abmd->amd", c["w"], gp)
+    assert rel_err(grad, c["grad_w"]) <= GRAD_TOL
+    if "grad_xx_sum" in c:
+        gp_xx = O.gram_grad_points(X, X, make_kernel(c), int(c["dyadic"]), bool(c["naive"]))
+        assert rel_err(2 * gp_xx.sum(axis=1), c["grad_xx_sum"]) <= GRAD_TOL   # the 2x rule, sigkernel.py:410-412
+
+
+def test_adjoint_weights_are_the_exact_derivative_of_the_surrogate():
+    # W = d/d inc_c of sum(KK * inc) with KK frozen: check against its definition on a tiny grid
+    rng = np.random.default_rng(3)
+    inc_c = rng.normal(scale=0.3, size=(2, 3, 4))
+    for d in (0, 1, 2):
+        r = 1 << d
+        out, W = O.adjoint_coarse(inc_c, d)
+        fine = np.repeat(np.repeat(inc_c, r, axis=1) / r, r, axis=2) / r
+        K = O.solve_fine(fine)
+        Kr = O.solve_fine(fine[:, ::-1, ::-1].copy())[:, ::-1, ::-1]
+        KK = K[:, :-1, :-1] * Kr[:, 1:, 1:]                                   # sigkernel.py:469-470
+        Wref = KK.reshape(2, 3, r, 4, r).sum(axis=(2, 4)) / r / r
+        assert rel_err(W, Wref) <= 1e-14
+        assert np.array_equal(out, K[:, -1, -1])
+
+
+def test_increments_and_adjoint_are_transposes():
+    rng = np.random.default_rng(5)
+    G = rng.normal(size=(3, 6, 5))
+    W = rng.normal(size=(3, 5, 4))
+    lhs = np.sum(O.increments(G) * W)
+    rhs = np.sum(G * O.increments_adjoint(W))
+    assert abs(lhs - rhs) <= 1e-12 * abs(lhs)
+
+
+def test_straight_line_known_answers():
+    """<dx,dy> = c = 1: d=0 gives exactly 2.25 and the scheme converges to I0(2)."""
+    k = golden("kat_straight_lines")
+    inc_c = np.ones((1, 1, 1))
+    assert O.solve_coarse(inc_c, 0)[0] == 2.25 == k["d0"][0]
+    for d in (1, 4, 8):
+        assert O.solve_coarse(inc_c, d)[0] == k["d%d" % d][0]
+    assert abs(O.solve_coarse(inc_c, 8)[0] - scipy.special.i0(2.0)) < 1e-6
+
+
+def test_readme_example_values():
+    c = golden("readme_c1")
+    import sigkernel_amd
+    X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
+    K = O.gram_forward(X, Y, sigkernel_amd.RBFKernel(float(c["sigma"])), int(c["dyadic"]))
+    assert rel_err(K, c["gram"]) <= FWD_TOL
+    assert rel_err(np.diag(K), c["kernel"]) <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["gram_c2mini_rbf_d1", "gram_lin_d2_ragged"])
+def test_adjoint_vs_noise_free_reference_formula(name):
+    """prep_backward's formula (sigkernel.py:469-500) with its h = 1e-9 forward difference evaluated in
+    long double, so that only the O(h) truncation error is left: the analytic adjoint must match to 1e-7."""
+    c = golden(name)
+    X, Y, d = c["X"], c["Y"], int(c["dyadic"])
+    A, M, D = X.shape
+    LD = np.longdouble
+    lin = str(c["kernel"]) == "linear"
+
+    def gram_ld(Xa, Yb):
+        Xa, Yb = Xa.astype(LD), Yb.astype(LD)
+        xy = np.einsum("ipk,jqk->ijpq", Xa, Yb)
+        if lin:
+            return xy
+        dist = -2 * xy + ((Xa ** 2).sum(2)[:, None, :, None] + (Yb ** 2).sum(2)[None, :, None, :])
+        return np.exp(-dist / LD(float(c["param"])))
+
+    def inc_of(G):
+        return G[:, :, 1:, 1:] + G[:, :, :-1, :-1] - G[:, :, 1:, :-1] - G[:, :, :-1, 1:]
+
+    G0 = gram_ld(X, Y)
+    _, W = O.adjoint_coarse(inc_of(G0).astype(np.float64), d, bool(c["naive"]))
+    h = LD(1e-9)
+    fd = np.zeros((A, Y.shape[0], M, D))
+    for m in range(M):
+        for k in range(D):
+            Xh = X.astype(LD).copy()
+            Xh[:, m, k] += h
+            dinc = ((inc_of(gram_ld(Xh, Y)) - inc_of(G0)) / h).astype(np.float64)
+            fd[:, :, m, k] = (W * dinc).sum(axis=(2, 3))
+    gp = O.gram_grad_points(torch.from_numpy(X), torch.from_numpy(Y), make_kernel(c), d, bool(c["naive"]))
+    assert rel_err(gp, fd) <= 1e-7
+    assert rel_err(np.einsum("ab,abmd->amd", c["w"], fd), c["grad_w"]) <= GRAD_TOL
