@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gram entries/s of SigKernel.compute_Gram on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4mini]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one compute_Gram call (static kernel -> increments -> PDE solve) over one batch of synthetic
+paths already resident in HBM.  At N = 1 the workload is BASELINE.json configs[2] (the headline:
+batch 512 x 512, len 128, dim 8, LinearKernel, dyadic 1, fp64, sym=False).  At N > 1 every rank owns 512
+rows of X (weak scaling: global Gram is (512 N) x 512), solves them with no data-path collective and one
+RCCL all-gather assembles the full matrix on every rank, exactly as sigkernel_amd.distributed does it.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the solver kernel against the HBM roofline (algorithmic bytes = coarse increment
+                 matrix read once + one value written per pair)
+  cpu_baseline : the CPU oracle (the C restatement of the reference's Cython solver) timed on this
+                 box's host cores on a bounded sample of the same workload
+  parity       : 64 random pairs of the timed input re-solved by the oracle
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sigkernel_amd  # noqa: E402
+from sigkernel_amd import _lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (A per rank, B, M, N, D, kernel, dyadic, dtype, description)
+    "c3": (512, 512, 128, 128, 8, "linear", 1, torch.float64,
+           "BASELINE configs[2]: batch 512x512, len 128, dim 8, LinearKernel, dyadic 1, fp64, compute_Gram sym=False"),
+    "c2": (128, 128, 64, 64, 3, "rbf", 1, torch.float64,
+           "BASELINE configs[1]: batch 128x128, len 64, dim 3, RBFKernel(1.0), dyadic 1, fp64, compute_Gram"),
+    "c4mini": (512, 512, 64, 64, 4, "rbf", 2, torch.float64,
+               "BASELINE configs[3] reduced to 512x512 pairs: len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64"),
+}
+
+
+def make_paths(A, M, D, seed, dtype):
+    """Scaled random walks: kernel values stay O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    X = torch.cumsum(torch.randn(A, M, D, generator=g, dtype=torch.float64), dim=1) / np.sqrt(M * D)
+    return X.to(dtype)
+
+
+def static_kernel(name):
+    return sigkernel_amd.LinearKernel() if name == "linear" else sigkernel_amd.RBFKernel(1.0)
+
+
+def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
+    """Time the CPU oracle on a bounded sample of the SAME workload: the first `rows` rows of X against
+    all of Y, static kernel (torch, CPU) + increments + PDE solve with OpenMP over pairs on every host core."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, O.max_threads()) if O.max_threads() > 1 else cores
+    B, M, N = Yc.shape[0], Xc.shape[1], Yc.shape[1]
+    sk = static_kernel(kname)
+    # calibrate on a few pairs, then size the sample to ~budget_s seconds
+    G = sk.Gram_matrix(Xc[:1].double(), Yc[: min(B, 4 * threads)].double()).numpy()
+    inc = O.increments(G)
+    t0 = time.perf_counter()
+    O.solve_coarse(inc, dyadic, nthreads=threads)
+    per_pair = (time.perf_counter() - t0) / inc.shape[1]
+    rows = int(max(1, min(Xc.shape[0], budget_s / max(per_pair * B, 1e-9))))
+    t0 = time.perf_counter()
+    G = sk.Gram_matrix(Xc[:rows].double(), Yc.double()).numpy()
+    inc = O.increments(G)
+    t1 = time.perf_counter()
+    vals = O.solve_coarse(inc, dyadic, nthreads=threads)
+    t2 = time.perf_counter()
+    pairs = rows * B
+    return {
+        "value": pairs / (t2 - t0),
+        "unit": "entries/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "first %d of %d rows of X against all %d paths of Y (%d pairs, len %dx%d, dyadic %d); "
+                  "static kernel + increments + solve, OpenMP over pairs" % (rows, Xc.shape[0], B, pairs, M, N, dyadic),
+        "solver_only_value": pairs / (t2 - t1),
+        "seconds": t2 - t0,
+    }, vals, rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    A, B, M, N, D, kname, dyadic, dtype, desc = CONFIGS[args.config]
+    Xc = make_paths(A, M, D, seed=1000 + rank, dtype=dtype)      # this rank's rows (weak scaling)
+    Yc = make_paths(B, N, D, seed=7, dtype=dtype)                 # replicated
+    X, Y = Xc.to(dev), Yc.to(dev)
+    sk = sigkernel_amd.SigKernel(static_kernel(kname), dyadic)
+    be = _lib.get_backend()
+    assert isinstance(be, _lib.HipBackend), "bench must run on the HIP back-end"
+
+    def step():
+        Kloc = sk.compute_Gram(X, Y)                     # this rank's (A x B) block
+        if world > 1:
+            out = torch.empty((world * A, B), dtype=Kloc.dtype, device=dev)
+            dist.all_gather_into_tensor(out, Kloc)       # the one collective of the path
+            return out
+        return Kloc
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        K = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        K = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    entries_per_step = world * A * B
+    cells_per_entry = ((M - 1) << dyadic) * ((N - 1) << dyadic)
+    value = entries_per_step * args.steps / elapsed
+
+    result = {
+        "metric": "Gram entries/sec (fp64)",
+        "value": value,
+        "unit": "entries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if dtype == torch.float64 else "f32",
+        "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": A, "batch_y": B, "len_x": M, "len_y": N, "dim": D,
+                   "static_kernel": kname, "dyadic_order": dyadic,
+                   "parallelism": "gram rows sharded over %d GPU(s), 1 all-gather" % world},
+        "grid_cells_per_s": value * cells_per_entry,
+    }
+
+    if rank == 0:
+        # ---- solver kernel alone, timed with HIP events on the launch stream ----------------------------
+        s = X.element_size()
+        rows = A
+        while rows > 1 and 2 * rows * B * M * N * s > 40e9:
+            rows //= 2
+        with torch.no_grad():
+            G = sk.static_kernel.Gram_matrix(X[:rows], Y).contiguous()
+            inc = be.increments(G)
+            del G
+        for _ in range(2):
+            be.solve_fwd(inc, dyadic)
+        reps = max(3, args.steps)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
+            be.solve_fwd(inc, dyadic)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        launch_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
+        avg_ms = float(np.mean(launch_ms))
+        pairs = rows * B
+        alg_bytes = pairs * ((M - 1) * (N - 1) * s + s)            # inc_c read once + 1 value out
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(args.config)
+                if ent and ent.get("pairs_per_launch") == pairs:
+                    traffic = ent.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "sk_solve_fwd_f64", "pairs_per_launch": pairs,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "min_launch_ms": float(np.min(launch_ms)),
+            "solver_only_entries_per_s": pairs / (avg_ms * 1e-3),
+            "solver_only_cells_per_s": pairs * cells_per_entry / (avg_ms * 1e-3),
+        }
+        del inc
+
+        # ---- parity of the timed output + CPU baseline ---------------------------------------------------
+        from oracle import oracle as O
+        Kc = K[:A].cpu().numpy()
+        rng = np.random.default_rng(0)
+        idx = rng.integers(0, A * B, size=64)
+        worst = 0.0
+        for p in idx:
+            a, b = divmod(int(p), B)
+            want = O.gram_forward(Xc[a:a + 1], Yc[b:b + 1], static_kernel(kname), dyadic)[0, 0]
+            worst = max(worst, abs(float(Kc[a, b]) - want) / abs(want))
+        result["parity"] = {"pairs_checked": 64, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "ok": bool(worst <= 1e-6)}
+        if world == 1 and not args.no_cpu_baseline:
+            cb, vals, nrows = cpu_baseline(Xc, Yc, kname, dyadic, args.cpu_budget_s)
+            cb["max_rel_err_gpu_vs_cpu_sample"] = float(np.max(np.abs(Kc[:nrows] - vals) / np.abs(vals)))
+            result["cpu_baseline"] = cb
+            result["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(result))
+        sys.stdout.flush()
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+"""Parity of the HIP path against the CPU oracle and the reference's golden vectors.  Needs an MI355X.
+
+Everything goes through the C ABI (sigkernel_amd._lib.HipBackend -> libsigkernel_amd.so).
+Tolerances: north_star asks for <= 1e-6 relative error in fp64; the simple/exact kernels are
+bit-identical to the oracle, the fast kernels (FMA-contracted) are held to 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+import sigkernel_amd
+from sigkernel_amd import _lib
+from conftest import golden, golden_gram_cases, make_kernel, rel_err, walk
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FAST_TOL = 1e-12
+GRAD_TOL = 2e-5      # vs reference fixtures (reference FD noise floor, tests/test_oracle.py)
+ADJ_TOL = 1e-10      # vs the CPU oracle's closed form
+F32_RTOL, F32_ATOL = 1e-4, 1e-5   # the reference's own fp32 acceptance (sigkernel/test_mps.py:32)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def be():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    lib = _lib.load()
+    assert lib.sk_device_count() >= 1
+    return _lib.HipBackend()
+
+
+SHAPES = [  # P, Mc, Nc, dyadic
+    (3, 1, 1, 0), (3, 1, 1, 3), (5, 9, 19, 1), (4, 7, 3, 2), (6, 63, 63, 1), (2, 127, 127, 1),
+    (3, 64, 65, 0), (2, 130, 70, 1), (2, 33, 200, 2), (7, 5, 6, 3), (1, 300, 17, 0), (2, 20, 20, 4),
+]
+
+
+def _inc(P, Mc, Nc, seed, scale=0.05):
+    rng = np.random.default_rng(seed)
+    return rng.normal(scale=scale, size=(P, Mc, Nc))
+
+
+@pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
+@pytest.mark.parametrize("naive", [False, True])
+def test_forward_exact_kernels_bit_identical_to_oracle(be, P, Mc, Nc, d, naive):
+    inc = _inc(P, Mc, Nc, seed=Mc * 1000 + Nc + d)
+    want, grid = O.solve_coarse(inc, d, naive, want_grid=True)
+    t = torch.from_numpy(inc).to(DEV)
+    out, g, e = be.solve_fwd(t, d, naive, flags=_lib.FLAG_EXACT | _lib.FLAG_SIMPLE, want_grid=True, want_edges=True)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(g.cpu().numpy(), grid)
+    edges = np.concatenate([grid[:, -1, :], grid[:, :, -1]], axis=1)
+    assert np.array_equal(e.cpu().numpy(), edges)
+
+
+@pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
+@pytest.mark.parametrize("naive", [False, True])
+def test_forward_default_path_matches_oracle(be, P, Mc, Nc, d, naive):
+    inc = _inc(P, Mc, Nc, seed=7 + Mc * 1000 + Nc + d)
+    want = O.solve_coarse(inc, d, naive)
+    out = be.solve_fwd(torch.from_numpy(inc).to(DEV), d, naive)
+    assert rel_err(out.cpu().numpy(), want) <= FAST_TOL
+
+
+@pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
+def test_forward_fp32_io(be, P, Mc, Nc, d):
+    inc = _inc(P, Mc, Nc, seed=11 + Mc + Nc + d).astype(np.float32)
+    want = O.solve_coarse(inc.astype(np.float64), d)
+    out = be.solve_fwd(torch.from_numpy(inc).to(DEV), d)
+    assert out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=F32_RTOL, atol=F32_ATOL)
+
+
+@pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
+@pytest.mark.parametrize("naive", [False, True])
+def test_adjoint_matches_oracle(be, P, Mc, Nc, d, naive):
+    inc = _inc(P, Mc, Nc, seed=3 + Mc * 1000 + Nc + d)
+    want_k, want_w = O.adjoint_coarse(inc, d, naive)
+    k, W = be.solve_adj(torch.from_numpy(inc).to(DEV), d, naive)
+    assert rel_err(k.cpu().numpy(), want_k) <= FAST_TOL
+    assert rel_err(W.cpu().numpy(), want_w) <= ADJ_TOL
+    k2, W2 = be.solve_adj(torch.from_numpy(inc).to(DEV), d, naive, flags=_lib.FLAG_EXACT | _lib.FLAG_SIMPLE)
+    assert np.array_equal(W2.cpu().numpy(), want_w) and np.array_equal(k2.cpu().numpy(), want_k)
+
+
+def test_increments_and_transpose_bit_identical(be):
+    rng = np.random.default_rng(0)
+    for shape in [(3, 2, 2), (4, 10, 20), (2, 3, 128, 128), (5, 65, 7), (1, 300, 300)]:
+        G = rng.normal(size=shape)
+        got = be.increments(torch.from_numpy(G).to(DEV)).cpu().numpy()
+        assert np.array_equal(got, O.increments(G))
+        W = rng.normal(size=shape[:-2] + (shape[-2] - 1, shape[-1] - 1))
+        got = be.increments_adjoint(torch.from_numpy(W).to(DEV)).cpu().numpy()
+        assert np.array_equal(got, O.increments_adjoint(W))
+        s = rng.normal(size=shape[:-2])
+        got = be.increments_adjoint(torch.from_numpy(W).to(DEV), torch.from_numpy(s).to(DEV)).cpu().numpy()
+        assert rel_err(got, O.increments_adjoint(W) * s[..., None, None]) <= 1e-15
+    G32 = rng.normal(size=(3, 9, 11)).astype(np.float32)
+    got = be.increments(torch.from_numpy(G32).to(DEV)).cpu().numpy()
+    want = ((G32[:, 1:, 1:] + G32[:, :-1, :-1]) - G32[:, 1:, :-1]) - G32[:, :-1, 1:]
+    assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------
+# API level, against the golden vectors produced by the real reference
+# ---------------------------------------------------------------------------------------------
+def _sk(c, **kw):
+    return sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"]), _naive_solver=bool(c["naive"]), **kw)
+
+
+@pytest.mark.parametrize("name", golden_gram_cases())
+def test_api_gram_and_gradients_vs_reference(be, name):
+    c = golden(name)
+    X, Y, w = (torch.from_numpy(c[k]).to(DEV) for k in ("X", "Y", "w"))
+    sk = _sk(c)
+    K = sk.compute_Gram(X, Y)
+    assert K.device == X.device and K.dtype == X.dtype
+    assert rel_err(K.cpu().numpy(), c["gram"]) <= 1e-11
+    Xg = X.clone().requires_grad_(True)
+    (sk.compute_Gram(Xg, Y) * w).sum().backward()
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_w"]) <= GRAD_TOL
+    n = c["paired"].shape[0]
+    Xg = X[:n].clone().requires_grad_(True)
+    Kp = sk.compute_kernel(Xg, Y[:n])
+    assert rel_err(Kp.detach().cpu().numpy(), c["paired"]) <= 1e-11
+    (Kp * torch.from_numpy(c["wp"]).to(DEV)).sum().backward()
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_paired"]) <= GRAD_TOL
+    if "mmd" in c:
+        Xg = X.clone().requires_grad_(True)
+        mmd = sk.compute_mmd(Xg, Y)
+        mmd.backward()
+        assert abs(float(mmd.detach()) - float(c["mmd"])) <= 1e-11
+        assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= GRAD_TOL
+        Xg = X.clone().requires_grad_(True)
+        G = sk.compute_Gram(Xg, Xg, sym=True)
+        G.sum().backward()
+        assert rel_err(G.detach().cpu().numpy(), c["gram_xx_sym"]) <= 1e-11
+        assert rel_err(Xg.grad.cpu().numpy(), c["grad_xx_sum"]) <= GRAD_TOL
+
+
+def test_api_readme_example(be):
+    c = golden("readme_c1")
+    X, Y, Z = (torch.from_numpy(c[k]).to(DEV) for k in ("X", "Y", "Z"))
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(sigma=0.5), dyadic_order=1)
+    assert rel_err(sk.compute_kernel(X, Y).cpu().numpy(), c["kernel"]) <= 1e-11
+    assert rel_err(sk.compute_Gram(X, Y, sym=False).cpu().numpy(), c["gram"]) <= 1e-11
+    Xg = X.clone().requires_grad_(True)
+    mmd = sk.compute_mmd(Xg, Y)
+    mmd.backward()
+    assert abs(float(mmd.detach()) - float(c["mmd"])) <= 1e-11
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= GRAD_TOL
+    assert abs(float(sk.compute_scoring_rule(X, Z[:1])) - float(c["scoring_rule"])) <= 1e-11
+    assert abs(float(sk.compute_expected_scoring_rule(X, Z)) - float(c["expected_scoring_rule"])) <= 1e-11
+    assert abs(float(sk.compute_distance(X, Y)) - float(c["distance"])) <= 1e-11
+
+
+def test_api_tiling_independence_on_device(be):
+    c = golden("gram_c2mini_rbf_d1")
+    X, Y = torch.from_numpy(c["X"]).to(DEV), torch.from_numpy(c["Y"]).to(DEV)
+    a = _sk(c).compute_Gram(X, Y)
+    b = _sk(c, workspace_bytes=1).compute_Gram(X, Y, max_batch=2)
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE-size inputs: size-independent properties + spot checks against the oracle
+# ---------------------------------------------------------------------------------------------
+def test_headline_size_properties(be):
+    """C3-sized problems (len 128, dim 8, Linear, d=1): a 96 x 96 block of the headline Gram.
+    (the full 512 x 512 is run by bench.py with the same spot check)"""
+    gen = torch.Generator().manual_seed(0)
+    A = B = 96
+    X = walk(gen, A, 128, 8).to(DEV)
+    Y = walk(gen, B, 128, 8).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1)
+    K = sk.compute_Gram(X, Y)
+    # (1) spot check 64 random pairs against the oracle
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, A * B, size=64)
+    Xc, Yc = X.cpu(), Y.cpu()
+    for p in idx:
+        a, b = divmod(int(p), B)
+        want = O.gram_forward(Xc[a:a + 1], Yc[b:b + 1], sigkernel_amd.LinearKernel(), 1)[0, 0]
+        assert abs(float(K[a, b]) - want) <= 1e-11 * abs(want)
+    # (2) symmetry k(x,y) = k(y,x)
+    Kt = sk.compute_Gram(Y, X)
+    assert rel_err(Kt.t().cpu().numpy(), K.cpu().numpy()) <= 1e-12
+    # (3) a constant path has zero increments: k = 1 exactly; translating x leaves a linear-kernel Gram unchanged
+    Yconst = Y[:, :1, :].expand(-1, 128, -1).contiguous()
+    assert torch.all(sk.compute_Gram(X, Yconst) == 1.0)
+    Ks = sk.compute_Gram(X + 0.25, Y)
+    assert rel_err(Ks.cpu().numpy(), K.cpu().numpy()) <= 1e-9
+    # (4) invariance under a permutation of the batch
+    perm = torch.randperm(A, generator=gen).to(DEV)
+    assert torch.equal(sk.compute_Gram(X[perm].contiguous(), Y), K[perm])
+    # (5) paired kernel is the Gram diagonal
+    assert rel_err(sk.compute_kernel(X, Y).cpu().numpy(), torch.diagonal(K).cpu().numpy()) <= 1e-12
+
+
+def test_straight_line_known_answer_in_a_batch(be):
+    # two straight lines with <dx,dy> = 1: d=0 gives exactly 2.25, any length
+    for M in (2, 9, 128):
+        t = torch.linspace(0, 1, M, dtype=torch.float64)[None, :, None].to(DEV)
+        X = t.repeat(70, 1, 1).contiguous()
+        k0 = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 0).compute_kernel(X[:, :2], X[:, :2])
+        assert torch.all(k0 == 2.25)
+        k8 = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 3).compute_kernel(X, X)
+        assert torch.all((k8 - 2.2795853).abs() < 1e-4)      # -> I0(2) = 2.27958530...
+        assert torch.all(k8 == k8[0])
+
+
+def test_long_paths_beyond_the_reference_gpu_limit(be):
+    """The reference's GPU path asserts max(MM,NN) < 1024 (sigkernel.py:222,368); ours must not."""
+    gen = torch.Generator().manual_seed(1)
+    X = walk(gen, 2, 700, 3).to(DEV)
+    Y = walk(gen, 2, 640, 3).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1)
+    K = sk.compute_Gram(X, Y)
+    want = O.gram_forward(X.cpu(), Y.cpu(), sigkernel_amd.RBFKernel(1.0), 1)
+    assert rel_err(K.cpu().numpy(), want) <= 1e-11
