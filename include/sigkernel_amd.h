@@ -14,8 +14,12 @@
  *     Dyadic refinement is index arithmetic inside the kernels
  *     (fine increment (i,j) = inc_c[i>>d][j>>d] / 4^d); the refined matrix that
  *     the reference materialises with tile() (sigkernel.py:218, :364) never exists.
- *   - all arrays are dense row-major device pointers owned by the caller; the
- *     library keeps no reference after return and allocates nothing.
+ *   - all arrays are row-major device pointers owned by the caller; the library keeps no
+ *     reference after return and allocates nothing.  Increment matrices carry a row stride
+ *     `ld` (in elements, ld >= Nc; 0 means dense, ld = Nc): the fast kernels want 16-byte
+ *     aligned rows (ld*sizeof(T) % 16 == 0, base pointer 16-byte aligned, which
+ *     sk_increments_* produces when asked); any other layout is served by the simple
+ *     kernels.  Everything else is dense.
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     every call only enqueues work on it -- no hidden synchronisation.
  *   - return value: SK_OK or an sk_status error code (see sk_status_string).
@@ -50,6 +54,8 @@ typedef enum sk_status {
 #define SK_FLAG_EXACT 1  /* FMA-free arithmetic in the reference's operand order: results are
                             bit-identical to the reference's Cython CPU solver (slower path)   */
 #define SK_FLAG_SIMPLE 2 /* force the simple one-wavefront-per-pair anti-diagonal kernels       */
+#define SK_FLAG_FAST_ONLY 4 /* never fall back: SK_ERR_UNSUPPORTED if the tiled kernels do not
+                               cover the shape/layout (used by tests and benchmarks)            */
 
 int sk_version(void);
 const char *sk_status_string(int status);
@@ -59,9 +65,9 @@ int sk_device_count(void);
 /* ---- increments ---------------------------------------------------------------------------
  * inc_c[p][i][j] = G[p][i+1][j+1] + G[p][i][j] - G[p][i+1][j] - G[p][i][j+1]
  * Replaces the 4-corner difference at sigkernel.py:217 (paired) and :363 (Gram); recomputed in
- * backward at :264 and :421.   G [P,M,N] -> inc_c [P,M-1,N-1]. */
-int sk_increments_f64(const double *G, int64_t P, int M, int N, double *inc_c, void *stream);
-int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, void *stream);
+ * backward at :264 and :421.   G [P,M,N] -> inc_c [P,M-1,ld] (columns >= N-1 are zero-filled). */
+int sk_increments_f64(const double *G, int64_t P, int M, int N, double *inc_c, int64_t ld, void *stream);
+int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int64_t ld, void *stream);
 
 /* Transpose of the above, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
  * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
@@ -79,14 +85,14 @@ int sk_increments_adjoint_f32(const float *W, const float *scale, int64_t P, int
  * twins sigkernel_cython / sigkernel_Gram_cython (sigkernel.py:246, :395;
  * cython_backend.pyx:7-33, :64-119).  Unlike the reference there is no 1024-thread limit
  * (sigkernel.py:222, :368) and no out-of-bounds extra row/column.
- *   inc_c     [P,Mc,Nc]  coarse increments
+ *   inc_c     [P,Mc,ld]  coarse increments, row stride ld
  *   out_final [P]        K[MM][NN]
  *   out_grid  nullable   [P,MM+1,NN+1] full solution grid (what the reference returns)
  *   out_edges nullable   [P,MM+NN+2]: K[MM][0..NN] followed by K[0..MM][NN] -- the terminal
  *                        row and column, the only forward state the adjoint needs. */
-int sk_solve_fwd_f64(const double *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+int sk_solve_fwd_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      double *out_final, double *out_grid, double *out_edges, void *stream);
-int sk_solve_fwd_f32(const float *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      float *out_final, float *out_grid, double *out_edges, void *stream);
 
 /* ---- adjoint solve ------------------------------------------------------------------------
@@ -96,11 +102,11 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t P, int Mc, int Nc, int dyadic, 
  * Replaces the second solver launch and the KK product at sigkernel.py:282-311 (_SigKernel.backward)
  * and :438-470 (prep_backward).
  *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch (may be 0 -> NULL allowed).
- *   out_final nullable [P]; W [P,Mc,Nc]. */
+ *   inc_c [P,Mc,ld]; out_final nullable [P]; W [P,Mc,Nc] dense. */
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size);
-int sk_solve_adj_f64(const double *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      double *out_final, double *W, void *workspace, size_t workspace_bytes, void *stream);
-int sk_solve_adj_f32(const float *inc_c, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      float *out_final, float *W, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus

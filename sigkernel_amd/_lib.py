@@ -16,6 +16,7 @@ SCHEME_DEFAULT = 0
 SCHEME_NAIVE = 1
 FLAG_EXACT = 1
 FLAG_SIMPLE = 2
+FLAG_FAST_ONLY = 4
 
 _lib = None
 
@@ -29,15 +30,15 @@ SIGNATURES = {
     "sk_version": (_int, []),
     "sk_status_string": (ctypes.c_char_p, [_int]),
     "sk_device_count": (_int, []),
-    "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
-    "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
+    "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
     "sk_increments_adjoint_f64": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_f64": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_solve_fwd_f32": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
-    "sk_solve_adj_f64": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "sk_solve_adj_f32": (_int, [_vp, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
 }
 
 
@@ -87,6 +88,32 @@ def _dev(t, name):
     return t
 
 
+def _padded_ld(n, elem_size):
+    """Row stride (elements) that keeps every increment row 16-byte aligned for the LDS-DMA kernels."""
+    q = 16 // elem_size
+    return (n + q - 1) // q * q
+
+
+def _row_stride(t, name):
+    """inc_c [..., Mc, Nc] with unit column stride and batch dims packed over rows of stride ld >= Nc.
+    Returns (tensor, ld); anything else is densified."""
+    if t.device.type != "cuda":
+        _dev(t, name)
+    Mc, Nc = t.shape[-2:]
+    if t.dim() >= 2 and t.stride(-1) == 1 and t.stride(-2) >= Nc:
+        ld = t.stride(-2)
+        expect, ok = Mc * ld, True
+        for size, stride in zip(reversed(t.shape[:-2]), reversed(t.stride()[:-2])):
+            if size != 1 and stride != expect:
+                ok = False
+                break
+            expect *= size
+        if ok:
+            return t, ld
+    t = t.contiguous()
+    return t, Nc
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -105,11 +132,12 @@ class HipBackend:
         _dev(G, "G")
         M, N = G.shape[-2:]
         P = G.numel() // (M * N)
-        out = torch.empty(G.shape[:-2] + (M - 1, N - 1), dtype=G.dtype, device=G.device)
+        ld = _padded_ld(N - 1, G.element_size())
+        out = torch.empty(G.shape[:-2] + (M - 1, ld), dtype=G.dtype, device=G.device)
         with torch.cuda.device(G.device):
             fn = getattr(load(), "sk_increments_" + _suffix(G))
-            _check(fn(_ptr(G), P, M, N, _ptr(out), _stream(G)), "sk_increments")
-        return out
+            _check(fn(_ptr(G), P, M, N, _ptr(out), ld, _stream(G)), "sk_increments")
+        return out[..., : N - 1]      # rows stay 16-byte aligned underneath (stride(-2) == ld)
 
     def increments_adjoint(self, W, scale=None):
         """W [..., M-1, N-1] (+ per-pair scale [...]) -> dG [..., M, N]."""
@@ -128,7 +156,7 @@ class HipBackend:
 
     def solve_fwd(self, inc_c, dyadic, naive=False, flags=0, want_grid=False, want_edges=False):
         """inc_c [..., Mc, Nc] -> final [...]; optionally (grid [..., MM+1, NN+1], edges [..., MM+NN+2])."""
-        _dev(inc_c, "inc_c")
+        inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
         P = inc_c.numel() // (Mc * Nc)
@@ -138,7 +166,7 @@ class HipBackend:
         edges = torch.empty(batch + (MM + NN + 2,), dtype=torch.float64, device=inc_c.device) if want_edges else None
         with torch.cuda.device(inc_c.device):
             fn = getattr(load(), "sk_solve_fwd_" + _suffix(inc_c))
-            _check(fn(_ptr(inc_c), P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
+            _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
                       _ptr(out), _ptr(grid), _ptr(edges), _stream(inc_c)), "sk_solve_fwd")
         if want_grid or want_edges:
             return out, grid, edges
@@ -146,18 +174,18 @@ class HipBackend:
 
     def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
         """inc_c [..., Mc, Nc] -> (final [...], W [..., Mc, Nc] = d final / d inc_c)."""
-        _dev(inc_c, "inc_c")
+        inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
         P = inc_c.numel() // (Mc * Nc)
         out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
-        W = torch.empty_like(inc_c)
+        W = torch.empty(inc_c.shape, dtype=inc_c.dtype, device=inc_c.device)
         lib = load()
         nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=inc_c.device)
         with torch.cuda.device(inc_c.device):
             fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
-            _check(fn(_ptr(inc_c), P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
+            _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
                       _ptr(out), _ptr(W), _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
         # the caching allocator keeps `ws` alive for later work queued on this same stream
         return out, W

@@ -15,18 +15,20 @@ constexpr int ROWS = 16;  // output rows per block strip
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void k_increments(const T *__restrict__ G, int M, int N, int strips,
-                                                    T *__restrict__ inc) {
+                                                    T *__restrict__ inc, int64_t ld) {
     const int Mc = M - 1, Nc = N - 1;
     const int64_t p = blockIdx.x / strips;
     const int i0 = (int)(blockIdx.x % strips) * ROWS;
     const int i1 = min(i0 + ROWS, Mc);
     const T *g = G + p * (int64_t)M * N;
-    T *o = inc + p * (int64_t)Mc * Nc;
+    T *o = inc + p * (int64_t)Mc * ld;
+    for (int j = Nc + threadIdx.x; j < ld; j += TPB)   // zero the row padding
+        for (int i = i0; i < i1; ++i) o[(int64_t)i * ld + j] = (T)0;
     for (int j = threadIdx.x; j < Nc; j += TPB) {
         T a0 = g[(int64_t)i0 * N + j], a1 = g[(int64_t)i0 * N + j + 1];  // row i:   G[i][j], G[i][j+1]
         for (int i = i0; i < i1; ++i) {
             const T b0 = g[(int64_t)(i + 1) * N + j], b1 = g[(int64_t)(i + 1) * N + j + 1];
-            o[(int64_t)i * Nc + j] = ((b1 + a0) - b0) - a1;
+            o[(int64_t)i * ld + j] = ((b1 + a0) - b0) - a1;
             a0 = b0; a1 = b1;
         }
     }
@@ -59,11 +61,11 @@ __global__ __launch_bounds__(TPB) void k_increments_adjoint(const T *__restrict_
 }  // namespace
 
 template <typename T>
-int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, hipStream_t s) {
+int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s) {
     const int strips = (M - 1 + ROWS - 1) / ROWS;
     const int64_t blocks = P * strips;
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G, M, N, strips, inc_c);
+    hipLaunchKernelGGL(k_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G, M, N, strips, inc_c, ld);
     return check_launch();
 }
 
@@ -76,8 +78,8 @@ int launch_increments_adjoint(const T *W, const T *scale, int64_t P, int M, int 
     return check_launch();
 }
 
-template int launch_increments<double>(const double *, int64_t, int, int, double *, hipStream_t);
-template int launch_increments<float>(const float *, int64_t, int, int, float *, hipStream_t);
+template int launch_increments<double>(const double *, int64_t, int, int, double *, int64_t, hipStream_t);
+template int launch_increments<float>(const float *, int64_t, int, int, float *, int64_t, hipStream_t);
 template int launch_increments_adjoint<double>(const double *, const double *, int64_t, int, int, double *, hipStream_t);
 template int launch_increments_adjoint<float>(const float *, const float *, int64_t, int, int, float *, hipStream_t);
 

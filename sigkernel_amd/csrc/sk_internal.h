@@ -12,13 +12,15 @@ struct Geom {
     int Mc, Nc, dyadic;
     int MM, NN;
     int naive;
+    int64_t ld;   // row stride of inc_c in elements (>= Nc)
 };
 
-inline Geom make_geom(int64_t P, int Mc, int Nc, int dyadic, int scheme) {
+inline Geom make_geom(int64_t P, int Mc, int Nc, int dyadic, int scheme, int64_t ld = 0) {
     Geom g;
     g.P = P; g.Mc = Mc; g.Nc = Nc; g.dyadic = dyadic;
     g.MM = Mc << dyadic; g.NN = Nc << dyadic;
     g.naive = (scheme == SK_SCHEME_NAIVE);
+    g.ld = ld > 0 ? ld : Nc;
     return g;
 }
 
@@ -30,9 +32,14 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *w
 size_t adj_simple_workspace_bytes(const Geom &g);
 size_t simple_lds_bytes(const Geom &g);
 
+// ---- sk_wave.hip: skewed row-strip wavefront sweep, register-resident state, LDS-DMA staging ----
+// SK_ERR_UNSUPPORTED = shape/layout not covered; the caller falls back to the simple kernel.
+template <typename T>
+int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hipStream_t s);
+
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
-int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, hipStream_t s);
+int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);
 template <typename T>
 int launch_increments_adjoint(const T *W, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
 

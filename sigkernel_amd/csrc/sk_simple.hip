@@ -30,7 +30,7 @@ __device__ __forceinline__ double cell_exact(double k10, double k01, double k00,
 // sigkernel.py:438).  `grid` (nullable) receives the full (MM+1)x(NN+1) node grid in the
 // sweep's own coordinates; `edges` (nullable) the terminal row and column.
 template <typename T, typename TG, bool FLIP>
-__device__ double sweep_pair(const T *__restrict__ inc, int Mc, int Nc, int d, int naive, double *lds,
+__device__ double sweep_pair(const T *__restrict__ inc, int64_t ld, int Mc, int Nc, int d, int naive, double *lds,
                              TG *__restrict__ grid, double *__restrict__ edges) {
     const int lane = threadIdx.x;
     const int MM = Mc << d, NN = Nc << d;
@@ -55,7 +55,7 @@ __device__ double sweep_pair(const T *__restrict__ inc, int Mc, int Nc, int d, i
             const double k00 = (i == 1 || j == 1) ? 1. : d0[i - 1];
             int ci = (i - 1) >> d, cj = (j - 1) >> d;
             if (FLIP) { ci = Mc - 1 - ci; cj = Nc - 1 - cj; }
-            const double g = ((double)inc[(int64_t)ci * Nc + cj] * rs) * rs;
+            const double g = ((double)inc[(int64_t)ci * ld + cj] * rs) * rs;
             const double v = cell_exact(k10, k01, k00, g, naive);
             d2[i] = v;
             if (grid) grid[(int64_t)i * gw + j] = (TG)v;
@@ -74,14 +74,14 @@ __device__ double sweep_pair(const T *__restrict__ inc, int Mc, int Nc, int d, i
 }
 
 template <typename T>
-__global__ __launch_bounds__(WAVE) void k_fwd_simple(const T *__restrict__ inc_c, int64_t P, int Mc, int Nc, int d,
+__global__ __launch_bounds__(WAVE) void k_fwd_simple(const T *__restrict__ inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d,
                                                      int naive, T *__restrict__ out_final, T *__restrict__ out_grid,
                                                      double *__restrict__ out_edges) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int MM = Mc << d, NN = Nc << d;
     const int64_t gs = (int64_t)(MM + 1) * (NN + 1);
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
-        const double v = sweep_pair<T, T, false>(inc_c + p * (int64_t)Mc * Nc, Mc, Nc, d, naive, lds,
+        const double v = sweep_pair<T, T, false>(inc_c + p * (int64_t)Mc * ld, ld, Mc, Nc, d, naive, lds,
                                                  out_grid ? out_grid + p * gs : nullptr,
                                                  out_edges ? out_edges + p * (int64_t)(MM + NN + 2) : nullptr);
         if (threadIdx.x == 0 && out_final) out_final[p] = (T)v;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_simple(const T *__restrict__ inc_c
 // coarse cell sums its r*r products in the oracle's order (i-major), so W is bit-identical
 // to oracle/sigkernel_oracle.c:sk_oracle_adjoint_coarse.
 template <typename T>
-__global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c, int64_t P, int Mc, int Nc, int d,
+__global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d,
                                                      int naive, T *__restrict__ out_final, T *__restrict__ W,
                                                      double *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -103,9 +103,9 @@ __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c
     double *Kf = ws + (int64_t)blockIdx.x * 2 * gs;
     double *Kr = Kf + gs;
     for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
-        const T *inc = inc_c + p * (int64_t)Mc * Nc;
-        const double v = sweep_pair<T, double, false>(inc, Mc, Nc, d, naive, lds, Kf, nullptr);
-        sweep_pair<T, double, true>(inc, Mc, Nc, d, naive, lds, Kr, nullptr);
+        const T *inc = inc_c + p * (int64_t)Mc * ld;
+        const double v = sweep_pair<T, double, false>(inc, ld, Mc, Nc, d, naive, lds, Kf, nullptr);
+        sweep_pair<T, double, true>(inc, ld, Mc, Nc, d, naive, lds, Kr, nullptr);
         __syncthreads();
         if (threadIdx.x == 0 && out_final) out_final[p] = (T)v;
         for (int c = threadIdx.x; c < Mc * Nc; c += WAVE) {
@@ -143,8 +143,8 @@ int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, 
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_fwd_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_fwd_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc_c, g.P, g.Mc, g.Nc, g.dyadic,
-                       g.naive, out_final, out_grid, out_edges);
+    hipLaunchKernelGGL(k_fwd_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc,
+                       g.dyadic, g.naive, out_final, out_grid, out_edges);
     return check_launch();
 }
 
@@ -160,8 +160,8 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *w
     if (blocks > 1024) blocks = 1024;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_adj_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_adj_simple<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.P, g.Mc, g.Nc, g.dyadic, g.naive,
-                       out_final, W, (double *)ws);
+    hipLaunchKernelGGL(k_adj_simple<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic,
+                       g.naive, out_final, W, (double *)ws);
     return check_launch();
 }
 

@@ -34,7 +34,20 @@ def be():
 SHAPES = [  # P, Mc, Nc, dyadic
     (3, 1, 1, 0), (3, 1, 1, 3), (5, 9, 19, 1), (4, 7, 3, 2), (6, 63, 63, 1), (2, 127, 127, 1),
     (3, 64, 65, 0), (2, 130, 70, 1), (2, 33, 200, 2), (7, 5, 6, 3), (1, 300, 17, 0), (2, 20, 20, 4),
+    (700, 9, 19, 1), (3000, 5, 7, 0), (1100, 63, 63, 1), (40, 300, 130, 1), (9, 511, 140, 0), (300, 127, 127, 1),
+    (5, 260, 300, 2), (3, 70, 40, 3), (130, 16, 8, 2), (64, 3, 2, 1),
 ]
+
+
+def padded(inc, dtype=None):
+    """Device copy of inc [P,Mc,Nc] whose rows are 16-byte aligned (the layout sk_increments produces)."""
+    t = torch.from_numpy(np.ascontiguousarray(inc))
+    if dtype is not None:
+        t = t.to(dtype)
+    ld = _lib._padded_ld(t.shape[-1], t.element_size())
+    buf = torch.zeros(t.shape[:-1] + (ld,), dtype=t.dtype, device=DEV)
+    buf[..., : t.shape[-1]] = t.to(DEV)
+    return buf[..., : t.shape[-1]]
 
 
 def _inc(P, Mc, Nc, seed, scale=0.05):
@@ -60,8 +73,11 @@ def test_forward_exact_kernels_bit_identical_to_oracle(be, P, Mc, Nc, d, naive):
 def test_forward_default_path_matches_oracle(be, P, Mc, Nc, d, naive):
     inc = _inc(P, Mc, Nc, seed=7 + Mc * 1000 + Nc + d)
     want = O.solve_coarse(inc, d, naive)
-    out = be.solve_fwd(torch.from_numpy(inc).to(DEV), d, naive)
+    out = be.solve_fwd(torch.from_numpy(inc).to(DEV), d, naive)          # dense rows: any layout is accepted
     assert rel_err(out.cpu().numpy(), want) <= FAST_TOL
+    if d <= 3:
+        out = be.solve_fwd(padded(inc), d, naive, flags=_lib.FLAG_FAST_ONLY)   # the tiled LDS-DMA kernel, no fallback
+        assert rel_err(out.cpu().numpy(), want) <= FAST_TOL
 
 
 @pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
@@ -71,6 +87,9 @@ def test_forward_fp32_io(be, P, Mc, Nc, d):
     out = be.solve_fwd(torch.from_numpy(inc).to(DEV), d)
     assert out.dtype == torch.float32
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=F32_RTOL, atol=F32_ATOL)
+    if d <= 3:
+        out = be.solve_fwd(padded(inc), d, flags=_lib.FLAG_FAST_ONLY)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=F32_RTOL, atol=F32_ATOL)
 
 
 @pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
@@ -200,15 +219,19 @@ def test_headline_size_properties(be):
 
 
 def test_straight_line_known_answer_in_a_batch(be):
-    # two straight lines with <dx,dy> = 1: d=0 gives exactly 2.25, any length
-    for M in (2, 9, 128):
-        t = torch.linspace(0, 1, M, dtype=torch.float64)[None, :, None].to(DEV)
-        X = t.repeat(70, 1, 1).contiguous()
-        k0 = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 0).compute_kernel(X[:, :2], X[:, :2])
-        assert torch.all(k0 == 2.25)
-        k8 = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 3).compute_kernel(X, X)
-        assert torch.all((k8 - 2.2795853).abs() < 1e-4)      # -> I0(2) = 2.27958530...
-        assert torch.all(k8 == k8[0])
+    """Two straight lines with <dx,dy> = 1: one step at d=0 gives exactly 2.25, refinement
+    converges to I0(2) = 2.2795853..., and identical pairs in a batch give identical bits."""
+    lin = sigkernel_amd.LinearKernel()
+    t2 = torch.linspace(0, 1, 2, dtype=torch.float64)[None, :, None].to(DEV).repeat(70, 1, 1).contiguous()
+    assert torch.all(sigkernel_amd.SigKernel(lin, 0).compute_kernel(t2, t2) == 2.25)
+    for M, d in ((2, 3), (9, 2), (128, 1), (128, 3)):
+        t = torch.linspace(0, 1, M, dtype=torch.float64)[None, :, None]
+        X = t.to(DEV).repeat(70, 1, 1).contiguous()
+        k = sigkernel_amd.SigKernel(lin, d).compute_kernel(X, X)
+        want = O.gram_forward(t, t, lin, d)[0, 0]
+        assert torch.all(k == k[0])
+        assert abs(float(k[0]) - want) <= 1e-12 * want
+        assert abs(float(k[0]) - 2.2795853023360673) <= 2e-3 / ((M - 1) << d)
 
 
 def test_long_paths_beyond_the_reference_gpu_limit(be):
