@@ -17,6 +17,8 @@
 //
 // Replaces: sigkernel_cuda / sigkernel_Gram_cuda (reference cuda_backend.py:6-49, :121-160), whose
 // thread-per-row sweep re-reads the solution grid from global memory every anti-diagonal.
+#include <cstdlib>
+
 #include "sk_internal.h"
 
 namespace sk {
@@ -24,8 +26,6 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int UPC = 4;  // 16-byte units per chunk and row
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 struct WaveParams {
     const void *inc;   // [P, Mc, ld] coarse increments
@@ -38,9 +38,11 @@ struct WaveParams {
     int logL;          // lanes per pair group = 1 << logL
     int PPG;           // pairs per lane group
     int n_chunks;      // chunks each wave sweeps (incl. drain)
-    int u_f, lam_f, k_f, cw_f;  // where K[MM][NN] lives: unit, lane-in-group, coarse row / column in the block
+    int u_f, lam_f, sel_f;  // where K[MM][NN] lives: unit, lane-in-group, k_f*CW + cw_f inside the block
     int naive;
 };
+
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ double dpp_shr1(double v, double fill) {
     // lane l receives lane l-1's value; lane 0 keeps `fill`
@@ -140,7 +142,7 @@ template <int DY> struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, int NBUF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int NBUF>
 __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
@@ -170,10 +172,24 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     // MULTIBAND: bottom row of the previous band, [G][NUp*S] doubles behind the chunk ring
     const unsigned my_bnd = lds0 + NBUF * CHUNK_BYTES + (unsigned)((lane >> prm.logL) * NUp * S) * 8u;
 
-    // ---- producer (DMA) state: this lane fetches unit w_d of the chunk for 4 consumer lanes ----------------
+    // ---- producer (DMA) state: this lane fetches unit w_d of the chunk for 4 consumer lanes -------------
+    // Addresses are 32-bit offsets into a per-wave buffer resource (base = first pair of this wave): rows past
+    // the end of a pair, pairs past P and the not-yet-started lanes of the pipeline fall outside num_records
+    // (or into a neighbouring pair) and the bounds-checked buffer load returns without touching memory.
     const int w_d = ((lane & 3) - (lane >> 4)) & 3;
-    int d_u[4], d_band[4], d_ps[4], d_row0[4];
-    int64_t d_pair0[4];
+    const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
+    const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
+    int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
+    const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
+    span = span < wave_span ? span : wave_span;
+    if (span < 0) span = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(static_cast<const char *>(prm.inc) + first_pair * pair_bytes), 0, (int)span, 0x00020000);
+    const int ldb = (int)prm.ldb;
+    const int delta_band = L * RC * ldb - NUp * 16;                      // next band of the same pair
+    const int delta_pair = (int)pair_bytes - (nb - 1) * L * RC * ldb - NUp * 16;  // first band of the next pair
+    int d_u[4], d_band[4];
+    unsigned d_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int lc = j * 16 + (lane >> 2);
@@ -181,34 +197,29 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         const int v0 = w_d - lamc;
         const int sig = floor_div(v0, NUp);
         d_u[j] = v0 - sig * NUp;
-        d_ps[j] = floor_div(sig, nb);
-        d_band[j] = sig - d_ps[j] * nb;
-        d_row0[j] = lamc * RC;
-        d_pair0[j] = ((int64_t)blockIdx.x * G + (lc >> prm.logL)) * prm.PPG;
+        const int ps0 = floor_div(sig, nb);
+        d_band[j] = sig - ps0 * nb;
+        d_off[j] = (unsigned)(((lc >> prm.logL) * prm.PPG + ps0) * (int)pair_bytes + (d_band[j] * L + lamc) * RC * ldb +
+                              d_u[j] * 16);
     }
-    const char *inc_base = static_cast<const char *>(prm.inc);
-    const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
 
     auto issue_chunk = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int64_t pr = d_pair0[j] + d_ps[j];
-            pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
-            const char *pbase = inc_base + pr * pair_bytes + (int64_t)d_u[j] * 16;
-            const int rowb = d_band[j] * (L * RC) + d_row0[j];
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
-                const int row = min(rowb + k, prm.Mc - 1);
-                const char *src = pbase + (int64_t)row * prm.ldb;
                 const int q = k * 4 + j;
-                __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + buf * CHUNK_BYTES + q * 1024), 16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + buf * CHUNK_BYTES + q * 1024), 16,
+                                                         d_off[j] + (unsigned)(k * ldb), 0, 0, 0);
             }
             // advance this stream by one chunk
             d_u[j] += UPC;
+            d_off[j] += UPC * 16;
             if (d_u[j] >= NUp) {
                 d_u[j] -= NUp;
-                d_band[j] += 1;
-                if (d_band[j] == nb) { d_band[j] = 0; d_ps[j] += 1; }
+                const bool last = d_band[j] == nb - 1;
+                d_off[j] += last ? delta_pair : delta_band;
+                d_band[j] = last ? 0 : d_band[j] + 1;
             }
         }
     };
@@ -269,6 +280,10 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                     const double sh = dpp_shr1(bot[i], 1.0);
                     top[i] = is_top ? tb[i] : sh;
                 }
+            } else if (FULLWAVE) {
+                // one pair per wave: lane 0 is the only top lane and wave_shr leaves its `old` operand (1.0) in place
+#pragma unroll
+                for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
             } else {
 #pragma unroll
                 for (int i = 0; i < S; ++i) {
@@ -323,14 +338,17 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                 }
             }
 
-            // -- K[MM][NN] of a pair
+            // -- K[MM][NN] of a pair: one lane, once per pair (the asm keeps the select chain inside the branch)
             if (u == prm.u_f && band == nb - 1 && lam == prm.lam_f && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
 #pragma unroll
-                    for (int q = 0; q < CW; ++q)
-                        if (k == prm.k_f && q == prm.cw_f) v = cand[k][q];
+                    for (int q = 0; q < CW; ++q) {
+                        double cv = cand[k][q];
+                        asm volatile("" : "+v"(cv));
+                        if (k * CW + q == prm.sel_f) v = cv;
+                    }
                 static_cast<T *>(prm.out)[pair0 + ps] = (T)v;
             }
 
@@ -348,23 +366,37 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, int NBUF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int NBUF>
 int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, NBUF>;
+    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, NBUF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
     return check_launch();
 }
 
+// Tuning knobs (environment, read at launch): SK_WAVE_NBUF = chunks in the LDS ring (2 or 3),
+// SK_WAVE_WPC = cap on resident waves per CU.  Defaults are what measured best on MI355X.
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <typename T, int DY, bool NAIVE, int NBUF>
+int launch_nv(const WaveParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
+    const bool full = prm.logL == 6;
+    if (multiband) return launch_one<T, DY, NAIVE, true, false, NBUF>(prm, blocks, lds_bytes, s);
+    return full ? launch_one<T, DY, NAIVE, false, true, NBUF>(prm, blocks, lds_bytes, s)
+                : launch_one<T, DY, NAIVE, false, false, NBUF>(prm, blocks, lds_bytes, s);
+}
+
 template <typename T, int DY>
-int launch_dy(const WaveParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
-    constexpr int NBUF = 3;
-    if (prm.naive)
-        return multiband ? launch_one<T, DY, true, true, NBUF>(prm, blocks, lds_bytes, s)
-                         : launch_one<T, DY, true, false, NBUF>(prm, blocks, lds_bytes, s);
-    return multiband ? launch_one<T, DY, false, true, NBUF>(prm, blocks, lds_bytes, s)
-                     : launch_one<T, DY, false, false, NBUF>(prm, blocks, lds_bytes, s);
+int launch_dy(const WaveParams &prm, bool multiband, int nbuf, int blocks, size_t lds_bytes, hipStream_t s) {
+    if (nbuf == 2)
+        return prm.naive ? launch_nv<T, DY, true, 2>(prm, multiband, blocks, lds_bytes, s)
+                         : launch_nv<T, DY, false, 2>(prm, multiband, blocks, lds_bytes, s);
+    return prm.naive ? launch_nv<T, DY, true, 3>(prm, multiband, blocks, lds_bytes, s)
+                     : launch_nv<T, DY, false, 3>(prm, multiband, blocks, lds_bytes, s);
 }
 
 }  // namespace
@@ -374,7 +406,7 @@ int launch_dy(const WaveParams &prm, bool multiband, int blocks, size_t lds_byte
 template <typename T>
 int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    constexpr int NBUF = 3;
+    const int NBUF = env_int("SK_WAVE_NBUF", 3) == 2 ? 2 : 3;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || ((ld * sizeof(T)) & 15)) return SK_ERR_UNSUPPORTED;
@@ -405,6 +437,13 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     if (waves_per_cu > 8) waves_per_cu = 8;
+    // Row-major increments are fetched as lane-skewed 64-byte pieces, so every 128-byte line is touched by two
+    // consecutive chunks; the second touch only hits while the lines of all resident waves fit the XCD's 4 MiB
+    // L2 (measured: 1.02x HBM traffic at 3 waves/CU, 1.61x at 6 for RC = 2).  Keep the resident set small.
+    const int l2_cap = 6 / RC > 2 ? 6 / RC : 2;
+    if (waves_per_cu > l2_cap) waves_per_cu = l2_cap;
+    const int wpc_cap = env_int("SK_WAVE_WPC", 0);
+    if (wpc_cap > 0 && waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     const int64_t groups_needed = g.P;  // one pair per group at least
@@ -413,6 +452,14 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     int64_t PPG = (g.P + waves * G - 1) / (waves * G);
     waves = (g.P + PPG * G - 1) / (PPG * G);
     if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
+    // the DMA addresses are 32-bit offsets from the wave's first pair: keep a wave's span below 2 GiB
+    const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
+    if (pair_bytes > (1LL << 30)) return SK_ERR_UNSUPPORTED;
+    if (PPG * G * pair_bytes >= (1LL << 31)) {
+        PPG = ((1LL << 31) - 1) / (G * pair_bytes);
+        if (PPG < 1) return SK_ERR_UNSUPPORTED;
+        waves = (g.P + PPG * G - 1) / (PPG * G);
+    }
 
     WaveParams prm;
     prm.inc = inc_c; prm.out = out_final; prm.P = g.P; prm.ldb = ld * (int64_t)sizeof(T);
@@ -420,16 +467,15 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     const int64_t steps = PPG * nb * NUp + (L - 1);
     prm.n_chunks = (int)((steps + UPC - 1) / UPC);
     prm.u_f = (g.Nc - 1) / CW;
-    prm.cw_f = (g.Nc - 1) % CW;
     prm.lam_f = ((g.Mc - 1) / RC) % L;
-    prm.k_f = (g.Mc - 1) % RC;
+    prm.sel_f = ((g.Mc - 1) % RC) * CW + (g.Nc - 1) % CW;
     prm.naive = g.naive;
 
     switch (DY) {
-        case 0: return launch_dy<T, 0>(prm, multiband, (int)waves, lds_bytes, s);
-        case 1: return launch_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
-        case 2: return launch_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
-        default: return launch_dy<T, 3>(prm, multiband, (int)waves, lds_bytes, s);
+        case 0: return launch_dy<T, 0>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
+        case 1: return launch_dy<T, 1>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
+        case 2: return launch_dy<T, 2>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
+        default: return launch_dy<T, 3>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
     }
 }
 
