@@ -1,19 +1,24 @@
 // sk_wave.hip -- the fast forward solver: skewed row-strip wavefront sweep, one 64-lane wavefront per
-// 64/L pairs, PDE state in registers, increments streamed HBM -> LDS by LDS-DMA.
+// 64/L pairs, PDE state in registers, increments streamed HBM -> LDS by LDS-DMA, one 128-byte line per row
+// at a time.
 //
-// Mapping.  A lane owns R = RC<<DY consecutive fine rows of a "band" of
-// L*R fine rows and walks along the columns in macro-steps of S = CW<<DY fine columns (CW coarse
-// columns = one 16-byte unit of the increment row).  Lane l runs l macro-steps behind lane l-1, so the
-// bottom row of lane l-1's block is exactly what lane l needs next: it arrives by one DPP wave_shr:1
-// per 32-bit half, no LDS round trip.  Bands of one pair, and then the next pair of the lane group,
-// follow each other without draining the skew (the top lane starts the next band while the bottom lanes
-// finish the previous one), so the pipeline fills once per kernel, not once per pair.
+// Mapping.  A lane owns R = RC<<DY consecutive fine rows of a "band" of L*R fine rows
+// and walks along the columns in macro-steps of S = CW<<DY fine columns (CW coarse columns = one 16-byte
+// unit of the increment row).  Lane l runs l macro-steps behind lane l-1, so the bottom row of lane l-1's
+// block is exactly what lane l needs next: it arrives by one DPP wave_shr:1 per 32-bit half, no LDS round
+// trip.  Bands of one pair, and then the next pair of the lane group, follow each other without draining
+// the skew (the top lane starts the next band while the bottom lanes finish the previous one), so the
+// pipeline fills once per kernel, not once per pair.
 //
-// Increments: the coarse matrix is read exactly once.  Each chunk (4 units = 64 B per row) is fetched
-// with global_load_lds_dwordx4: 4 adjacent lanes fetch one row segment, and the (row, unit) each DMA
-// lane fetches is chosen so that the linear LDS image is bank-conflict-free for the consumers'
-// ds_read_b128 (slot = (k*64 + lane)*4 + ((unit + (lane>>2)) & 3)).  The fetch for lane l is skewed by l
-// units, so a 2- or 3-deep ring of chunks is all the LDS the sweep needs.
+// Increments: the coarse matrix is read exactly once, in whole 128-byte lines.  The skew staggers the lanes
+// over the 8 units of a line: at macro-step t exactly the 8 lanes with lane % 8 == t % 8 start a new line.
+// So every macro-step the wave issues RC LDS-DMA instructions (buffer_load_dwordx4 ... lds, bounds-checked)
+// that fetch, PF macro-steps ahead, the next line of those 8 lanes' rows: 8 DMA lanes per row, 8 rows per
+// instruction, landing as [row k][lane/8][128 B] in slot (t+PF) % (8+PF) of an LDS ring.  A line is touched
+// by exactly one fetch (measured: fetching 64-byte halves in separate passes costs 1.4-1.9x HBM traffic once
+// the resident lines outgrow the XCD's 4 MiB L2, because L2 fills are always whole 128-byte lines), the
+// ring holds (8+PF)/8 lines per row instead of 2, and the consumers' ds_read_b128 are conflict-free
+// without any swizzle because the skew itself spreads a 16-lane group over 16 distinct 16-byte slots.
 //
 // Replaces: sigkernel_cuda / sigkernel_Gram_cuda (reference cuda_backend.py:6-49, :121-160), whose
 // thread-per-row sweep re-reads the solution grid from global memory every anti-diagonal.
@@ -25,7 +30,9 @@ namespace sk {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int UPC = 4;  // 16-byte units per chunk and row
+constexpr int LINE_UNITS = 8;  // 16-byte units per 128-byte line
+
+typedef __attribute__((address_space(3))) void lds_void;
 
 struct WaveParams {
     const void *inc;   // [P, Mc, ld] coarse increments
@@ -33,16 +40,14 @@ struct WaveParams {
     int64_t P;
     int64_t ldb;       // row stride in bytes
     int Mc, Nc;
-    int NUp;           // 16-byte units per row, padded to a multiple of UPC
+    int NUp;           // 16-byte units per row, padded to whole lines
     int nb;            // bands per pair
-    int logL;          // lanes per pair group = 1 << logL
+    int logL;          // lanes per pair group = 1 << logL (>= 8)
     int PPG;           // pairs per lane group
-    int n_chunks;      // chunks each wave sweeps (incl. drain)
+    int n_steps;       // macro-steps each wave sweeps (incl. drain)
     int u_f, lam_f, sel_f;  // where K[MM][NN] lives: unit, lane-in-group, k_f*CW + cw_f inside the block
     int naive;
 };
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ double dpp_shr1(double v, double fill) {
     // lane l receives lane l-1's value; lane 0 keeps `fill`
@@ -68,61 +73,32 @@ template <typename V> __device__ __forceinline__ double vec_get(const V &v, int 
 
 // All LDS traffic of the sweep goes through inline asm.  hipcc cannot tell that a ds_read does not alias
 // an LDS-DMA still in flight and would drain the whole prefetch ring with s_waitcnt vmcnt(0) before every
-// read; here the DMA queue is counted by hand (vmcnt(N) = chunks still allowed in flight) and the asm
+// read; here the DMA queue is counted by hand (vmcnt(N) = fetches still allowed in flight) and the asm
 // block itself waits for its own reads (lgkmcnt(0)) before any output is consumed.
 template <int VM, typename V>
-__device__ __forceinline__ void lds_read_chunk(V (&g)[4], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
-    asm volatile("s_waitcnt vmcnt(%8)\n\t"
+__device__ __forceinline__ void lds_read_rows(V (&g)[1], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%2)\n\t"
+                 "ds_read_b128 %0, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]) : "v"(a), "n"(VM) : "memory");
+}
+template <int VM, typename V>
+__device__ __forceinline__ void lds_read_rows(V (&g)[2], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%3)\n\t"
+                 "ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]) : "v"(a), "n"(VM) : "memory");
+}
+template <int VM, typename V>
+__device__ __forceinline__ void lds_read_rows(V (&g)[4], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%5)\n\t"
                  "ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %5\n\t"
-                 "ds_read_b128 %2, %6\n\t"
-                 "ds_read_b128 %3, %7\n\t"
+                 "ds_read_b128 %1, %4 offset:1024\n\t"
+                 "ds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(VM)
-                 : "memory");
-}
-template <int VM, typename V>
-__device__ __forceinline__ void lds_read_chunk(V (&g)[8], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
-    asm volatile("s_waitcnt vmcnt(%12)\n\t"
-                 "ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %10\n\t"
-                 "ds_read_b128 %3, %11\n\t"
-                 "ds_read_b128 %4, %8 offset:4096\n\t"
-                 "ds_read_b128 %5, %9 offset:4096\n\t"
-                 "ds_read_b128 %6, %10 offset:4096\n\t"
-                 "ds_read_b128 %7, %11 offset:4096\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(VM)
-                 : "memory");
-}
-template <int VM, typename V>
-__device__ __forceinline__ void lds_read_chunk(V (&g)[16], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
-    asm volatile("s_waitcnt vmcnt(%20)\n\t"
-                 "ds_read_b128 %0, %16\n\t"
-                 "ds_read_b128 %1, %17\n\t"
-                 "ds_read_b128 %2, %18\n\t"
-                 "ds_read_b128 %3, %19\n\t"
-                 "ds_read_b128 %4, %16 offset:4096\n\t"
-                 "ds_read_b128 %5, %17 offset:4096\n\t"
-                 "ds_read_b128 %6, %18 offset:4096\n\t"
-                 "ds_read_b128 %7, %19 offset:4096\n\t"
-                 "ds_read_b128 %8, %16 offset:8192\n\t"
-                 "ds_read_b128 %9, %17 offset:8192\n\t"
-                 "ds_read_b128 %10, %18 offset:8192\n\t"
-                 "ds_read_b128 %11, %19 offset:8192\n\t"
-                 "ds_read_b128 %12, %16 offset:12288\n\t"
-                 "ds_read_b128 %13, %17 offset:12288\n\t"
-                 "ds_read_b128 %14, %18 offset:12288\n\t"
-                 "ds_read_b128 %15, %19 offset:12288\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
-                   "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]),
-                   "=&v"(g[15])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(VM)
-                 : "memory");
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a), "n"(VM) : "memory");
 }
 __device__ __forceinline__ double lds_read_f64(unsigned addr) {
     double v;
@@ -142,41 +118,47 @@ template <int DY> struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int NBUF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int PF>
 __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
-    constexpr int IPC = RC * UPC;             // DMA instructions per chunk
-    constexpr int CHUNK_BYTES = IPC * 1024;   // 64 lanes x 16 B each
+    constexpr int NSLOT = LINE_UNITS + PF;    // ring slots; one slot = the next line of 8 lanes' rows
+    constexpr int SLOT_BYTES = RC * 1024;     // [k][lane/8][128 B]
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const unsigned lds0 = lds_offset(lds);
 
     const int lane = threadIdx.x;
     const int L = 1 << prm.logL, G = WAVE >> prm.logL;
     const int lam = lane & (L - 1);
-    const int NUp = prm.NUp, nb = prm.nb;
+    const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
     const double sc = 1.0 / (double)(1 << (2 * DY));  // 4^-d
     const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
 
-    // ---- consumer state: virtual unit v = t - lam, row unit sigma = floor(v / NUp), pair = sigma / nb ----
-    int u, band, ps;
+    // ---- consumer state: virtual unit v = t - lam, row unit sig = floor(v / NUp), u = v mod NUp ----------
+    int u, band, ps;   // ps = pair index inside the lane group
     {
         const int sig = floor_div(-lam, NUp);
         u = -lam - sig * NUp;
         ps = floor_div(sig, nb);
         band = sig - ps * nb;
     }
+    const int my_uf = lam == prm.lam_f ? prm.u_f : -1;   // the unit at which this lane holds K[MM][NN] (if ever)
     const int64_t pair0 = ((int64_t)blockIdx.x * G + (lane >> prm.logL)) * prm.PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
-    // MULTIBAND: bottom row of the previous band, [G][NUp*S] doubles behind the chunk ring
-    const unsigned my_bnd = lds0 + NBUF * CHUNK_BYTES + (unsigned)((lane >> prm.logL) * NUp * S) * 8u;
+    // ring slot of the line this lane is reading: the line it started at macro-step ts sits in slot ts % NSLOT
+    int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
+    const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
+    // MULTIBAND: bottom row of the previous band, [G][NUp*S] doubles behind the ring
+    const unsigned my_bnd = lds0 + NSLOT * SLOT_BYTES + (unsigned)((lane >> prm.logL) * NUp * S) * 8u;
 
-    // ---- producer (DMA) state: this lane fetches unit w_d of the chunk for 4 consumer lanes -------------
+    // ---- producer (DMA) state ---------------------------------------------------------------------------
+    // Fetch step f = 8q + j serves the 8 consumer lanes lc = j + 8*(lane/8); all of them are about to start
+    // line number n = q - i' (i' = (lane/8) mod (L/8)) of their virtual row stream, so one (band, line)
+    // cursor per DMA lane covers all 8 classes j; only the row offset j*RC*ldb differs, and that is uniform.
     // Addresses are 32-bit offsets into a per-wave buffer resource (base = first pair of this wave): rows past
     // the end of a pair, pairs past P and the not-yet-started lanes of the pipeline fall outside num_records
     // (or into a neighbouring pair) and the bounds-checked buffer load returns without touching memory.
-    const int w_d = ((lane & 3) - (lane >> 4)) & 3;
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
     const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
     int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
@@ -186,49 +168,42 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(static_cast<const char *>(prm.inc) + first_pair * pair_bytes), 0, (int)span, 0x00020000);
     const int ldb = (int)prm.ldb;
-    const int delta_band = L * RC * ldb - NUp * 16;                      // next band of the same pair
-    const int delta_pair = (int)pair_bytes - (nb - 1) * L * RC * ldb - NUp * 16;  // first band of the next pair
-    int d_u[4], d_band[4];
-    unsigned d_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int lc = j * 16 + (lane >> 2);
-        const int lamc = lc & (L - 1);
-        const int v0 = w_d - lamc;
-        const int sig = floor_div(v0, NUp);
-        d_u[j] = v0 - sig * NUp;
-        const int ps0 = floor_div(sig, nb);
-        d_band[j] = sig - ps0 * nb;
-        d_off[j] = (unsigned)(((lc >> prm.logL) * prm.PPG + ps0) * (int)pair_bytes + (d_band[j] * L + lamc) * RC * ldb +
-                              d_u[j] * 16);
+    const int delta_band = L * RC * ldb - NLp * 128;                                  // next band of the same pair
+    const int delta_pair = (int)pair_bytes - (nb - 1) * L * RC * ldb - NLp * 128;    // first band of the next pair
+    int st_m, st_band;
+    unsigned st_off;
+    {
+        const int ip = (lane >> 3) & ((L >> 3) - 1);   // i'
+        const int gc = (lane >> 3) >> (prm.logL - 3);    // lane group of the consumers this DMA lane serves
+        const int v0 = -ip * LINE_UNITS;
+        const int sg = floor_div(v0, NUp);
+        st_m = (v0 - sg * NUp) / LINE_UNITS;
+        const int ps0 = floor_div(sg, nb);
+        st_band = sg - ps0 * nb;
+        st_off = (unsigned)((gc * prm.PPG + ps0) * (int)pair_bytes + (st_band * L + ip * LINE_UNITS) * RC * ldb +
+                            st_m * 128 + (lane & 7) * 16);
     }
+    int fj = 0, fslot = 0;   // class and ring slot of the next fetch step (uniform)
 
-    auto issue_chunk = [&](int buf) {
+    auto issue_fetch = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                const int q = k * 4 + j;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + buf * CHUNK_BYTES + q * 1024), 16,
-                                                         d_off[j] + (unsigned)(k * ldb), 0, 0, 0);
-            }
-            // advance this stream by one chunk
-            d_u[j] += UPC;
-            d_off[j] += UPC * 16;
-            if (d_u[j] >= NUp) {
-                d_u[j] -= NUp;
-                const bool last = d_band[j] == nb - 1;
-                d_off[j] += last ? delta_pair : delta_band;
-                d_band[j] = last ? 0 : d_band[j] + 1;
+        for (int k = 0; k < RC; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                     st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
+        fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
+        fj += 1;
+        if (fj == LINE_UNITS) {   // all 8 classes have their line number n: move the cursor to n + 1
+            fj = 0;
+            st_m += 1;
+            st_off += 128;
+            if (st_m == NLp) {
+                st_m = 0;
+                const bool last = st_band == nb - 1;
+                st_off += last ? delta_pair : delta_band;
+                st_band = last ? 0 : st_band + 1;
             }
         }
     };
-
-    // consumer LDS offsets: slot(l,k,w) = (k*64 + l)*4 + ((w + (l>>2)) & 3)
-    const int rot = (lane >> 2) & 3;
-    unsigned rd_off[UPC];
-#pragma unroll
-    for (int w = 0; w < UPC; ++w) rd_off[w] = lds0 + lane * 64 + (((w + rot) & 3) << 4);
 
     double left[R], bot[S], corner = 1.0;
 #pragma unroll
@@ -236,110 +211,100 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
 #pragma unroll
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
 
-    // prologue: NBUF-1 chunks in flight
+    // prologue: the lines needed at macro-steps 0 .. PF-1
 #pragma unroll
-    for (int c = 0; c < NBUF - 1; ++c) issue_chunk(c);
+    for (int f = 0; f < PF; ++f) issue_fetch();
 
-    int buf = 0, pbuf = NBUF - 1;
-    for (int c = 0; c < prm.n_chunks; ++c) {
-        issue_chunk(pbuf);
-        // this lane's increments for the 4 macro-steps of the chunk: gall[k*UPC + w]
-        vec_t gall[RC * UPC];
-        {
-            const unsigned cbo = buf * CHUNK_BYTES;
-            lds_read_chunk<(NBUF - 1) * IPC>(gall, rd_off[0] + cbo, rd_off[1] + cbo, rd_off[2] + cbo, rd_off[3] + cbo);
+    for (int t = 0; t < prm.n_steps; ++t) {
+        issue_fetch();   // the line needed at macro-step t + PF
+        // -- increments of this macro-step: RC rows x CW coarse columns (waits for the fetch of step t)
+        vec_t gv[RC];
+        lds_read_rows<PF * RC>(gv, rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4)));
+
+        // -- row-unit start: left boundary K[i][0] = 1
+        if (u == 0) {
+            corner = 1.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) left[i] = 1.0;
         }
 
+        // -- top row of the block: bottom row of the lane above (previous macro-step), or the band boundary
+        double top[S];
+        if (MULTIBAND) {
+            double tb[S];
+            if (is_top && band > 0) {
 #pragma unroll
-        for (int w = 0; w < UPC; ++w) {
-            // -- increments of this macro-step: RC rows x CW coarse columns
-            vec_t gv[RC];
-#pragma unroll
-            for (int k = 0; k < RC; ++k) gv[k] = gall[k * UPC + w];
-
-            // -- row-unit start: left boundary K[i][0] = 1
-            if (u == 0) {
-                corner = 1.0;
-#pragma unroll
-                for (int i = 0; i < R; ++i) left[i] = 1.0;
-            }
-
-            // -- top row of the block: bottom row of the lane above (previous macro-step), or the band boundary
-            double top[S];
-            if (MULTIBAND) {
-                double tb[S];
-                if (is_top && band > 0) {
-#pragma unroll
-                    for (int i = 0; i < S; ++i) tb[i] = lds_read_f64(my_bnd + (unsigned)(u * S + i) * 8u);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < S; ++i) tb[i] = 1.0;
-                }
-#pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    const double sh = dpp_shr1(bot[i], 1.0);
-                    top[i] = is_top ? tb[i] : sh;
-                }
-            } else if (FULLWAVE) {
-                // one pair per wave: lane 0 is the only top lane and wave_shr leaves its `old` operand (1.0) in place
-#pragma unroll
-                for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
+                for (int i = 0; i < S; ++i) tb[i] = lds_read_f64(my_bnd + (unsigned)(u * S + i) * 8u);
             } else {
 #pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    const double sh = dpp_shr1(bot[i], 1.0);
-                    top[i] = is_top ? 1.0 : sh;
+                for (int i = 0; i < S; ++i) tb[i] = 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const double sh = dpp_shr1(bot[i], 1.0);
+                top[i] = is_top ? tb[i] : sh;
+            }
+        } else if (FULLWAVE) {
+            // one pair per wave: lane 0 is the only top lane and wave_shr leaves its `old` operand (1.0) in place
+#pragma unroll
+            for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const double sh = dpp_shr1(bot[i], 1.0);
+                top[i] = is_top ? 1.0 : sh;
+            }
+        }
+
+        // -- coefficients per coarse cell
+        double ca[RC][CW], cbm[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const double g = vec_get<vec_t>(gv[k], q);
+                if (NAIVE) {
+                    ca[k][q] = fma(g, c_half, 1.0);
+                    cbm[k][q] = 1.0;
+                } else {
+                    const double g2 = g * g;
+                    ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                    cbm[k][q] = fma(g2, -c_12, 1.0);
                 }
             }
 
-            // -- coefficients per coarse cell
-            double ca[RC][CW], cbm[RC][CW];
+        // -- sweep the R x S block column by column: K11 = a (K10 + K01) - b K00 as fma(K01, a, fma(K10, a, -b K00))
+        double cand[RC][CW];
 #pragma unroll
-            for (int k = 0; k < RC; ++k)
+        for (int cc = 0; cc < S; ++cc) {
+            double above = top[cc];                        // K[i0][j+1]
+            double diag = cc == 0 ? corner : top[cc - 1];  // K[i0][j]
 #pragma unroll
-                for (int q = 0; q < CW; ++q) {
-                    const double g = vec_get<vec_t>(gv[k], q);
-                    if (NAIVE) {
-                        ca[k][q] = fma(g, c_half, 1.0);
-                        cbm[k][q] = 1.0;
-                    } else {
-                        const double g2 = g * g;
-                        ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
-                        cbm[k][q] = fma(g2, -c_12, 1.0);
-                    }
-                }
-
-            // -- sweep the R x S block column by column
-            double cand[RC][CW];
-#pragma unroll
-            for (int cc = 0; cc < S; ++cc) {
-                double above = top[cc];                      // K[i0][j+1]
-                double diag = cc == 0 ? corner : top[cc - 1];  // K[i0][j]
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                    const double a = ca[rr >> DY][cc >> DY], b = cbm[rr >> DY][cc >> DY];
-                    const double k10 = left[rr];
-                    double v;
-                    if (NAIVE) v = fma(above, a, fma(k10, a, -diag));
-                    else v = fma(above, a, fma(k10, a, -(diag * b)));
-                    diag = k10;
-                    above = v;
-                    left[rr] = v;
-                    if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
-                }
-                bot[cc] = above;
+            for (int rr = 0; rr < R; ++rr) {
+                const double a = ca[rr >> DY][cc >> DY], b = cbm[rr >> DY][cc >> DY];
+                const double k10 = left[rr];
+                double v;
+                if (NAIVE) v = fma(above, a, fma(k10, a, -diag));
+                else v = fma(above, a, fma(k10, a, -(diag * b)));
+                diag = k10;
+                above = v;
+                left[rr] = v;
+                if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
             }
-            corner = top[S - 1];
+            bot[cc] = above;
+        }
+        corner = top[S - 1];
 
-            if (MULTIBAND) {
-                if (is_bot) {
+        if (MULTIBAND) {
+            if (is_bot) {
 #pragma unroll
-                    for (int i = 0; i < S; ++i) lds_write_f64(my_bnd + (unsigned)(u * S + i) * 8u, bot[i]);
-                }
+                for (int i = 0; i < S; ++i) lds_write_f64(my_bnd + (unsigned)(u * S + i) * 8u, bot[i]);
             }
+        }
 
-            // -- K[MM][NN] of a pair: one lane, once per pair (the asm keeps the select chain inside the branch)
-            if (u == prm.u_f && band == nb - 1 && lam == prm.lam_f && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+        // -- K[MM][NN] of a pair: one lane, once per pair (the asm keeps the select chain inside the branch)
+        if (u == my_uf) {
+            if (band == nb - 1 && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -351,52 +316,57 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                     }
                 static_cast<T *>(prm.out)[pair0 + ps] = (T)v;
             }
+        }
 
-            // -- advance
-            u += 1;
+        // -- advance
+        u += 1;
+        if ((u & 7) == 0) {   // next line of this lane: it was fetched into the slot 8 steps further
+            slot += LINE_UNITS;
+            if (slot >= NSLOT) slot -= NSLOT;
             if (u == NUp) {
                 u = 0;
                 band += 1;
                 if (band == nb) { band = 0; ps += 1; }
             }
         }
-        buf = buf + 1 == NBUF ? 0 : buf + 1;
-        pbuf = pbuf + 1 == NBUF ? 0 : pbuf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int NBUF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int PF>
 int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, NBUF>;
+    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
     return check_launch();
 }
 
-// Tuning knobs (environment, read at launch): SK_WAVE_NBUF = chunks in the LDS ring (2 or 3),
+// Tuning knobs (environment, read at launch): SK_WAVE_PF = prefetch distance in macro-steps (2 (default), 3 or 4),
 // SK_WAVE_WPC = cap on resident waves per CU.  Defaults are what measured best on MI355X.
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
 
-template <typename T, int DY, bool NAIVE, int NBUF>
+template <typename T, int DY, bool NAIVE, int PF>
 int launch_nv(const WaveParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
     const bool full = prm.logL == 6;
-    if (multiband) return launch_one<T, DY, NAIVE, true, false, NBUF>(prm, blocks, lds_bytes, s);
-    return full ? launch_one<T, DY, NAIVE, false, true, NBUF>(prm, blocks, lds_bytes, s)
-                : launch_one<T, DY, NAIVE, false, false, NBUF>(prm, blocks, lds_bytes, s);
+    if (multiband) return launch_one<T, DY, NAIVE, true, false, PF>(prm, blocks, lds_bytes, s);
+    return full ? launch_one<T, DY, NAIVE, false, true, PF>(prm, blocks, lds_bytes, s)
+                : launch_one<T, DY, NAIVE, false, false, PF>(prm, blocks, lds_bytes, s);
 }
 
 template <typename T, int DY>
-int launch_dy(const WaveParams &prm, bool multiband, int nbuf, int blocks, size_t lds_bytes, hipStream_t s) {
-    if (nbuf == 2)
-        return prm.naive ? launch_nv<T, DY, true, 2>(prm, multiband, blocks, lds_bytes, s)
-                         : launch_nv<T, DY, false, 2>(prm, multiband, blocks, lds_bytes, s);
-    return prm.naive ? launch_nv<T, DY, true, 3>(prm, multiband, blocks, lds_bytes, s)
-                     : launch_nv<T, DY, false, 3>(prm, multiband, blocks, lds_bytes, s);
+int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t lds_bytes, hipStream_t s) {
+    switch (pf) {
+        case 2: return prm.naive ? launch_nv<T, DY, true, 2>(prm, multiband, blocks, lds_bytes, s)
+                                 : launch_nv<T, DY, false, 2>(prm, multiband, blocks, lds_bytes, s);
+        case 4: return prm.naive ? launch_nv<T, DY, true, 4>(prm, multiband, blocks, lds_bytes, s)
+                                 : launch_nv<T, DY, false, 4>(prm, multiband, blocks, lds_bytes, s);
+        default: return prm.naive ? launch_nv<T, DY, true, 3>(prm, multiband, blocks, lds_bytes, s)
+                                  : launch_nv<T, DY, false, 3>(prm, multiband, blocks, lds_bytes, s);
+    }
 }
 
 }  // namespace
@@ -406,48 +376,46 @@ int launch_dy(const WaveParams &prm, bool multiband, int nbuf, int blocks, size_
 template <typename T>
 int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    const int NBUF = env_int("SK_WAVE_NBUF", 3) == 2 ? 2 : 3;
+    int PF = env_int("SK_WAVE_PF", 2);
+    if (PF != 3 && PF != 4) PF = 2;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || ((ld * sizeof(T)) & 15)) return SK_ERR_UNSUPPORTED;
     const int NU = (g.Nc + CW - 1) / CW;
     if ((int64_t)NU * CW > ld) return SK_ERR_UNSUPPORTED;  // the last unit must stay inside the row
-    const int NUp = (NU + UPC - 1) / UPC * UPC;
+    const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
     const int S = CW << DY;
 
-    // lanes per pair: the smallest power of two whose band covers all rows; else full waves and bands
-    int logL = 2;
+    // lanes per pair: the smallest power of two (>= 8) whose band covers all rows; else full waves and bands
+    int logL = 3;
     while (logL < 6 && (RC << logL) < g.Mc) ++logL;
     int L = 1 << logL;
     int nb = (g.Mc + L * RC - 1) / (L * RC);
     if (nb > 1) {
         // band b+1 reads what band b's bottom lane wrote L-1 macro-steps after the top lane: needs NUp >= L
-        while (L > NUp && logL > 2) { --logL; L >>= 1; }
+        while (L > NUp && logL > 3) { --logL; L >>= 1; }
         if (L > NUp) return SK_ERR_UNSUPPORTED;
         nb = (g.Mc + L * RC - 1) / (L * RC);
     }
     const int G = WAVE / L;
     const bool multiband = nb > 1;
 
-    size_t lds_bytes = (size_t)NBUF * RC * UPC * 1024;
+    size_t lds_bytes = (size_t)(LINE_UNITS + PF) * RC * 1024;
     if (multiband) lds_bytes += (size_t)G * NUp * S * sizeof(double);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     if (waves_per_cu > 8) waves_per_cu = 8;
-    // Row-major increments are fetched as lane-skewed 64-byte pieces, so every 128-byte line is touched by two
-    // consecutive chunks; the second touch only hits while the lines of all resident waves fit the XCD's 4 MiB
-    // L2 (measured: 1.02x HBM traffic at 3 waves/CU, 1.61x at 6 for RC = 2).  Keep the resident set small.
-    const int l2_cap = 6 / RC > 2 ? 6 / RC : 2;
-    if (waves_per_cu > l2_cap) waves_per_cu = l2_cap;
-    const int wpc_cap = env_int("SK_WAVE_WPC", 0);
-    if (wpc_cap > 0 && waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
+    const int wpc_env = env_int("SK_WAVE_WPC", 0);
+    if (wpc_env > 0 && waves_per_cu > wpc_env) waves_per_cu = wpc_env;
+    // persistent waves all carry the same work: an uneven count per SIMD (5, 6, 7 waves on 4 SIMDs) makes the
+    // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4)
+    else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
-    const int64_t groups_needed = g.P;  // one pair per group at least
-    int64_t waves = (groups_needed + G - 1) / G;
+    int64_t waves = (g.P + G - 1) / G;   // one pair per lane group at least
     if (waves > max_waves) waves = max_waves;
     int64_t PPG = (g.P + waves * G - 1) / (waves * G);
     waves = (g.P + PPG * G - 1) / (PPG * G);
@@ -464,18 +432,17 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     WaveParams prm;
     prm.inc = inc_c; prm.out = out_final; prm.P = g.P; prm.ldb = ld * (int64_t)sizeof(T);
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.nb = nb; prm.logL = logL; prm.PPG = (int)PPG;
-    const int64_t steps = PPG * nb * NUp + (L - 1);
-    prm.n_chunks = (int)((steps + UPC - 1) / UPC);
+    prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
     prm.u_f = (g.Nc - 1) / CW;
     prm.lam_f = ((g.Mc - 1) / RC) % L;
     prm.sel_f = ((g.Mc - 1) % RC) * CW + (g.Nc - 1) % CW;
     prm.naive = g.naive;
 
     switch (DY) {
-        case 0: return launch_dy<T, 0>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
-        case 1: return launch_dy<T, 1>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
-        case 2: return launch_dy<T, 2>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
-        default: return launch_dy<T, 3>(prm, multiband, NBUF, (int)waves, lds_bytes, s);
+        case 0: return launch_dy<T, 0>(prm, multiband, PF, (int)waves, lds_bytes, s);
+        case 1: return launch_dy<T, 1>(prm, multiband, PF, (int)waves, lds_bytes, s);
+        case 2: return launch_dy<T, 2>(prm, multiband, PF, (int)waves, lds_bytes, s);
+        default: return launch_dy<T, 3>(prm, multiband, PF, (int)waves, lds_bytes, s);
     }
 }
 

@@ -38,6 +38,6 @@ def run(label, **env):
         os.environ.pop(k)
 
 
-for nbuf in (2, 3):
-    for wpc in (2, 3, 4, 5, 6, 8):
-        run("NBUF=%d WPC=%d" % (nbuf, wpc), SK_WAVE_NBUF=nbuf, SK_WAVE_WPC=wpc)
+for pf in (2, 3):
+    for wpc in (4, 8):
+        run("PF=%d WPC=%d" % (pf, wpc), SK_WAVE_PF=pf, SK_WAVE_WPC=wpc)
