@@ -19,8 +19,11 @@ class LinearKernel:
         return torch.bmm(self.scale * X, (self.scale * Y).transpose(1, 2))
 
     def Gram_matrix(self, X, Y):
-        """(A,M,D), (B,N,D) -> (A,B,M,N); like the reference this ignores ``scale`` (static_kernels.py:33)."""
-        return torch.einsum("ipk,jqk->ijpq", X, Y)
+        """(A,M,D), (B,N,D) -> (A,B,M,N); like the reference this ignores ``scale`` (static_kernels.py:33).
+
+        Same contraction as the reference's ``einsum('ipk,jqk->ijpq')``, issued as one broadcast batched GEMM so
+        that the result is produced directly in (A,B,M,N) order (no 34 GB transpose copy at the headline size)."""
+        return torch.matmul(X[:, None], Y[None].transpose(-1, -2))
 
 
 class RBFKernel:
@@ -41,6 +44,6 @@ class RBFKernel:
         A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
         Xs = torch.sum(X ** 2, dim=2)
         Ys = torch.sum(Y ** 2, dim=2)
-        dist = -2. * torch.einsum("ipk,jqk->ijpq", X, Y)
+        dist = -2. * torch.matmul(X[:, None], Y[None].transpose(-1, -2))   # einsum('ipk,jqk->ijpq') in (A,B,M,N) order
         dist = dist + (torch.reshape(Xs, (A, 1, M, 1)) + torch.reshape(Ys, (1, B, 1, N)))
         return torch.exp(-dist / self.sigma)

@@ -4,7 +4,7 @@
 # Usage: tools/profile_bench.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${*:-"--steps 5 --warmup 2 --no-cpu-baseline"}
+ARGS=${*:-"--steps 5 --warmup 2"}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -16,7 +16,8 @@ rocprofv3 --kernel-trace --stats -f csv -d "$OUT/trace" -o trace -- python "$REP
 PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+           "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+           "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   name=$(echo $set | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_fwd_wave|k_fwd_simple|k_adj|k_increments" -f csv \
       -d "$OUT/pmc_$name" -o pmc -- python "$REPO/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_$name.err" || echo "pmc set failed: $set" >> "$OUT/failed.txt"
