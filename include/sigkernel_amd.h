@@ -74,9 +74,11 @@ int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int
  * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference
  * differentiates the increments numerically with h = 1e-9; here dL/dG_static is formed
  * exactly and the static kernel is differentiated by the caller).
- * W [P,M-1,N-1], scale [P] -> dG [P,M,N]. */
-int sk_increments_adjoint_f64(const double *W, const double *scale, int64_t P, int M, int N, double *dG, void *stream);
-int sk_increments_adjoint_f32(const float *W, const float *scale, int64_t P, int M, int N, float *dG, void *stream);
+ * W [P,M-1,ldw] (row stride ldw >= N-1, 0 = dense), scale [P] -> dG [P,M,N]. */
+int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
+                              void *stream);
+int sk_increments_adjoint_f32(const float *W, int64_t ldw, const float *scale, int64_t P, int M, int N, float *dG,
+                              void *stream);
 
 /* ---- forward solve ------------------------------------------------------------------------
  * Solves the Goursat PDE for every pair and returns K[MM][NN].
@@ -89,7 +91,9 @@ int sk_increments_adjoint_f32(const float *W, const float *scale, int64_t P, int
  *   out_final [P]        K[MM][NN]
  *   out_grid  nullable   [P,MM+1,NN+1] full solution grid (what the reference returns)
  *   out_edges nullable   [P,MM+NN+2]: K[MM][0..NN] followed by K[0..MM][NN] -- the terminal
- *                        row and column, the only forward state the adjoint needs. */
+ *                        row and column, the only forward state the adjoint needs.  (The tiled
+ *                        kernel derives the column from zero padding: columns [Nc, ld) of inc_c
+ *                        must be zero when out_edges is requested.) */
 int sk_solve_fwd_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      double *out_final, double *out_grid, double *out_edges, void *stream);
 int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
@@ -101,13 +105,26 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
  * K[i][j] * Krev[MM-1-i][NN-1-j], Krev = solution on the doubly flipped increments.
  * Replaces the second solver launch and the KK product at sigkernel.py:282-311 (_SigKernel.backward)
  * and :438-470 (prep_backward).
- *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch (may be 0 -> NULL allowed).
- *   inc_c [P,Mc,ld]; out_final nullable [P]; W [P,Mc,Nc] dense. */
+ * Two implementations behind one entry point:
+ *   fast   -- forward sweep emitting the terminal row/column of K, then ONE fused sweep that runs the reverse
+ *             PDE and recomputes K backwards from those edges (no grid is stored; csrc/sk_wave_adj.hip).
+ *             Needs dyadic 1..2, increment rows zero-padded to whole 128-byte lines
+ *             (ld*sizeof(T) % 128 == 0, as sk_increments_* produces when given such an ld), ldw >= that padded
+ *             width, MM+NN+2 <= 1024, and out_err != NULL.  out_err[p] receives the self-check residual
+ *             max_i |K_recomputed[i][0] - 1| of pair p: the caller re-solves pairs whose residual is too
+ *             large with SK_FLAG_SIMPLE (only ever seen when K explodes, |K| >~ 1e4).
+ *   simple -- both grids stored in `workspace`, products summed in the reference's order: bit-identical to the
+ *             reference formula evaluated by the CPU oracle (SK_FLAG_EXACT / SK_FLAG_SIMPLE, or any shape
+ *             the fast path does not cover).  out_err is zero-filled.
+ *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch.
+ *   inc_c [P,Mc,ld]; out_final nullable [P]; W [P,Mc,ldw] (ldw = 0: dense); out_err nullable [P] doubles. */
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size);
 int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
-                     double *out_final, double *W, void *workspace, size_t workspace_bytes, void *stream);
+                     double *out_final, double *W, int64_t ldw, double *out_err, void *workspace,
+                     size_t workspace_bytes, void *stream);
 int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
-                     float *out_final, float *W, void *workspace, size_t workspace_bytes, void *stream);
+                     float *out_final, float *W, int64_t ldw, double *out_err, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -32,13 +32,13 @@ SIGNATURES = {
     "sk_device_count": (_int, []),
     "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
     "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
-    "sk_increments_adjoint_f64": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
-    "sk_increments_adjoint_f32": (_int, [_vp, _vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
+    "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
-    "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
 }
 
 
@@ -89,8 +89,9 @@ def _dev(t, name):
 
 
 def _padded_ld(n, elem_size):
-    """Row stride (elements) that keeps every increment row 16-byte aligned for the LDS-DMA kernels."""
-    q = 16 // elem_size
+    """Row stride (elements) that pads every increment row to whole 128-byte cache lines: the LDS-DMA kernels
+    fetch rows line by line, and the adjoint sweep needs the (zero) padding to exist."""
+    q = 128 // elem_size
     return (n + q - 1) // q * q
 
 
@@ -141,7 +142,7 @@ class HipBackend:
 
     def increments_adjoint(self, W, scale=None):
         """W [..., M-1, N-1] (+ per-pair scale [...]) -> dG [..., M, N]."""
-        _dev(W, "W")
+        W, ldw = _row_stride(W, "W")
         Mc, Nc = W.shape[-2:]
         P = W.numel() // (Mc * Nc)
         if scale is not None:
@@ -151,7 +152,7 @@ class HipBackend:
         out = torch.empty(W.shape[:-2] + (Mc + 1, Nc + 1), dtype=W.dtype, device=W.device)
         with torch.cuda.device(W.device):
             fn = getattr(load(), "sk_increments_adjoint_" + _suffix(W))
-            _check(fn(_ptr(W), _ptr(scale), P, Mc + 1, Nc + 1, _ptr(out), _stream(W)), "sk_increments_adjoint")
+            _check(fn(_ptr(W), ldw, _ptr(scale), P, Mc + 1, Nc + 1, _ptr(out), _stream(W)), "sk_increments_adjoint")
         return out
 
     def solve_fwd(self, inc_c, dyadic, naive=False, flags=0, want_grid=False, want_edges=False):
@@ -172,22 +173,48 @@ class HipBackend:
             return out, grid, edges
         return out
 
-    def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
-        """inc_c [..., Mc, Nc] -> (final [...], W [..., Mc, Nc] = d final / d inc_c)."""
+    # residual of the fast adjoint's self-check above which a pair is re-solved by the stored-grid kernel
+    ADJ_RESIDUAL_TOL = 1e-8
+
+    def solve_adj(self, inc_c, dyadic, naive=False, flags=0, return_residual=False):
+        """inc_c [..., Mc, Nc] -> (final [...], W [..., Mc, Nc] = d final / d inc_c).
+
+        The fast kernel recomputes K backwards instead of storing it and reports a per-pair residual; pairs whose
+        residual exceeds ADJ_RESIDUAL_TOL (K exploding beyond ~1e4) are re-solved by the stored-grid kernel."""
         inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
         P = inc_c.numel() // (Mc * Nc)
-        out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
-        W = torch.empty(inc_c.shape, dtype=inc_c.dtype, device=inc_c.device)
+        dev = inc_c.device
+        out = torch.empty(batch, dtype=inc_c.dtype, device=dev)
+        ldw = _padded_ld(Nc, inc_c.element_size())
+        Wp = torch.empty(batch + (Mc, ldw), dtype=inc_c.dtype, device=dev)
+        err = torch.empty(batch, dtype=torch.float64, device=dev)
         lib = load()
         nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=inc_c.device)
-        with torch.cuda.device(inc_c.device):
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        with torch.cuda.device(dev):
             fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
-            _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
-                      _ptr(out), _ptr(W), _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
+            _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags), _ptr(out), _ptr(Wp), ldw, _ptr(err),
+                      _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
+            W = Wp[..., :Nc]
+            if not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+                bad = torch.nonzero((err.reshape(-1) > self.ADJ_RESIDUAL_TOL) | torch.isnan(err.reshape(-1))).reshape(-1)
+                if bad.numel():      # rare: re-solve those pairs with both grids stored
+                    sub = inc_c.reshape(P, Mc, Nc)[bad].contiguous()
+                    n = int(bad.numel())
+                    o2 = torch.empty(n, dtype=inc_c.dtype, device=dev)
+                    W2 = torch.empty(n, Mc, Nc, dtype=inc_c.dtype, device=dev)
+                    nb2 = int(lib.sk_adj_workspace_bytes(n, Mc, Nc, int(dyadic), FLAG_SIMPLE, inc_c.element_size()))
+                    ws2 = torch.empty(max(nb2, 1), dtype=torch.uint8, device=dev)
+                    _check(fn(_ptr(sub), Nc, n, Mc, Nc, int(dyadic), scheme, FLAG_SIMPLE, _ptr(o2), _ptr(W2), Nc, None,
+                              _ptr(ws2), nb2, _stream(inc_c)), "sk_solve_adj (stored-grid re-solve)")
+                    Wp.reshape(P, Mc, ldw)[bad, :, :Nc] = W2
+                    out.reshape(-1)[bad] = o2
         # the caching allocator keeps `ws` alive for later work queued on this same stream
+        if return_residual:
+            return out, W, err
         return out, W
 
 

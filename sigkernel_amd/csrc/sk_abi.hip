@@ -22,8 +22,8 @@ int solve_fwd(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     if (!out_final && !out_grid && !out_edges) return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
-    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_final && !out_grid && !out_edges) {
-        const int rc = launch_fwd_wave<T>(inc_c, g.ld, g, out_final, (hipStream_t)stream);
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_final && !out_grid) {
+        const int rc = launch_fwd_wave<T>(inc_c, g.ld, g, out_final, out_edges, (hipStream_t)stream);
         if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
     } else if (flags & SK_FLAG_FAST_ONLY) {
         return SK_ERR_UNSUPPORTED;
@@ -31,13 +31,32 @@ int solve_fwd(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     return launch_fwd_simple<T>(inc_c, g, out_final, out_grid, out_edges, (hipStream_t)stream);
 }
 
+// workspace of the fast adjoint: terminal edges [P, MM+NN+2] doubles + a dummy K[MM][NN] vector [P] doubles
+size_t adj_fast_workspace_bytes(const Geom &g) {
+    return (size_t)g.P * (size_t)(g.MM + g.NN + 2 + 1) * sizeof(double);
+}
+
 template <typename T>
 int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags, T *out_final, T *W,
-              void *ws, size_t ws_bytes, void *stream) {
-    if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, flags) || !W || (ld != 0 && ld < Nc)) return SK_ERR_BAD_ARG;
+              int64_t ldw, double *out_err, void *ws, size_t ws_bytes, void *stream) {
+    if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, flags) || !W || (ld != 0 && ld < Nc) || (ldw != 0 && ldw < Nc))
+        return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
-    return launch_adj_simple<T>(inc_c, g, out_final, W, ws, ws_bytes, (hipStream_t)stream);
+    if (ldw == 0) ldw = Nc;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_err && ws && ws_bytes >= adj_fast_workspace_bytes(g)) {
+        // forward sweep that also emits the terminal row/column, then the fused reverse sweep + recompute of K
+        double *edges = static_cast<double *>(ws);
+        T *kfin = out_final ? out_final : reinterpret_cast<T *>(edges + (size_t)P * (g.MM + g.NN + 2));
+        int rc = launch_fwd_wave<T>(inc_c, g.ld, g, kfin, edges, s);
+        if (rc == SK_OK) rc = launch_adj_wave<T>(inc_c, g.ld, g, edges, W, ldw, out_err, s);
+        if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
+    } else if (flags & SK_FLAG_FAST_ONLY) {
+        return SK_ERR_UNSUPPORTED;
+    }
+    return launch_adj_simple<T>(inc_c, g, out_final, W, ldw, ws, ws_bytes, s);
 }
 
 }  // namespace
@@ -74,15 +93,17 @@ int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int
     if (P == 0) return SK_OK;
     return launch_increments<float>(G, P, M, N, inc_c, ld ? ld : N - 1, (hipStream_t)stream);
 }
-int sk_increments_adjoint_f64(const double *W, const double *scale, int64_t P, int M, int N, double *dG, void *stream) {
-    if (!W || !dG || P < 0 || M < 2 || N < 2) return SK_ERR_BAD_ARG;
+int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
+                              void *stream) {
+    if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
-    return launch_increments_adjoint<double>(W, scale, P, M, N, dG, (hipStream_t)stream);
+    return launch_increments_adjoint<double>(W, ldw ? ldw : N - 1, scale, P, M, N, dG, (hipStream_t)stream);
 }
-int sk_increments_adjoint_f32(const float *W, const float *scale, int64_t P, int M, int N, float *dG, void *stream) {
-    if (!W || !dG || P < 0 || M < 2 || N < 2) return SK_ERR_BAD_ARG;
+int sk_increments_adjoint_f32(const float *W, int64_t ldw, const float *scale, int64_t P, int M, int N, float *dG,
+                              void *stream) {
+    if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
-    return launch_increments_adjoint<float>(W, scale, P, M, N, dG, (hipStream_t)stream);
+    return launch_increments_adjoint<float>(W, ldw ? ldw : N - 1, scale, P, M, N, dG, (hipStream_t)stream);
 }
 
 int sk_solve_fwd_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags, double *out_final,
@@ -95,18 +116,26 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {
-    (void)flags; (void)elem_size;
+    (void)elem_size;
     if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
-    return adj_simple_workspace_bytes(make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT));
+    const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);
+    const size_t simple = adj_simple_workspace_bytes(g);
+    if (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) return simple;
+    const size_t fast = adj_fast_workspace_bytes(g);
+    return fast > simple ? fast : simple;
 }
 
-int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags, double *out_final,
-                     double *W, void *workspace, size_t workspace_bytes, void *stream) {
-    return solve_adj<double>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, W, workspace, workspace_bytes, stream);
+int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     double *out_final, double *W, int64_t ldw, double *out_err, void *workspace, size_t workspace_bytes,
+                     void *stream) {
+    return solve_adj<double>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, W, ldw, out_err, workspace,
+                             workspace_bytes, stream);
 }
-int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags, float *out_final,
-                     float *W, void *workspace, size_t workspace_bytes, void *stream) {
-    return solve_adj<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, W, workspace, workspace_bytes, stream);
+int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
+                     float *out_final, float *W, int64_t ldw, double *out_err, void *workspace, size_t workspace_bytes,
+                     void *stream) {
+    return solve_adj<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, W, ldw, out_err, workspace,
+                            workspace_bytes, stream);
 }
 
 }  // extern "C"

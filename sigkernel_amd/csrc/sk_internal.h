@@ -28,20 +28,25 @@ inline Geom make_geom(int64_t P, int Mc, int Nc, int dyadic, int scheme, int64_t
 template <typename T>
 int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, double *out_edges, hipStream_t s);
 template <typename T>
-int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *ws, size_t ws_bytes, hipStream_t s);
+int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t ldw, void *ws, size_t ws_bytes, hipStream_t s);
 size_t adj_simple_workspace_bytes(const Geom &g);
 size_t simple_lds_bytes(const Geom &g);
 
 // ---- sk_wave.hip: skewed row-strip wavefront sweep, register-resident state, LDS-DMA staging ----
 // SK_ERR_UNSUPPORTED = shape/layout not covered; the caller falls back to the simple kernel.
 template <typename T>
-int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hipStream_t s);
+int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *out_edges, hipStream_t s);
+
+// ---- sk_wave_adj.hip: fused reverse sweep + backward recompute of K (needs the forward kernel's edges) ----
+template <typename T>
+int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
+                    hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);
 template <typename T>
-int launch_increments_adjoint(const T *W, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
+int launch_increments_adjoint(const T *W, int64_t ldw, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
 
 inline int check_launch() {
     return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_simple(const T *__restrict__ inc_c
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d,
                                                      int naive, T *__restrict__ out_final, T *__restrict__ W,
-                                                     double *__restrict__ ws) {
+                                                     int64_t ldw, double *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int MM = Mc << d, NN = Nc << d, r = 1 << d;
     const int64_t gs = (int64_t)(MM + 1) * (NN + 1);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c
                     const int i = a * r + ii, j = b * r + jj;
                     acc += Kf[(int64_t)i * (NN + 1) + j] * Kr[(int64_t)(MM - 1 - i) * (NN + 1) + (NN - 1 - j)];
                 }
-            W[p * (int64_t)Mc * Nc + c] = (T)((acc * rs) * rs);
+            W[p * (int64_t)Mc * ldw + (int64_t)a * ldw + b] = (T)((acc * rs) * rs);
         }
         __syncthreads();
     }
@@ -149,7 +149,8 @@ int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, 
 }
 
 template <typename T>
-int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *ws, size_t ws_bytes, hipStream_t s) {
+int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t ldw, void *ws, size_t ws_bytes,
+                      hipStream_t s) {
     const size_t lds = simple_lds_bytes(g);
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     const int64_t gs = (int64_t)(g.MM + 1) * (g.NN + 1);
@@ -161,13 +162,14 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, void *w
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_adj_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_adj_simple<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic,
-                       g.naive, out_final, W, (double *)ws);
+                       g.naive, out_final, W, ldw, (double *)ws);
     return check_launch();
 }
 
 template int launch_fwd_simple<double>(const double *, const Geom &, double *, double *, double *, hipStream_t);
 template int launch_fwd_simple<float>(const float *, const Geom &, float *, float *, double *, hipStream_t);
-template int launch_adj_simple<double>(const double *, const Geom &, double *, double *, void *, size_t, hipStream_t);
-template int launch_adj_simple<float>(const float *, const Geom &, float *, float *, void *, size_t, hipStream_t);
+template int launch_adj_simple<double>(const double *, const Geom &, double *, double *, int64_t, void *, size_t,
+                                       hipStream_t);
+template int launch_adj_simple<float>(const float *, const Geom &, float *, float *, int64_t, void *, size_t, hipStream_t);
 
 }  // namespace sk

@@ -22,17 +22,10 @@
 //
 // Replaces: sigkernel_cuda / sigkernel_Gram_cuda (reference cuda_backend.py:6-49, :121-160), whose
 // thread-per-row sweep re-reads the solution grid from global memory every anti-diagonal.
-#include <cstdlib>
-
-#include "sk_internal.h"
+#include "sk_wave_common.h"
 
 namespace sk {
 namespace {
-
-constexpr int WAVE = 64;
-constexpr int LINE_UNITS = 8;  // 16-byte units per 128-byte line
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 struct WaveParams {
     const void *inc;   // [P, Mc, ld] coarse increments
@@ -47,78 +40,14 @@ struct WaveParams {
     int n_steps;       // macro-steps each wave sweeps (incl. drain)
     int u_f, lam_f, sel_f;  // where K[MM][NN] lives: unit, lane-in-group, k_f*CW + cw_f inside the block
     int naive;
-};
-
-__device__ __forceinline__ double dpp_shr1(double v, double fill) {
-    // lane l receives lane l-1's value; lane 0 keeps `fill`
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ int floor_div(int a, int b) {  // b > 0
-    int q = a / b;
-    return (a % b < 0) ? q - 1 : q;
-}
-
-typedef double d2_t __attribute__((ext_vector_type(2)));
-typedef float f4_t __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Unit;  // one 16-byte unit of increments
-template <> struct Unit<double> { static constexpr int CW = 2; typedef d2_t vec; };
-template <> struct Unit<float> { static constexpr int CW = 4; typedef f4_t vec; };
-
-template <typename V> __device__ __forceinline__ double vec_get(const V &v, int i) { return (double)v[i]; }
-
-// All LDS traffic of the sweep goes through inline asm.  hipcc cannot tell that a ds_read does not alias
-// an LDS-DMA still in flight and would drain the whole prefetch ring with s_waitcnt vmcnt(0) before every
-// read; here the DMA queue is counted by hand (vmcnt(N) = fetches still allowed in flight) and the asm
-// block itself waits for its own reads (lgkmcnt(0)) before any output is consumed.
-template <int VM, typename V>
-__device__ __forceinline__ void lds_read_rows(V (&g)[1], unsigned a) {
-    asm volatile("s_waitcnt vmcnt(%2)\n\t"
-                 "ds_read_b128 %0, %1\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]) : "v"(a), "n"(VM) : "memory");
-}
-template <int VM, typename V>
-__device__ __forceinline__ void lds_read_rows(V (&g)[2], unsigned a) {
-    asm volatile("s_waitcnt vmcnt(%3)\n\t"
-                 "ds_read_b128 %0, %2\n\t"
-                 "ds_read_b128 %1, %2 offset:1024\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]) : "v"(a), "n"(VM) : "memory");
-}
-template <int VM, typename V>
-__device__ __forceinline__ void lds_read_rows(V (&g)[4], unsigned a) {
-    asm volatile("s_waitcnt vmcnt(%5)\n\t"
-                 "ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %4 offset:1024\n\t"
-                 "ds_read_b128 %2, %4 offset:2048\n\t"
-                 "ds_read_b128 %3, %4 offset:3072\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a), "n"(VM) : "memory");
-}
-__device__ __forceinline__ double lds_read_f64(unsigned addr) {
-    double v;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_write_f64(unsigned addr, double v) {
-    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ unsigned lds_offset(const void *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-template <int DY> struct Tile {
-    static constexpr int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;  // coarse rows per lane
-    static constexpr int R = RC << DY;                         // fine rows per lane
+    double *edges;     // nullable [P, MM+NN+2]: K[MM][0..NN] then K[0..MM][NN] (EDGES variant)
+    int k_f;           // coarse row inside the lane's block that holds the pair's last row
+    int nt;            // non-temporal cache policy on the increment loads
+    int n_edge_slots, edge_slot_bytes;   // EDGES: LDS ring of per-pair edge buffers (per lane group)
 };
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int PF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, bool EDGES, int PF>
 __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
@@ -151,6 +80,12 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
     // MULTIBAND: bottom row of the previous band, [G][NUp*S] doubles behind the ring
     const unsigned my_bnd = lds0 + NSLOT * SLOT_BYTES + (unsigned)((lane >> prm.logL) * NUp * S) * 8u;
+    // EDGES: the terminal row/column of each pair is collected in LDS ([G][n_edge_slots][edge_slot_bytes] behind
+    // the boundary rows) and flushed with coalesced stores once the group's last lane has left the pair
+    const unsigned edges_lds = NSLOT * SLOT_BYTES + (MULTIBAND ? (unsigned)(G * NUp * S) * 8u : 0u);
+    const int NES = EDGES ? prm.n_edge_slots : 1;
+    int es = ((ps % NES) + NES) % NES;
+    const unsigned my_edges = lds0 + edges_lds + (unsigned)((lane >> prm.logL) * NES * prm.edge_slot_bytes);
 
     // ---- producer (DMA) state ---------------------------------------------------------------------------
     // Fetch step f = 8q + j serves the 8 consumer lanes lc = j + 8*(lane/8); all of them are about to start
@@ -188,8 +123,12 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     auto issue_fetch = [&]() {
 #pragma unroll
         for (int k = 0; k < RC; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
-                                                     st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
+            if (prm.nt)   // streaming hint: the line is read exactly once
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                         st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                         st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
         fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
         fj += 1;
         if (fj == LINE_UNITS) {   // all 8 classes have their line number n: move the cursor to n + 1
@@ -210,6 +149,28 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     for (int i = 0; i < R; ++i) left[i] = 1.0;
 #pragma unroll
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
+
+    // EDGES flush: pair `fl_pair` of every lane group, slot fl_slot; the first one is due after L-1 + pair_steps steps
+    const int pair_steps = nb * NUp;
+    int fl_t = -(L - 1), fl_pair = 0, fl_slot = 0;
+    auto flush_edges = [&]() {
+        const int MM = prm.Mc << DY, NN = prm.Nc << DY, E = MM + NN + 2;
+        for (int g = 0; g < G; ++g) {
+            const int64_t pr = ((int64_t)blockIdx.x * G + g) * prm.PPG + fl_pair;
+            if (fl_pair >= prm.PPG || pr >= prm.P) continue;
+            double *dst = prm.edges + pr * (int64_t)E;
+            const unsigned src = lds0 + edges_lds + (unsigned)((g * NES + fl_slot) * prm.edge_slot_bytes);
+            for (int idx = lane; idx < E; idx += WAVE) {
+                // dense layout: [0] = K[MM][0] = 1, [1..NN] row, [NN+1] = K[0][NN] = 1, [NN+2..] column
+                const bool one = idx == 0 || idx == NN + 1;
+                const int li = idx <= NN ? idx - 1 : NUp * S + (idx - NN - 2);
+                const double v = lds_read_f64(src + (unsigned)(one ? 0 : li) * 8u);
+                dst[idx] = one ? 1.0 : v;
+            }
+        }
+        fl_pair += 1;
+        fl_slot = fl_slot + 1 == NES ? 0 : fl_slot + 1;
+    };
 
     // prologue: the lines needed at macro-steps 0 .. PF-1
 #pragma unroll
@@ -233,8 +194,12 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         if (MULTIBAND) {
             double tb[S];
             if (is_top && band > 0) {
+                if constexpr (S % 4 == 0) {
+                    lds_read_row<S>(tb, my_bnd + (unsigned)(u * S) * 8u);
+                } else {
 #pragma unroll
-                for (int i = 0; i < S; ++i) tb[i] = lds_read_f64(my_bnd + (unsigned)(u * S + i) * 8u);
+                    for (int i = 0; i < S; ++i) tb[i] = lds_read_f64(my_bnd + (unsigned)(u * S + i) * 8u);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < S; ++i) tb[i] = 1.0;
@@ -275,6 +240,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
 
         // -- sweep the R x S block column by column: K11 = a (K10 + K01) - b K00 as fma(K01, a, fma(K10, a, -b K00))
         double cand[RC][CW];
+        double rowv[RC][S];   // EDGES: K on the last fine row of each coarse row of the block
 #pragma unroll
         for (int cc = 0; cc < S; ++cc) {
             double above = top[cc];                        // K[i0][j+1]
@@ -290,6 +256,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                 above = v;
                 left[rr] = v;
                 if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
+                if (EDGES && (rr & (r - 1)) == r - 1) rowv[rr >> DY][cc] = v;
             }
             bot[cc] = above;
         }
@@ -299,6 +266,34 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
             if (is_bot) {
 #pragma unroll
                 for (int i = 0; i < S; ++i) lds_write_f64(my_bnd + (unsigned)(u * S + i) * 8u, bot[i]);
+            }
+        }
+
+        // -- terminal row and column of the pair (what the adjoint kernel starts from) -> LDS, whole blocks at a time:
+        //    slot layout [K[MM][1..NNp]] [K[1..MMp][NN]] (padded sizes, so no bounds tests here; flush_edges() maps it
+        //    to the dense [P, MM+NN+2] array).  The column relies on the padding columns of the last unit being zero
+        //    (K is constant along zero increments).
+        if (EDGES) {
+            const unsigned e = my_edges + (unsigned)(es * prm.edge_slot_bytes);
+            if (lam == prm.lam_f && band == nb - 1) {
+                const unsigned a = e + (unsigned)(u * S) * 8u;
+#pragma unroll
+                for (int kk = 0; kk < RC; ++kk)
+                    if (kk == prm.k_f) {   // uniform: which coarse row of the block is the pair's last row
+#pragma unroll
+                        for (int cc = 0; cc < S; cc += 2) {
+                            d2_t v = {rowv[kk][cc], rowv[kk][cc + 1]};
+                            lds_write_b128(a + cc * 8u, v);
+                        }
+                    }
+            }
+            if (u == prm.u_f) {
+                const unsigned a = e + (unsigned)(NUp * S + (band * L + lam) * R) * 8u;
+#pragma unroll
+                for (int rr = 0; rr < R; rr += 2) {
+                    d2_t v = {left[rr], left[rr + 1]};
+                    lds_write_b128(a + rr * 8u, v);
+                }
             }
         }
 
@@ -326,16 +321,28 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
             if (u == NUp) {
                 u = 0;
                 band += 1;
-                if (band == nb) { band = 0; ps += 1; }
+                if (band == nb) {
+                    band = 0;
+                    ps += 1;
+                    if (EDGES) es = es + 1 == NES ? 0 : es + 1;
+                }
+            }
+        }
+        if (EDGES) {
+            // the group's last lane (lam = L-1) has just finished a pair: flush that pair's edges
+            fl_t += 1;
+            if (fl_t == pair_steps) {
+                fl_t = 0;
+                flush_edges();
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, int PF>
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, bool EDGES, int PF>
 int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, PF>;
+    auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, EDGES, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
@@ -344,17 +351,18 @@ int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t 
 
 // Tuning knobs (environment, read at launch): SK_WAVE_PF = prefetch distance in macro-steps (2 (default), 3 or 4),
 // SK_WAVE_WPC = cap on resident waves per CU.  Defaults are what measured best on MI355X.
-int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
 
 template <typename T, int DY, bool NAIVE, int PF>
 int launch_nv(const WaveParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
     const bool full = prm.logL == 6;
-    if (multiband) return launch_one<T, DY, NAIVE, true, false, PF>(prm, blocks, lds_bytes, s);
-    return full ? launch_one<T, DY, NAIVE, false, true, PF>(prm, blocks, lds_bytes, s)
-                : launch_one<T, DY, NAIVE, false, false, PF>(prm, blocks, lds_bytes, s);
+    if (prm.edges) {   // the adjoint's forward pass: one prefetch depth is enough variants
+        if (multiband) return launch_one<T, DY, NAIVE, true, false, true, 2>(prm, blocks, lds_bytes, s);
+        return full ? launch_one<T, DY, NAIVE, false, true, true, 2>(prm, blocks, lds_bytes, s)
+                    : launch_one<T, DY, NAIVE, false, false, true, 2>(prm, blocks, lds_bytes, s);
+    }
+    if (multiband) return launch_one<T, DY, NAIVE, true, false, false, PF>(prm, blocks, lds_bytes, s);
+    return full ? launch_one<T, DY, NAIVE, false, true, false, PF>(prm, blocks, lds_bytes, s)
+                : launch_one<T, DY, NAIVE, false, false, false, PF>(prm, blocks, lds_bytes, s);
 }
 
 template <typename T, int DY>
@@ -374,10 +382,10 @@ int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t 
 // Returns SK_ERR_UNSUPPORTED when the shape / layout is outside what this kernel handles; the caller
 // then falls back to the simple kernel.
 template <typename T>
-int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hipStream_t s) {
+int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *out_edges, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
     int PF = env_int("SK_WAVE_PF", 2);
-    if (PF != 3 && PF != 4) PF = 2;
+    if ((PF != 3 && PF != 4) || out_edges) PF = 2;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || ((ld * sizeof(T)) & 15)) return SK_ERR_UNSUPPORTED;
@@ -403,6 +411,10 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
 
     size_t lds_bytes = (size_t)(LINE_UNITS + PF) * RC * 1024;
     if (multiband) lds_bytes += (size_t)G * NUp * S * sizeof(double);
+    // edges: a lane group is spread over ceil((L-1)/pair_steps) + 1 pairs, plus the pair being flushed
+    const int edge_slot_bytes = (NUp * S + nb * L * (RC << DY)) * 8;   // K[MM][1..NNp] and K[1..MMp][NN]
+    const int n_edge_slots = (L - 1 + nb * NUp - 1) / (nb * NUp) + 2;
+    if (out_edges) lds_bytes += (size_t)G * n_edge_slots * edge_slot_bytes;
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
@@ -437,6 +449,11 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     prm.lam_f = ((g.Mc - 1) / RC) % L;
     prm.sel_f = ((g.Mc - 1) % RC) * CW + (g.Nc - 1) % CW;
     prm.naive = g.naive;
+    prm.edges = out_edges;
+    prm.k_f = (g.Mc - 1) % RC;
+    prm.nt = env_int("SK_WAVE_NT", 1);
+    prm.n_edge_slots = n_edge_slots;
+    prm.edge_slot_bytes = edge_slot_bytes;
 
     switch (DY) {
         case 0: return launch_dy<T, 0>(prm, multiband, PF, (int)waves, lds_bytes, s);
@@ -446,7 +463,7 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, hip
     }
 }
 
-template int launch_fwd_wave<double>(const double *, int64_t, const Geom &, double *, hipStream_t);
-template int launch_fwd_wave<float>(const float *, int64_t, const Geom &, float *, hipStream_t);
+template int launch_fwd_wave<double>(const double *, int64_t, const Geom &, double *, double *, hipStream_t);
+template int launch_fwd_wave<float>(const float *, int64_t, const Geom &, float *, double *, hipStream_t);
 
 }  // namespace sk

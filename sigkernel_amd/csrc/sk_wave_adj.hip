@@ -1,0 +1,518 @@
+// sk_wave_adj.hip -- the fast adjoint solver.
+//
+// What it computes (reference: prep_backward, sigkernel.py:438-470, and _SigKernel.backward :282-311):
+//   W[a][b] = 4^-d * sum over the fine cells (i,j) of coarse cell (a,b) of  K[i][j] * Krev[MM-1-i][NN-1-j]
+// with K the forward solution and Krev the solution on the doubly flipped increments.
+//
+// How.  In flipped coordinates (i' = MM-1-i, j' = NN-1-j) the product is (K at the cell's far corner, seen
+// from the flipped origin) x (Krev at the cell's near corner).  The kernel makes ONE sweep over the flipped grid,
+// with exactly the machinery of the forward kernel (sk_wave.hip: skewed row strips in registers, DPP neighbour
+// exchange, persistent pipelining over bands and pairs, just-in-time whole-line LDS-DMA of the increments --
+// here fetched back to front), carrying two states per node:
+//   Kr : the reverse PDE, ordinary recurrence                    Kr11 = a (Kr10 + Kr01) - b Kr00
+//   Kf : the forward solution RECOMPUTED backwards from its terminal row and column (the `edges` the forward
+//        kernel emitted, (MM+NN+2) doubles per pair) by solving the same stencil for the far corner:
+//                                                                Kf11 = (a (Kf10 + Kf01) - Kf00) / b
+// and accumulates Kf11 * Kr00 per coarse cell.  So the forward grid is never stored: forward + adjoint read the
+// increments twice and write W once -- the algorithmic 3 (M-1)(N-1) s bytes of SURVEY 8(d) -- where storing
+// K would cost 16 B per CELL.  The backward recurrence is as stable as the forward one while K stays O(1..1e3)
+// (error ~ 1e-16 K_max^2); the kernel checks itself: the recomputed K must come out as 1 on the j = 0 boundary,
+// the worst deviation per pair goes to `err`, and the host re-solves flagged pairs with the stored-grid kernel
+// (sk_simple.hip).
+//
+// The sweep runs on the grid padded to whole bands and whole 128-byte lines; padding columns must hold zero
+// increments (sk_increments_* writes them), padding rows are masked to zero here.  Zero increments propagate
+// K unchanged, so the terminal edges are simply clamped.
+#include "sk_wave_common.h"
+
+namespace sk {
+namespace {
+
+struct AdjParams {
+    const void *inc;       // [P, Mc, ld]
+    const double *edges;   // [P, MM+NN+2]
+    void *W;               // [P, Mc, ldw]
+    double *err;           // [P] (zero-initialised by the caller) worst |Kf - 1| on the recomputed j=0 boundary
+    int64_t P;
+    int64_t ldb, ldwb;     // row strides in bytes
+    int Mc, Nc;
+    int NUp, nb, logL, PPG, n_steps, naive;
+    int n_edge_dma;        // 1-KiB DMA pieces per pair of edges
+    int edge_slot_bytes;   // LDS bytes per staged pair of edges
+    int nt;                // non-temporal cache policy on the increment loads
+    int n_edge_slots;      // pairs of edges resident per lane group: the pairs a group spans, + 1 in flight
+};
+
+constexpr int ADJ_PF = 2;
+
+// 1/b for b = 1 - g^2/12 (close to 1): hardware estimate + two Newton steps, instead of the ~20-instruction IEEE
+// division sequence.  The result only has to be a consistent multiplier: a/b and 1/b are formed from the same value.
+__device__ __forceinline__ double fast_rcp(double b) {
+    double x = __builtin_amdgcn_rcp(b);
+    x = fma(x, fma(-b, x, 1.0), x);
+    x = fma(x, fma(-b, x, 1.0), x);
+    return x;
+}
+
+__device__ __forceinline__ void store_unit(double *dst, double a, double b) {
+    d2_t v = {a, b};
+    *reinterpret_cast<d2_t *>(dst) = v;
+}
+__device__ __forceinline__ void store_unit(float *dst, double a, double b, double c, double d) {
+    f4_t v = {(float)a, (float)b, (float)c, (float)d};
+    *reinterpret_cast<f4_t *>(dst) = v;
+}
+
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE>
+__global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
+    constexpr int PF = ADJ_PF;
+    constexpr int CW = Unit<T>::CW;
+    typedef typename Unit<T>::vec vec_t;
+    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    // ring slots: a slot is fetched PF steps ahead, consumed for 8 steps while its units are overwritten in place by
+    // the W units of the same positions, and written out as whole lines on the 9th step
+    constexpr int NSLOT = LINE_UNITS + 1 + PF;
+    constexpr int SLOT_BYTES = RC * 1024;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const unsigned lds0 = lds_offset(lds);
+
+    const int lane = threadIdx.x;
+    const int L = 1 << prm.logL, G = WAVE >> prm.logL;
+    const int lam = lane & (L - 1), grp = lane >> prm.logL;
+    const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
+    const int Mcp = nb * L * RC;                       // padded coarse rows
+    const int MM = prm.Mc << DY, NN = prm.Nc << DY, MMp = Mcp << DY, NNp = (NUp * CW) << DY;
+    const double sc = 1.0 / (double)(1 << (2 * DY));
+    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+
+    // ---- consumer state (flipped coordinates) ----------------------------------------------------------
+    int u, band, ps;
+    {
+        const int sig = floor_div(-lam, NUp);
+        u = -lam - sig * NUp;
+        ps = floor_div(sig, nb);
+        band = sig - ps * nb;
+    }
+    const int64_t pair0 = ((int64_t)blockIdx.x * G + grp) * prm.PPG;
+    const bool is_top = lam == 0, is_bot = lam == L - 1;
+    int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
+    const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
+    // LDS map: [increment ring][edges: G groups x EDGE_SLOTS pairs][MULTIBAND: Kr and Kf band boundary rows]
+    const int EDGE_SLOTS = prm.n_edge_slots;
+    const unsigned edge_base = lds0 + NSLOT * SLOT_BYTES + (unsigned)(grp * EDGE_SLOTS * prm.edge_slot_bytes);
+    int es = ((ps % EDGE_SLOTS) + EDGE_SLOTS) % EDGE_SLOTS;   // ring slot holding the edges of this lane's pair
+    const unsigned bnd_r = lds0 + NSLOT * SLOT_BYTES + (unsigned)(G * EDGE_SLOTS * prm.edge_slot_bytes) +
+                           (unsigned)(grp * 2 * NUp * S) * 8u;
+    const unsigned bnd_f = bnd_r + (unsigned)(NUp * S) * 8u;
+
+    // ---- producer: increments, whole lines, back to front (see sk_wave.hip for the forward-order twin) ----
+    const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
+    const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
+    int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
+    const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
+    span = span < wave_span ? span : wave_span;
+    if (span < 0) span = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(static_cast<const char *>(prm.inc) + first_pair * pair_bytes), 0, (int)span, 0x00020000);
+    const int ldb = (int)prm.ldb;
+    const int delta_band = NLp * 128 - L * RC * ldb;                                   // next (higher) band
+    const int delta_pair = NLp * 128 + (nb - 1) * L * RC * ldb + (int)pair_bytes;   // bottom band of the next pair
+    int st_m, st_band;
+    unsigned st_off;
+    {
+        const int ip = (lane >> 3) & ((L >> 3) - 1);
+        const int gc = (lane >> 3) >> (prm.logL - 3);
+        const int v0 = -ip * LINE_UNITS;
+        const int sg = floor_div(v0, NUp);
+        st_m = (v0 - sg * NUp) / LINE_UNITS;
+        const int ps0 = floor_div(sg, nb);
+        st_band = sg - ps0 * nb;
+        st_off = (unsigned)((gc * prm.PPG + ps0) * (int)pair_bytes +
+                            (Mcp - 1 - (st_band * L + ip * LINE_UNITS) * RC) * ldb + (NLp - 1 - st_m) * 128 +
+                            (7 - (lane & 7)) * 16);
+    }
+    int fj = 0, fslot = 0;
+    auto issue_fetch = [&]() {
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+            if (prm.nt)   // streaming hint: the line is read exactly once, keep L2 for the W lines being written
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                         st_off - (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                         st_off - (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
+        fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
+        fj += 1;
+        if (fj == LINE_UNITS) {
+            fj = 0;
+            st_m += 1;
+            st_off -= 128;
+            if (st_m == NLp) {
+                st_m = 0;
+                const bool last = st_band == nb - 1;
+                st_off += last ? delta_pair : delta_band;
+                st_band = last ? 0 : st_band + 1;
+            }
+        }
+    };
+
+    // ---- W write-out cursor: the same walk as the fetch cursor, 8 + PF steps later, on W's strides ------------
+    const int ldwb = (int)prm.ldwb;
+    const int64_t pairw_bytes = (int64_t)prm.Mc * prm.ldwb;
+    const int wdelta_band = NLp * 128 - L * RC * ldwb;
+    const int wdelta_pair = NLp * 128 + (nb - 1) * L * RC * ldwb + (int)pairw_bytes;
+    int wt_m, wt_band, wt_ps, wt_row;   // line, band, pair-in-group, first flipped coarse row (class 0, k 0)
+    unsigned wt_off;
+    const int wt_gc = (lane >> 3) >> (prm.logL - 3);
+    {
+        const int ip = (lane >> 3) & ((L >> 3) - 1);
+        const int v0 = -ip * LINE_UNITS;
+        const int sg = floor_div(v0, NUp);
+        wt_m = (v0 - sg * NUp) / LINE_UNITS;
+        wt_ps = floor_div(sg, nb);
+        wt_band = sg - wt_ps * nb;
+        wt_row = (wt_band * L + ip * LINE_UNITS) * RC;
+        wt_off = (unsigned)((wt_gc * prm.PPG + wt_ps) * (int)pairw_bytes + (Mcp - 1 - wt_row) * ldwb +
+                            (NLp - 1 - wt_m) * 128 + (7 - (lane & 7)) * 16);
+    }
+    char *const w_wave = static_cast<char *>(prm.W) + first_pair * pairw_bytes;
+    int wj = 0, wslot = 0;
+    // write the finished line of class wj (8 lanes x RC rows per instruction, 128 contiguous bytes per row)
+    auto store_lines = [&]() {
+        vec_t wv[RC];
+        lds_read_rows<63>(wv, lds0 + (unsigned)(wslot * SLOT_BYTES + lane * 16));
+        const bool pair_ok = wt_ps >= 0 && wt_ps < prm.PPG && first_pair + (int64_t)wt_gc * prm.PPG + wt_ps < prm.P;
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int orow = Mcp - 1 - (wt_row + wj * RC + k);
+            if (pair_ok && orow < prm.Mc)
+                *reinterpret_cast<vec_t *>(w_wave + (wt_off - (unsigned)((wj * RC + k) * ldwb))) = wv[k];
+        }
+        wslot = wslot + 1 == NSLOT ? 0 : wslot + 1;
+        wj += 1;
+        if (wj == LINE_UNITS) {
+            wj = 0;
+            wt_m += 1;
+            wt_off -= 128;
+            if (wt_m == NLp) {
+                wt_m = 0;
+                const bool last = wt_band == nb - 1;
+                wt_off += last ? wdelta_pair : wdelta_band;
+                wt_band = last ? 0 : wt_band + 1;
+                wt_ps += last ? 1 : 0;
+                wt_row = (wt_band * L + ((lane >> 3) & ((L >> 3) - 1)) * LINE_UNITS) * RC;
+            }
+        }
+    };
+
+    // ---- producer: terminal edges of pair `pi` of every lane group into its ring slot pi % EDGE_SLOTS -------
+    const int E = MM + NN + 2;
+    const int64_t edges_total = (int64_t)prm.P * E * 8;
+    auto issue_edges = [&](int pi, int pslot) {
+        for (int g = 0; g < G; ++g) {
+            const int64_t pr = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
+            if (pi >= prm.PPG || pr >= prm.P) continue;
+            const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(reinterpret_cast<const char *>(prm.edges) + pr * E * 8), 0, E * 8, 0x00020000);
+            const unsigned dst = NSLOT * SLOT_BYTES + (unsigned)((g * EDGE_SLOTS + pslot) * prm.edge_slot_bytes);
+            for (int c = 0; c < prm.n_edge_dma; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(er, (lds_void *)(lds + dst + c * 1024), 16,
+                                                         (unsigned)(c * 1024 + lane * 16), 0, 0, 0);
+        }
+    };
+    (void)edges_total;
+
+    double leftR[R], botR[S], cornerR = 1.0;
+    double leftF[R], botF[S], cornerF = 1.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = 1.0; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { botR[i] = 1.0; botF[i] = 1.0; }
+
+    issue_edges(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < PF; ++f) issue_fetch();
+
+    const int pair_steps = nb * NUp;
+    int t_in_pair = 0, pair_idx = 0, next_slot = 1 % EDGE_SLOTS;   // uniform: position of the group-top lanes
+    for (int t = 0; t < prm.n_steps; ++t) {
+        if (t_in_pair == 0) issue_edges(pair_idx + 1, next_slot);   // needed one whole pair later
+        issue_fetch();
+        vec_t gv[RC];
+        const unsigned my_unit = rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4));
+        lds_read_rows<PF * RC>(gv, my_unit);
+        if (t >= LINE_UNITS) store_lines();   // the lines whose last unit was written in the previous macro-step
+
+        const int prow0 = (band * L + lam) * RC;          // first flipped coarse row of this lane
+        const unsigned eslot = edge_base + (unsigned)(es * prm.edge_slot_bytes);
+
+        // -- row-unit start: left boundaries.  Kr[i'][0] = 1;  Kf[i'][0] = K[min(MM, MMp - i')][NN]
+        if (u == 0) {
+            const int i0 = prow0 * r;   // = i' of the block's top node
+            cornerR = 1.0;
+            cornerF = lds_read_f64(eslot + (unsigned)(NN + 1 + min(MM, MMp - i0)) * 8u);
+#pragma unroll
+            for (int i = 0; i < R; ++i) leftR[i] = 1.0;
+#pragma unroll
+            for (int i = 0; i < R; i += 4)
+                lds_read_f64x4(leftF[i], leftF[i + 1], leftF[i + 2], leftF[i + 3],
+                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 1 + i))) * 8u,
+                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 2 + i))) * 8u,
+                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 3 + i))) * 8u,
+                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 4 + i))) * 8u);
+        }
+
+        // -- top rows: from the lane above, or (top lane) the band boundary / the pair's terminal row
+        double topR[S], topF[S];
+        {
+            double tbR[S], tbF[S];
+            if (is_top) {
+                if (MULTIBAND && band > 0) {
+                    lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
+                    lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
+                } else {
+                    // Kr[0][j'] = 1;  Kf[0][j'] = K[MM][min(NN, NNp - j')], j' = u*S + i + 1
+#pragma unroll
+                    for (int i = 0; i < S; ++i) tbR[i] = 1.0;
+                    const int jb = NNp - u * S - 1;
+#pragma unroll
+                    for (int i = 0; i < S; i += 4)
+                        lds_read_f64x4(tbF[i], tbF[i + 1], tbF[i + 2], tbF[i + 3], eslot + (unsigned)min(NN, jb - i) * 8u,
+                                       eslot + (unsigned)min(NN, jb - i - 1) * 8u, eslot + (unsigned)min(NN, jb - i - 2) * 8u,
+                                       eslot + (unsigned)min(NN, jb - i - 3) * 8u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = 1.0; }
+            }
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const double shR = dpp_shr1(botR[i], 1.0);
+                const double shF = dpp_shr1(botF[i], 1.0);
+                topR[i] = (FULLWAVE && !MULTIBAND) ? shR : (is_top ? tbR[i] : shR);
+                topF[i] = is_top ? tbF[i] : shF;
+            }
+        }
+
+        // -- coefficients per coarse cell: a, b for Kr;  a/b, 1/b for the backward recompute of K
+        double ca[RC][CW], cb[RC][CW], ca2[RC][CW], cib[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const bool row_ok = Mcp - 1 - (prow0 + k) < prm.Mc;   // padding rows carry zero increments
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                double g = vec_get<vec_t>(gv[k], CW - 1 - q);      // flipped column order inside the unit
+                g = row_ok ? g : 0.0;
+                if (NAIVE) {
+                    ca[k][q] = fma(g, c_half, 1.0);
+                    cb[k][q] = 1.0;
+                    ca2[k][q] = ca[k][q];
+                    cib[k][q] = 1.0;
+                } else {
+                    const double g2 = g * g;
+                    ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                    cb[k][q] = fma(g2, -c_12, 1.0);
+                    cib[k][q] = fast_rcp(cb[k][q]);
+                    ca2[k][q] = ca[k][q] * cib[k][q];
+                }
+            }
+        }
+
+        // -- sweep the block, accumulate K * Krev per coarse cell
+        double acc[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) acc[k][q] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+            double aboveR = topR[cc], diagR = cc == 0 ? cornerR : topR[cc - 1];
+            double aboveF = topF[cc], diagF = cc == 0 ? cornerF : topF[cc - 1];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int k = rr >> DY, q = cc >> DY;
+                const double a = ca[k][q], b = cb[k][q], a2 = ca2[k][q], ib = cib[k][q];
+                const double lR = leftR[rr], lF = leftF[rr];
+                double vR, vF;
+                if (NAIVE) {
+                    vR = fma(aboveR, a, fma(lR, a, -diagR));
+                    vF = fma(aboveF, a, fma(lF, a, -diagF));
+                } else {
+                    vR = fma(aboveR, a, fma(lR, a, -(diagR * b)));
+                    vF = fma(aboveF, a2, fma(lF, a2, -(diagF * ib)));
+                }
+                acc[k][q] = fma(vF, diagR, acc[k][q]);   // K[i][j] * Krev[i'][j'] for this fine cell
+                diagR = lR; aboveR = vR; leftR[rr] = vR;
+                diagF = lF; aboveF = vF; leftF[rr] = vF;
+            }
+            botR[cc] = aboveR;
+            botF[cc] = aboveF;
+        }
+        cornerR = topR[S - 1];
+        cornerF = topF[S - 1];
+
+        if (MULTIBAND) {
+            if (is_bot) {
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    lds_write_f64(bnd_r + (unsigned)(u * S + i) * 8u, botR[i]);
+                    lds_write_f64(bnd_f + (unsigned)(u * S + i) * 8u, botF[i]);
+                }
+            }
+        }
+
+        // -- W: one 16-byte unit per coarse row, original column order, written over the increment unit just consumed;
+        //    store_lines() sends the line to HBM once all 8 units are in
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            vec_t wu;
+            if constexpr (CW == 2) { wu[0] = acc[k][1] * sc; wu[1] = acc[k][0] * sc; }
+            else { wu[0] = (float)(acc[k][3] * sc); wu[1] = (float)(acc[k][2] * sc); wu[2] = (float)(acc[k][1] * sc); wu[3] = (float)(acc[k][0] * sc); }
+            lds_write_b128(my_unit + k * 1024u, wu);
+        }
+        const bool valid = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
+        if (valid) {
+            // -- self-check on the last flipped unit: the recomputed K on the j = 0 boundary must be 1
+            if (u == NUp - 1 && prm.err) {
+                double e = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
+                atomicMax(reinterpret_cast<unsigned long long *>(prm.err + pair0 + ps),
+                          (unsigned long long)__double_as_longlong(e));
+            }
+        }
+
+        // -- advance
+        u += 1;
+        if ((u & 7) == 0) {
+            slot += LINE_UNITS;
+            if (slot >= NSLOT) slot -= NSLOT;
+            if (u == NUp) {
+                u = 0;
+                band += 1;
+                if (band == nb) {
+                    band = 0;
+                    ps += 1;
+                    es = es + 1 == EDGE_SLOTS ? 0 : es + 1;
+                }
+            }
+        }
+        t_in_pair += 1;
+        if (t_in_pair == pair_steps) {
+            t_in_pair = 0;
+            pair_idx += 1;
+            next_slot = next_slot + 1 == EDGE_SLOTS ? 0 : next_slot + 1;
+        }
+    }
+    for (int t = 0; t < LINE_UNITS; ++t) store_lines();   // the lines completed in the last 8 macro-steps
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE>
+int launch_adj_one(const AdjParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    auto kern = k_adj_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    return check_launch();
+}
+
+template <typename T, int DY>
+int launch_adj_dy(const AdjParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
+    const bool full = prm.logL == 6;
+    if (prm.naive) {
+        if (multiband) return launch_adj_one<T, DY, true, true, false>(prm, blocks, lds_bytes, s);
+        return full ? launch_adj_one<T, DY, true, false, true>(prm, blocks, lds_bytes, s)
+                    : launch_adj_one<T, DY, true, false, false>(prm, blocks, lds_bytes, s);
+    }
+    if (multiband) return launch_adj_one<T, DY, false, true, false>(prm, blocks, lds_bytes, s);
+    return full ? launch_adj_one<T, DY, false, false, true>(prm, blocks, lds_bytes, s)
+                : launch_adj_one<T, DY, false, false, false>(prm, blocks, lds_bytes, s);
+}
+
+}  // namespace
+
+// SK_ERR_UNSUPPORTED when the shape / layout is not covered (the caller falls back to the stored-grid kernel).
+// Requirements: dyadic 1..2 (a lane block must cover whole coarse cells; d = 3 would spill), increment rows padded with ZEROS to whole
+// 128-byte lines (ld*sizeof(T) % 128 == 0 and ld >= the padded width), W with the same row stride rule, and
+// (MM + NN + 2) <= 1024 so that three pairs of terminal edges fit next to the increment ring.
+template <typename T>
+int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
+                    hipStream_t s) {
+    constexpr int CW = Unit<T>::CW;
+    const int DY = g.dyadic;
+    if (DY < 1 || DY > 2) return SK_ERR_UNSUPPORTED;   // d = 3 needs > 256 VGPRs for the two states: stored-grid kernel
+    if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return SK_ERR_UNSUPPORTED;
+    const int NU = (g.Nc + CW - 1) / CW;
+    const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
+    if ((ld * sizeof(T)) % 128 || ld < (int64_t)NUp * CW) return SK_ERR_UNSUPPORTED;
+    if ((ldw * sizeof(T)) % 16 || ldw < (int64_t)NUp * CW) return SK_ERR_UNSUPPORTED;
+    const int RC = DY == 1 ? 2 : 1;
+    const int S = CW << DY;
+    const int E = g.MM + g.NN + 2;
+    if (E > 1024) return SK_ERR_UNSUPPORTED;
+
+    int logL = 3;
+    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
+    int L = 1 << logL;
+    int nb = (g.Mc + L * RC - 1) / (L * RC);
+    if (nb > 1) {
+        while (L > NUp && logL > 3) { --logL; L >>= 1; }
+        if (L > NUp) return SK_ERR_UNSUPPORTED;
+        nb = (g.Mc + L * RC - 1) / (L * RC);
+    }
+    const int G = WAVE / L;
+    const bool multiband = nb > 1;
+
+    const int n_edge_dma = (E * 8 + 1023) / 1024;
+    const int edge_slot_bytes = n_edge_dma * 1024;
+    // a lane group is spread over ceil((L-1)/pair_steps) + 1 pairs; one more slot receives the next pair's edges
+    const int n_edge_slots = (L - 1 + nb * NUp - 1) / (nb * NUp) + 2;
+    size_t lds_bytes = (size_t)(LINE_UNITS + 1 + ADJ_PF) * RC * 1024 + (size_t)G * n_edge_slots * edge_slot_bytes;
+    if (multiband) lds_bytes += (size_t)G * 2 * NUp * S * sizeof(double);
+    if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
+
+    int waves_per_cu = (int)((160 * 1024) / lds_bytes);
+    if (waves_per_cu > 8) waves_per_cu = 8;
+    const int wpc_env = env_int("SK_ADJ_WPC", 0);
+    if (wpc_env > 0 && waves_per_cu > wpc_env) waves_per_cu = wpc_env;
+    else if (waves_per_cu > 4) waves_per_cu &= ~3;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    const int64_t max_waves = 256LL * waves_per_cu;
+    int64_t waves = (g.P + G - 1) / G;
+    if (waves > max_waves) waves = max_waves;
+    int64_t PPG = (g.P + waves * G - 1) / (waves * G);
+    waves = (g.P + PPG * G - 1) / (PPG * G);
+    if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
+    const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
+    if (pair_bytes > (1LL << 29)) return SK_ERR_UNSUPPORTED;
+    if ((PPG * G + 1) * pair_bytes >= (1LL << 31)) {
+        PPG = ((1LL << 31) - 1) / (G * pair_bytes) - 1;
+        if (PPG < 1) return SK_ERR_UNSUPPORTED;
+        waves = (g.P + PPG * G - 1) / (PPG * G);
+    }
+
+    AdjParams prm;
+    prm.inc = inc_c; prm.edges = edges; prm.W = W; prm.err = err; prm.P = g.P;
+    prm.ldb = ld * (int64_t)sizeof(T); prm.ldwb = ldw * (int64_t)sizeof(T);
+    prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.nb = nb; prm.logL = logL; prm.PPG = (int)PPG;
+    prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
+    prm.naive = g.naive;
+    prm.n_edge_dma = n_edge_dma;
+    prm.edge_slot_bytes = edge_slot_bytes;
+    prm.n_edge_slots = n_edge_slots;
+    prm.nt = env_int("SK_WAVE_NT", 1);
+
+    switch (DY) {
+        case 1: return launch_adj_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
+        default: return launch_adj_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
+    }
+}
+
+template int launch_adj_wave<double>(const double *, int64_t, const Geom &, const double *, double *, int64_t, double *,
+                                     hipStream_t);
+template int launch_adj_wave<float>(const float *, int64_t, const Geom &, const double *, float *, int64_t, double *,
+                                    hipStream_t);
+
+}  // namespace sk

@@ -1,0 +1,116 @@
+// sk_wave_common.h -- device helpers shared by the tiled wavefront kernels (sk_wave.hip, sk_wave_adj.hip).
+#pragma once
+#include <cstdlib>
+
+#include "sk_internal.h"
+
+namespace sk {
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int LINE_UNITS = 8;  // 16-byte units per 128-byte line
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+
+__device__ __forceinline__ double dpp_shr1(double v, double fill) {
+    // lane l receives lane l-1's value; lane 0 keeps `fill`
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int floor_div(int a, int b) {  // b > 0
+    int q = a / b;
+    return (a % b < 0) ? q - 1 : q;
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Unit;  // one 16-byte unit of increments
+template <> struct Unit<double> { static constexpr int CW = 2; typedef d2_t vec; };
+template <> struct Unit<float> { static constexpr int CW = 4; typedef f4_t vec; };
+
+template <typename V> __device__ __forceinline__ double vec_get(const V &v, int i) { return (double)v[i]; }
+
+// All LDS traffic of the sweep goes through inline asm.  hipcc cannot tell that a ds_read does not alias
+// an LDS-DMA still in flight and would drain the whole prefetch ring with s_waitcnt vmcnt(0) before every
+// read; here the DMA queue is counted by hand (vmcnt(N) = fetches still allowed in flight) and the asm
+// block itself waits for its own reads (lgkmcnt(0)) before any output is consumed.
+template <int VM, typename V>
+__device__ __forceinline__ void lds_read_rows(V (&g)[1], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%2)\n\t"
+                 "ds_read_b128 %0, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]) : "v"(a), "n"(VM) : "memory");
+}
+template <int VM, typename V>
+__device__ __forceinline__ void lds_read_rows(V (&g)[2], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%3)\n\t"
+                 "ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]) : "v"(a), "n"(VM) : "memory");
+}
+template <int VM, typename V>
+__device__ __forceinline__ void lds_read_rows(V (&g)[4], unsigned a) {
+    asm volatile("s_waitcnt vmcnt(%5)\n\t"
+                 "ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:1024\n\t"
+                 "ds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a), "n"(VM) : "memory");
+}
+__device__ __forceinline__ double lds_read_f64(unsigned addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// four independent 8-byte reads, one wait (a top lane reading its boundary row pays one LDS round trip, not four)
+__device__ __forceinline__ void lds_read_f64x4(double &v0, double &v1, double &v2, double &v3, unsigned a0, unsigned a1,
+                                               unsigned a2, unsigned a3) {
+    asm volatile("ds_read_b64 %0, %4\n\t"
+                 "ds_read_b64 %1, %5\n\t"
+                 "ds_read_b64 %2, %6\n\t"
+                 "ds_read_b64 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+}
+// N consecutive doubles starting at `addr` (N a multiple of 4)
+template <int N>
+__device__ __forceinline__ void lds_read_row(double (&v)[N], unsigned addr) {
+    static_assert(N % 4 == 0, "boundary rows are read four values at a time");
+#pragma unroll
+    for (int i = 0; i < N; i += 4)
+        lds_read_f64x4(v[i], v[i + 1], v[i + 2], v[i + 3], addr + i * 8u, addr + (i + 1) * 8u, addr + (i + 2) * 8u,
+                       addr + (i + 3) * 8u);
+}
+__device__ __forceinline__ void lds_write_f64(unsigned addr, double v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void lds_write_b128(unsigned addr, V v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+template <int DY> struct Tile {
+    static constexpr int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;  // coarse rows per lane
+    static constexpr int R = RC << DY;                         // fine rows per lane
+};
+
+// Tuning knobs are read from the environment at launch (see the launchers).
+inline int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+}  // namespace
+}  // namespace sk

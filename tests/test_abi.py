@@ -44,7 +44,7 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_fwd_f64(ctypes.c_void_p(16), 0, 1, 4, 4, 0, 7, 0, ctypes.c_void_p(16), None, None, None) == 1
     assert lib.sk_solve_fwd_f64(ctypes.c_void_p(16), 3, 1, 4, 4, 0, 0, 0, ctypes.c_void_p(16), None, None, None) == 1   # ld < Nc
     assert lib.sk_increments_f64(None, 1, 4, 4, None, 0, None) == 1
-    assert lib.sk_solve_adj_f64(ctypes.c_void_p(16), 0, 1, 4, 4, 0, 0, 0, None, None, None, 0, None) == 1
+    assert lib.sk_solve_adj_f64(ctypes.c_void_p(16), 0, 1, 4, 4, 0, 0, 0, None, None, 0, None, None, 0, None) == 1
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():

@@ -18,6 +18,9 @@ ld = _lib._padded_ld(Nc, 8 if dt == torch.float64 else 4)
 buf = torch.randn(P, Mc, ld, device="cuda", dtype=dt) * 0.01
 inc = buf[..., :Nc]
 for _ in range(reps):
-    out = be.solve_fwd(inc, d, flags=_lib.FLAG_FAST_ONLY)
+    if os.environ.get('SK_RUN_EDGES'):
+        out = be.solve_fwd(inc, d, flags=_lib.FLAG_FAST_ONLY, want_edges=True)[0]
+    else:
+        out = be.solve_fwd(inc, d, flags=_lib.FLAG_FAST_ONLY)
 torch.cuda.synchronize()
 print("ok", float(out[0]))
