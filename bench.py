@@ -181,10 +181,9 @@ def main():
         rows = A
         while rows > 1 and 2 * rows * B * M * N * s > 40e9:
             rows //= 2
+        from sigkernel_amd.sigkernel import _increments
         with torch.no_grad():
-            G = sk.static_kernel.Gram_matrix(X[:rows], Y).contiguous()
-            inc = be.increments(G)
-            del G
+            inc = _increments(be, sk.static_kernel, X[:rows], Y, gram=True)
         for _ in range(2):
             be.solve_fwd(inc, dyadic)
         reps = max(3, args.steps)

@@ -69,7 +69,20 @@ int sk_device_count(void);
 int sk_increments_f64(const double *G, int64_t P, int M, int N, double *inc_c, int64_t ld, void *stream);
 int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int64_t ld, void *stream);
 
-/* Transpose of the above, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
+/* Static kernel + increments in ONE pass for the reference's two standard static kernels, straight from the paths:
+ * replaces static_kernel.Gram_matrix(X, Y) / batch_kernel(X, Y) (static_kernels.py:24,33,56,73) followed by the
+ * 4-corner difference (sigkernel.py:216-217, :362-363) -- G_static is never materialised.
+ *   kind 0: linear, inc = param^2 <dx_p, dy_q>  (param = 1 reproduces Gram_matrix, which ignores `scale`;
+ *           param = scale reproduces batch_kernel)
+ *   kind 1: rbf,    G = exp(-|x_p - y_q|^2 / param) (param = sigma), inc = ((G11 + G00) - G10) - G01
+ *   X [A,M,D], Y [B,N,D] dense; B > 0: Gram, pair (a,b) at a*B+b; B == 0: paired, pair a = (x_a, y_a), Y [A,N,D].
+ *   inc_c [P,M-1,ld] with zero-filled padding columns.  D <= 32 (else SK_ERR_UNSUPPORTED: use the generic path). */
+int sk_static_increments_f64(int kind, double param, const double *X, const double *Y, int64_t A, int64_t B, int M, int N,
+                             int D, double *inc_c, int64_t ld, void *stream);
+int sk_static_increments_f32(int kind, double param, const float *X, const float *Y, int64_t A, int64_t B, int M, int N,
+                             int D, float *inc_c, int64_t ld, void *stream);
+
+/* Transpose of sk_increments_*, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
  * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
  * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference
  * differentiates the increments numerically with h = 1e-9; here dL/dG_static is formed

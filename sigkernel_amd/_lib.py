@@ -32,6 +32,8 @@ SIGNATURES = {
     "sk_device_count": (_int, []),
     "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
     "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
+    "sk_static_increments_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _vp, _i64, _vp]),
+    "sk_static_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "sk_increments_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -139,6 +141,28 @@ class HipBackend:
             fn = getattr(load(), "sk_increments_" + _suffix(G))
             _check(fn(_ptr(G), P, M, N, _ptr(out), ld, _stream(G)), "sk_increments")
         return out[..., : N - 1]      # rows stay 16-byte aligned underneath (stride(-2) == ld)
+
+    MAX_FUSED_DIM = 32
+
+    def static_increments(self, kind, param, X, Y, gram):
+        """Static kernel + increments in one pass (kind 0 = linear with param = scale, 1 = rbf with param = sigma).
+
+        gram=True: X (A,M,D), Y (B,N,D) -> inc_c (A,B,M-1,N-1); gram=False (paired): Y (A,N,D) -> (A,M-1,N-1).
+        Returns None when the shape is outside the fused kernels (D > 32): the caller takes the generic path."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        if D > self.MAX_FUSED_DIM or M < 2 or N < 2:
+            return None
+        ld = _padded_ld(N - 1, X.element_size())
+        shape = (A, B, M - 1, ld) if gram else (A, M - 1, ld)
+        out = torch.empty(shape, dtype=X.dtype, device=X.device)
+        with torch.cuda.device(X.device):
+            fn = getattr(load(), "sk_static_increments_" + _suffix(X))
+            _check(fn(int(kind), float(param), _ptr(X), _ptr(Y), A, B if gram else 0, M, N, D, _ptr(out), ld, _stream(X)),
+                   "sk_static_increments")
+        return out[..., : N - 1]
 
     def increments_adjoint(self, W, scale=None):
         """W [..., M-1, N-1] (+ per-pair scale [...]) -> dG [..., M, N]."""

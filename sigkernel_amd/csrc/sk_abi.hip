@@ -93,6 +93,21 @@ int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int
     if (P == 0) return SK_OK;
     return launch_increments<float>(G, P, M, N, inc_c, ld ? ld : N - 1, (hipStream_t)stream);
 }
+int sk_static_increments_f64(int kind, double param, const double *X, const double *Y, int64_t A, int64_t B, int M, int N,
+                             int D, double *inc_c, int64_t ld, void *stream) {
+    if (!X || !Y || !inc_c || A < 0 || B < 0 || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ld != 0 && ld < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_increments<double>(kind, param, X, Y, A, B, M, N, D, inc_c, ld ? ld : N - 1, (hipStream_t)stream);
+}
+int sk_static_increments_f32(int kind, double param, const float *X, const float *Y, int64_t A, int64_t B, int M, int N,
+                             int D, float *inc_c, int64_t ld, void *stream) {
+    if (!X || !Y || !inc_c || A < 0 || B < 0 || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ld != 0 && ld < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_increments<float>(kind, param, X, Y, A, B, M, N, D, inc_c, ld ? ld : N - 1, (hipStream_t)stream);
+}
+
 int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
                               void *stream) {
     if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;

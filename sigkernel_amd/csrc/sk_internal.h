@@ -48,6 +48,11 @@ int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld,
 template <typename T>
 int launch_increments_adjoint(const T *W, int64_t ldw, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
 
+// ---- sk_static.hip: static kernel (linear / rbf) + increments in one pass ---------------------------------
+template <typename T>
+int launch_static_increments(int kind, double param, const T *X, const T *Y, int64_t A, int64_t B, int M, int N, int D,
+                             T *inc, int64_t ld, hipStream_t s);
+
 inline int check_launch() {
     return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;
 }

@@ -14,6 +14,7 @@ Goursat PDE solve and the adjoint PDE run in the HIP kernels of libsigkernel_amd
 import torch
 
 from . import _lib
+from .static_kernels import LinearKernel, RBFKernel
 
 __all__ = ["SigKernel", "_SigKernel", "_SigKernelGram"]
 
@@ -32,6 +33,30 @@ def _budget(device, requested):
 def _tiles(n_rows, bytes_per_row, budget):
     rows = int(max(1, min(n_rows, budget // max(1, bytes_per_row))))
     return [(a, min(a + rows, n_rows)) for a in range(0, n_rows, rows)]
+
+
+def _fused_static(static_kernel, gram):
+    """(kind, param) when the static kernel is exactly one of the two the fused HIP kernels implement
+    (sk_static_increments_*: static kernel + increments in one pass, G_static never materialised), else None.
+    Subclasses and user-defined kernels always take the generic Gram_matrix / batch_kernel path."""
+    if type(static_kernel) is LinearKernel:
+        # the reference's Gram_matrix ignores `scale`, batch_kernel applies it to both arguments (static_kernels.py:24,33)
+        return 0, (1.0 if gram else float(static_kernel.scale))
+    if type(static_kernel) is RBFKernel and float(static_kernel.sigma) > 0:
+        return 1, float(static_kernel.sigma)
+    return None
+
+
+def _increments(be, static_kernel, Xd, Yd, gram):
+    """Coarse increments of the static Gram for a tile: fused kernel when available, else the reference's route
+    (static kernel in torch -> 4-corner difference, sigkernel.py:216-217 / :362-363)."""
+    fused = _fused_static(static_kernel, gram)
+    if fused is not None and hasattr(be, "static_increments"):
+        inc = be.static_increments(fused[0], fused[1], Xd.contiguous(), Yd.contiguous(), gram)
+        if inc is not None:
+            return inc
+    G = (static_kernel.Gram_matrix(Xd, Yd) if gram else static_kernel.batch_kernel(Xd, Yd)).contiguous()
+    return be.increments(G)
 
 
 def _check_inputs(X, Y, paired):
@@ -62,9 +87,8 @@ class _SigKernel(torch.autograd.Function):
         K = torch.empty(A, dtype=X.dtype, device=X.device)
         per_row = 2 * M * N * X.element_size()
         for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
-            G = static_kernel.batch_kernel(Xd[a0:a1], Yd[a0:a1]).contiguous()  # sigkernel.py:216
-            inc = be.increments(G)                                           # :217 (and :218 by index)
-            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)         # :231 / :246
+            inc = _increments(be, static_kernel, Xd[a0:a1], Yd[a0:a1], gram=False)   # sigkernel.py:216-217 (:218 by index)
+            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)               # :231 / :246
         return K
 
     @staticmethod
@@ -105,14 +129,13 @@ class _SigKernelGram(torch.autograd.Function):
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
         K = torch.empty(A, B, dtype=X.dtype, device=X.device)
-        per_row = 2 * B * M * N * X.element_size()
+        # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
+        per_row = (1 if _fused_static(static_kernel, True) is not None else 2) * B * M * N * X.element_size()
         # `sym` is accepted and, like the reference's GPU path (sigkernel.py:366-382), not needed:
         # every pair is solved; the result equals the sym=False one.
         for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
-            G = static_kernel.Gram_matrix(Xd[a0:a1], Yd).contiguous()         # sigkernel.py:362
-            inc = be.increments(G)                                           # :363 (and :364 by index)
-            del G
-            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)         # :378 / :395
+            inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
+            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)               # :378 / :395
         return K
 
     @staticmethod

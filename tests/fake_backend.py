@@ -15,6 +15,14 @@ class OracleBackend:
     def increments(self, G):
         return torch.from_numpy(O.increments(G.detach().double().numpy())).to(G.dtype)
 
+    def static_increments(self, kind, param, X, Y, gram):
+        import sigkernel_amd
+        k = sigkernel_amd.LinearKernel(param) if kind == 0 else sigkernel_amd.RBFKernel(param)
+        if kind == 0 and gram:
+            k = sigkernel_amd.LinearKernel()
+        G = k.Gram_matrix(X, Y) if gram else k.batch_kernel(X, Y)
+        return self.increments(G)
+
     def increments_adjoint(self, W, scale=None):
         dG = torch.from_numpy(O.increments_adjoint(W.detach().double().numpy())).to(W.dtype)
         if scale is not None:

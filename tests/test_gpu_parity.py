@@ -157,6 +157,34 @@ def test_increments_and_transpose_bit_identical(be):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+@pytest.mark.parametrize("A,B,M,N,D", [(3, 4, 10, 20, 2), (2, 3, 128, 128, 8), (5, 2, 64, 64, 4), (2, 2, 70, 131, 17),
+                                       (1, 1, 2, 2, 1), (3, 3, 33, 64, 32)])
+def test_fused_static_increments_match_the_generic_route(be, kind, A, B, M, N, D):
+    gen = torch.Generator().manual_seed(A * 100 + M + N + D)
+    for dtype, tol in ((torch.float64, 2e-15), (torch.float32, 2e-6)):
+        X = walk(gen, A, M, D).to(dtype).to(DEV) * 3
+        Y = walk(gen, B, N, D).to(dtype).to(DEV) * 3
+        for scale in ((1.0, 0.7) if kind == "linear" else (0.5, 2.0)):
+            k = sigkernel_amd.LinearKernel(scale) if kind == "linear" else sigkernel_amd.RBFKernel(scale)
+            code, param = (0, scale) if kind == "linear" else (1, scale)
+            # Gram: the reference's linear Gram_matrix ignores `scale` -> param 1
+            G = k.Gram_matrix(X.double(), Y.double())
+            want = be.increments(G.contiguous()).cpu().numpy()
+            got = be.static_increments(code, 1.0 if kind == "linear" else param, X, Y, gram=True)
+            assert got.shape == (A, B, M - 1, N - 1) and got.stride(-2) * got.element_size() % 128 == 0
+            assert np.max(np.abs(got.double().cpu().numpy() - want)) <= tol * max(1.0, float(G.abs().max()))
+            # zero padding behind the view (the adjoint sweep and the edge output rely on it)
+            base = got.as_strided((A, B, M - 1, got.stride(-2)), got.stride())
+            assert torch.all(base[..., N - 1:] == 0)
+            # paired
+            n = min(A, B)
+            Gp = k.batch_kernel(X[:n].double(), Y[:n].double())
+            wantp = be.increments(Gp.contiguous()).cpu().numpy()
+            gotp = be.static_increments(code, param, X[:n].contiguous(), Y[:n].contiguous(), gram=False)
+            assert np.max(np.abs(gotp.double().cpu().numpy() - wantp)) <= tol * max(1.0, float(Gp.abs().max()))
+
+
 # ---------------------------------------------------------------------------------------------
 # API level, against the golden vectors produced by the real reference
 # ---------------------------------------------------------------------------------------------
