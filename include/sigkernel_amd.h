@@ -82,6 +82,18 @@ int sk_static_increments_f64(int kind, double param, const double *X, const doub
 int sk_static_increments_f32(int kind, double param, const float *X, const float *Y, int64_t A, int64_t B, int M, int N,
                              int D, float *inc_c, int64_t ld, void *stream);
 
+/* Adjoint of sk_static_increments_*: dL/dX from W = dL/d inc_c and the per-pair upstream gradient, with neither G_static
+ * nor dL/dG_static materialised.  Replaces the finite-difference contraction (sigkernel.py:313-341, :472-500) and the
+ * `grad_output * grad_points` reduction over the second batch index (:343, :410-416) for these two static kernels.
+ *   W [P,M-1,ldw]; scale [P] = upstream gradient per pair (NULL = 1); pairs as in sk_static_increments_*.
+ *   kind 0 (linear): out = T [A,M-1,D], T[a][p] = sum_b scale_ab sum_q W[a,b,p,q] (y[b,q+1]-y[b,q]); the caller forms
+ *                    dL/dx[a][m] = param^2 (T[a][m-1] - T[a][m]).
+ *   kind 1 (rbf):    out = dL/dX [A,M,D]. */
+int sk_static_adjoint_f64(int kind, double param, const double *X, const double *Y, const double *W, int64_t ldw,
+                          const double *scale, int64_t A, int64_t B, int M, int N, int D, double *out, void *stream);
+int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y, const float *W, int64_t ldw,
+                          const float *scale, int64_t A, int64_t B, int M, int N, int D, float *out, void *stream);
+
 /* Transpose of sk_increments_*, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
  * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
  * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sk_increments_f32": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
     "sk_static_increments_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "sk_static_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _vp, _i64, _vp]),
+    "sk_static_adjoint_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "sk_static_adjoint_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -163,6 +165,33 @@ class HipBackend:
             _check(fn(int(kind), float(param), _ptr(X), _ptr(Y), A, B if gram else 0, M, N, D, _ptr(out), ld, _stream(X)),
                    "sk_static_increments")
         return out[..., : N - 1]
+
+    def static_adjoint(self, kind, param, X, Y, W, scale, gram):
+        """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels
+        (adjoint of static_increments; neither G_static nor dL/dG_static is materialised)."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        W, ldw = _row_stride(W, "W")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        if scale is not None:
+            _dev(scale, "scale")
+            if scale.dtype != W.dtype:
+                raise ValueError("scale must have W's dtype")
+        with torch.cuda.device(X.device):
+            fn = getattr(load(), "sk_static_adjoint_" + _suffix(X))
+            if kind == 0:
+                T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
+                _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(T),
+                          _stream(X)), "sk_static_adjoint")
+                g = torch.zeros(A, M, D, dtype=X.dtype, device=X.device)
+                g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
+                g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
+                return g * (float(param) ** 2) if float(param) != 1.0 else g
+            g = torch.empty(A, M, D, dtype=X.dtype, device=X.device)
+            _check(fn(1, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(g),
+                      _stream(X)), "sk_static_adjoint")
+            return g
 
     def increments_adjoint(self, W, scale=None):
         """W [..., M-1, N-1] (+ per-pair scale [...]) -> dG [..., M, N]."""

@@ -108,6 +108,23 @@ int sk_static_increments_f32(int kind, double param, const float *X, const float
     return launch_static_increments<float>(kind, param, X, Y, A, B, M, N, D, inc_c, ld ? ld : N - 1, (hipStream_t)stream);
 }
 
+int sk_static_adjoint_f64(int kind, double param, const double *X, const double *Y, const double *W, int64_t ldw,
+                          const double *scale, int64_t A, int64_t B, int M, int N, int D, double *out, void *stream) {
+    if (!X || !Y || !W || !out || A < 0 || B < 0 || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ldw != 0 && ldw < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_adjoint<double>(kind, param, X, Y, W, ldw ? ldw : N - 1, scale, A, B, M, N, D, out,
+                                         (hipStream_t)stream);
+}
+int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y, const float *W, int64_t ldw,
+                          const float *scale, int64_t A, int64_t B, int M, int N, int D, float *out, void *stream) {
+    if (!X || !Y || !W || !out || A < 0 || B < 0 || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ldw != 0 && ldw < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_adjoint<float>(kind, param, X, Y, W, ldw ? ldw : N - 1, scale, A, B, M, N, D, out,
+                                        (hipStream_t)stream);
+}
+
 int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
                               void *stream) {
     if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;

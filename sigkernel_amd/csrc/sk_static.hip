@@ -100,6 +100,147 @@ __global__ __launch_bounds__(SK_TPB) void k_static_rbf(const T *__restrict__ X, 
     }
 }
 
+// ---- adjoints: dL/dX from W = dL/d inc_c, without materialising dL/dG_static ------------------------------
+// (replaces the finite-difference contraction of sigkernel.py:313-341 / :472-500 together with the
+//  `grad_output * grad_points` reduction of :343 / :410-416, for these two static kernels)
+
+// block-wide sum of `v` over all threads (64 or 128 threads); result valid in thread 0
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (NT > 64) {
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < NT / 64; ++w) v += red[w];
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// linear: T[a][p][k] = sum_b s_ab sum_q W[a,b,p,q] * (y[b,q+1,k] - y[b,q,k]);  dL/dx[a,m] = s^2 (T[a][m-1] - T[a][m])
+template <typename T, int DMAX, int NT>
+__global__ __launch_bounds__(NT) void k_static_linear_adj(const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
+                                                          const T *__restrict__ scale, int64_t B, int M, int N, int D,
+                                                          int strips, T *__restrict__ Tout) {
+    constexpr int RS = 64 / DMAX;   // rows per block: RS * DMAX accumulators per thread
+    __shared__ double red[NT / 64 + 1];
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t a = blockIdx.x / strips;
+    const int p0 = (int)(blockIdx.x % strips) * RS;
+    double acc[RS][DMAX];
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) acc[r][k] = 0.0;
+    const int64_t nb = B > 0 ? B : 1;
+    for (int64_t bb = 0; bb < nb; ++bb) {
+        const int64_t b = B > 0 ? bb : a, p = B > 0 ? a * B + bb : a;
+        const double s = scale ? (double)scale[p] : 1.0;
+        const T *y = Y + b * (int64_t)N * D;
+        const T *w = W + p * (int64_t)Mc * ldw;
+        for (int q = threadIdx.x; q < Nc; q += NT) {
+            double dy[DMAX];
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k)
+                dy[k] = k < D ? s * ((double)y[(int64_t)(q + 1) * D + k] - (double)y[(int64_t)q * D + k]) : 0.0;
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                if (p0 + r < Mc) {
+                    const double wv = (double)w[(int64_t)(p0 + r) * ldw + q];
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(wv, dy[k], acc[r][k]);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            const double v = block_sum<NT>(acc[r][k], red);
+            if (threadIdx.x == 0 && p0 + r < Mc && k < D) Tout[(a * Mc + p0 + r) * (int64_t)D + k] = (T)v;
+        }
+}
+
+// rbf: dL/dx[a,m,k] = (-2/sigma) sum_b s_ab sum_n dG[m,n] G[m,n] (x[a,m,k] - y[b,n,k]),
+//      dG[m,n] = W[m-1,n-1] + W[m,n] - W[m-1,n] - W[m,n-1]   (transpose of the 4-corner difference)
+template <typename T, int DMAX, int NT>
+__global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, const T *__restrict__ Y,
+                                                       const T *__restrict__ W, int64_t ldw, const T *__restrict__ scale,
+                                                       int64_t B, int M, int N, int D, double inv_sigma,
+                                                       T *__restrict__ gX) {
+    __shared__ double red[NT / 64 + 1];
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t a = blockIdx.x / M;
+    const int m = (int)(blockIdx.x % M);
+    const T *x = X + (a * M + m) * (int64_t)D;
+    double xm[DMAX], xs = 0.0, acc[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        xm[k] = k < D ? (double)x[k] : 0.0;
+        xs = fma(xm[k], xm[k], xs);
+        acc[k] = 0.0;
+    }
+    const int64_t nb = B > 0 ? B : 1;
+    for (int64_t bb = 0; bb < nb; ++bb) {
+        const int64_t b = B > 0 ? bb : a, p = B > 0 ? a * B + bb : a;
+        const double s = scale ? (double)scale[p] : 1.0;
+        const T *y = Y + b * (int64_t)N * D;
+        const T *w = W + p * (int64_t)Mc * ldw;
+        for (int n = threadIdx.x; n < N; n += NT) {
+            double yn[DMAX], ys = 0.0, xy = 0.0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                yn[k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
+                ys = fma(yn[k], yn[k], ys);
+                xy = fma(xm[k], yn[k], xy);
+            }
+            const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+            const bool up = m >= 1, dn = m < Mc, lf = n >= 1, rt = n < Nc;
+            const double w00 = (up && lf) ? (double)w[(int64_t)(m - 1) * ldw + n - 1] : 0.0;
+            const double w01 = (up && rt) ? (double)w[(int64_t)(m - 1) * ldw + n] : 0.0;
+            const double w10 = (dn && lf) ? (double)w[(int64_t)m * ldw + n - 1] : 0.0;
+            const double w11 = (dn && rt) ? (double)w[(int64_t)m * ldw + n] : 0.0;
+            const double c = s * (((w00 + w11) - w01) - w10) * g;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xm[k] - yn[k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        const double v = block_sum<NT>(acc[k], red);
+        if (threadIdx.x == 0 && k < D) gX[(a * M + m) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
+    }
+}
+
+template <typename T, int DMAX, int NT>
+int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
+                        int64_t B, int M, int N, int D, T *out, hipStream_t s) {
+    if (kind == 0) {
+        constexpr int RS = 64 / DMAX;
+        const int strips = (M - 1 + RS - 1) / RS;
+        const int64_t blocks = A * strips;
+        if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_static_linear_adj<T, DMAX, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, Y, W, ldw, scale, B,
+                           M, N, D, strips, out);
+    } else {
+        const int64_t blocks = A * M;
+        if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_static_rbf_adj<T, DMAX, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, X, Y, W, ldw, scale, B, M,
+                           N, D, 1.0 / param, out);
+    }
+    return check_launch();
+}
+
+template <typename T, int DMAX>
+int launch_static_adj_nt(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
+                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
+    if (N <= 80) return launch_static_adj_d<T, DMAX, 64>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    return launch_static_adj_d<T, DMAX, 128>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+}
+
 template <typename T, int DMAX>
 int launch_static_d(int kind, double param, const T *X, const T *Y, int64_t A, int64_t B, int M, int N, int D, T *inc,
                     int64_t ld, hipStream_t s) {
@@ -131,6 +272,22 @@ int launch_static_increments(int kind, double param, const T *X, const T *Y, int
     if (D <= 32) return launch_static_d<T, 32>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);
     return SK_ERR_UNSUPPORTED;   // wide paths: the caller uses the generic static kernel + sk_increments
 }
+
+// out: kind 0 -> T [A, M-1, D] (the caller differences it along M and applies scale^2); kind 1 -> dL/dX [A, M, D]
+template <typename T>
+int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
+                          int64_t B, int M, int N, int D, T *out, hipStream_t s) {
+    if (D <= 4) return launch_static_adj_nt<T, 4>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    if (D <= 8) return launch_static_adj_nt<T, 8>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    if (D <= 16) return launch_static_adj_nt<T, 16>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    if (D <= 32) return launch_static_adj_nt<T, 32>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    return SK_ERR_UNSUPPORTED;
+}
+
+template int launch_static_adjoint<double>(int, double, const double *, const double *, const double *, int64_t,
+                                           const double *, int64_t, int64_t, int, int, int, double *, hipStream_t);
+template int launch_static_adjoint<float>(int, double, const float *, const float *, const float *, int64_t, const float *,
+                                          int64_t, int64_t, int, int, int, float *, hipStream_t);
 
 template int launch_static_increments<double>(int, double, const double *, const double *, int64_t, int64_t, int, int, int,
                                               double *, int64_t, hipStream_t);

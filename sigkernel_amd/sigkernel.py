@@ -59,6 +59,32 @@ def _increments(be, static_kernel, Xd, Yd, gram):
     return be.increments(G)
 
 
+def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram):
+    """dL/dX for one tile: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
+
+    Fused route (LinearKernel / RBFKernel): sk_static_increments -> sk_solve_adj -> sk_static_adjoint.
+    Generic route (any duck-typed static kernel): G with autograd -> sk_increments -> sk_solve_adj ->
+    sk_increments_adjoint (scaled by the upstream gradient) -> one vector-Jacobian product through the static kernel;
+    this replaces the reference's h = 1e-9 finite difference (sigkernel.py:313-341, :472-500)."""
+    fused = _fused_static(static_kernel, gram)
+    if fused is not None and hasattr(be, "static_adjoint"):
+        inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
+        if inc is not None:
+            _, W = be.solve_adj(inc, dyadic, naive)
+            del inc
+            return be.static_adjoint(fused[0], fused[1], Xt, Yt, W, go, gram)
+    Xg = Xt.clone().requires_grad_(True)
+    with torch.enable_grad():
+        G = static_kernel.Gram_matrix(Xg, Yt) if gram else static_kernel.batch_kernel(Xg, Yt)
+    inc = be.increments(G.detach().contiguous())
+    _, W = be.solve_adj(inc, dyadic, naive)
+    del inc
+    dG = be.increments_adjoint(W, go)
+    del W
+    (g,) = torch.autograd.grad(G, Xg, dG)
+    return g
+
+
 def _check_inputs(X, Y, paired):
     if X.dim() != 3 or Y.dim() != 3:
         raise ValueError("X and Y must have shape (batch, length, dim)")
@@ -100,17 +126,12 @@ class _SigKernel(torch.autograd.Function):
         grad_X = torch.zeros_like(X)
         if M >= 2 and N >= 2:
             Yd = Y.detach()
-            per_row = 8 * M * N * X.element_size()
+            fused = _fused_static(sk, False) is not None
+            per_row = (3 if fused else 8) * M * N * X.element_size()
             go = grad_output.to(X.dtype).contiguous()
             for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
-                Xt = X.detach()[a0:a1].clone().requires_grad_(True)
-                with torch.enable_grad():
-                    G = sk.batch_kernel(Xt, Yd[a0:a1])
-                inc = be.increments(G.detach().contiguous())
-                _, W = be.solve_adj(inc, d, naive)                            # sigkernel.py:282-311
-                dG = be.increments_adjoint(W, go[a0:a1].contiguous())         # replaces :313-341
-                (g,) = torch.autograd.grad(G, Xt, dG)
-                grad_X[a0:a1] = g
+                grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd[a0:a1].contiguous(),
+                                               go[a0:a1].contiguous(), d, naive, gram=False)
         return grad_X, None, None, None, None, None
 
 
@@ -130,7 +151,10 @@ class _SigKernelGram(torch.autograd.Function):
         Xd, Yd = X.detach(), Y.detach()
         K = torch.empty(A, B, dtype=X.dtype, device=X.device)
         # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
-        per_row = (1 if _fused_static(static_kernel, True) is not None else 2) * B * M * N * X.element_size()
+        fused = _fused_static(static_kernel, True) is not None
+        per_row = (1 if fused else 2) * B * M * N * X.element_size()
+        if X.requires_grad:   # tile like backward will, so that the caching allocator can reuse the same blocks
+            per_row = (3 if fused else 8) * B * M * N * X.element_size()
         # `sym` is accepted and, like the reference's GPU path (sigkernel.py:366-382), not needed:
         # every pair is solved; the result equals the sym=False one.
         for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
@@ -148,18 +172,11 @@ class _SigKernelGram(torch.autograd.Function):
         if M >= 2 and N >= 2:
             Yd = Y.detach()
             go = grad_output.to(X.dtype).contiguous()
-            per_row = 8 * B * M * N * X.element_size()
+            fused = _fused_static(sk, True) is not None
+            per_row = (3 if fused else 8) * B * M * N * X.element_size()
             for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
-                Xt = X.detach()[a0:a1].clone().requires_grad_(True)
-                with torch.enable_grad():
-                    G = sk.Gram_matrix(Xt, Yd)
-                inc = be.increments(G.detach().contiguous())
-                _, W = be.solve_adj(inc, d, naive)                            # sigkernel.py:438-470
-                del inc
-                dG = be.increments_adjoint(W, go[a0:a1].contiguous())         # replaces :472-500 and :410-416
-                del W
-                (g,) = torch.autograd.grad(G, Xt, dG)
-                grad_X[a0:a1] = g
+                grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd.contiguous(),
+                                               go[a0:a1].contiguous(), d, naive, gram=True)
         # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
         # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
         if ctx.needs_input_grad[1]:

@@ -23,6 +23,18 @@ class OracleBackend:
         G = k.Gram_matrix(X, Y) if gram else k.batch_kernel(X, Y)
         return self.increments(G)
 
+    def static_adjoint(self, kind, param, X, Y, W, scale, gram):
+        import sigkernel_amd
+        k = sigkernel_amd.LinearKernel(param) if kind == 0 else sigkernel_amd.RBFKernel(param)
+        if kind == 0 and gram:
+            k = sigkernel_amd.LinearKernel()
+        Xg = X.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            G = k.Gram_matrix(Xg, Y) if gram else k.batch_kernel(Xg, Y)
+        dG = self.increments_adjoint(W, scale)
+        (g,) = torch.autograd.grad(G, Xg, dG)
+        return g
+
     def increments_adjoint(self, W, scale=None):
         dG = torch.from_numpy(O.increments_adjoint(W.detach().double().numpy())).to(W.dtype)
         if scale is not None:

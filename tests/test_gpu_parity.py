@@ -185,6 +185,46 @@ def test_fused_static_increments_match_the_generic_route(be, kind, A, B, M, N, D
             assert np.max(np.abs(gotp.double().cpu().numpy() - wantp)) <= tol * max(1.0, float(Gp.abs().max()))
 
 
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+@pytest.mark.parametrize("A,B,M,N,D", [(3, 4, 10, 20, 2), (2, 3, 128, 128, 8), (5, 2, 64, 64, 4), (2, 2, 70, 131, 17), (1, 1, 2, 2, 1)])
+def test_fused_static_adjoint_matches_autograd_through_the_static_kernel(be, kind, A, B, M, N, D):
+    gen = torch.Generator().manual_seed(7 + A * 100 + M + N + D)
+    X = (walk(gen, A, M, D) * 3).to(DEV)
+    Y = (walk(gen, B, N, D) * 3).to(DEV)
+    for scale in ((1.0, 0.7) if kind == "linear" else (0.5, 2.0)):
+        k = sigkernel_amd.LinearKernel(scale) if kind == "linear" else sigkernel_amd.RBFKernel(scale)
+        code = 0 if kind == "linear" else 1
+        for gram in (True, False):
+            Xt, Yt = (X, Y) if gram else (X[:min(A, B)].contiguous(), Y[:min(A, B)].contiguous())
+            shape = (Xt.shape[0], Yt.shape[0], M - 1, N - 1) if gram else (Xt.shape[0], M - 1, N - 1)
+            W = padded(np.random.default_rng(3).normal(size=shape))
+            go = torch.randn(shape[:-2], generator=gen, dtype=torch.float64).to(DEV)
+            Xg = Xt.clone().requires_grad_(True)
+            G = k.Gram_matrix(Xg, Yt) if gram else k.batch_kernel(Xg, Yt)
+            (want,) = torch.autograd.grad(G, Xg, be.increments_adjoint(W, go))
+            param = (1.0 if gram else scale) if kind == "linear" else scale
+            got = be.static_adjoint(code, param, Xt, Yt, W, go, gram)
+            assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
+
+
+class _SubclassedLinear(sigkernel_amd.LinearKernel):
+    """Not `type(...) is LinearKernel`: must take the generic Gram_matrix / autograd route."""
+
+
+def test_generic_static_kernel_route_agrees_with_the_fused_one(be):
+    gen = torch.Generator().manual_seed(11)
+    X, Y = walk(gen, 6, 40, 3).to(DEV), walk(gen, 5, 33, 3).to(DEV)
+    w = torch.randn(6, 5, generator=gen, dtype=torch.float64).to(DEV)
+    res = []
+    for k in (sigkernel_amd.LinearKernel(), _SubclassedLinear()):
+        sk = sigkernel_amd.SigKernel(k, 1)
+        Xg = X.clone().requires_grad_(True)
+        K = sk.compute_Gram(Xg, Y)
+        (K * w).sum().backward()
+        res.append((K.detach().cpu().numpy(), Xg.grad.cpu().numpy()))
+    assert rel_err(res[0][0], res[1][0]) <= 1e-12 and rel_err(res[0][1], res[1][1]) <= 1e-10
+
+
 # ---------------------------------------------------------------------------------------------
 # API level, against the golden vectors produced by the real reference
 # ---------------------------------------------------------------------------------------------
