@@ -124,6 +124,20 @@ int sk_solve_fwd_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc,
 int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      float *out_final, float *out_grid, double *out_edges, void *stream);
 
+/* Forward solve with the LINEAR static kernel fused in (csrc/sk_wave_fused.hip): the increments
+ * s^2 <x[p+1]-x[p], y[q+1]-y[q]> are formed inside the sweep, nothing of size P*M*N ever exists in HBM.
+ * Replaces, for LinearKernel, the whole of sigkernel.py:362-382 (Gram) / :216-234 (paired).
+ *   dXr [A][Mrows][8] fp64: s^2 (x[p+1]-x[p]) for p < Mc, zero for the padding rows (Mrows >= 256 is always enough)
+ *                           and padding dims (path dim <= 8);
+ *   dYt [Bn][8][Ncp] fp64: y[q+1]-y[q], dimension-major, zero-padded; Ncp = Nc rounded up to a multiple of 16;
+ *   B > 0: Gram (Bn = B, pair (a,b) at a*B+b); B == 0: paired (Bn = A).  out_final [P].
+ * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M-1 > 256/128/64 for dyadic 0/1/2):
+ * use sk_static_increments_* + sk_solve_fwd_*. */
+int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                            int dyadic, int scheme, double *out_final, void *stream);
+int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                            int dyadic, int scheme, float *out_final, void *stream);
+
 /* ---- adjoint solve ------------------------------------------------------------------------
  * W[p][a][b] = d K_p[MM][NN] / d inc_c[p][a][b] by the reference's variation-of-parameters
  * formula:  W = 4^-d * sum over the fine cells (i,j) of coarse cell (a,b) of

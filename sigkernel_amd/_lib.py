@@ -40,6 +40,8 @@ SIGNATURES = {
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
@@ -165,6 +167,32 @@ class HipBackend:
             _check(fn(int(kind), float(param), _ptr(X), _ptr(Y), A, B if gram else 0, M, N, D, _ptr(out), ld, _stream(X)),
                    "sk_static_increments")
         return out[..., : N - 1]
+
+    def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram):
+        """K[MM][NN] for the LINEAR static kernel with the increments formed inside the solver (nothing of size
+        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band)."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if D > 8 or dyadic > 2 or Mc < 1 or Nc < 1 or Mc > 64 * (4 >> min(dyadic, 2)):
+            return None
+        Mrows, Ncp = 256, (Nc + 15) // 16 * 16
+        dev = X.device
+        dXr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
+        dXr[:, :Mc, :D] = (X[:, 1:] - X[:, :-1]).double() * (float(scale) ** 2)
+        dYt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
+        dYt[:, :D, :Nc] = (Y[:, 1:] - Y[:, :-1]).double().transpose(1, 2)
+        out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
+        with torch.cuda.device(dev):
+            fn = getattr(load(), "sk_solve_fwd_linear_" + _suffix(X))
+            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic),
+                    SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(out), _stream(X))
+        if rc == 2:
+            return None
+        _check(rc, "sk_solve_fwd_linear")
+        return out
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

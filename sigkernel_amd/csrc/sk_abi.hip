@@ -147,6 +147,23 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
     return solve_fwd<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, out_grid, out_edges, stream);
 }
 
+int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                            int dyadic, int scheme, double *out_final, void *stream) {
+    if (!dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, (hipStream_t)stream);
+}
+int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                            int dyadic, int scheme, float *out_final, void *stream) {
+    if (!dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, (hipStream_t)stream);
+}
+
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {
     (void)elem_size;
     if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;

@@ -42,6 +42,11 @@ template <typename T>
 int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
                     hipStream_t s);
 
+// ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
+template <typename TO>
+int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            TO *out, hipStream_t s);
+
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);

@@ -1,0 +1,330 @@
+// sk_wave_fused.hip -- forward solver with the LINEAR static kernel fused in: the increments
+//     inc[p][q] = s^2 <x[p+1]-x[p], y[q+1]-y[q]>
+// are formed inside the sweep from the path differences, so neither G_static nor the increment matrix exists in HBM
+// (SURVEY 8(f) #1 taken to its end).  The sweep is the one of sk_wave.hip (skewed row strips in registers, DPP neighbour
+// exchange, persistent pipelining over pairs); what changes is where a macro-step's RC x 2 coarse increments come from:
+//   * a lane keeps the (scaled) differences of ITS rows in registers, dxr[RC][8], reloaded when it starts a new pair
+//     from a small LDS ring that the wave fills 8 lanes at a time, one macro-step ahead of the first lane that needs it;
+//   * the y differences of the 2 coarse columns of the macro-step, dy[8][2], are read from an LDS ring over the lane
+//     group's virtual column stream: slabs of 8 units x 8 dims (1 KiB, one LDS-DMA instruction every 8 macro-steps,
+//     fetched a whole slab ahead), slab pitch 1152 B so that lanes 8 apart -- same unit, neighbouring slabs -- hit
+//     different halves of the 256-byte bank row;
+//   * 32 extra FMAs per macro-step (RC*2 coarse cells x 8 dims) replace the increment read.
+// HBM traffic: the paths (MBs).  The kernel is bound by fp64 issue.  Scope: dim <= 8 (zero-padded), one band per
+// pair (M-1 <= 64*RC), dyadic <= 2; everything else takes sk_static_increments + sk_solve_fwd.
+#include "sk_wave_common.h"
+
+namespace sk {
+namespace {
+
+constexpr int FD = 8;              // dims carried (inputs are zero-padded to 8)
+constexpr int Y_SLAB_PITCH = FD * 128 + 128;
+constexpr int X_SLOTS = 3;
+
+struct FusedParams {
+    const double *dXr;   // [A][Mrows][8]: s^2 (x[p+1]-x[p]), zero rows/dims beyond Mc / D
+    const double *dYt;   // [Bn][8][Ncp]: y[q+1]-y[q], dimension-major, zero columns/dims beyond Nc / D
+    void *out;           // [P] K[MM][NN]
+    int64_t P, B;        // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p)
+    int Mrows, Ncp;
+    int Mc, Nc, NUp, logL, PPG, n_steps;
+    int u_f, lam_f, sel_f, naive;
+};
+
+template <int N>
+__device__ __forceinline__ void lds_read_units(d2_t (&v)[N], unsigned addr);
+template <>
+__device__ __forceinline__ void lds_read_units<8>(d2_t (&v)[8], unsigned a) {
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %8 offset:128\n\t"
+                 "ds_read_b128 %2, %8 offset:256\n\t"
+                 "ds_read_b128 %3, %8 offset:384\n\t"
+                 "ds_read_b128 %4, %8 offset:512\n\t"
+                 "ds_read_b128 %5, %8 offset:640\n\t"
+                 "ds_read_b128 %6, %8 offset:768\n\t"
+                 "ds_read_b128 %7, %8 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a)
+                 : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a)
+                 : "memory");
+}
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
+__global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm) {
+    constexpr int CW = 2;
+    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int XSLAB = RC * 512;   // 8 lanes x RC rows x 64 B
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const unsigned lds0 = lds_offset(lds);
+
+    const int lane = threadIdx.x;
+    const int L = 1 << prm.logL, G = WAVE >> prm.logL;
+    const int lam = lane & (L - 1), grp = lane >> prm.logL;
+    const int NUp = prm.NUp;
+    const int NSLAB = (L >> 3) + 2;                       // y slabs resident per lane group
+    const unsigned y_bytes = (unsigned)(NSLAB * Y_SLAB_PITCH);
+    const unsigned x_base0 = (unsigned)G * y_bytes;       // x rings behind all y rings
+    const double sc = 1.0 / (double)(1 << (2 * DY));
+    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+
+    // ---- consumer state: virtual unit v = t - lam; one band per pair, so the row unit IS the pair ----------
+    int u, ps;
+    {
+        ps = floor_div(-lam, NUp);
+        u = -lam - ps * NUp;
+    }
+    int yslab;   // slab of the y ring holding virtual unit v
+    {
+        const int s0 = floor_div(-lam, 8);
+        yslab = ((s0 % NSLAB) + NSLAB) % NSLAB;
+    }
+    const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
+    const int64_t pair0 = ((int64_t)blockIdx.x * G + grp) * prm.PPG;
+    const bool is_top = lam == 0;
+    const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
+    // lanes NUp apart start (different) pairs at the same macro-step: one x slab per such "lap" j = lam / NUp
+    const int JMAX = (L + NUp - 1) / NUp;
+    const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * X_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
+                          (unsigned)((lam & 7) * RC * 64);
+
+    // ---- producers (uniform control; per-lane source offsets) ------------------------------------------------
+    // y slab s = virtual units [8s, 8s+8) of every lane group: dims k = lane/8, unit x = lane%8
+    auto issue_y = [&](int s) {
+        const int v0 = s * 8;
+        const int pi = v0 / NUp, u0 = v0 - pi * NUp;   // pair-in-group and first unit (NUp % 8 == 0: no straddling)
+        for (int g = 0; g < G; ++g) {
+            int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
+            if (pi >= prm.PPG || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
+            const int64_t b = prm.B > 0 ? p % prm.B : p;
+            const double *src = prm.dYt + ((b * FD + (lane >> 3)) * (int64_t)prm.Ncp + (int64_t)(u0 + (lane & 7)) * 2);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + (s % NSLAB) * Y_SLAB_PITCH), 16, 0, 0);
+        }
+    };
+    // x slabs for the lanes that start a pair during macro-steps [t0, t0+8): lanes lam0 + j*NUp .. +7 start pair
+    // t0/NUp - j, rows (lam0 + j*NUp .. +7)*RC of its x
+    auto issue_x = [&](int t0) {
+        const int q0 = t0 / NUp, lam0 = t0 - q0 * NUp;
+        for (int j = 0; j < JMAX; ++j) {
+            const int lamj = lam0 + j * NUp, pi = q0 - j;
+            if (lamj >= L) break;
+            for (int g = 0; g < G; ++g) {
+                int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
+                if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
+                const int64_t a = prm.B > 0 ? p / prm.B : p;
+                const char *src = reinterpret_cast<const char *>(prm.dXr + (a * prm.Mrows + (int64_t)lamj * RC) * FD);
+                char *dst = lds + x_base0 + ((g * X_SLOTS + (t0 >> 3) % X_SLOTS) * JMAX + j) * XSLAB;
+#pragma unroll
+                for (int c = 0; c < (XSLAB + 1023) / 1024; ++c)
+                    if (c * 1024 + lane * 16 < XSLAB)
+                        __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, (lds_void *)(dst + c * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    double dxr[RC][FD];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int j = 0; j < FD; ++j) dxr[k][j] = 0.0;
+    double left[R], bot[S], corner = 1.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) left[i] = 1.0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) bot[i] = 1.0;
+
+    issue_y(0);
+    issue_x(0);
+    for (int t = 0; t < prm.n_steps; ++t) {
+        if ((t & 7) == 0) {
+            // everything issued 8 macro-steps ago has had a whole slab period to land
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue_y((t >> 3) + 1);
+            issue_x(t + 8);
+        }
+
+        // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows
+        if (u == 0) {
+            corner = 1.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) left[i] = 1.0;
+            const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                d2_t xv[4];
+                lds_read_units<4>(xv, xa + k * 64u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+            }
+        }
+
+        // -- y differences of the two coarse columns of this macro-step, all 8 dims
+        d2_t dyv[FD];
+        lds_read_units<8>(dyv, my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4)));
+
+        // -- top row of the block from the lane above
+        double top[S];
+        if (FULLWAVE) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const double sh = dpp_shr1(bot[i], 1.0);
+                top[i] = is_top ? 1.0 : sh;
+            }
+        }
+
+        // -- increments and coefficients per coarse cell
+        double ca[RC][CW], cbm[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                double g = 0.0;
+#pragma unroll
+                for (int j = 0; j < FD; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                if (NAIVE) {
+                    ca[k][q] = fma(g, c_half, 1.0);
+                    cbm[k][q] = 1.0;
+                } else {
+                    const double g2 = g * g;
+                    ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                    cbm[k][q] = fma(g2, -c_12, 1.0);
+                }
+            }
+
+        // -- sweep the R x S block
+        double cand[RC][CW];
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+            double above = top[cc];
+            double diag = cc == 0 ? corner : top[cc - 1];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const double a = ca[rr >> DY][cc >> DY], b = cbm[rr >> DY][cc >> DY];
+                const double k10 = left[rr];
+                double v;
+                if (NAIVE) v = fma(above, a, fma(k10, a, -diag));
+                else v = fma(above, a, fma(k10, a, -(diag * b)));
+                diag = k10;
+                above = v;
+                left[rr] = v;
+                if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
+            }
+            bot[cc] = above;
+        }
+        corner = top[S - 1];
+
+        // -- K[MM][NN] of a pair
+        if (u == my_uf) {
+            if (ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+                double v = cand[0][0];
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        double cv = cand[k][q];
+                        asm volatile("" : "+v"(cv));
+                        if (k * CW + q == prm.sel_f) v = cv;
+                    }
+                static_cast<TO *>(prm.out)[pair0 + ps] = (TO)v;
+            }
+        }
+
+        // -- advance
+        u += 1;
+        if ((u & 7) == 0) {
+            yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
+            if (u == NUp) { u = 0; ps += 1; }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
+int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    auto kern = k_fwd_fused_linear<TO, DY, NAIVE, FULLWAVE>;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    return check_launch();
+}
+
+template <typename TO, int DY>
+int launch_fused_dy(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    const bool full = prm.logL == 6;
+    if (prm.naive)
+        return full ? launch_fused_one<TO, DY, true, true>(prm, blocks, lds_bytes, s)
+                    : launch_fused_one<TO, DY, true, false>(prm, blocks, lds_bytes, s);
+    return full ? launch_fused_one<TO, DY, false, true>(prm, blocks, lds_bytes, s)
+                : launch_fused_one<TO, DY, false, false>(prm, blocks, lds_bytes, s);
+}
+
+}  // namespace
+
+// dXr [A][Mrows][8], dYt [Bn][8][Ncp] (see FusedParams).  SK_ERR_UNSUPPORTED outside the kernel's scope.
+template <typename TO>
+int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            TO *out, hipStream_t s) {
+    const int DY = g.dyadic;
+    if (DY > 2) return SK_ERR_UNSUPPORTED;
+    const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
+    const int NU = (g.Nc + 1) / 2;
+    const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
+    if (Ncp < NUp * 2 || (Ncp & 1)) return SK_ERR_UNSUPPORTED;
+    int logL = 3;
+    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
+    const int L = 1 << logL;
+    if (L * RC < g.Mc) return SK_ERR_UNSUPPORTED;   // more than one band per pair
+    if (Mrows < L * RC) return SK_ERR_UNSUPPORTED;
+    const int G = WAVE / L;
+    const int JMAX = (L + NUp - 1) / NUp;
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);
+    if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
+
+    int waves_per_cu = (int)((160 * 1024) / lds_bytes);
+    if (waves_per_cu > 8) waves_per_cu = 8;
+    const int wpc_env = env_int("SK_FUSED_WPC", 0);
+    if (wpc_env > 0 && waves_per_cu > wpc_env) waves_per_cu = wpc_env;
+    else if (waves_per_cu > 4) waves_per_cu &= ~3;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    const int64_t max_waves = 256LL * waves_per_cu;
+    int64_t waves = (g.P + G - 1) / G;
+    if (waves > max_waves) waves = max_waves;
+    int64_t PPG = (g.P + waves * G - 1) / (waves * G);
+    waves = (g.P + PPG * G - 1) / (PPG * G);
+    if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+
+    FusedParams prm;
+    prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.P = g.P; prm.B = B;
+    prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
+    prm.n_steps = (int)(PPG * NUp + (L - 1));
+    prm.u_f = (g.Nc - 1) / 2;
+    prm.lam_f = ((g.Mc - 1) / RC) % L;
+    prm.sel_f = ((g.Mc - 1) % RC) * 2 + (g.Nc - 1) % 2;
+    prm.naive = g.naive;
+    (void)A;
+    switch (DY) {
+        case 0: return launch_fused_dy<TO, 0>(prm, (int)waves, lds_bytes, s);
+        case 1: return launch_fused_dy<TO, 1>(prm, (int)waves, lds_bytes, s);
+        default: return launch_fused_dy<TO, 2>(prm, (int)waves, lds_bytes, s);
+    }
+}
+
+template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double *,
+                                             hipStream_t);
+template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, float *,
+                                            hipStream_t);
+
+}  // namespace sk

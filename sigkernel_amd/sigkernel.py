@@ -47,6 +47,15 @@ def _fused_static(static_kernel, gram):
     return None
 
 
+def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram):
+    """Whole forward in one kernel when the static kernel is exactly LinearKernel and the shape fits
+    (sk_solve_fwd_linear_*: increments formed inside the solver); None otherwise."""
+    if type(static_kernel) is LinearKernel and hasattr(be, "solve_fwd_fused_linear"):
+        return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), 1.0 if gram else float(static_kernel.scale),
+                                         dyadic, naive, gram)
+    return None
+
+
 def _increments(be, static_kernel, Xd, Yd, gram):
     """Coarse increments of the static Gram for a tile: fused kernel when available, else the reference's route
     (static kernel in torch -> 4-corner difference, sigkernel.py:216-217 / :362-363)."""
@@ -110,6 +119,9 @@ class _SigKernel(torch.autograd.Function):
         if M < 2 or N < 2:  # a single point: the grid is its boundary, k = 1 (sigkernel.py:212-253 with MM = 0)
             return torch.ones(A, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
+        K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False)
+        if K is not None:
+            return K
         K = torch.empty(A, dtype=X.dtype, device=X.device)
         per_row = 2 * M * N * X.element_size()
         for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
@@ -149,6 +161,9 @@ class _SigKernelGram(torch.autograd.Function):
         if M < 2 or N < 2:
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
+        K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=True)
+        if K is not None:
+            return K
         K = torch.empty(A, B, dtype=X.dtype, device=X.device)
         # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
         fused = _fused_static(static_kernel, True) is not None

@@ -207,6 +207,36 @@ def test_fused_static_adjoint_matches_autograd_through_the_static_kernel(be, kin
             assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
 
 
+@pytest.mark.parametrize("A,B,M,N,D,d", [(3, 4, 10, 20, 2, 1), (2, 3, 128, 128, 8, 1), (70, 9, 64, 64, 4, 2), (5, 130, 33, 17, 3, 0),
+                                            (1, 1, 2, 2, 1, 0), (9, 7, 128, 40, 8, 1), (4, 4, 65, 128, 5, 2), (300, 300, 20, 24, 8, 1),
+                                            (2, 2, 257, 30, 6, 0)])
+@pytest.mark.parametrize("naive", [False, True])
+def test_fused_linear_forward_matches_oracle(be, A, B, M, N, D, d, naive):
+    gen = torch.Generator().manual_seed(A + B + M + N + D + d)
+    Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
+    X, Y = Xc.to(DEV), Yc.to(DEV)
+    K = be.solve_fwd_fused_linear(X, Y, 1.0, d, naive, gram=True)
+    assert K is not None, "shape is inside the fused kernel's scope"
+    G = torch.einsum("ipk,jqk->ijpq", Xc, Yc).numpy()
+    want = O.solve_coarse(O.increments(G), d, naive, nthreads=8)
+    assert rel_err(K.cpu().numpy(), want) <= 1e-11
+    n = min(A, B)
+    Kp = be.solve_fwd_fused_linear(X[:n].contiguous(), Y[:n].contiguous(), 0.8, d, naive, gram=False)
+    Gp = torch.bmm(0.8 * Xc[:n], (0.8 * Yc[:n]).transpose(1, 2)).numpy()
+    assert rel_err(Kp.cpu().numpy(), O.solve_coarse(O.increments(Gp), d, naive, nthreads=8)) <= 1e-11
+    K32 = be.solve_fwd_fused_linear(X.float(), Y.float(), 1.0, d, naive, gram=True)
+    np.testing.assert_allclose(K32.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_linear_forward_scope(be):
+    X = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
+    assert be.solve_fwd_fused_linear(X, X, 1.0, 1, False, True) is None          # 299 coarse rows > 128: two bands
+    Xs = X[:, :20].contiguous()
+    assert be.solve_fwd_fused_linear(Xs, Xs, 1.0, 3, False, True) is None      # dyadic 3
+    X9 = torch.zeros(2, 20, 9, dtype=torch.float64, device=DEV)
+    assert be.solve_fwd_fused_linear(X9, X9, 1.0, 1, False, True) is None        # dim 9
+
+
 class _SubclassedLinear(sigkernel_amd.LinearKernel):
     """Not `type(...) is LinearKernel`: must take the generic Gram_matrix / autograd route."""
 
