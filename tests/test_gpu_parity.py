@@ -308,6 +308,33 @@ def test_api_readme_example(be):
     assert abs(float(sk.compute_distance(X, Y)) - float(c["distance"])) <= 1e-11
 
 
+@pytest.mark.parametrize("name", ["gram_c2mini_rbf_d1", "gram_c3mini_lin_d1", "gram_c4mini_rbf_d2", "gram_lin_d0_ragged"])
+def test_api_float32_tensors(be, name):
+    """The reference's CPU path rejects float32 (cython_backend.pyx:7,64); ours accepts it (fp32 I/O, fp64 PDE state) and
+    is held to the reference's own fp32 bar (test_mps.py:32) against the fp64 fixtures."""
+    c = golden(name)
+    X, Y, w = (torch.from_numpy(c[k]).float().to(DEV) for k in ("X", "Y", "w"))
+    sk = _sk(c)
+    Xg = X.clone().requires_grad_(True)
+    K = sk.compute_Gram(Xg, Y)
+    assert K.dtype == torch.float32
+    np.testing.assert_allclose(K.detach().cpu().numpy(), c["gram"], rtol=F32_RTOL, atol=F32_ATOL)
+    (K * w).sum().backward()
+    assert Xg.grad.dtype == torch.float32
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_w"]) <= 2e-4
+    n = c["paired"].shape[0]
+    np.testing.assert_allclose(sk.compute_kernel(X[:n], Y[:n]).cpu().numpy(), c["paired"], rtol=F32_RTOL, atol=F32_ATOL)
+
+
+def test_api_rejects_other_dtypes_and_cpu(be):
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 0)
+    X = torch.rand(2, 5, 2, device=DEV).half()
+    with pytest.raises((TypeError, RuntimeError)):
+        sk.compute_Gram(X, X)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sk.compute_Gram(torch.rand(2, 5, 2, dtype=torch.float64), torch.rand(2, 5, 2, dtype=torch.float64))
+
+
 def test_api_tiling_independence_on_device(be):
     c = golden("gram_c2mini_rbf_d1")
     X, Y = torch.from_numpy(c["X"]).to(DEV), torch.from_numpy(c["Y"]).to(DEV)
