@@ -6,6 +6,9 @@ crispitagorico/sigkernel: Python host code on PyTorch-ROCm calling hand-written 
 """
 from .static_kernels import LinearKernel, RBFKernel
 from .sigkernel import SigKernel, _SigKernel, _SigKernelGram
+from .stats import SigCHSIC, c_alpha, hypothesis_test
+from .transforms import add_time, lead_lag, transform
 
-__all__ = ["SigKernel", "LinearKernel", "RBFKernel", "_SigKernel", "_SigKernelGram"]
+__all__ = ["SigKernel", "LinearKernel", "RBFKernel", "_SigKernel", "_SigKernelGram", "hypothesis_test", "SigCHSIC",
+           "c_alpha", "transform", "add_time", "lead_lag"]
 __version__ = "0.1.0"

@@ -150,8 +150,32 @@ def kat_case():
     save("kat_straight_lines", X=X, Y=Y, **vals)
 
 
+# ---------------------------------------------------------------------------------------------
+# 5. callers either side of the path: path transforms, hypothesis test statistic, SigCHSIC
+# ---------------------------------------------------------------------------------------------
+def wrappers_case():
+    import contextlib, io
+    gen = torch.Generator().manual_seed(5)
+    P = walk(gen, 4, 9, 2)
+    out = dict(paths=P)
+    for at in (0, 1):
+        for ll in (0, 1):
+            out["transform_at%d_ll%d" % (at, ll)] = ref.transform(P.numpy(), at=bool(at), ll=bool(ll), scale=0.5)
+    X, Y, Z = walk(gen, 6, 8, 2) * 2, walk(gen, 6, 8, 2) * 2, walk(gen, 6, 7, 3) * 2
+    k = ref.RBFKernel(1.0)
+    out.update(X=X, Y=Y, Z=Z, chsic=ref.SigCHSIC(X, Y, Z, k, dyadic_order=1, eps=0.1))
+    sk = ref.SigKernel(k, 0)
+    out.update(mmd_d0=sk.compute_mmd(X, Y), c_alpha=ref.c_alpha(6, 0.99))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ref.hypothesis_test(X, Y, k, confidence_level=0.99, dyadic_order=0)
+    out["verdict_rejected"] = int("rejected" in buf.getvalue())
+    save("wrappers", **out)
+
+
 if __name__ == "__main__":
     solver_cases()
     readme_case()
     gram_cases()
     kat_case()
+    wrappers_case()
