@@ -147,6 +147,48 @@ class _SigKernel(torch.autograd.Function):
         return grad_X, None, None, None, None, None
 
 
+_SYM_TILES = 8   # row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
+
+
+def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes, rows_factor=None):
+    """K[a, b] for every pair of Xd x Yd (no autograd): fused kernel, or increments + solver tiled over rows of Xd."""
+    K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, naive, gram=True)
+    if K is not None:
+        return K
+    A, B, M, N = Xd.shape[0], Yd.shape[0], Xd.shape[1], Yd.shape[1]
+    K = torch.empty(A, B, dtype=Xd.dtype, device=Xd.device)
+    fused = _fused_static(static_kernel, True) is not None
+    # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
+    per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
+    for a0, a1 in _tiles(A, per_row, _budget(Xd.device, workspace_bytes)):
+        inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
+        K[a0:a1] = be.solve_fwd(inc, dyadic_order, naive)                        # :378 / :395
+    return K
+
+
+def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes):
+    """compute_Gram(X, X, sym=True) without a gradient: only the blocks on and above the diagonal of a T x T tiling are
+    solved and mirrored, like the reference's CPU solver does pair by pair (cython_backend.pyx:74-97; its GPU path
+    ignores `sym`).  The result is exactly symmetric."""
+    A = Xd.shape[0]
+    K = torch.empty(A, A, dtype=Xd.dtype, device=Xd.device)
+    cells = float(A) * A * ((Xd.shape[1] - 1) << dyadic_order) ** 2
+    # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of
+    # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
+    T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= 5e9) else 1
+    step = -(-A // T)
+    for r0 in range(0, A, step):
+        r1 = min(r0 + step, A)
+        blk = _gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes)
+        K[r0:r1, r0:] = blk
+        if r1 < A:
+            K[r1:, r0:r1] = blk[:, r1 - r0:].t()
+    # the diagonal blocks were solved in full: symmetrise them to the upper triangle too
+    iu = torch.triu_indices(A, A, offset=1, device=Xd.device)
+    K[iu[1], iu[0]] = K[iu[0], iu[1]]
+    return K
+
+
 class _SigKernelGram(torch.autograd.Function):
     """Gram matrix k_sig(x_i, y_j) -- the reference's ``_SigKernelGram`` (sigkernel.py:347-416)."""
 
@@ -161,21 +203,15 @@ class _SigKernelGram(torch.autograd.Function):
         if M < 2 or N < 2:
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
-        K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=True)
-        if K is not None:
-            return K
-        K = torch.empty(A, B, dtype=X.dtype, device=X.device)
-        # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
+        # `sym`: the reference's GPU path ignores it (sigkernel.py:366-382) and its CPU path silently assumes X is Y.
+        # Here it halves the work when that assumption can be checked (same storage) and no gradient is needed.
+        if (sym and not X.requires_grad and not Y.requires_grad and Xd.shape == Yd.shape
+                and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()):
+            return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes)
         fused = _fused_static(static_kernel, True) is not None
-        per_row = (1 if fused else 2) * B * M * N * X.element_size()
-        if X.requires_grad:   # tile like backward will, so that the caching allocator can reuse the same blocks
-            per_row = (3 if fused else 8) * B * M * N * X.element_size()
-        # `sym` is accepted and, like the reference's GPU path (sigkernel.py:366-382), not needed:
-        # every pair is solved; the result equals the sym=False one.
-        for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
-            inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
-            K[a0:a1] = be.solve_fwd(inc, dyadic_order, _naive_solver)               # :378 / :395
-        return K
+        # with a gradient pending, tile like backward will, so that the caching allocator can reuse the same blocks
+        rows_factor = (3 if fused else 8) if X.requires_grad else None
+        return _gram_block(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, workspace_bytes, rows_factor)
 
     @staticmethod
     def backward(ctx, grad_output):

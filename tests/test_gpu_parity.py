@@ -335,6 +335,29 @@ def test_api_rejects_other_dtypes_and_cpu(be):
         sk.compute_Gram(torch.rand(2, 5, 2, dtype=torch.float64), torch.rand(2, 5, 2, dtype=torch.float64))
 
 
+@pytest.mark.parametrize("kern", ["linear", "rbf"])
+@pytest.mark.parametrize("A,M", [(5, 40), (64, 40), (150, 40), (256, 150)])
+def test_symmetric_gram_shortcut(be, kern, A, M):
+    """sym=True on X against itself without a gradient solves only the blocks on/above the diagonal (large problems)."""
+    gen = torch.Generator().manual_seed(A)
+    X = walk(gen, A, M, 3).to(DEV)
+    k = sigkernel_amd.LinearKernel() if kern == "linear" else sigkernel_amd.RBFKernel(1.0)
+    sk = sigkernel_amd.SigKernel(k, 1)
+    Ks = sk.compute_Gram(X, X, sym=True)
+    Kf = sk.compute_Gram(X, X, sym=False)
+    assert torch.equal(Ks, Ks.t())                               # exactly symmetric, like the reference's sym=True
+    assert rel_err(Ks.cpu().numpy(), Kf.cpu().numpy()) <= 1e-12
+    # with a gradient pending the full matrix is solved and the 2x rule applies (fixtures cover its values)
+    Xg = X.clone().requires_grad_(True)
+    Kg = sk.compute_Gram(Xg, Xg, sym=True)
+    assert rel_err(Kg.detach().cpu().numpy(), Kf.cpu().numpy()) <= 1e-12
+    Kg.sum().backward()
+    assert Xg.grad is not None and torch.isfinite(Xg.grad).all()
+    # different tensors with sym=True: no shortcut, plain result
+    Y = walk(gen, A, M, 3).to(DEV)
+    assert rel_err(sk.compute_Gram(X, Y, sym=True).cpu().numpy(), sk.compute_Gram(X, Y).cpu().numpy()) <= 1e-15
+
+
 def test_api_tiling_independence_on_device(be):
     c = golden("gram_c2mini_rbf_d1")
     X, Y = torch.from_numpy(c["X"]).to(DEV), torch.from_numpy(c["Y"]).to(DEV)
