@@ -139,6 +139,38 @@ def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
     assert rel_err(np.delete(W.cpu().numpy(), 2, axis=0), np.delete(want_w, 2, axis=0)) <= ADJ_TOL
 
 
+def test_fuzz_random_shapes_against_oracle(be):
+    """60 random shapes (ragged, tiny, multi-band, every dyadic order the tiled kernels cover) through every fast kernel."""
+    rng = np.random.default_rng(2024)
+    lin = sigkernel_amd.LinearKernel()
+    for it in range(60):
+        d = int(rng.integers(0, 4))
+        Mc = int(rng.integers(1, 330 >> (d // 2)))
+        Nc = int(rng.integers(1, 330 >> (d // 2)))
+        P = int(rng.integers(1, 40))
+        naive = bool(rng.integers(0, 2))
+        inc = rng.normal(scale=0.03, size=(P, Mc, Nc))
+        want = O.solve_coarse(inc, d, naive, nthreads=8)
+        got = be.solve_fwd(padded(inc), d, naive, flags=_lib.FLAG_FAST_ONLY)
+        assert rel_err(got.cpu().numpy(), want) <= FAST_TOL, (it, P, Mc, Nc, d, naive)
+        got32 = be.solve_fwd(padded(inc.astype(np.float32)), d, naive, flags=_lib.FLAG_FAST_ONLY)
+        np.testing.assert_allclose(got32.cpu().numpy(), O.solve_coarse(inc.astype(np.float32).astype(np.float64), d, naive),
+                                   rtol=F32_RTOL, atol=F32_ATOL)
+        if d <= 2 and P * (Mc << d) * (Nc << d) < 4e7:
+            wk, ww = O.adjoint_coarse(inc, d, naive, nthreads=8)
+            k, W, res = be.solve_adj(padded(inc), d, naive, return_residual=True)
+            assert rel_err(W.cpu().numpy(), ww) <= max(ADJ_TOL, 10 * float(res.max())), (it, P, Mc, Nc, d, naive)
+            assert rel_err(k.cpu().numpy(), wk) <= FAST_TOL
+        if d <= 2 and it % 3 == 0:
+            A, B, D = int(rng.integers(1, 7)), int(rng.integers(1, 7)), int(rng.integers(1, 9))
+            gen = torch.Generator().manual_seed(it)
+            Xc, Yc = walk(gen, A, Mc + 1, D) * 2, walk(gen, B, Nc + 1, D) * 2
+            K = be.solve_fwd_fused_linear(Xc.to(DEV), Yc.to(DEV), 1.0, d, naive, gram=True)
+            if K is not None:
+                G = torch.einsum("ipk,jqk->ijpq", Xc, Yc).numpy()
+                assert rel_err(K.cpu().numpy(), O.solve_coarse(O.increments(G), d, naive, nthreads=8)) <= 1e-11, (it, A, B, Mc, Nc, D, d)
+
+
 def test_increments_and_transpose_bit_identical(be):
     rng = np.random.default_rng(0)
     for shape in [(3, 2, 2), (4, 10, 20), (2, 3, 128, 128), (5, 65, 7), (1, 300, 300)]:
