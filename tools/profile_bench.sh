@@ -19,7 +19,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_
            "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
            "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   name=$(echo $set | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_fwd_wave|k_fwd_simple|k_adj|k_increments|k_static" -f csv \
+  rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_fwd_fused|k_fwd_wave|k_fwd_simple|k_adj|k_increments|k_static" -f csv \
       -d "$OUT/pmc_$name" -o pmc -- python "$REPO/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_$name.err" || echo "pmc set failed: $set" >> "$OUT/failed.txt"
 done
 cd "$REPO"
