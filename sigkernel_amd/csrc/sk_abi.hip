@@ -46,7 +46,8 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     if (ldw == 0) ldw = Nc;
     hipStream_t s = (hipStream_t)stream;
     if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
-    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_err && ws && ws_bytes >= adj_fast_workspace_bytes(g)) {
+    const bool fast_shape = dyadic >= 1 && dyadic <= 2 && g.MM + g.NN + 2 <= 1024;   // launch_adj_wave's scope
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && fast_shape && out_err && ws && ws_bytes >= adj_fast_workspace_bytes(g)) {
         // forward sweep that also emits the terminal row/column, then the fused reverse sweep + recompute of K
         double *edges = static_cast<double *>(ws);
         T *kfin = out_final ? out_final : reinterpret_cast<T *>(edges + (size_t)P * (g.MM + g.NN + 2));

@@ -421,9 +421,9 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     if (waves_per_cu > 8) waves_per_cu = 8;
     const int wpc_env = env_int("SK_WAVE_WPC", 0);
-    if (wpc_env > 0 && waves_per_cu > wpc_env) waves_per_cu = wpc_env;
     // persistent waves all carry the same work: an uneven count per SIMD (5, 6, 7 waves on 4 SIMDs) makes the
-    // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4)
+    // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4); an explicit override is taken as is
+    if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
