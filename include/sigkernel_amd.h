@@ -165,6 +165,28 @@ int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
                      float *out_final, float *W, int64_t ldw, double *out_err, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* ---- directional derivatives --------------------------------------------------------
+ * Replaces: sigkernel_derivatives_Gram_cuda[(A,B),T](M_inc, M_inc_diff, M_inc_diffdiff, MM+1, NN+1, n_anti_diagonals,
+ *           M_sol, M_sol_diff, M_sol_diffdiff)  (cuda_backend.py:166-223, launched at sigkernel.py:546-566) and the
+ *           three tile() refinements before it (sigkernel.py:543-545).
+ * inc, inc_d, inc_dd: [P, Mc, ld] COARSE increments of the static kernel, of its first and of its second
+ * finite-difference derivative along gamma (what sigkernel.py:526-541 builds before refinement); all three share
+ * `ld` (0 = Nc).  out_k / out_kd / out_kdd: [P] = K[MM][NN], K_gamma[MM][NN], K_gamma_gamma[MM][NN] (each
+ * nullable, at least one non-null).  The scheme is the reference's (no _naive_solver variant exists for this
+ * path).  flags: SK_FLAG_EXACT / SK_FLAG_SIMPLE = anti-diagonal kernel in the reference's operand order
+ * (bit-identical to the CPU oracle); SK_FLAG_FAST_ONLY = fail with SK_ERR_UNSUPPORTED instead of falling back. */
+/* Replaces: the finite-difference pre-processing of k_kgrad (sigkernel.py:526-541).  G0, G1, G2: [P, M, N] static Gram
+ * matrices of (X, Y), (X + eps*gamma, Y), (X + 2*eps*gamma, Y); inc, inc_d, inc_dd: [P, M-1, ld] (ld 0 = N-1, padding
+ * columns are zeroed) -- the inputs of sk_solve_deriv_*.  Operand order as in the reference (the sums cancel 1/eps^2). */
+int sk_deriv_increments_f64(const double *G0, const double *G1, const double *G2, double eps, int64_t P, int M, int N,
+                            double *inc, double *inc_d, double *inc_dd, int64_t ld, void *stream);
+int sk_deriv_increments_f32(const float *G0, const float *G1, const float *G2, double eps, int64_t P, int M, int N,
+                            float *inc, float *inc_d, float *inc_dd, int64_t ld, void *stream);
+int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
+                       int dyadic, int flags, double *out_k, double *out_kd, double *out_kdd, void *stream);
+int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
+                       int dyadic, int flags, float *out_k, float *out_kd, float *out_kdd, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,8 @@ _SO = os.path.join(_HERE, "libsk_oracle.so")
 _lib = None
 
 __all__ = ["build", "solve_fine", "gram_sym_fine", "solve_coarse", "adjoint_coarse",
-           "increments", "increments_adjoint", "max_threads", "gram_forward", "gram_grad_points"]
+           "increments", "increments_adjoint", "max_threads", "gram_forward", "gram_grad_points",
+           "solve_deriv_coarse", "kgrad"]
 
 
 def build(force=False):
@@ -45,6 +46,9 @@ def _load():
         lib.sk_oracle_increments.restype = None
         lib.sk_oracle_increments_adjoint.argtypes = [d, ctypes.c_int64, ctypes.c_int, ctypes.c_int, d]
         lib.sk_oracle_increments_adjoint.restype = None
+        lib.sk_oracle_solve_deriv_coarse.argtypes = [d, d, d, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     d, d, d, d, ctypes.c_int]
+        lib.sk_oracle_solve_deriv_coarse.restype = ctypes.c_int
         lib.sk_oracle_max_threads.restype = ctypes.c_int
         _lib = lib
     return _lib
@@ -131,6 +135,25 @@ def increments_adjoint(W):
     return out
 
 
+def solve_deriv_coarse(inc_c, incd_c, incdd_c, dyadic, want_grid=False, nthreads=1):
+    """Three coarse increment arrays [..., Mc, Nc] -> (k, k_gamma, k_gamma_gamma) [...] each
+    (cuda_backend.py:166-223); with want_grid also the three full grids [3, ..., MM+1, NN+1]."""
+    inc_c, incd_c, incdd_c = _c(inc_c), _c(incd_c), _c(incdd_c)
+    assert inc_c.shape == incd_c.shape == incdd_c.shape
+    Mc, Nc = inc_c.shape[-2:]
+    P = int(np.prod(inc_c.shape[:-2], dtype=np.int64))
+    outs = [np.empty(inc_c.shape[:-2], dtype=np.float64) for _ in range(3)]
+    grids = None
+    if want_grid:
+        grids = np.empty((3,) + inc_c.shape[:-2] + ((Mc << dyadic) + 1, (Nc << dyadic) + 1), dtype=np.float64)
+    rc = _load().sk_oracle_solve_deriv_coarse(_p(inc_c), _p(incd_c), _p(incdd_c), P, Mc, Nc, int(dyadic), _p(outs[0]),
+                                              _p(outs[1]), _p(outs[2]), _p(grids) if grids is not None else None,
+                                              int(nthreads))
+    if rc:
+        raise RuntimeError("sk_oracle_solve_deriv_coarse failed (%d)" % rc)
+    return tuple(outs) + ((grids,) if want_grid else ())
+
+
 # ---------------------------------------------------------------------------
 # End-to-end restatements of the reference's autograd functions, composed from
 # the C pieces above plus torch for the static kernel (the reference also uses
@@ -163,3 +186,21 @@ def gram_grad_points(X, Y, static_kernel, dyadic, naive=False, nthreads=1):
         (g,) = torch.autograd.grad(G, Xd, grad_outputs=mask, retain_graph=True)
         out[:, b] = g.numpy()
     return out
+
+
+def kgrad(X, Y, gamma, static_kernel, dyadic, eps=1e-4, nthreads=1):
+    """k_kgrad (sigkernel.py:504-593): (k, k_gamma, k_gamma_gamma), numpy (A,B) each.
+
+    The three increment arrays are the 4-corner differences of the scaled static Gram matrices of
+    X, X + eps*gamma and X + 2*eps*gamma, combined in the reference's order (sigkernel.py:526-541)."""
+    Xd, Yd, gd = (t.detach().double().cpu() for t in (X, Y, gamma))
+    G0 = static_kernel.Gram_matrix(Xd, Yd)
+    d1 = -(1. / eps) * G0
+    d2 = (1. / eps) * static_kernel.Gram_matrix(Xd + eps * gd, Yd)
+    dd1 = -(1. / eps) * d1
+    dd2 = -(2. / eps) * d2
+    dd3 = (1. / eps ** 2) * static_kernel.Gram_matrix(Xd + 2. * eps * gd, Yd)
+    inc = increments(G0.numpy())
+    inc_d = increments(d1.numpy()) + increments(d2.numpy())
+    inc_dd = increments(dd1.numpy()) + increments(dd2.numpy()) + increments(dd3.numpy())
+    return solve_deriv_coarse(inc, inc_d, inc_dd, dyadic, nthreads=nthreads)

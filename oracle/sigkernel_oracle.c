@@ -222,6 +222,85 @@ void sk_oracle_increments_adjoint(const double *W, int64_t P, int M, int N, doub
             }
 }
 
+/* Directional-derivative solver: K, K_gamma, K_gamma_gamma in one sweep.
+ * Stencil of sigkernel_derivatives_Gram_cuda (cuda_backend.py:206-220), identical to
+ * sigkernel_derivatives_Gram_mps (mps_backend.py:118-131), in their operand order; boundary
+ * K = 1, K_gamma = K_gamma_gamma = 0 on the first row and column (sigkernel.py:553-558).
+ * The reference's Cython twin (cython_backend.pyx:122-184) uses a different stencil and its
+ * call site is broken (sigkernel.py:588), so the CUDA/MPS formulas define the behaviour.
+ * inc_c, incd_c, incdd_c [P, Mc, Nc] coarse increments of k, of its first and of its second
+ * finite-difference derivative along gamma (sigkernel.py:526-541); all three are refined by
+ * index and divided by 4^d like sigkernel.py:543-545.  out_* [P] (each nullable) receive the
+ * values at (MM, NN); grids (nullable) [3, P, MM+1, NN+1]. */
+int sk_oracle_solve_deriv_coarse(const double *inc_c, const double *incd_c, const double *incdd_c, int64_t P, int Mc,
+                                 int Nc, int dyadic, double *out_k, double *out_kd, double *out_kdd, double *grids,
+                                 int nthreads)
+{
+    if (P < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 20) return 1;
+    const int MM = Mc << dyadic, NN = Nc << dyadic;
+    const double r = (double)(1 << dyadic);
+    const int64_t gs = (int64_t)(MM + 1) * (NN + 1);
+    int fail = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        double *rows = (double *)malloc(sizeof(double) * 6 * (size_t)(NN + 1));
+        if (!rows) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t l = 0; l < P; ++l) {
+            if (!rows) continue;
+            const double *g0 = inc_c + l * (int64_t)Mc * Nc, *g1 = incd_c + l * (int64_t)Mc * Nc,
+                         *g2 = incdd_c + l * (int64_t)Mc * Nc;
+            double *pk = rows, *pd = rows + (NN + 1), *pdd = rows + 2 * (NN + 1);
+            double *ck = rows + 3 * (NN + 1), *cd = rows + 4 * (NN + 1), *cdd = rows + 5 * (NN + 1);
+            for (int j = 0; j <= NN; ++j) { pk[j] = 1.; pd[j] = 0.; pdd[j] = 0.; }
+            for (int s = 0; grids && s < 3; ++s)
+                memcpy(grids + (s * P + l) * gs, s == 0 ? pk : s == 1 ? pd : pdd, sizeof(double) * (NN + 1));
+            for (int i = 0; i < MM; ++i) {
+                ck[0] = 1.; cd[0] = 0.; cdd[0] = 0.;
+                for (int j = 0; j < NN; ++j) {
+                    const double inc = sk_fine_inc(g0, Nc, dyadic, r, i, j);
+                    const double incd = sk_fine_inc(g1, Nc, dyadic, r, i, j);
+                    const double incdd = sk_fine_inc(g2, Nc, dyadic, r, i, j);
+                    const double k01 = pk[j + 1], k10 = ck[j], k00 = pk[j];
+                    const double k01d = pd[j + 1], k10d = cd[j], k00d = pd[j];
+                    const double k01dd = pdd[j + 1], k10dd = cdd[j], k00dd = pdd[j];
+                    const double k11 = (k01 + k10) * ((1. + 0.5 * inc) + (1. / 12) * (inc * inc)) -
+                                       k00 * (1. - (1. / 12) * (inc * inc));
+                    const double f1 = k00 * incd + k00d * inc;
+                    const double f2 = k01 * incd + k01d * inc;
+                    const double f3 = k10 * incd + k10d * inc;
+                    const double f4 = k11 * incd + (((k01d + k10d) - k00d) + f1) * inc;
+                    const double k11d = ((k01d + k10d) - k00d) + 0.25 * (((f1 + f2) + f3) + f4);
+                    const double h1 = (k00 * incdd + (2. * k00d) * incd) + k00dd * inc;
+                    const double h2 = (k01 * incdd + (2. * k01d) * incd) + k01dd * inc;
+                    const double h3 = (k10 * incdd + (2. * k10d) * incd) + k10dd * inc;
+                    const double h4 = (k11 * incdd + (2. * k11d) * incd) + (((k01dd + k10dd) - k00dd) + h1) * inc;
+                    const double k11dd = ((k01dd + k10dd) - k00dd) + 0.25 * (((h1 + h2) + h3) + h4);
+                    ck[j + 1] = k11; cd[j + 1] = k11d; cdd[j + 1] = k11dd;
+                }
+                if (grids) {
+                    memcpy(grids + (0 * P + l) * gs + (int64_t)(i + 1) * (NN + 1), ck, sizeof(double) * (NN + 1));
+                    memcpy(grids + (1 * P + l) * gs + (int64_t)(i + 1) * (NN + 1), cd, sizeof(double) * (NN + 1));
+                    memcpy(grids + (2 * P + l) * gs + (int64_t)(i + 1) * (NN + 1), cdd, sizeof(double) * (NN + 1));
+                }
+                double *t;
+                t = pk; pk = ck; ck = t;
+                t = pd; pd = cd; cd = t;
+                t = pdd; pdd = cdd; cdd = t;
+            }
+            if (out_k) out_k[l] = pk[NN];
+            if (out_kd) out_kd[l] = pd[NN];
+            if (out_kdd) out_kdd[l] = pdd[NN];
+        }
+        free(rows);
+    }
+    return fail;
+}
+
 int sk_oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -45,6 +45,10 @@ SIGNATURES = {
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "sk_deriv_increments_f64": (_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _int, _int, _vp, _vp, _vp, _i64, _vp]),
+    "sk_deriv_increments_f32": (_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _int, _int, _vp, _vp, _vp, _i64, _vp]),
+    "sk_solve_deriv_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_solve_deriv_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
 
@@ -297,6 +301,38 @@ class HipBackend:
         if return_residual:
             return out, W, err
         return out, W
+
+    def deriv_increments(self, G0, G1, G2, eps):
+        """Static Gram matrices [..., M, N] of X, X + eps*gamma, X + 2*eps*gamma -> one tensor [3, ..., M-1, N-1]:
+        increments of k and of its first / second finite-difference derivative along gamma (sigkernel.py:526-541)."""
+        for t, n in ((G0, "G0"), (G1, "G1"), (G2, "G2")):
+            _dev(t, n)
+        if not (G0.shape == G1.shape == G2.shape and G0.dtype == G1.dtype == G2.dtype):
+            raise ValueError("G0, G1, G2 must share shape and dtype")
+        M, N = G0.shape[-2:]
+        P = G0.numel() // (M * N)
+        ld = _padded_ld(N - 1, G0.element_size())
+        out = torch.empty((3,) + G0.shape[:-2] + (M - 1, ld), dtype=G0.dtype, device=G0.device)
+        with torch.cuda.device(G0.device):
+            fn = getattr(load(), "sk_deriv_increments_" + _suffix(G0))
+            _check(fn(_ptr(G0), _ptr(G1), _ptr(G2), float(eps), P, M, N, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), ld,
+                      _stream(G0)), "sk_deriv_increments")
+        return out[..., : N - 1]
+
+    def solve_deriv(self, inc3, dyadic, flags=0):
+        """inc3 [3, ..., Mc, Nc] (increments of k, d/dgamma, d2/dgamma2) -> (k, k_gamma, k_gamma_gamma), [...] each."""
+        if inc3.shape[0] != 3:
+            raise ValueError("inc3 must stack the three increment arrays on dim 0")
+        inc3, ld = _row_stride(inc3, "inc3")
+        Mc, Nc = inc3.shape[-2:]
+        batch = inc3.shape[1:-2]
+        P = inc3[0].numel() // (Mc * Nc)
+        out = torch.empty((3,) + batch, dtype=inc3.dtype, device=inc3.device)
+        with torch.cuda.device(inc3.device):
+            fn = getattr(load(), "sk_solve_deriv_" + _suffix(inc3))
+            _check(fn(_ptr(inc3[0]), _ptr(inc3[1]), _ptr(inc3[2]), ld, P, Mc, Nc, int(dyadic), int(flags), _ptr(out[0]),
+                      _ptr(out[1]), _ptr(out[2]), _stream(inc3)), "sk_solve_deriv")
+        return out[0], out[1], out[2]
 
 
 _backend = HipBackend()

@@ -60,6 +60,21 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     return launch_adj_simple<T>(inc_c, g, out_final, W, ldw, ws, ws_bytes, s);
 }
 
+template <typename T>
+int solve_deriv(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int flags,
+                T *out_k, T *out_kd, T *out_kdd, void *stream) {
+    if (bad_common(inc, P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT, flags) || !inc_d || !inc_dd || (ld != 0 && ld < Nc))
+        return SK_ERR_BAD_ARG;
+    if (!out_k && !out_kd && !out_kdd) return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT, ld);
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE))) {
+        const int rc = launch_deriv_wave<T>(inc, inc_d, inc_dd, g.ld, g, out_k, out_kd, out_kdd, (hipStream_t)stream);
+        if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
+    }
+    return launch_deriv_simple<T>(inc, inc_d, inc_dd, g, out_k, out_kd, out_kdd, (hipStream_t)stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,6 +201,29 @@ int sk_solve_adj_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
                      void *stream) {
     return solve_adj<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, W, ldw, out_err, workspace,
                             workspace_bytes, stream);
+}
+
+int sk_deriv_increments_f64(const double *G0, const double *G1, const double *G2, double eps, int64_t P, int M, int N,
+                            double *inc, double *inc_d, double *inc_dd, int64_t ld, void *stream) {
+    if (!G0 || !G1 || !G2 || !inc || !inc_d || !inc_dd || !(eps > 0) || P < 0 || M < 2 || N < 2 || (ld != 0 && ld < N - 1))
+        return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    return launch_deriv_increments<double>(G0, G1, G2, eps, P, M, N, inc, inc_d, inc_dd, ld ? ld : N - 1, (hipStream_t)stream);
+}
+int sk_deriv_increments_f32(const float *G0, const float *G1, const float *G2, double eps, int64_t P, int M, int N,
+                            float *inc, float *inc_d, float *inc_dd, int64_t ld, void *stream) {
+    if (!G0 || !G1 || !G2 || !inc || !inc_d || !inc_dd || !(eps > 0) || P < 0 || M < 2 || N < 2 || (ld != 0 && ld < N - 1))
+        return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    return launch_deriv_increments<float>(G0, G1, G2, eps, P, M, N, inc, inc_d, inc_dd, ld ? ld : N - 1, (hipStream_t)stream);
+}
+int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
+                       int dyadic, int flags, double *out_k, double *out_kd, double *out_kdd, void *stream) {
+    return solve_deriv<double>(inc, inc_d, inc_dd, ld, P, Mc, Nc, dyadic, flags, out_k, out_kd, out_kdd, stream);
+}
+int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
+                       int dyadic, int flags, float *out_k, float *out_kd, float *out_kdd, void *stream) {
+    return solve_deriv<float>(inc, inc_d, inc_dd, ld, P, Mc, Nc, dyadic, flags, out_k, out_kd, out_kdd, stream);
 }
 
 }  // extern "C"

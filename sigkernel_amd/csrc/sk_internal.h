@@ -29,6 +29,10 @@ template <typename T>
 int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, double *out_edges, hipStream_t s);
 template <typename T>
 int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t ldw, void *ws, size_t ws_bytes, hipStream_t s);
+// K, K_gamma, K_gamma_gamma (directional derivatives) from three increment arrays of equal layout
+template <typename T>
+int launch_deriv_simple(const T *inc, const T *inc_d, const T *inc_dd, const Geom &g, T *out_k, T *out_kd, T *out_kdd,
+                        hipStream_t s);
 size_t adj_simple_workspace_bytes(const Geom &g);
 size_t simple_lds_bytes(const Geom &g);
 
@@ -42,6 +46,11 @@ template <typename T>
 int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
                     hipStream_t s);
 
+// ---- sk_wave_deriv.hip: K, K_gamma, K_gamma_gamma in one skewed sweep, three increment streams ----
+template <typename T>
+int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld, const Geom &g, T *out_k, T *out_kd,
+                      T *out_kdd, hipStream_t s);
+
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
@@ -52,6 +61,10 @@ template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);
 template <typename T>
 int launch_increments_adjoint(const T *W, int64_t ldw, const T *scale, int64_t P, int M, int N, T *dG, hipStream_t s);
+
+template <typename T>
+int launch_deriv_increments(const T *G0, const T *G1, const T *G2, double eps, int64_t P, int M, int N, T *inc, T *inc_d,
+                            T *inc_dd, int64_t ld, hipStream_t s);
 
 // ---- sk_static.hip: static kernel (linear / rbf) + increments in one pass ---------------------------------
 template <typename T>

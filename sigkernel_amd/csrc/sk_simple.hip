@@ -122,6 +122,64 @@ __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c
     }
 }
 
+// Directional-derivative sweep: K, K_gamma, K_gamma_gamma on the same anti-diagonals (nine live diagonals in
+// LDS), every cell in the operand order of sigkernel_derivatives_Gram_cuda (cuda_backend.py:206-220), so the
+// results are bit-identical to oracle/sigkernel_oracle.c:sk_oracle_solve_deriv_coarse.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_deriv_simple(const T *__restrict__ inc0, const T *__restrict__ inc1,
+                                                       const T *__restrict__ inc2, int64_t ld, int64_t P, int Mc, int Nc,
+                                                       int d, T *__restrict__ out_k, T *__restrict__ out_kd,
+                                                       T *__restrict__ out_kdd) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    const int MM = Mc << d, NN = Nc << d;
+    const double rs = 1.0 / (double)(1 << d);
+    const int W1 = MM + 1;
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
+        const int64_t base = p * (int64_t)Mc * ld;
+        // q[s][n]: diagonal n (0 = two back, 1 = previous, 2 = current) of state s
+        double *q[3][3];
+        for (int s = 0; s < 3; ++s)
+            for (int n = 0; n < 3; ++n) q[s][n] = lds + (s * 3 + n) * W1;
+        for (int sd = 2; sd <= MM + NN; ++sd) {
+            const int ilo = max(1, sd - NN), ihi = min(MM, sd - 1);
+            for (int i = ilo + lane; i <= ihi; i += WAVE) {
+                const int j = sd - i;
+                const bool e10 = j == 1, e01 = i == 1, e00 = i == 1 || j == 1;
+                const double k10 = e10 ? 1. : q[0][1][i], k01 = e01 ? 1. : q[0][1][i - 1], k00 = e00 ? 1. : q[0][0][i - 1];
+                const double k10d = e10 ? 0. : q[1][1][i], k01d = e01 ? 0. : q[1][1][i - 1], k00d = e00 ? 0. : q[1][0][i - 1];
+                const double k10dd = e10 ? 0. : q[2][1][i], k01dd = e01 ? 0. : q[2][1][i - 1],
+                             k00dd = e00 ? 0. : q[2][0][i - 1];
+                const int64_t o = base + (int64_t)((i - 1) >> d) * ld + ((j - 1) >> d);
+                const double inc = ((double)inc0[o] * rs) * rs, incd = ((double)inc1[o] * rs) * rs,
+                             incdd = ((double)inc2[o] * rs) * rs;
+                const double k11 = (k01 + k10) * ((1. + 0.5 * inc) + (1. / 12) * (inc * inc)) -
+                                   k00 * (1. - (1. / 12) * (inc * inc));
+                const double f1 = k00 * incd + k00d * inc;
+                const double f2 = k01 * incd + k01d * inc;
+                const double f3 = k10 * incd + k10d * inc;
+                const double f4 = k11 * incd + (((k01d + k10d) - k00d) + f1) * inc;
+                const double k11d = ((k01d + k10d) - k00d) + 0.25 * (((f1 + f2) + f3) + f4);
+                const double h1 = (k00 * incdd + (2. * k00d) * incd) + k00dd * inc;
+                const double h2 = (k01 * incdd + (2. * k01d) * incd) + k01dd * inc;
+                const double h3 = (k10 * incdd + (2. * k10d) * incd) + k10dd * inc;
+                const double h4 = (k11 * incdd + (2. * k11d) * incd) + (((k01dd + k10dd) - k00dd) + h1) * inc;
+                const double k11dd = ((k01dd + k10dd) - k00dd) + 0.25 * (((h1 + h2) + h3) + h4);
+                q[0][2][i] = k11; q[1][2][i] = k11d; q[2][2][i] = k11dd;
+                if (i == MM && j == NN) {
+                    if (out_k) out_k[p] = (T)k11;
+                    if (out_kd) out_kd[p] = (T)k11d;
+                    if (out_kdd) out_kdd[p] = (T)k11dd;
+                }
+            }
+            __syncthreads();
+            for (int s = 0; s < 3; ++s) {
+                double *t = q[s][0]; q[s][0] = q[s][1]; q[s][1] = q[s][2]; q[s][2] = t;
+            }
+        }
+    }
+}
+
 int pick_blocks(int64_t P) {
     const int64_t cap = 256 * 16;  // 16 single-wave workgroups per CU keep every SIMD busy
     return (int)(P < cap ? P : cap);
@@ -171,5 +229,22 @@ template int launch_fwd_simple<float>(const float *, const Geom &, float *, floa
 template int launch_adj_simple<double>(const double *, const Geom &, double *, double *, int64_t, void *, size_t,
                                        hipStream_t);
 template int launch_adj_simple<float>(const float *, const Geom &, float *, float *, int64_t, void *, size_t, hipStream_t);
+
+template <typename T>
+int launch_deriv_simple(const T *inc, const T *inc_d, const T *inc_dd, const Geom &g, T *out_k, T *out_kd, T *out_kdd,
+                        hipStream_t s) {
+    const size_t lds = 3 * simple_lds_bytes(g);
+    if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_deriv_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_deriv_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc, inc_d, inc_dd, g.ld, g.P, g.Mc,
+                       g.Nc, g.dyadic, out_k, out_kd, out_kdd);
+    return check_launch();
+}
+
+template int launch_deriv_simple<double>(const double *, const double *, const double *, const Geom &, double *, double *,
+                                         double *, hipStream_t);
+template int launch_deriv_simple<float>(const float *, const float *, const float *, const Geom &, float *, float *, float *,
+                                        hipStream_t);
 
 }  // namespace sk

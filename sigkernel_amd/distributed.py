@@ -13,9 +13,9 @@ Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo
 import torch
 import torch.distributed as dist
 
-from .sigkernel import _SigKernelGram
+from .sigkernel import _SigKernelGram, k_kgrad
 
-__all__ = ["row_range", "sharded_gram", "ShardedGram"]
+__all__ = ["row_range", "sharded_gram", "ShardedGram", "sharded_kgrad"]
 
 
 def row_range(n_rows, rank, world):
@@ -79,3 +79,20 @@ def sharded_gram(sigkernel, X, Y, sym=False, group=None):
         raise RuntimeError("sharded_gram needs torch.distributed to be initialised (one process per GPU)")
     return ShardedGram.apply(X, Y, sigkernel.static_kernel, sigkernel.dyadic_order, sym, sigkernel._naive_solver,
                              sigkernel.workspace_bytes, group)
+
+
+def sharded_kgrad(sigkernel, X, Y, gamma, group=None):
+    """compute_kernel_and_derivatives_Gram with the rows of (X, gamma) sharded: three full (A, B) matrices on every
+    rank from one all-gather of the stacked (rows, 3, B) blocks."""
+    if not dist.is_initialized():
+        raise RuntimeError("sharded_kgrad needs torch.distributed to be initialised (one process per GPU)")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    A, B = X.shape[0], Y.shape[0]
+    lo, hi, chunk = row_range(A, rank, world)
+    if hi > lo:
+        loc = torch.stack(k_kgrad(X[lo:hi].contiguous(), Y, gamma[lo:hi].contiguous(), sigkernel.dyadic_order,
+                                  sigkernel.static_kernel, workspace_bytes=sigkernel.workspace_bytes), dim=1)
+    else:
+        loc = torch.empty((0, 3, B), dtype=X.dtype, device=X.device)
+    full = _all_gather_rows(loc, A, chunk, group)
+    return full[:, 0].contiguous(), full[:, 1].contiguous(), full[:, 2].contiguous()

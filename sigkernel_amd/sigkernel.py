@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .static_kernels import LinearKernel, RBFKernel
 
-__all__ = ["SigKernel", "_SigKernel", "_SigKernelGram"]
+__all__ = ["SigKernel", "_SigKernel", "_SigKernelGram", "k_kgrad"]
 
 _DEFAULT_WORKSPACE = 48 << 30  # bytes of transient HBM one call may use (288 GB part)
 
@@ -235,6 +235,39 @@ class _SigKernelGram(torch.autograd.Function):
         return grad_X, None, None, None, None, None, None
 
 
+def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=None):
+    """Signature kernel and its first / second directional derivative along gamma -- the reference's ``k_kgrad``
+    (sigkernel.py:504-593): X (A,M,D), Y (B,N,D), gamma (A,M,D) -> three (A,B) matrices
+    k(x_a, y_b), d/ds k(x_a + s gamma_a, y_b)|_0, d2/ds2 k(x_a + s gamma_a, y_b)|_0.
+
+    Like the reference, the derivatives of the static kernel are one-sided finite differences with step ``eps``
+    (sigkernel.py:529-541; their truncation error is part of the reference's result, so it is reproduced, not
+    "fixed"); the three increment arrays then drive ONE sweep of the coupled PDE stencil (cuda_backend.py:206-220)
+    in sk_solve_deriv_*.  No autograd: the reference's outputs carry none either (solution buffers are fresh
+    tensors, sigkernel.py:553-566)."""
+    _check_inputs(X, Y, paired=False)
+    if gamma.shape != X.shape or gamma.dtype != X.dtype or gamma.device != X.device:
+        raise ValueError("gamma must have X's shape, dtype and device")
+    be = _lib.get_backend()
+    A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
+    out = torch.zeros(3, A, B, dtype=X.dtype, device=X.device)
+    if M < 2 or N < 2:
+        out[0] = 1.
+        return out[0], out[1], out[2]
+    Xd, Yd, gd = X.detach(), Y.detach(), gamma.detach()
+    per_row = 6 * B * M * N * X.element_size()      # three static Gram matrices + three increment arrays
+    for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
+        Xt, gt = Xd[a0:a1], gd[a0:a1]
+        G0 = static_kernel.Gram_matrix(Xt, Yd).contiguous()                          # sigkernel.py:526
+        G1 = static_kernel.Gram_matrix(Xt + eps * gt, Yd).contiguous()               # :530
+        G2 = static_kernel.Gram_matrix(Xt + 2. * eps * gt, Yd).contiguous()          # :537
+        inc3 = be.deriv_increments(G0, G1, G2, eps)                                  # :527-541
+        del G0, G1, G2
+        k, kd, kdd = be.solve_deriv(inc3, dyadic_order)                              # :543-566 (tile() by index)
+        out[0, a0:a1], out[1, a0:a1], out[2, a0:a1] = k, kd, kdd
+    return out[0], out[1], out[2]
+
+
 class SigKernel:
     """Signature kernel k_sig(x, y) = <S(f(x)), S(f(y))> for a static kernel k(x, y) = <f(x), f(y)>.
 
@@ -258,6 +291,14 @@ class SigKernel:
 
         ``max_batch`` is kept for signature compatibility (sigkernel.py:23); tiling is by HBM budget."""
         return _SigKernel.apply(X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)
+
+    def compute_kernel_and_derivatives_Gram(self, X, Y, gamma, max_batch=100):
+        """X (batch_X, len_x, dim), Y (batch_Y, len_y, dim), gamma (batch_X, len_x, dim) -> three (batch_X, batch_Y)
+        matrices: k(X^i, Y^j) and its first and second directional derivative along gamma^i (sigkernel.py:43-89)."""
+        if self.process_group is not None:
+            from .distributed import sharded_kgrad
+            return sharded_kgrad(self, X, Y, gamma, self.process_group)
+        return k_kgrad(X, Y, gamma, self.dyadic_order, self.static_kernel, workspace_bytes=self.workspace_bytes)
 
     def compute_Gram(self, X, Y, sym=False, max_batch=100):
         """X (batch_X, len_x, dim), Y (batch_Y, len_y, dim) -> (batch_X, batch_Y) matrix k(X^i_T, Y^j_T)."""

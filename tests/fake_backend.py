@@ -53,3 +53,18 @@ class OracleBackend:
     def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
         out, W = O.adjoint_coarse(inc_c.detach().double().numpy(), dyadic, naive)
         return torch.from_numpy(out).to(inc_c.dtype), torch.from_numpy(W).to(inc_c.dtype)
+
+    def deriv_increments(self, G0, G1, G2, eps):
+        d1 = -(1. / eps) * G0
+        d2 = (1. / eps) * G1
+        dd1 = -(1. / eps) * d1
+        dd2 = -(2. / eps) * d2
+        dd3 = (1. / eps ** 2) * G2
+        inc = self.increments(G0)
+        inc_d = self.increments(d1) + self.increments(d2)
+        inc_dd = self.increments(dd1) + self.increments(dd2) + self.increments(dd3)
+        return torch.stack([inc, inc_d, inc_dd])
+
+    def solve_deriv(self, inc3, dyadic, flags=0):
+        a = inc3.detach().double().numpy()
+        return tuple(torch.from_numpy(v).to(inc3.dtype) for v in O.solve_deriv_coarse(a[0], a[1], a[2], dyadic))

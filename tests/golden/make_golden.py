@@ -172,10 +172,78 @@ def wrappers_case():
     out["verdict_rejected"] = int("rejected" in buf.getvalue())
     save("wrappers", **out)
 
+# ---------------------------------------------------------------------------------------------
+# 6. directional-derivative solver: K, K_gamma, K_gamma_gamma
+#
+# The reference's CPU dispatch of k_kgrad is broken (sigkernel.py:588 unpacks three values from
+# sigkernel_derivatives_Gram_cython, which returns one array and uses another stencil), so the
+# behaviour is defined by the CUDA/MPS stencil (cuda_backend.py:206-220 == mps_backend.py:118-131).
+# The MPS solver is plain torch and runs on CPU tensors: it is called here, unmodified, on exactly
+# the (MM, NN) increment grid the valid outputs depend on (the reference launches it with MM+1, NN+1
+# and throws the out-of-bounds last row/column away, sigkernel.py:584-586).  The pre-processing
+# (finite differences of the static Gram matrix with eps = 1e-4, 4-corner difference, dyadic tiling)
+# follows k_kgrad line by line (sigkernel.py:526-547) using the reference's own Gram_matrix and tile.
+# ---------------------------------------------------------------------------------------------
+def _ref_derivative_solve(inc, inc_d, inc_dd):
+    from sigkernel.mps_backend import sigkernel_derivatives_Gram_mps
+    A, B, MM, NN = inc.shape
+    K = torch.zeros((A, B, MM + 1, NN + 1), dtype=inc.dtype)
+    Kd = torch.zeros_like(K)
+    Kdd = torch.zeros_like(K)
+    K[:, :, 0, :] = 1.
+    K[:, :, :, 0] = 1.
+    sigkernel_derivatives_Gram_mps(inc, inc_d, inc_dd, MM, NN, K, Kd, Kdd)
+    return K, Kd, Kdd
+
+
+def _ref_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4):
+    from sigkernel.sigkernel import tile
+
+    def corner(G):
+        return G[:, :, 1:, 1:] + G[:, :, :-1, :-1] - G[:, :, 1:, :-1] - G[:, :, :-1, 1:]
+
+    G0 = static_kernel.Gram_matrix(X, Y)
+    inc = corner(G0)
+    d1 = -(1. / eps) * G0
+    d2 = (1. / eps) * static_kernel.Gram_matrix(X + eps * gamma, Y)
+    inc_d = corner(d1) + corner(d2)
+    dd1 = -(1. / eps) * d1
+    dd2 = -(2. / eps) * d2
+    dd3 = (1. / eps ** 2) * static_kernel.Gram_matrix(X + 2. * eps * gamma, Y)
+    inc_dd = corner(dd1) + corner(dd2) + corner(dd3)
+    r = 2 ** dyadic_order
+    inc, inc_d, inc_dd = (tile(tile(t, 2, r) / float(r), 3, r) / float(r) for t in (inc, inc_d, inc_dd))
+    K, Kd, Kdd = _ref_derivative_solve(inc, inc_d, inc_dd)
+    return K[:, :, -1, -1], Kd[:, :, -1, -1], Kdd[:, :, -1, -1]
+
+
+def derivative_cases():
+    rng = np.random.default_rng(77)
+    out = {}
+    # solver level: random fine increments in, full grids out
+    inc = torch.tensor(rng.normal(scale=0.3, size=(2, 3, 6, 7)))
+    inc_d = torch.tensor(rng.normal(scale=0.5, size=(2, 3, 6, 7)))
+    inc_dd = torch.tensor(rng.normal(scale=0.5, size=(2, 3, 6, 7)))
+    K, Kd, Kdd = _ref_derivative_solve(inc, inc_d, inc_dd)
+    out.update(inc=inc, inc_d=inc_d, inc_dd=inc_dd, K=K, Kd=Kd, Kdd=Kdd)
+    # API level
+    gen = torch.Generator().manual_seed(11)
+    cases = [("rbf_d1", "rbf", 1.0, 1, 4, 5, 9, 12, 3), ("lin_d0", "linear", 0.0, 0, 3, 4, 10, 7, 2),
+             ("rbf_d2", "rbf", 0.5, 2, 3, 3, 6, 6, 2), ("lin_d1", "linear", 0.0, 1, 5, 4, 17, 20, 4)]
+    for name, kn, param, d, A, B, M, N, D in cases:
+        X = walk(gen, A, M, D) * 2
+        Y = walk(gen, B, N, D) * 2
+        gamma = torch.randn(A, M, D, generator=gen, dtype=torch.float64)
+        k, kd, kdd = _ref_kgrad(X, Y, gamma, d, kernel_of(kn, param))
+        out.update({name + "_X": X, name + "_Y": Y, name + "_gamma": gamma, name + "_kernel": kn, name + "_param": param,
+                    name + "_dyadic": d, name + "_k": k, name + "_kd": kd, name + "_kdd": kdd})
+    out["api_cases"] = np.array([c[0] for c in cases])
+    save("derivatives", **out)
+
 
 if __name__ == "__main__":
-    solver_cases()
-    readme_case()
-    gram_cases()
-    kat_case()
-    wrappers_case()
+    which = sys.argv[1:] or ["solver", "readme", "gram", "kat", "wrappers", "derivatives"]
+    table = dict(solver=solver_cases, readme=readme_case, gram=gram_cases, kat=kat_case, wrappers=wrappers_case,
+                 derivatives=derivative_cases)
+    for w in which:
+        table[w]()
