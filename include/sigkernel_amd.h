@@ -182,6 +182,15 @@ int sk_deriv_increments_f64(const double *G0, const double *G1, const double *G2
                             double *inc, double *inc_d, double *inc_dd, int64_t ld, void *stream);
 int sk_deriv_increments_f32(const float *G0, const float *G1, const float *G2, double eps, int64_t P, int M, int N,
                             float *inc, float *inc_d, float *inc_dd, int64_t ld, void *stream);
+/* The same with the static kernel fused in (kind 0 = linear, 1 = rbf with param = sigma, like sk_static_increments_*):
+ * replaces the three Gram_matrix calls of k_kgrad (sigkernel.py:526, :530, :537) as well.  X0 = X, X1 = X + eps*gamma,
+ * X2 = X + 2*eps*gamma: [A, M, D] each (formed by the caller); Y [B, N, D]; outputs [A*B, M-1, ld].  D <= 32. */
+int sk_static_deriv_increments_f64(int kind, double param, const double *X0, const double *X1, const double *X2,
+                                   const double *Y, int64_t A, int64_t B, int M, int N, int D, double eps, double *inc,
+                                   double *inc_d, double *inc_dd, int64_t ld, void *stream);
+int sk_static_deriv_increments_f32(int kind, double param, const float *X0, const float *X1, const float *X2, const float *Y,
+                                   int64_t A, int64_t B, int M, int N, int D, double eps, float *inc, float *inc_d,
+                                   float *inc_dd, int64_t ld, void *stream);
 int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
                        int dyadic, int flags, double *out_k, double *out_kd, double *out_kdd, void *stream);
 int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,

@@ -47,6 +47,10 @@ SIGNATURES = {
     "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sk_deriv_increments_f64": (_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _int, _int, _vp, _vp, _vp, _i64, _vp]),
     "sk_deriv_increments_f32": (_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _int, _int, _vp, _vp, _vp, _i64, _vp]),
+    "sk_static_deriv_increments_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int,
+                                              ctypes.c_double, _vp, _vp, _vp, _i64, _vp]),
+    "sk_static_deriv_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int,
+                                              ctypes.c_double, _vp, _vp, _vp, _i64, _vp]),
     "sk_solve_deriv_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_deriv_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
@@ -317,6 +321,23 @@ class HipBackend:
             fn = getattr(load(), "sk_deriv_increments_" + _suffix(G0))
             _check(fn(_ptr(G0), _ptr(G1), _ptr(G2), float(eps), P, M, N, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), ld,
                       _stream(G0)), "sk_deriv_increments")
+        return out[..., : N - 1]
+
+    def static_deriv_increments(self, kind, param, X0, X1, X2, Y, eps):
+        """deriv_increments with the static kernel fused in (kind 0 = linear, 1 = rbf/sigma): X0 = X, X1 = X + eps*gamma,
+        X2 = X + 2*eps*gamma (A,M,D), Y (B,N,D) -> [3, A, B, M-1, N-1]; None when D > 32 (generic route instead)."""
+        for t, n in ((X0, "X0"), (X1, "X1"), (X2, "X2"), (Y, "Y")):
+            _dev(t, n)
+        A, M, D = X0.shape
+        B, N = Y.shape[0], Y.shape[1]
+        if D > self.MAX_FUSED_DIM or M < 2 or N < 2:
+            return None
+        ld = _padded_ld(N - 1, X0.element_size())
+        out = torch.empty(3, A, B, M - 1, ld, dtype=X0.dtype, device=X0.device)
+        with torch.cuda.device(X0.device):
+            fn = getattr(load(), "sk_static_deriv_increments_" + _suffix(X0))
+            _check(fn(int(kind), float(param), _ptr(X0), _ptr(X1), _ptr(X2), _ptr(Y), A, B, M, N, D, float(eps), _ptr(out[0]),
+                      _ptr(out[1]), _ptr(out[2]), ld, _stream(X0)), "sk_static_deriv_increments")
         return out[..., : N - 1]
 
     def solve_deriv(self, inc3, dyadic, flags=0):

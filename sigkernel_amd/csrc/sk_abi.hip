@@ -217,6 +217,26 @@ int sk_deriv_increments_f32(const float *G0, const float *G1, const float *G2, d
     if (P == 0) return SK_OK;
     return launch_deriv_increments<float>(G0, G1, G2, eps, P, M, N, inc, inc_d, inc_dd, ld ? ld : N - 1, (hipStream_t)stream);
 }
+int sk_static_deriv_increments_f64(int kind, double param, const double *X0, const double *X1, const double *X2,
+                                   const double *Y, int64_t A, int64_t B, int M, int N, int D, double eps, double *inc,
+                                   double *inc_d, double *inc_dd, int64_t ld, void *stream) {
+    if (!X0 || !X1 || !X2 || !Y || !inc || !inc_d || !inc_dd || A < 0 || B < 1 || M < 2 || N < 2 || D < 1 || !(eps > 0))
+        return SK_ERR_BAD_ARG;
+    if ((kind != 0 && kind != 1) || (ld != 0 && ld < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_deriv_increments<double>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd,
+                                                  ld ? ld : N - 1, (hipStream_t)stream);
+}
+int sk_static_deriv_increments_f32(int kind, double param, const float *X0, const float *X1, const float *X2, const float *Y,
+                                   int64_t A, int64_t B, int M, int N, int D, double eps, float *inc, float *inc_d,
+                                   float *inc_dd, int64_t ld, void *stream) {
+    if (!X0 || !X1 || !X2 || !Y || !inc || !inc_d || !inc_dd || A < 0 || B < 1 || M < 2 || N < 2 || D < 1 || !(eps > 0))
+        return SK_ERR_BAD_ARG;
+    if ((kind != 0 && kind != 1) || (ld != 0 && ld < N - 1) || (kind == 1 && !(param > 0))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_deriv_increments<float>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd,
+                                                 ld ? ld : N - 1, (hipStream_t)stream);
+}
 int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
                        int dyadic, int flags, double *out_k, double *out_kd, double *out_kdd, void *stream) {
     return solve_deriv<double>(inc, inc_d, inc_dd, ld, P, Mc, Nc, dyadic, flags, out_k, out_kd, out_kdd, stream);

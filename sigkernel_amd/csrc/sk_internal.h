@@ -72,6 +72,11 @@ int launch_static_increments(int kind, double param, const T *X, const T *Y, int
                              T *inc, int64_t ld, hipStream_t s);
 
 template <typename T>
+int launch_static_deriv_increments(int kind, double param, const T *X0, const T *X1, const T *X2, const T *Y, int64_t A,
+                                   int64_t B, int M, int N, int D, double eps, T *inc, T *inc_d, T *inc_dd, int64_t ld,
+                                   hipStream_t s);
+
+template <typename T>
 int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                           int64_t B, int M, int N, int D, T *out, hipStream_t s);
 

@@ -10,6 +10,8 @@
 //   rbf    : G[p][q] = exp(-(|x_p|^2 + |y_q|^2 - 2<x_p,y_q>)/sigma), inc = ((G11 + G00) - G10) - G01
 // The linear form is algebraically the 4-corner difference of <x_p, y_q>; it is evaluated as a product of
 // differences (no cancellation), so it agrees with the reference to rounding (1e-16 absolute), not bit for bit.
+#include <type_traits>
+
 #include "sk_internal.h"
 
 namespace sk {
@@ -57,46 +59,147 @@ __global__ __launch_bounds__(SK_TPB) void k_static_linear(const T *__restrict__ 
     }
 }
 
-template <typename T, int DMAX>
-__global__ __launch_bounds__(SK_TPB) void k_static_rbf(const T *__restrict__ X, const T *__restrict__ Y, int64_t B, int M,
-                                                       int N, int D, double inv_sigma, T *__restrict__ inc, int64_t ld,
-                                                       int col_tiles) {
-    const int Mc = M - 1, Nc = N - 1;
-    const int64_t p = blockIdx.x / col_tiles;
-    const int c0 = (int)(blockIdx.x % col_tiles) * (SK_TPB - 1);   // node columns c0 .. c0+63, outputs c0 .. c0+62
-    const int64_t a = B > 0 ? p / B : p, b = B > 0 ? p % B : p;
-    const T *x = X + a * (int64_t)M * D;
-    const T *y = Y + b * (int64_t)N * D;
-    T *o = inc + p * (int64_t)Mc * ld;
-    const int lane = threadIdx.x;
-    const int n = min(c0 + lane, N - 1);   // node column of this lane
-    double yn[DMAX], ys = 0.0;
+// ---- node-evaluating kernels: rbf increments, and the increments of the directional-derivative path ------------
+//
+// One wavefront per (pair, tile of 64*CPT output columns); lane l owns output columns c0 + 64c + l (c < CPT), i.e.
+// whole 128-byte lines per store.  An output needs the static kernel at node columns q and q+1: q+1 comes from the
+// next lane (next chunk for lane 63); the one node column past the tile is evaluated for 64 node rows at a time with
+// lanes = rows, and read back row by row with v_readlane -- 1/64 extra evaluation instead of a second, nearly empty
+// tile.  NV = 1: G -> inc (rbf).  NV = 3: the directional-derivative path, fusing the three Gram_matrix calls of
+// k_kgrad (sigkernel.py:526, :530, :537) with its finite-difference pre-processing (:527-541): X0 = X,
+// X1 = X + eps*gamma, X2 = X + 2*eps*gamma are formed by the caller (tiny); each node value is scaled like the
+// reference (-(1/eps)*G0, (1/eps)*G1, -(1/eps)*(-(1/eps)*G0), -(2/eps)*((1/eps)*G1), (1/eps^2)*G2), every scaled
+// array is 4-corner-differenced and the differences are added left to right -- the operand order of
+// k_deriv_increments, without the three (A,B,M,N) Gram matrices in HBM.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float readlane_f64(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int DMAX, int KIND>
+__device__ __forceinline__ double static_node(const double (&xv)[DMAX], const double (&yv)[DMAX], double ys, double inv_sigma) {
+    double sq = 0.0, xy = 0.0;
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) {
-        yn[k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
-        ys = fma(yn[k], yn[k], ys);
+        sq = fma(xv[k], xv[k], sq);
+        xy = fma(xv[k], yv[k], xy);
     }
-    const int q = c0 + lane;   // output column (needs node columns q and q+1 = this lane and the next)
-    const bool writes = lane < SK_TPB - 1 && q < ld;
-    double g_prev = 0.0, g_prev_r = 0.0;
-    for (int i = 0; i < M; ++i) {
-        double xs = 0.0, xy = 0.0;
+    // rbf: dist = -2 xy + (xs + ys);  G = exp(-dist / sigma)          (static_kernels.py:53-56, :70-73)
+    return KIND == 0 ? xy : exp(-(fma(-2.0, xy, sq + ys)) * inv_sigma);
+}
+
+template <typename T, int DMAX, int KIND, int NV, int CPT>
+__global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X0, const T *__restrict__ X1,
+                                                         const T *__restrict__ X2, const T *__restrict__ Y, int64_t B, int M,
+                                                         int N, int D, double inv_sigma, T c1, T c2, T c3,
+                                                         T *__restrict__ inc, T *__restrict__ inc_d, T *__restrict__ inc_dd,
+                                                         int64_t ld, int col_tiles) {
+    typedef typename std::conditional<NV == 1, double, T>::type TA;   // NV = 1 keeps G in double until the store
+    constexpr int NS = NV == 1 ? 1 : 6;                              // scaled arrays per node
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t p = blockIdx.x / col_tiles;
+    const int c0 = (int)(blockIdx.x % col_tiles) * (SK_TPB * CPT);
+    const int64_t a = B > 0 ? p / B : p, b = B > 0 ? p % B : p;
+    const T *xs[3] = {X0 + a * (int64_t)M * D, X1 + a * (int64_t)M * D, X2 + a * (int64_t)M * D};
+    const T *y = Y + b * (int64_t)N * D;
+    const int64_t o = p * (int64_t)Mc * ld;
+    const int lane = threadIdx.x;
+
+    double yn[CPT][DMAX], ys[CPT], ye[DMAX], yse = 0.0;
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k)
-            if (k < D) {
-                const double xv = (double)x[(int64_t)i * D + k];
-                xs = fma(xv, xv, xs);
-                xy = fma(xv, yn[k], xy);
-            }
-        // dist = -2 xy + (xs + ys);  G = exp(-dist / sigma)          (static_kernels.py:53-56, :70-73)
-        const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
-        const double g_r = __shfl_down(g, 1, SK_TPB);   // node (i, q+1)
-        if (i > 0 && writes) {
-            const double v = ((g_r + g_prev) - g) - g_prev_r;   // ((G11 + G00) - G10) - G01
-            o[(int64_t)(i - 1) * ld + q] = (T)(q < Nc ? v : 0.0);
+    for (int c = 0; c < CPT; ++c) {
+        const int n = min(c0 + c * SK_TPB + lane, N - 1);
+        ys[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            yn[c][k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
+            ys[c] = fma(yn[c][k], yn[c][k], ys[c]);
         }
-        g_prev = g;
-        g_prev_r = g_r;
+    }
+    {
+        const int ne = min(c0 + CPT * SK_TPB, N - 1);   // the node column just past the tile
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            ye[k] = k < D ? (double)y[(int64_t)ne * D + k] : 0.0;
+            yse = fma(ye[k], ye[k], yse);
+        }
+    }
+
+    auto scaled = [&](const TA (&g)[NV], TA (&v)[NS]) {
+#pragma clang fp contract(off)
+        v[0] = g[0];
+        if constexpr (NV == 3) {
+            v[1] = -c1 * g[0];
+            v[2] = c1 * g[1];
+            v[3] = -c1 * v[1];
+            v[4] = -c2 * v[2];
+            v[5] = c3 * g[2];
+        }
+    };
+
+    TA vp[CPT][NS], vpr[CPT][NS];   // scaled values of the previous node row at columns q and q + 1
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) vp[c][k] = vpr[c][k] = (TA)0;
+
+    for (int i0 = 0; i0 < M; i0 += SK_TPB) {
+        // the extra node column for node rows i0 .. i0+63, lanes = rows
+        TA E[NV];
+        {
+            const int ir = min(i0 + lane, M - 1);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double xv[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? (double)xs[v][(int64_t)ir * D + k] : 0.0;
+                E[v] = (TA)static_node<DMAX, KIND>(xv, ye, yse, inv_sigma);
+            }
+        }
+        const int rows = min(SK_TPB, M - i0);
+        for (int r = 0; r < rows; ++r) {
+            const int i = i0 + r;
+            TA g[CPT][NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double xv[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? (double)xs[v][(int64_t)i * D + k] : 0.0;   // wave-uniform
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND>(xv, yn[c], ys[c], inv_sigma);
+            }
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                TA gr[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const TA nxt = __shfl_down(g[c][v], 1, SK_TPB);
+                    const TA wrap = c + 1 < CPT ? readlane_f64(g[c + 1 < CPT ? c + 1 : c][v], 0) : readlane_f64(E[v], r);
+                    gr[v] = lane == SK_TPB - 1 ? wrap : nxt;
+                }
+                TA v0[NS], v1[NS];
+                scaled(g[c], v0);
+                scaled(gr, v1);
+                const int q = c0 + c * SK_TPB + lane;
+                if (i > 0 && q < ld) {
+#pragma clang fp contract(off)
+                    TA d[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) d[k] = ((v1[k] + vp[c][k]) - v0[k]) - vpr[c][k];   // ((G11 + G00) - G10) - G01
+                    const bool in = q < Nc;
+                    const int64_t at = o + (int64_t)(i - 1) * ld + q;
+                    inc[at] = in ? (T)d[0] : (T)0;
+                    if constexpr (NV == 3) {
+                        inc_d[at] = in ? (T)(d[1] + d[2]) : (T)0;
+                        inc_dd[at] = in ? (T)((d[3] + d[4]) + d[5]) : (T)0;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { vp[c][k] = v0[k]; vpr[c][k] = v1[k]; }
+            }
+        }
     }
 }
 
@@ -252,16 +355,63 @@ int launch_static_d(int kind, double param, const T *X, const T *Y, int64_t A, i
         hipLaunchKernelGGL((k_static_linear<T, DMAX>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
                            param * param, inc, ld, col_tiles);
     } else {
-        const int col_tiles = (int)((ld + SK_TPB - 2) / (SK_TPB - 1));
-        const int64_t blocks = P * col_tiles;
-        if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_static_rbf<T, DMAX>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
-                           1.0 / param, inc, ld, col_tiles);
+        const T z = (T)0;
+        if (ld <= SK_TPB) {
+            const int col_tiles = 1;
+            const int64_t blocks = P;
+            if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_static_nodes<T, DMAX, 1, 1, 1>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
+                               N, D, 1.0 / param, z, z, z, inc, (T *)nullptr, (T *)nullptr, ld, col_tiles);
+        } else {
+            const int col_tiles = (int)((ld + 2 * SK_TPB - 1) / (2 * SK_TPB));
+            const int64_t blocks = P * col_tiles;
+            if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_static_nodes<T, DMAX, 1, 1, 2>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
+                               N, D, 1.0 / param, z, z, z, inc, (T *)nullptr, (T *)nullptr, ld, col_tiles);
+        }
     }
     return check_launch();
 }
 
+template <typename T, int DMAX>
+int launch_static_deriv_d(int kind, double param, const T *X0, const T *X1, const T *X2, const T *Y, int64_t A, int64_t B,
+                          int M, int N, int D, double eps, T *inc, T *inc_d, T *inc_dd, int64_t ld, hipStream_t s) {
+    const T c1 = (T)(1. / eps), c2 = (T)(2. / eps), c3 = (T)(1. / (eps * eps));
+    const double inv_sigma = kind == 0 ? 0.0 : 1.0 / param;
+    const bool narrow = ld <= SK_TPB;
+    const int col_tiles = narrow ? 1 : (int)((ld + 2 * SK_TPB - 1) / (2 * SK_TPB));
+    const int64_t blocks = A * B * col_tiles;
+    if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+#define SK_LAUNCH_NODES(KIND, CPT)                                                                                      \
+    hipLaunchKernelGGL((k_static_nodes<T, DMAX, KIND, 3, CPT>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X0, X1, X2, Y, B, \
+                       M, N, D, inv_sigma, c1, c2, c3, inc, inc_d, inc_dd, ld, col_tiles)
+    if (kind == 0) {
+        if (narrow) SK_LAUNCH_NODES(0, 1); else SK_LAUNCH_NODES(0, 2);
+    } else {
+        if (narrow) SK_LAUNCH_NODES(1, 1); else SK_LAUNCH_NODES(1, 2);
+    }
+#undef SK_LAUNCH_NODES
+    return check_launch();
+}
+
 }  // namespace
+
+template <typename T>
+int launch_static_deriv_increments(int kind, double param, const T *X0, const T *X1, const T *X2, const T *Y, int64_t A,
+                                   int64_t B, int M, int N, int D, double eps, T *inc, T *inc_d, T *inc_dd, int64_t ld,
+                                   hipStream_t s) {
+    if (D <= 4) return launch_static_deriv_d<T, 4>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd, ld, s);
+    if (D <= 8) return launch_static_deriv_d<T, 8>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd, ld, s);
+    if (D <= 16) return launch_static_deriv_d<T, 16>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd, ld, s);
+    if (D <= 32) return launch_static_deriv_d<T, 32>(kind, param, X0, X1, X2, Y, A, B, M, N, D, eps, inc, inc_d, inc_dd, ld, s);
+    return SK_ERR_UNSUPPORTED;
+}
+template int launch_static_deriv_increments<double>(int, double, const double *, const double *, const double *, const double *,
+                                                    int64_t, int64_t, int, int, int, double, double *, double *, double *,
+                                                    int64_t, hipStream_t);
+template int launch_static_deriv_increments<float>(int, double, const float *, const float *, const float *, const float *,
+                                                   int64_t, int64_t, int, int, int, double, float *, float *, float *, int64_t,
+                                                   hipStream_t);
 
 template <typename T>
 int launch_static_increments(int kind, double param, const T *X, const T *Y, int64_t A, int64_t B, int M, int N, int D,

@@ -255,14 +255,21 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
         out[0] = 1.
         return out[0], out[1], out[2]
     Xd, Yd, gd = X.detach(), Y.detach(), gamma.detach()
-    per_row = 6 * B * M * N * X.element_size()      # three static Gram matrices + three increment arrays
+    fused = _fused_static(static_kernel, True) if hasattr(be, "static_deriv_increments") else None
+    # transient bytes per row of X: three increment arrays (+ three static Gram matrices on the generic route)
+    per_row = (3 if fused is not None else 6) * B * M * N * X.element_size()
     for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
         Xt, gt = Xd[a0:a1], gd[a0:a1]
-        G0 = static_kernel.Gram_matrix(Xt, Yd).contiguous()                          # sigkernel.py:526
-        G1 = static_kernel.Gram_matrix(Xt + eps * gt, Yd).contiguous()               # :530
-        G2 = static_kernel.Gram_matrix(Xt + 2. * eps * gt, Yd).contiguous()          # :537
-        inc3 = be.deriv_increments(G0, G1, G2, eps)                                  # :527-541
-        del G0, G1, G2
+        X1, X2 = Xt + eps * gt, Xt + 2. * eps * gt                                   # sigkernel.py:530, :537
+        inc3 = None
+        if fused is not None:    # static kernel + finite differences + increments in one pass (sk_static_deriv_increments_*)
+            inc3 = be.static_deriv_increments(fused[0], fused[1], Xt.contiguous(), X1, X2, Yd.contiguous(), eps)
+        if inc3 is None:
+            G0 = static_kernel.Gram_matrix(Xt, Yd).contiguous()                      # :526
+            G1 = static_kernel.Gram_matrix(X1, Yd).contiguous()                      # :530
+            G2 = static_kernel.Gram_matrix(X2, Yd).contiguous()                      # :537
+            inc3 = be.deriv_increments(G0, G1, G2, eps)                              # :527-541
+            del G0, G1, G2
         k, kd, kdd = be.solve_deriv(inc3, dyadic_order)                              # :543-566 (tile() by index)
         out[0, a0:a1], out[1, a0:a1], out[2, a0:a1] = k, kd, kdd
     return out[0], out[1], out[2]

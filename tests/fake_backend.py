@@ -68,3 +68,8 @@ class OracleBackend:
     def solve_deriv(self, inc3, dyadic, flags=0):
         a = inc3.detach().double().numpy()
         return tuple(torch.from_numpy(v).to(inc3.dtype) for v in O.solve_deriv_coarse(a[0], a[1], a[2], dyadic))
+
+    def static_deriv_increments(self, kind, param, X0, X1, X2, Y, eps):
+        import sigkernel_amd
+        k = sigkernel_amd.LinearKernel() if kind == 0 else sigkernel_amd.RBFKernel(param)
+        return self.deriv_increments(k.Gram_matrix(X0, Y), k.Gram_matrix(X1, Y), k.Gram_matrix(X2, Y), eps)

@@ -232,6 +232,49 @@ def test_gpu_deriv_increments_match_reference_order():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,M,N", [(0, 3, 9, 12), (1, 2, 20, 70), (1, 8, 33, 64), (0, 32, 5, 130)])
+def test_gpu_fused_static_deriv_increments_against_generic_route(kind, D, M, N):
+    """sk_static_deriv_increments_* (static kernel fused in) against Gram_matrix x 3 + sk_deriv_increments_*.  The two
+    evaluate the static kernel in different summation orders, and the 1/eps, 1/eps^2 scaling amplifies that last-bit
+    difference of G: tolerances 1e-14 / 1e-10 / 1e-6 times max|G| (absolute -- for the linear kernel the second-derivative
+    increments are round-off around an exact zero)."""
+    import sigkernel_amd
+    from sigkernel_amd import _lib
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(M)
+    X, Y = (walk(gen, 4, M, D) * 2).cuda(), (walk(gen, 3, N, D) * 2).cuda()
+    g = torch.randn(4, M, D, generator=gen, dtype=torch.float64).cuda()
+    eps = 1e-4
+    k = sigkernel_amd.LinearKernel() if kind == 0 else sigkernel_amd.RBFKernel(0.7)
+    fused = be.static_deriv_increments(kind, 1.0 if kind == 0 else 0.7, X, X + eps * g, X + 2. * eps * g, Y, eps)
+    ref = be.deriv_increments(k.Gram_matrix(X, Y).contiguous(), k.Gram_matrix(X + eps * g, Y).contiguous(),
+                              k.Gram_matrix(X + 2. * eps * g, Y).contiguous(), eps)
+    assert fused.shape == ref.shape == (3, 4, 3, M - 1, N - 1) and fused.stride(-2) % 16 == 0
+    gmax = float(k.Gram_matrix(X, Y).abs().max())
+    for i, tol in enumerate((1e-14, 1e-10, 1e-6)):
+        assert float((fused[i] - ref[i]).abs().max()) <= tol * max(gmax, 1.0), i
+    # the padding columns the solver streams are zero
+    ld = fused.stride(-2)
+    raw = torch.as_strided(fused, (3, 4, 3, M - 1, ld), fused.stride())
+    assert float(raw[..., N - 1:].abs().max()) == 0.0 if ld > N - 1 else True
+
+
+@pytest.mark.gpu
+def test_gpu_user_defined_static_kernel_takes_the_generic_route():
+    import sigkernel_amd
+
+    class MyRBF(sigkernel_amd.RBFKernel):     # a subclass is never fused
+        pass
+    gen = torch.Generator().manual_seed(1)
+    X, Y = (walk(gen, 5, 12, 3) * 2).cuda(), (walk(gen, 4, 10, 3) * 2).cuda()
+    g = torch.randn(5, 12, 3, generator=gen, dtype=torch.float64).cuda()
+    a = sigkernel_amd.SigKernel(MyRBF(0.8), 1).compute_kernel_and_derivatives_Gram(X, Y, g)
+    b = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.8), 1).compute_kernel_and_derivatives_Gram(X, Y, g)
+    for u, v, tol in zip(a, b, (TOL_K, TOL_KD, TOL_KDD)):
+        assert rel_err(u.cpu(), v.cpu()) <= tol
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", _api_cases())
 def test_gpu_api_matches_reference_fixture(name):
     import sigkernel_amd
