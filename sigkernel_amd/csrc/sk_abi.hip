@@ -22,8 +22,9 @@ int solve_fwd(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     if (!out_final && !out_grid && !out_edges) return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
-    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_final && !out_grid) {
-        const int rc = launch_fwd_wave<T>(inc_c, g.ld, g, out_final, out_edges, (hipStream_t)stream);
+    // full grids and terminal edges come from the anti-diagonal kernel (the strip kernel's edges use its own padded layout)
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && out_final && !out_grid && !out_edges) {
+        const int rc = launch_fwd_wave<T>(inc_c, g.ld, g, out_final, nullptr, (hipStream_t)stream);
         if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
     } else if (flags & SK_FLAG_FAST_ONLY) {
         return SK_ERR_UNSUPPORTED;
@@ -31,9 +32,11 @@ int solve_fwd(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     return launch_fwd_simple<T>(inc_c, g, out_final, out_grid, out_edges, (hipStream_t)stream);
 }
 
-// workspace of the fast adjoint: terminal edges [P, MM+NN+2] doubles + a dummy K[MM][NN] vector [P] doubles
-size_t adj_fast_workspace_bytes(const Geom &g) {
-    return (size_t)g.P * (size_t)(g.MM + g.NN + 2 + 1) * sizeof(double);
+// workspace of the fast adjoint: terminal edges in the strip layout [P, NNp + MMp] doubles + a dummy K[MM][NN] vector
+// [P] doubles; 0 when the strip kernels do not cover the shape
+size_t adj_fast_workspace_bytes(const Geom &g, int elem_size) {
+    const size_t e = strip_edge_doubles(g, elem_size);
+    return e ? (size_t)g.P * (e + 1) * sizeof(double) : 0;
 }
 
 template <typename T>
@@ -46,11 +49,12 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     if (ldw == 0) ldw = Nc;
     hipStream_t s = (hipStream_t)stream;
     if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
-    const bool fast_shape = dyadic >= 1 && dyadic <= 2 && g.MM + g.NN + 2 <= 1024;   // launch_adj_wave's scope
-    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && fast_shape && out_err && ws && ws_bytes >= adj_fast_workspace_bytes(g)) {
+    const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // launch_adj_wave's scope
+    const size_t fast_ws = fast_shape ? adj_fast_workspace_bytes(g, (int)sizeof(T)) : 0;
+    if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && fast_ws && out_err && ws && ws_bytes >= fast_ws) {
         // forward sweep that also emits the terminal row/column, then the fused reverse sweep + recompute of K
         double *edges = static_cast<double *>(ws);
-        T *kfin = out_final ? out_final : reinterpret_cast<T *>(edges + (size_t)P * (g.MM + g.NN + 2));
+        T *kfin = out_final ? out_final : reinterpret_cast<T *>(edges + (size_t)P * strip_edge_doubles(g, (int)sizeof(T)));
         int rc = launch_fwd_wave<T>(inc_c, g.ld, g, kfin, edges, s);
         if (rc == SK_OK) rc = launch_adj_wave<T>(inc_c, g.ld, g, edges, W, ldw, out_err, s);
         if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
@@ -181,12 +185,11 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {
-    (void)elem_size;
-    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
+    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16 || (elem_size != 4 && elem_size != 8)) return 0;
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);
     const size_t simple = adj_simple_workspace_bytes(g);
     if (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) return simple;
-    const size_t fast = adj_fast_workspace_bytes(g);
+    const size_t fast = adj_fast_workspace_bytes(g, elem_size);
     return fast > simple ? fast : simple;
 }
 

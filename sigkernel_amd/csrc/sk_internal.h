@@ -38,8 +38,44 @@ size_t simple_lds_bytes(const Geom &g);
 
 // ---- sk_wave.hip: skewed row-strip wavefront sweep, register-resident state, LDS-DMA staging ----
 // SK_ERR_UNSUPPORTED = shape/layout not covered; the caller falls back to the simple kernel.
+// `strip_edges` (nullable, internal): the pair's terminal row and column in the padded strip layout
+// [P][NNp + MMp] = K[MM][1..NNp], K[1..MMp][NN] that launch_adj_wave reads; strip_edge_doubles() gives NNp + MMp
+// (0 when the strip kernels do not cover the shape).
 template <typename T>
-int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *out_edges, hipStream_t s);
+int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *strip_edges, hipStream_t s);
+
+// Strip decomposition shared by the forward and adjoint wave kernels for dyadic 1..2 (where both use the same rows per
+// lane): NUp 16-byte units per padded row, L = 1 << logL lanes per pair, nb bands, RC coarse rows per lane.
+struct Strip {
+    int NUp, logL, nb, RC;
+    int NNp, MMp;   // padded fine columns / rows
+    bool ok;
+};
+inline Strip strip_geom(const Geom &g, int elem_size) {
+    Strip st{};
+    const int CW = 16 / elem_size, DY = g.dyadic;
+    st.RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
+    const int NU = (g.Nc + CW - 1) / CW;
+    st.NUp = (NU + 7) / 8 * 8;
+    st.logL = 3;
+    while (st.logL < 6 && (st.RC << st.logL) < g.Mc) ++st.logL;
+    int L = 1 << st.logL;
+    st.nb = (g.Mc + L * st.RC - 1) / (L * st.RC);
+    st.ok = true;
+    if (st.nb > 1) {
+        // band b+1 reads what band b's bottom lane wrote L-1 macro-steps after the top lane: needs NUp >= L
+        while (L > st.NUp && st.logL > 3) { --st.logL; L >>= 1; }
+        if (L > st.NUp) st.ok = false;
+        st.nb = (g.Mc + L * st.RC - 1) / (L * st.RC);
+    }
+    st.NNp = (st.NUp * CW) << DY;
+    st.MMp = (st.nb * L * st.RC) << DY;
+    return st;
+}
+inline size_t strip_edge_doubles(const Geom &g, int elem_size) {
+    const Strip st = strip_geom(g, elem_size);
+    return st.ok ? (size_t)st.NNp + (size_t)st.MMp : 0;
+}
 
 // ---- sk_wave_adj.hip: fused reverse sweep + backward recompute of K (needs the forward kernel's edges) ----
 template <typename T>

@@ -40,10 +40,9 @@ struct WaveParams {
     int n_steps;       // macro-steps each wave sweeps (incl. drain)
     int u_f, lam_f, sel_f;  // where K[MM][NN] lives: unit, lane-in-group, k_f*CW + cw_f inside the block
     int naive;
-    double *edges;     // nullable [P, MM+NN+2]: K[MM][0..NN] then K[0..MM][NN] (EDGES variant)
+    double *edges;     // nullable [P, NNp + MMp]: K[MM][1..NNp] then K[1..MMp][NN] (EDGES variant; padded strip sizes)
     int k_f;           // coarse row inside the lane's block that holds the pair's last row
     int nt;            // non-temporal cache policy on the increment loads
-    int n_edge_slots, edge_slot_bytes;   // EDGES: LDS ring of per-pair edge buffers (per lane group)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -80,12 +79,15 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
     // MULTIBAND: bottom row of the previous band, [G][NUp*S] doubles behind the ring
     const unsigned my_bnd = lds0 + NSLOT * SLOT_BYTES + (unsigned)((lane >> prm.logL) * NUp * S) * 8u;
-    // EDGES: the terminal row/column of each pair is collected in LDS ([G][n_edge_slots][edge_slot_bytes] behind
-    // the boundary rows) and flushed with coalesced stores once the group's last lane has left the pair
-    const unsigned edges_lds = NSLOT * SLOT_BYTES + (MULTIBAND ? (unsigned)(G * NUp * S) * 8u : 0u);
-    const int NES = EDGES ? prm.n_edge_slots : 1;
-    int es = ((ps % NES) + NES) % NES;
-    const unsigned my_edges = lds0 + edges_lds + (unsigned)((lane >> prm.logL) * NES * prm.edge_slot_bytes);
+    // EDGES: the terminal row and column of every pair (what the adjoint kernel's backward recompute of K starts
+    // from) go straight from registers to global memory, 32..64 bytes per lane and macro-step, in the padded layout
+    // [K[MM][1..NNp]] [K[1..MMp][NN]].  The values are held for one macro-step and stored right after the next
+    // step's DMA wait, so that the stores have a whole step to be acknowledged before the following wait (loads and
+    // stores share vmcnt on gfx9: a store still in flight at the wait costs a step of prefetch distance).
+    const int EP = EDGES ? (NUp * S + nb * L * R) : 0;   // doubles per pair
+    double erow[S], ecol[R];
+    int erow_at = -1, ecol_at = -1;                       // element offsets inside the pair's block, -1 = nothing held
+    int64_t e_pair = 0;
 
     // ---- producer (DMA) state ---------------------------------------------------------------------------
     // Fetch step f = 8q + j serves the 8 consumer lanes lc = j + 8*(lane/8); all of them are about to start
@@ -150,28 +152,6 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
 #pragma unroll
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
 
-    // EDGES flush: pair `fl_pair` of every lane group, slot fl_slot; the first one is due after L-1 + pair_steps steps
-    const int pair_steps = nb * NUp;
-    int fl_t = -(L - 1), fl_pair = 0, fl_slot = 0;
-    auto flush_edges = [&]() {
-        const int MM = prm.Mc << DY, NN = prm.Nc << DY, E = MM + NN + 2;
-        for (int g = 0; g < G; ++g) {
-            const int64_t pr = ((int64_t)blockIdx.x * G + g) * prm.PPG + fl_pair;
-            if (fl_pair >= prm.PPG || pr >= prm.P) continue;
-            double *dst = prm.edges + pr * (int64_t)E;
-            const unsigned src = lds0 + edges_lds + (unsigned)((g * NES + fl_slot) * prm.edge_slot_bytes);
-            for (int idx = lane; idx < E; idx += WAVE) {
-                // dense layout: [0] = K[MM][0] = 1, [1..NN] row, [NN+1] = K[0][NN] = 1, [NN+2..] column
-                const bool one = idx == 0 || idx == NN + 1;
-                const int li = idx <= NN ? idx - 1 : NUp * S + (idx - NN - 2);
-                const double v = lds_read_f64(src + (unsigned)(one ? 0 : li) * 8u);
-                dst[idx] = one ? 1.0 : v;
-            }
-        }
-        fl_pair += 1;
-        fl_slot = fl_slot + 1 == NES ? 0 : fl_slot + 1;
-    };
-
     // prologue: the lines needed at macro-steps 0 .. PF-1
 #pragma unroll
     for (int f = 0; f < PF; ++f) issue_fetch();
@@ -181,6 +161,26 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         // -- increments of this macro-step: RC rows x CW coarse columns (waits for the fetch of step t)
         vec_t gv[RC];
         lds_read_rows<PF * RC>(gv, rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4)));
+
+        if (EDGES) {   // the edge values produced in the previous macro-step
+            double *const ep = prm.edges + e_pair * EP;
+            if (erow_at >= 0) {
+#pragma unroll
+                for (int cc = 0; cc < S; cc += 2) {
+                    d2_t v = {erow[cc], erow[cc + 1]};
+                    *reinterpret_cast<d2_t *>(ep + erow_at + cc) = v;
+                }
+            }
+            if (ecol_at >= 0) {
+#pragma unroll
+                for (int rr = 0; rr < R; rr += 2) {
+                    d2_t v = {ecol[rr], ecol[rr + 1]};
+                    *reinterpret_cast<d2_t *>(ep + ecol_at + rr) = v;
+                }
+            }
+            erow_at = -1;
+            ecol_at = -1;
+        }
 
         // -- row-unit start: left boundary K[i][0] = 1
         if (u == 0) {
@@ -269,31 +269,24 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
             }
         }
 
-        // -- terminal row and column of the pair (what the adjoint kernel starts from) -> LDS, whole blocks at a time:
-        //    slot layout [K[MM][1..NNp]] [K[1..MMp][NN]] (padded sizes, so no bounds tests here; flush_edges() maps it
-        //    to the dense [P, MM+NN+2] array).  The column relies on the padding columns of the last unit being zero
-        //    (K is constant along zero increments).
+        // -- terminal row and column of the pair: hold them, the next macro-step stores them (see above).  The column
+        //    relies on the padding columns of the last unit being zero (K is constant along zero increments).
         if (EDGES) {
-            const unsigned e = my_edges + (unsigned)(es * prm.edge_slot_bytes);
-            if (lam == prm.lam_f && band == nb - 1) {
-                const unsigned a = e + (unsigned)(u * S) * 8u;
+            const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
+            if (pair_ok) e_pair = pair0 + ps;
+            if (pair_ok && lam == prm.lam_f && band == nb - 1) {
+                erow_at = u * S;
 #pragma unroll
                 for (int kk = 0; kk < RC; ++kk)
                     if (kk == prm.k_f) {   // uniform: which coarse row of the block is the pair's last row
 #pragma unroll
-                        for (int cc = 0; cc < S; cc += 2) {
-                            d2_t v = {rowv[kk][cc], rowv[kk][cc + 1]};
-                            lds_write_b128(a + cc * 8u, v);
-                        }
+                        for (int cc = 0; cc < S; ++cc) erow[cc] = rowv[kk][cc];
                     }
             }
-            if (u == prm.u_f) {
-                const unsigned a = e + (unsigned)(NUp * S + (band * L + lam) * R) * 8u;
+            if (pair_ok && u == prm.u_f) {
+                ecol_at = NUp * S + (band * L + lam) * R;
 #pragma unroll
-                for (int rr = 0; rr < R; rr += 2) {
-                    d2_t v = {left[rr], left[rr + 1]};
-                    lds_write_b128(a + rr * 8u, v);
-                }
+                for (int rr = 0; rr < R; ++rr) ecol[rr] = left[rr];
             }
         }
 
@@ -324,17 +317,19 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                 if (band == nb) {
                     band = 0;
                     ps += 1;
-                    if (EDGES) es = es + 1 == NES ? 0 : es + 1;
                 }
             }
         }
-        if (EDGES) {
-            // the group's last lane (lam = L-1) has just finished a pair: flush that pair's edges
-            fl_t += 1;
-            if (fl_t == pair_steps) {
-                fl_t = 0;
-                flush_edges();
-            }
+    }
+    if (EDGES) {   // the values of the very last macro-step
+        double *const ep = prm.edges + e_pair * EP;
+        if (erow_at >= 0) {
+#pragma unroll
+            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = erow[cc];
+        }
+        if (ecol_at >= 0) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = ecol[rr];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -382,39 +377,25 @@ int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t 
 // Returns SK_ERR_UNSUPPORTED when the shape / layout is outside what this kernel handles; the caller
 // then falls back to the simple kernel.
 template <typename T>
-int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *out_edges, hipStream_t s) {
+int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *strip_edges, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
     int PF = env_int("SK_WAVE_PF", 2);
-    if ((PF != 3 && PF != 4) || out_edges) PF = 2;
+    if ((PF != 3 && PF != 4) || strip_edges) PF = 2;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || ((ld * sizeof(T)) & 15)) return SK_ERR_UNSUPPORTED;
     const int NU = (g.Nc + CW - 1) / CW;
     if ((int64_t)NU * CW > ld) return SK_ERR_UNSUPPORTED;  // the last unit must stay inside the row
-    const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
-    const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
-    const int S = CW << DY;
-
     // lanes per pair: the smallest power of two (>= 8) whose band covers all rows; else full waves and bands
-    int logL = 3;
-    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
-    int L = 1 << logL;
-    int nb = (g.Mc + L * RC - 1) / (L * RC);
-    if (nb > 1) {
-        // band b+1 reads what band b's bottom lane wrote L-1 macro-steps after the top lane: needs NUp >= L
-        while (L > NUp && logL > 3) { --logL; L >>= 1; }
-        if (L > NUp) return SK_ERR_UNSUPPORTED;
-        nb = (g.Mc + L * RC - 1) / (L * RC);
-    }
+    const Strip st = strip_geom(g, (int)sizeof(T));
+    if (!st.ok) return SK_ERR_UNSUPPORTED;
+    const int NUp = st.NUp, RC = st.RC, logL = st.logL, nb = st.nb, L = 1 << logL;
+    const int S = CW << DY;
     const int G = WAVE / L;
     const bool multiband = nb > 1;
 
     size_t lds_bytes = (size_t)(LINE_UNITS + PF) * RC * 1024;
     if (multiband) lds_bytes += (size_t)G * NUp * S * sizeof(double);
-    // edges: a lane group is spread over ceil((L-1)/pair_steps) + 1 pairs, plus the pair being flushed
-    const int edge_slot_bytes = (NUp * S + nb * L * (RC << DY)) * 8;   // K[MM][1..NNp] and K[1..MMp][NN]
-    const int n_edge_slots = (L - 1 + nb * NUp - 1) / (nb * NUp) + 2;
-    if (out_edges) lds_bytes += (size_t)G * n_edge_slots * edge_slot_bytes;
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
@@ -449,11 +430,9 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     prm.lam_f = ((g.Mc - 1) / RC) % L;
     prm.sel_f = ((g.Mc - 1) % RC) * CW + (g.Nc - 1) % CW;
     prm.naive = g.naive;
-    prm.edges = out_edges;
+    prm.edges = strip_edges;
     prm.k_f = (g.Mc - 1) % RC;
     prm.nt = env_int("SK_WAVE_NT", 1);
-    prm.n_edge_slots = n_edge_slots;
-    prm.edge_slot_bytes = edge_slot_bytes;
 
     switch (DY) {
         case 0: return launch_dy<T, 0>(prm, multiband, PF, (int)waves, lds_bytes, s);

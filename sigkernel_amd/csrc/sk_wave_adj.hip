@@ -30,20 +30,35 @@ namespace {
 
 struct AdjParams {
     const void *inc;       // [P, Mc, ld]
-    const double *edges;   // [P, MM+NN+2]
+    const double *edges;   // [P, NNp + MMp]: K[MM][1..NNp], K[1..MMp][NN] (the forward strip kernel's layout)
     void *W;               // [P, Mc, ldw]
     double *err;           // [P] (zero-initialised by the caller) worst |Kf - 1| on the recomputed j=0 boundary
     int64_t P;
     int64_t ldb, ldwb;     // row strides in bytes
     int Mc, Nc;
     int NUp, nb, logL, PPG, n_steps, naive;
-    int n_edge_dma;        // 1-KiB DMA pieces per pair of edges
-    int edge_slot_bytes;   // LDS bytes per staged pair of edges
-    int nt;                // non-temporal cache policy on the increment loads
-    int n_edge_slots;      // pairs of edges resident per lane group: the pairs a group spans, + 1 in flight
 };
 
-constexpr int ADJ_PF = 2;
+// Prefetch distance of the increment lines, in macro-steps.  Memory operations of a macro-step are issued at its top in
+// the order [W line stores] [self-check atomic] [edge loads for the next step] [increment lines for step t + PF], and the
+// step closes with s_waitcnt vmcnt((PF-1)*RC): loads and stores share vmcnt on gfx9, so "at most the (PF-1)*RC newest
+// operations in flight" means everything but the newest increment lines has completed.  Ring = 8 (being consumed) + 1
+// (being written out as W) + PF (in flight) slots.  Measured at d = 1 (131072 pairs of 127x127, forward + adjoint):
+// PF = 1 with 8 waves/CU (20 KB of LDS per wave) 13.3 ms, PF = 2 with 7 waves/CU (22 KB) 14.4 ms, PF = 2 with 4 waves/CU
+// 14.8 ms, PF = 1 with 4 waves/CU 17.4 ms: occupancy buys more than prefetch depth.
+constexpr int ADJ_PF = 1;
+
+// An asynchronous 8-byte global load into a register: the caller must execute wait_loads() on the register before
+// any use.  (The compiler's own waitcnt insertion would wait for every LDS-DMA in flight at the first use.)
+__device__ __forceinline__ void load_async(double &dst, const double *p) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int VM, int N>
+__device__ __forceinline__ void wait_loads(double (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));   // orders every later use after the wait
+}
 
 // 1/b for b = 1 - g^2/12 (close to 1): hardware estimate + two Newton steps, instead of the ~20-instruction IEEE
 // division sequence.  The result only has to be a consistent multiplier: a/b and 1/b are formed from the same value.
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     const int lam = lane & (L - 1), grp = lane >> prm.logL;
     const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
     const int Mcp = nb * L * RC;                       // padded coarse rows
-    const int MM = prm.Mc << DY, NN = prm.Nc << DY, MMp = Mcp << DY, NNp = (NUp * CW) << DY;
+    const int MM = prm.Mc << DY, MMp = Mcp << DY, NNp = (NUp * CW) << DY;
     const double sc = 1.0 / (double)(1 << (2 * DY));
     const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
 
@@ -97,12 +112,8 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
-    // LDS map: [increment ring][edges: G groups x EDGE_SLOTS pairs][MULTIBAND: Kr and Kf band boundary rows]
-    const int EDGE_SLOTS = prm.n_edge_slots;
-    const unsigned edge_base = lds0 + NSLOT * SLOT_BYTES + (unsigned)(grp * EDGE_SLOTS * prm.edge_slot_bytes);
-    int es = ((ps % EDGE_SLOTS) + EDGE_SLOTS) % EDGE_SLOTS;   // ring slot holding the edges of this lane's pair
-    const unsigned bnd_r = lds0 + NSLOT * SLOT_BYTES + (unsigned)(G * EDGE_SLOTS * prm.edge_slot_bytes) +
-                           (unsigned)(grp * 2 * NUp * S) * 8u;
+    // LDS map: [increment ring][MULTIBAND: Kr and Kf band boundary rows]
+    const unsigned bnd_r = lds0 + NSLOT * SLOT_BYTES + (unsigned)(grp * 2 * NUp * S) * 8u;
     const unsigned bnd_f = bnd_r + (unsigned)(NUp * S) * 8u;
 
     // ---- producer: increments, whole lines, back to front (see sk_wave.hip for the forward-order twin) ----
@@ -134,13 +145,9 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     int fj = 0, fslot = 0;
     auto issue_fetch = [&]() {
 #pragma unroll
-        for (int k = 0; k < RC; ++k)
-            if (prm.nt)   // streaming hint: the line is read exactly once, keep L2 for the W lines being written
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
-                                                         st_off - (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
-                                                         st_off - (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
+        for (int k = 0; k < RC; ++k)   // aux = 2, streaming: the line is read exactly once, keep L2 for the W lines being written
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                     st_off - (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
         fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
         fj += 1;
         if (fj == LINE_UNITS) {
@@ -205,22 +212,31 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         }
     };
 
-    // ---- producer: terminal edges of pair `pi` of every lane group into its ring slot pi % EDGE_SLOTS -------
-    const int E = MM + NN + 2;
-    const int64_t edges_total = (int64_t)prm.P * E * 8;
-    auto issue_edges = [&](int pi, int pslot) {
-        for (int g = 0; g < G; ++g) {
-            const int64_t pr = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
-            if (pi >= prm.PPG || pr >= prm.P) continue;
-            const __amdgpu_buffer_rsrc_t er = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(reinterpret_cast<const char *>(prm.edges) + pr * E * 8), 0, E * 8, 0x00020000);
-            const unsigned dst = NSLOT * SLOT_BYTES + (unsigned)((g * EDGE_SLOTS + pslot) * prm.edge_slot_bytes);
-            for (int c = 0; c < prm.n_edge_dma; ++c)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(er, (lds_void *)(lds + dst + c * 1024), 16,
-                                                         (unsigned)(c * 1024 + lane * 16), 0, 0, 0);
+    // ---- terminal edges of the forward solution (what the backward recompute of K starts from) -----------------------
+    // K[MM][.] feeds the group's top lane, S values per macro-step; K[.][NN] feeds every lane at the start of its row
+    // unit, R + 1 values.  Both are fetched from global memory (L2-resident: the forward kernel has just written them)
+    // straight into registers ONE macro-step ahead -- asynchronously at the top of the step, waited for at its end --
+    // so no LDS is spent on them.  (The first version staged whole pairs of edges in an LDS ring: 12 KB per wave, which
+    // held the kernel at one wave per SIMD.)
+    const int E = NNp + MMp;
+    auto prefetch_edges = [&](int nu, int nband, int nps, double (&prow)[S], double (&pcol)[R + 1]) {
+        int64_t pr = pair0 + nps;
+        pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);     // not-yet-started / finished lanes: any valid pair, value unused
+        const double *e = prm.edges + pr * E;
+        if (is_top && (!MULTIBAND || nband == 0)) {
+            // Kf[0][j'] = K[MM][NNp - j'], j' = nu*S + i + 1; K[MM][0] = 1 is not stored (fixed up after the wait)
+            const int jb = NNp - nu * S - 1;
+#pragma unroll
+            for (int i = 0; i < S; ++i) load_async(prow[i], e + max(jb - i - 1, 0));
+        }
+        if (nu == 0) {
+            // Kf[i'][0] = K[min(MM, MMp - i')][NN], i' = i0 .. i0 + R (corner first); rows past MM of the padded strip
+            // hold garbage, hence the clamp; K[0][NN] = 1 is not stored (fixed up after the wait)
+            const int i0 = (nband * L + lam) * RC * r;
+#pragma unroll
+            for (int i = 0; i <= R; ++i) load_async(pcol[i], e + (NNp + max(min(MM, MMp - (i0 + i)) - 1, 0)));
         }
     };
-    (void)edges_total;
 
     double leftR[R], botR[S], cornerR = 1.0;
     double leftF[R], botF[S], cornerF = 1.0;
@@ -229,38 +245,61 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
 #pragma unroll
     for (int i = 0; i < S; ++i) { botR[i] = 1.0; botF[i] = 1.0; }
 
-    issue_edges(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double chk_val = 0.0;      // pending self-check result (see the end of the macro-step)
+    int64_t chk_pair = -1;
+    // edge values of the coming macro-step (complete: waited for at the end of the step that requested them)
+    double nrow[S], ncol[R + 1];
 #pragma unroll
-    for (int f = 0; f < PF; ++f) issue_fetch();
+    for (int i = 0; i < S; ++i) nrow[i] = 1.0;
+#pragma unroll
+    for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
+    {
+        double prow[S], pcol[R + 1];
+        prefetch_edges(u, band, ps, prow, pcol);
+#pragma unroll
+        for (int f = 0; f < PF; ++f) issue_fetch();
+        wait_loads<(PF - 1) * RC>(prow);   // the line of macro-step 0 and the edge values
+        wait_loads<(PF - 1) * RC>(pcol);
+        if (is_top && (!MULTIBAND || band == 0)) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) nrow[i] = (NNp - u * S - 1 - i) >= 1 ? prow[i] : 1.0;
+        }
+        if (u == 0) {
+            const int i0 = (band * L + lam) * RC * r;
+#pragma unroll
+            for (int i = 0; i <= R; ++i) ncol[i] = (MMp - (i0 + i)) >= 1 ? pcol[i] : 1.0;
+        }
+    }
 
-    const int pair_steps = nb * NUp;
-    int t_in_pair = 0, pair_idx = 0, next_slot = 1 % EDGE_SLOTS;   // uniform: position of the group-top lanes
     for (int t = 0; t < prm.n_steps; ++t) {
-        if (t_in_pair == 0) issue_edges(pair_idx + 1, next_slot);   // needed one whole pair later
-        issue_fetch();
         vec_t gv[RC];
         const unsigned my_unit = rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4));
-        lds_read_rows<PF * RC>(gv, my_unit);
+        lds_read_rows<63>(gv, my_unit);       // its line arrived before the previous step's closing wait
         if (t >= LINE_UNITS) store_lines();   // the lines whose last unit was written in the previous macro-step
+        if (chk_pair >= 0) {
+            atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
+            chk_pair = -1;
+        }
+
+        // -- state of this lane one macro-step ahead, and its edge values (asynchronous, see prefetch_edges)
+        int nu = u + 1, nband = band, nps = ps;
+        if (nu == NUp) {
+            nu = 0;
+            nband += 1;
+            if (nband == nb) { nband = 0; nps += 1; }
+        }
+        double prow[S], pcol[R + 1];
+        prefetch_edges(nu, nband, nps, prow, pcol);
+        issue_fetch();                        // the line of macro-step t + PF: the newest operations in flight
 
         const int prow0 = (band * L + lam) * RC;          // first flipped coarse row of this lane
-        const unsigned eslot = edge_base + (unsigned)(es * prm.edge_slot_bytes);
 
         // -- row-unit start: left boundaries.  Kr[i'][0] = 1;  Kf[i'][0] = K[min(MM, MMp - i')][NN]
         if (u == 0) {
-            const int i0 = prow0 * r;   // = i' of the block's top node
             cornerR = 1.0;
-            cornerF = lds_read_f64(eslot + (unsigned)(NN + 1 + min(MM, MMp - i0)) * 8u);
+            cornerF = ncol[0];
 #pragma unroll
-            for (int i = 0; i < R; ++i) leftR[i] = 1.0;
-#pragma unroll
-            for (int i = 0; i < R; i += 4)
-                lds_read_f64x4(leftF[i], leftF[i + 1], leftF[i + 2], leftF[i + 3],
-                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 1 + i))) * 8u,
-                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 2 + i))) * 8u,
-                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 3 + i))) * 8u,
-                               eslot + (unsigned)(NN + 1 + min(MM, MMp - (i0 + 4 + i))) * 8u);
+            for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = ncol[i + 1]; }
         }
 
         // -- top rows: from the lane above, or (top lane) the band boundary / the pair's terminal row
@@ -272,15 +311,9 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
                     lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
                     lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
                 } else {
-                    // Kr[0][j'] = 1;  Kf[0][j'] = K[MM][min(NN, NNp - j')], j' = u*S + i + 1
+                    // Kr[0][j'] = 1;  Kf[0][j'] = K[MM][min(NN, NNp - j')], j' = u*S + i + 1 (prefetched)
 #pragma unroll
-                    for (int i = 0; i < S; ++i) tbR[i] = 1.0;
-                    const int jb = NNp - u * S - 1;
-#pragma unroll
-                    for (int i = 0; i < S; i += 4)
-                        lds_read_f64x4(tbF[i], tbF[i + 1], tbF[i + 2], tbF[i + 3], eslot + (unsigned)min(NN, jb - i) * 8u,
-                                       eslot + (unsigned)min(NN, jb - i - 1) * 8u, eslot + (unsigned)min(NN, jb - i - 2) * 8u,
-                                       eslot + (unsigned)min(NN, jb - i - 3) * 8u);
+                    for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
                 }
             } else {
 #pragma unroll
@@ -371,41 +404,40 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
             else { wu[0] = (float)(acc[k][3] * sc); wu[1] = (float)(acc[k][2] * sc); wu[2] = (float)(acc[k][1] * sc); wu[3] = (float)(acc[k][0] * sc); }
             lds_write_b128(my_unit + k * 1024u, wu);
         }
-        const bool valid = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
-        if (valid) {
-            // -- self-check on the last flipped unit: the recomputed K on the j = 0 boundary must be 1
-            if (u == NUp - 1 && prm.err) {
-                double e = 0.0;
+        // -- self-check on the last flipped unit: the recomputed K on the j = 0 boundary must be 1.  The worst deviation is
+        //    held in a register and sent at the top of the next macro-step together with the other memory operations: an
+        //    atomic issued here would sit, with its whole latency, in front of the closing vmcnt(0).
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+            double e = 0.0;
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
-                atomicMax(reinterpret_cast<unsigned long long *>(prm.err + pair0 + ps),
-                          (unsigned long long)__double_as_longlong(e));
-            }
+            for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
+            chk_val = e;
+            chk_pair = pair0 + ps;
+        }
+
+        // -- close the step: everything requested from global memory in it (next line, W lines, edge values) has landed
+        wait_loads<(PF - 1) * RC>(prow);
+        wait_loads<(PF - 1) * RC>(pcol);
+        if (is_top && (!MULTIBAND || nband == 0)) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) nrow[i] = (NNp - nu * S - 1 - i) >= 1 ? prow[i] : 1.0;
+        }
+        if (nu == 0) {
+            const int i0 = (nband * L + lam) * RC * r;
+#pragma unroll
+            for (int i = 0; i <= R; ++i) ncol[i] = (MMp - (i0 + i)) >= 1 ? pcol[i] : 1.0;
         }
 
         // -- advance
-        u += 1;
-        if ((u & 7) == 0) {
+        if ((nu & 7) == 0) {
             slot += LINE_UNITS;
             if (slot >= NSLOT) slot -= NSLOT;
-            if (u == NUp) {
-                u = 0;
-                band += 1;
-                if (band == nb) {
-                    band = 0;
-                    ps += 1;
-                    es = es + 1 == EDGE_SLOTS ? 0 : es + 1;
-                }
-            }
         }
-        t_in_pair += 1;
-        if (t_in_pair == pair_steps) {
-            t_in_pair = 0;
-            pair_idx += 1;
-            next_slot = next_slot + 1 == EDGE_SLOTS ? 0 : next_slot + 1;
-        }
+        u = nu; band = nband; ps = nps;
     }
     for (int t = 0; t < LINE_UNITS; ++t) store_lines();   // the lines completed in the last 8 macro-steps
+    if (chk_pair >= 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -435,51 +467,34 @@ int launch_adj_dy(const AdjParams &prm, bool multiband, int blocks, size_t lds_b
 
 // SK_ERR_UNSUPPORTED when the shape / layout is not covered (the caller falls back to the stored-grid kernel).
 // Requirements: dyadic 1..2 (a lane block must cover whole coarse cells; d = 3 would spill), increment rows padded with ZEROS to whole
-// 128-byte lines (ld*sizeof(T) % 128 == 0 and ld >= the padded width), W with the same row stride rule, and
-// (MM + NN + 2) <= 1024 so that three pairs of terminal edges fit next to the increment ring.
+// 128-byte lines (ld*sizeof(T) % 128 == 0 and ld >= the padded width), W with the same row stride rule.
 template <typename T>
 int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
                     hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
     const int DY = g.dyadic;
-    if (DY < 1 || DY > 2) return SK_ERR_UNSUPPORTED;   // d = 3 needs > 256 VGPRs for the two states: stored-grid kernel
+    // d = 3 (and d = 2 with 4-column fp32 units) needs > 256 VGPRs for the two states: stored-grid kernel
+    if (DY < 1 || DY > (sizeof(T) == 8 ? 2 : 1)) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return SK_ERR_UNSUPPORTED;
-    const int NU = (g.Nc + CW - 1) / CW;
-    const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
+    const Strip st = strip_geom(g, (int)sizeof(T));   // the same decomposition as the forward kernel (it wrote `edges`)
+    if (!st.ok) return SK_ERR_UNSUPPORTED;
+    const int NUp = st.NUp, RC = st.RC, logL = st.logL, nb = st.nb, L = 1 << logL;
     if ((ld * sizeof(T)) % 128 || ld < (int64_t)NUp * CW) return SK_ERR_UNSUPPORTED;
     if ((ldw * sizeof(T)) % 16 || ldw < (int64_t)NUp * CW) return SK_ERR_UNSUPPORTED;
-    const int RC = DY == 1 ? 2 : 1;
     const int S = CW << DY;
-    const int E = g.MM + g.NN + 2;
-    if (E > 1024) return SK_ERR_UNSUPPORTED;
-
-    int logL = 3;
-    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
-    int L = 1 << logL;
-    int nb = (g.Mc + L * RC - 1) / (L * RC);
-    if (nb > 1) {
-        while (L > NUp && logL > 3) { --logL; L >>= 1; }
-        if (L > NUp) return SK_ERR_UNSUPPORTED;
-        nb = (g.Mc + L * RC - 1) / (L * RC);
-    }
     const int G = WAVE / L;
     const bool multiband = nb > 1;
 
-    const int n_edge_dma = (E * 8 + 1023) / 1024;
-    const int edge_slot_bytes = n_edge_dma * 1024;
-    // a lane group is spread over ceil((L-1)/pair_steps) + 1 pairs; one more slot receives the next pair's edges
-    const int n_edge_slots = (L - 1 + nb * NUp - 1) / (nb * NUp) + 2;
-    size_t lds_bytes = (size_t)(LINE_UNITS + 1 + ADJ_PF) * RC * 1024 + (size_t)G * n_edge_slots * edge_slot_bytes;
+    size_t lds_bytes = (size_t)(LINE_UNITS + 1 + ADJ_PF) * RC * 1024;
     if (multiband) lds_bytes += (size_t)G * 2 * NUp * S * sizeof(double);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    if (waves_per_cu > 8) waves_per_cu = 8;
     const int wpc_env = env_int("SK_ADJ_WPC", 0);
-    // persistent waves all carry the same work: an uneven count per SIMD (5, 6, 7 waves on 4 SIMDs) makes the
-    // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4); an explicit override is taken as is
+    if (waves_per_cu > (wpc_env > 0 ? 16 : 8)) waves_per_cu = wpc_env > 0 ? 16 : 8;
+    // this kernel waits on memory every macro-step, so every extra resident wave helps, also an uneven count per SIMD
+    // (7 waves/CU at d = 1); SK_ADJ_WPC overrides
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
-    else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
@@ -501,15 +516,10 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.nb = nb; prm.logL = logL; prm.PPG = (int)PPG;
     prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
     prm.naive = g.naive;
-    prm.n_edge_dma = n_edge_dma;
-    prm.edge_slot_bytes = edge_slot_bytes;
-    prm.n_edge_slots = n_edge_slots;
-    prm.nt = env_int("SK_WAVE_NT", 1);
 
-    switch (DY) {
-        case 1: return launch_adj_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
-        default: return launch_adj_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
-    }
+    if (DY == 1) return launch_adj_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
+    if constexpr (sizeof(T) == 8) return launch_adj_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
+    return SK_ERR_UNSUPPORTED;
 }
 
 template int launch_adj_wave<double>(const double *, int64_t, const Geom &, const double *, double *, int64_t, double *,

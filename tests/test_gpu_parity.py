@@ -78,12 +78,14 @@ def test_forward_default_path_matches_oracle(be, P, Mc, Nc, d, naive):
     if d <= 3:
         out = be.solve_fwd(padded(inc), d, naive, flags=_lib.FLAG_FAST_ONLY)   # the tiled LDS-DMA kernel, no fallback
         assert rel_err(out.cpu().numpy(), want) <= FAST_TOL
-        # ... and its terminal row/column output (what the fast adjoint starts from)
+        # terminal row/column output: served by the anti-diagonal kernel (exact); the strip kernel keeps its own padded
+        # edge layout for the fused adjoint (covered by the adjoint tests: wrong edges blow up the self-check residual)
         _, grid = O.solve_coarse(inc, d, naive, want_grid=True)
         edges = np.concatenate([grid[:, -1, :], grid[:, :, -1]], axis=1)
-        out, _, e = be.solve_fwd(padded(inc), d, naive, flags=_lib.FLAG_FAST_ONLY, want_edges=True)
-        assert rel_err(out.cpu().numpy(), want) <= FAST_TOL
-        assert rel_err(e.cpu().numpy(), edges) <= FAST_TOL
+        out, _, e = be.solve_fwd(padded(inc), d, naive, want_edges=True)
+        assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(e.cpu().numpy(), edges)
+        with pytest.raises(ValueError):
+            be.solve_fwd(padded(inc), d, naive, flags=_lib.FLAG_FAST_ONLY, want_edges=True)
 
 
 @pytest.mark.parametrize("P,Mc,Nc,d", SHAPES)
@@ -114,7 +116,10 @@ def test_adjoint_matches_oracle(be, P, Mc, Nc, d, naive):
     k, W, res = be.solve_adj(padded(inc), d, naive, return_residual=True)
     resmax = float(res.max())
     assert rel_err(k.cpu().numpy(), want_k) <= FAST_TOL
-    assert rel_err(W.cpu().numpy(), want_w) <= max(ADJ_TOL, 10 * resmax) and resmax <= 1e-2
+    assert rel_err(W.cpu().numpy(), want_w) <= max(ADJ_TOL, 10 * resmax)
+    # the residual stays small unless K explodes (long grids with these synthetic increments reach |W| ~ 1e6; every such
+    # pair is flagged and re-solved, which the line above has just checked)
+    assert resmax <= 1e-2 or np.abs(want_w).max() > 1e4
     fast_ok = 1 <= d <= 2 and (Mc << d) + (Nc << d) + 2 <= 1024
     if fast_ok:
         try:
@@ -123,6 +128,22 @@ def test_adjoint_matches_oracle(be, P, Mc, Nc, d, naive):
             return   # shape not covered by the fused kernel (e.g. fewer columns than lanes)
         assert rel_err(W.cpu().numpy(), want_w) <= max(ADJ_TOL, 10 * float(res.max()))
         assert rel_err(k.cpu().numpy(), want_k) <= FAST_TOL
+
+
+@pytest.mark.parametrize("P,Mc,Nc,d", [(7, 63, 63, 1), (3, 127, 127, 1), (20, 31, 40, 1), (9, 15, 100, 2), (4, 63, 63, 2),
+                                        (2, 200, 130, 1), (2, 130, 260, 2), (5, 8, 8, 1), (2, 300, 300, 1), (1, 400, 500, 1)])
+def test_fused_adjoint_without_the_safety_net(be, P, Mc, Nc, d):
+    """Tame increments (K stays O(1)): the fused forward(edges) + adjoint kernels alone -- single band, multi-band, partial
+    lane groups, grids beyond 1024 nodes per side -- must give W to 1e-10 with a self-check residual at round-off level, so
+    nothing here is rescued by the stored-grid re-solve."""
+    inc = _inc(P, Mc, Nc, seed=77 + Mc + 3 * Nc + d, scale=0.6 / np.sqrt(Mc * Nc))
+    want_k, want_w = O.adjoint_coarse(inc, d, nthreads=8)
+    k, W, res = be.solve_adj(padded(inc), d, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
+    assert float(res.max()) < 1e-10
+    assert rel_err(W.cpu().numpy(), want_w) <= ADJ_TOL and rel_err(k.cpu().numpy(), want_k) <= FAST_TOL
+    k32, W32, _ = be.solve_adj(padded(inc.astype(np.float32)), 1 if d == 2 else d, flags=0, return_residual=True)
+    w32 = O.adjoint_coarse(inc.astype(np.float32).astype(np.float64), 1 if d == 2 else d, nthreads=8)[1]
+    np.testing.assert_allclose(W32.cpu().numpy(), w32, rtol=1e-3, atol=2e-5 * np.abs(w32).max())
 
 
 def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):

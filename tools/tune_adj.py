@@ -37,5 +37,6 @@ def run(label, **env):
         os.environ.pop(k)
 
 
-for wpc in (2, 4):
+run("default")
+for wpc in [int(x) for x in os.environ.get("TUNE_WPC", "4,6,8").split(",")]:
     run("ADJ_WPC=%d" % wpc, SK_ADJ_WPC=wpc)
