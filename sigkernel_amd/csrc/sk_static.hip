@@ -269,22 +269,30 @@ __global__ __launch_bounds__(NT) void k_static_linear_adj(const T *__restrict__ 
 
 // rbf: dL/dx[a,m,k] = (-2/sigma) sum_b s_ab sum_n dG[m,n] G[m,n] (x[a,m,k] - y[b,n,k]),
 //      dG[m,n] = W[m-1,n-1] + W[m,n] - W[m-1,n] - W[m,n-1]   (transpose of the 4-corner difference)
-template <typename T, int DMAX, int NT>
+// One block per (path a, RM consecutive node rows): thread = node column n; per pair b the thread loads its y node
+// once for the RM rows, and RM + 1 rows of W (t_r = W[r][n] - W[r][n-1], dG[m,n] = t_m - t_{m-1}) instead of 4 W values
+// per node -- the first version (one row per block) re-read every W row twice and every y node RM times more often.
+template <typename T, int DMAX, int NT, int RM>
 __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, const T *__restrict__ Y,
                                                        const T *__restrict__ W, int64_t ldw, const T *__restrict__ scale,
-                                                       int64_t B, int M, int N, int D, double inv_sigma,
+                                                       int64_t B, int M, int N, int D, double inv_sigma, int row_groups,
                                                        T *__restrict__ gX) {
     __shared__ double red[NT / 64 + 1];
     const int Mc = M - 1, Nc = N - 1;
-    const int64_t a = blockIdx.x / M;
-    const int m = (int)(blockIdx.x % M);
-    const T *x = X + (a * M + m) * (int64_t)D;
-    double xm[DMAX], xs = 0.0, acc[DMAX];
+    const int64_t a = blockIdx.x / row_groups;
+    const int m0 = (int)(blockIdx.x % row_groups) * RM;
+    double xm[RM][DMAX], xs[RM], acc[RM][DMAX];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        xm[k] = k < D ? (double)x[k] : 0.0;
-        xs = fma(xm[k], xm[k], xs);
-        acc[k] = 0.0;
+    for (int r = 0; r < RM; ++r) {
+        const int m = min(m0 + r, M - 1);
+        const T *x = X + (a * M + m) * (int64_t)D;
+        xs[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            xm[r][k] = k < D ? (double)x[k] : 0.0;
+            xs[r] = fma(xm[r][k], xm[r][k], xs[r]);
+            acc[r][k] = 0.0;
+        }
     }
     const int64_t nb = B > 0 ? B : 1;
     for (int64_t bb = 0; bb < nb; ++bb) {
@@ -293,29 +301,42 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
         const T *y = Y + b * (int64_t)N * D;
         const T *w = W + p * (int64_t)Mc * ldw;
         for (int n = threadIdx.x; n < N; n += NT) {
-            double yn[DMAX], ys = 0.0, xy = 0.0;
+            double yn[DMAX], ys = 0.0;
 #pragma unroll
             for (int k = 0; k < DMAX; ++k) {
                 yn[k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
                 ys = fma(yn[k], yn[k], ys);
-                xy = fma(xm[k], yn[k], xy);
             }
-            const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
-            const bool up = m >= 1, dn = m < Mc, lf = n >= 1, rt = n < Nc;
-            const double w00 = (up && lf) ? (double)w[(int64_t)(m - 1) * ldw + n - 1] : 0.0;
-            const double w01 = (up && rt) ? (double)w[(int64_t)(m - 1) * ldw + n] : 0.0;
-            const double w10 = (dn && lf) ? (double)w[(int64_t)m * ldw + n - 1] : 0.0;
-            const double w11 = (dn && rt) ? (double)w[(int64_t)m * ldw + n] : 0.0;
-            const double c = s * (((w00 + w11) - w01) - w10) * g;
+            const bool lf = n >= 1, rt = n < Nc;
+            // t[r] for W rows m0 - 1 + r, r = 0 .. RM (zero outside the matrix)
+            double t[RM + 1];
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xm[k] - yn[k], acc[k]);
+            for (int r = 0; r <= RM; ++r) {
+                const int wr = m0 - 1 + r;
+                const bool ok = wr >= 0 && wr < Mc;
+                const double wl = (ok && lf) ? (double)w[(int64_t)wr * ldw + n - 1] : 0.0;
+                const double wv = (ok && rt) ? (double)w[(int64_t)wr * ldw + n] : 0.0;
+                t[r] = wv - wl;
+            }
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                double xy = 0.0;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) xy = fma(xm[r][k], yn[k], xy);
+                const double g = exp(-(fma(-2.0, xy, xs[r] + ys)) * inv_sigma);
+                const double c = (m0 + r < M ? s : 0.0) * (t[r + 1] - t[r]) * g;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(c, xm[r][k] - yn[k], acc[r][k]);
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        const double v = block_sum<NT>(acc[k], red);
-        if (threadIdx.x == 0 && k < D) gX[(a * M + m) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
-    }
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            const double v = block_sum<NT>(acc[r][k], red);
+            if (threadIdx.x == 0 && k < D && m0 + r < M) gX[(a * M + m0 + r) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
+        }
 }
 
 template <typename T, int DMAX, int NT>
@@ -329,10 +350,12 @@ int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T 
         hipLaunchKernelGGL((k_static_linear_adj<T, DMAX, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, Y, W, ldw, scale, B,
                            M, N, D, strips, out);
     } else {
-        const int64_t blocks = A * M;
+        constexpr int RM = DMAX <= 8 ? 4 : DMAX == 16 ? 2 : 1;   // node rows per block (RM * DMAX accumulators per thread)
+        const int row_groups = (M + RM - 1) / RM;
+        const int64_t blocks = A * row_groups;
         if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_static_rbf_adj<T, DMAX, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, X, Y, W, ldw, scale, B, M,
-                           N, D, 1.0 / param, out);
+        hipLaunchKernelGGL((k_static_rbf_adj<T, DMAX, NT, RM>), dim3((unsigned)blocks), dim3(NT), 0, s, X, Y, W, ldw, scale, B,
+                           M, N, D, 1.0 / param, row_groups, out);
     }
     return check_launch();
 }
