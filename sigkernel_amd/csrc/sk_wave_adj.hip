@@ -48,16 +48,44 @@ struct AdjParams {
 // 14.8 ms, PF = 1 with 4 waves/CU 17.4 ms: occupancy buys more than prefetch depth.
 constexpr int ADJ_PF = 1;
 
-// An asynchronous 8-byte global load into a register: the caller must execute wait_loads() on the register before
-// any use.  (The compiler's own waitcnt insertion would wait for every LDS-DMA in flight at the first use.)
+// Asynchronous 8-byte global loads into registers.  The compiler must never touch a destination register between the
+// load and the wait (it does not know the value is still in flight -- its own waitcnt insertion would drain every
+// LDS-DMA at the first use, which is why these are asm).  So the destinations are short-lived temporaries that nothing
+// reads: async_begin() defines them (no instruction), load_async() may or may not overwrite them (conditional code:
+// the merge is with an equally unread value, so no copy is needed), and async_wait() is the single instruction that
+// turns them into ordinary values -- its outputs are tied to the temporaries' registers.  tests/test_abi.py scans the
+// generated ISA for any instruction that touches a pending destination (tools/check_async_hazards.py).
+__device__ __forceinline__ void async_begin(double &t) { asm volatile("" : "=v"(t)); }
 __device__ __forceinline__ void load_async(double &dst, const double *p) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
-template <int VM, int N>
-__device__ __forceinline__ void wait_loads(double (&v)[N]) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));   // orders every later use after the wait
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[4], double (&t)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[1], double (&t)[1]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "=v"(o[0]) : "0"(t[0]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[2], double (&t)[2]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "=v"(o[0]), "=v"(o[1]) : "0"(t[0]), "1"(t[1]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[3], double (&t)[3]) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]) : "0"(t[0]), "1"(t[1]), "2"(t[2]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[5], double (&t)[5]) {
+    asm volatile("s_waitcnt vmcnt(%10)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait(double (&o)[8], double (&t)[8]) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "5"(t[5]), "6"(t[6]), "7"(t[7]), "n"(VM) : "memory");
 }
 
 // 1/b for b = 1 - g^2/12 (close to 1): hardware estimate + two Newton steps, instead of the ~20-instruction IEEE
@@ -224,18 +252,27 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);     // not-yet-started / finished lanes: any valid pair, value unused
         const double *e = prm.edges + pr * E;
         if (is_top && (!MULTIBAND || nband == 0)) {
-            // Kf[0][j'] = K[MM][NNp - j'], j' = nu*S + i + 1; K[MM][0] = 1 is not stored (fixed up after the wait)
-            const int jb = NNp - nu * S - 1;
+            // Kf[0][j'] = K[MM][NNp - j'], j' = nu*S + i + 1, stored at [NNp - j' - 1]; only the very last element of a row
+            // (nu = NUp-1, i = S-1) asks for K[MM][0] = 1, which is not stored: clamped here, fixed up after the wait
+            const double *q = e + (NNp - nu * S - 2);
 #pragma unroll
-            for (int i = 0; i < S; ++i) load_async(prow[i], e + max(jb - i - 1, 0));
+            for (int i = 0; i < S - 1; ++i) load_async(prow[i], q - i);
+            load_async(prow[S - 1], nu == NUp - 1 ? e : q - (S - 1));
         }
         if (nu == 0) {
-            // Kf[i'][0] = K[min(MM, MMp - i')][NN], i' = i0 .. i0 + R (corner first); rows past MM of the padded strip
-            // hold garbage, hence the clamp; K[0][NN] = 1 is not stored (fixed up after the wait)
+            // Kf[i'][0] = K[min(MM, MMp - i')][NN], i' = i0 .. i0 + R (corner first), stored at [NNp + row - 1]; rows past
+            // MM of the padded strip hold garbage, hence the min; only i' = MMp asks for K[0][NN] = 1 (fixed up after the wait)
             const int i0 = (nband * L + lam) * RC * r;
+            const double *q = e + (NNp - 1);
 #pragma unroll
-            for (int i = 0; i <= R; ++i) load_async(pcol[i], e + (NNp + max(min(MM, MMp - (i0 + i)) - 1, 0)));
+            for (int i = 0; i < R; ++i) load_async(pcol[i], q + min(MM, MMp - (i0 + i)));
+            load_async(pcol[R], q + max(min(MM, MMp - (i0 + R)), 1));
         }
+    };
+    // after the wait: the two positions whose value is the (unstored) boundary 1
+    auto fix_edges = [&](int nu, int nband, double (&prow)[S], double (&pcol)[R + 1]) {
+        if (nu == NUp - 1) prow[S - 1] = 1.0;
+        if (nu == 0 && (nband * L + lam) * RC * r + R == MMp) pcol[R] = 1.0;
     };
 
     double leftR[R], botR[S], cornerR = 1.0;
@@ -247,7 +284,8 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
 
     double chk_val = 0.0;      // pending self-check result (see the end of the macro-step)
     int64_t chk_pair = -1;
-    // edge values of the coming macro-step (complete: waited for at the end of the step that requested them)
+    // edge values of the coming macro-step: requested at the top of a step (after this step's values have been consumed),
+    // complete at its end
     double nrow[S], ncol[R + 1];
 #pragma unroll
     for (int i = 0; i < S; ++i) nrow[i] = 1.0;
@@ -255,20 +293,16 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
     {
         double prow[S], pcol[R + 1];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+#pragma unroll
+        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
         prefetch_edges(u, band, ps, prow, pcol);
 #pragma unroll
         for (int f = 0; f < PF; ++f) issue_fetch();
-        wait_loads<(PF - 1) * RC>(prow);   // the line of macro-step 0 and the edge values
-        wait_loads<(PF - 1) * RC>(pcol);
-        if (is_top && (!MULTIBAND || band == 0)) {
-#pragma unroll
-            for (int i = 0; i < S; ++i) nrow[i] = (NNp - u * S - 1 - i) >= 1 ? prow[i] : 1.0;
-        }
-        if (u == 0) {
-            const int i0 = (band * L + lam) * RC * r;
-#pragma unroll
-            for (int i = 0; i <= R; ++i) ncol[i] = (MMp - (i0 + i)) >= 1 ? pcol[i] : 1.0;
-        }
+        async_wait<(PF - 1) * RC>(nrow, prow);   // the line of macro-step 0 and the edge values
+        async_wait<(PF - 1) * RC>(ncol, pcol);
+        fix_edges(u, band, nrow, ncol);
     }
 
     for (int t = 0; t < prm.n_steps; ++t) {
@@ -288,10 +322,6 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
             nband += 1;
             if (nband == nb) { nband = 0; nps += 1; }
         }
-        double prow[S], pcol[R + 1];
-        prefetch_edges(nu, nband, nps, prow, pcol);
-        issue_fetch();                        // the line of macro-step t + PF: the newest operations in flight
-
         const int prow0 = (band * L + lam) * RC;          // first flipped coarse row of this lane
 
         // -- row-unit start: left boundaries.  Kr[i'][0] = 1;  Kf[i'][0] = K[min(MM, MMp - i')][NN]
@@ -305,28 +335,39 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         // -- top rows: from the lane above, or (top lane) the band boundary / the pair's terminal row
         double topR[S], topF[S];
         {
+            // what a top lane sees: Kr[0][j'] = 1 and Kf[0][j'] = the prefetched K[MM][.] values, or the band boundary
             double tbR[S], tbF[S];
-            if (is_top) {
-                if (MULTIBAND && band > 0) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
+            if (MULTIBAND) {
+                if (is_top && band > 0) {
                     lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
                     lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
-                } else {
-                    // Kr[0][j'] = 1;  Kf[0][j'] = K[MM][min(NN, NNp - j')], j' = u*S + i + 1 (prefetched)
-#pragma unroll
-                    for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = 1.0; }
             }
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                const double shR = dpp_shr1(botR[i], 1.0);
-                const double shF = dpp_shr1(botF[i], 1.0);
-                topR[i] = (FULLWAVE && !MULTIBAND) ? shR : (is_top ? tbR[i] : shR);
-                topF[i] = is_top ? tbF[i] : shF;
+                if (FULLWAVE) {   // lane 0 is the only top lane: wave_shr leaves its `old` operand in place there
+                    topR[i] = MULTIBAND ? dpp_shr1(botR[i], tbR[i]) : dpp_shr1(botR[i], 1.0);
+                    topF[i] = dpp_shr1(botF[i], tbF[i]);
+                } else {
+                    const double shR = dpp_shr1(botR[i], 1.0);
+                    const double shF = dpp_shr1(botF[i], 1.0);
+                    topR[i] = is_top ? tbR[i] : shR;
+                    topF[i] = is_top ? tbF[i] : shF;
+                }
             }
         }
+
+        // -- request the next step's edge values (asynchronously, into temporaries: see async_wait), then the increment
+        //    lines of macro-step t + PF, the newest operations in flight
+        double prow[S], pcol[R + 1];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+#pragma unroll
+        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
+        prefetch_edges(nu, nband, nps, prow, pcol);
+        issue_fetch();
 
         // -- coefficients per coarse cell: a, b for Kr;  a/b, 1/b for the backward recompute of K
         double ca[RC][CW], cb[RC][CW], ca2[RC][CW], cib[RC][CW];
@@ -416,17 +457,11 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         }
 
         // -- close the step: everything requested from global memory in it (next line, W lines, edge values) has landed
-        wait_loads<(PF - 1) * RC>(prow);
-        wait_loads<(PF - 1) * RC>(pcol);
-        if (is_top && (!MULTIBAND || nband == 0)) {
-#pragma unroll
-            for (int i = 0; i < S; ++i) nrow[i] = (NNp - nu * S - 1 - i) >= 1 ? prow[i] : 1.0;
-        }
-        if (nu == 0) {
-            const int i0 = (nband * L + lam) * RC * r;
-#pragma unroll
-            for (int i = 0; i <= R; ++i) ncol[i] = (MMp - (i0 + i)) >= 1 ? pcol[i] : 1.0;
-        }
+        // -- close the step.  Lanes that requested nothing get garbage here and never read it: nrow matters to a top lane
+        //    (which requests every step), ncol to a lane in the step right after its request
+        async_wait<(PF - 1) * RC>(nrow, prow);
+        async_wait<(PF - 1) * RC>(ncol, pcol);
+        fix_edges(nu, nband, nrow, ncol);
 
         // -- advance
         if ((nu & 7) == 0) {
@@ -454,11 +489,13 @@ template <typename T, int DY>
 int launch_adj_dy(const AdjParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
     const bool full = prm.logL == 6;
     if (prm.naive) {
-        if (multiband) return launch_adj_one<T, DY, true, true, false>(prm, blocks, lds_bytes, s);
+        if (multiband) return full ? launch_adj_one<T, DY, true, true, true>(prm, blocks, lds_bytes, s)
+                                   : launch_adj_one<T, DY, true, true, false>(prm, blocks, lds_bytes, s);
         return full ? launch_adj_one<T, DY, true, false, true>(prm, blocks, lds_bytes, s)
                     : launch_adj_one<T, DY, true, false, false>(prm, blocks, lds_bytes, s);
     }
-    if (multiband) return launch_adj_one<T, DY, false, true, false>(prm, blocks, lds_bytes, s);
+    if (multiband) return full ? launch_adj_one<T, DY, false, true, true>(prm, blocks, lds_bytes, s)
+                               : launch_adj_one<T, DY, false, true, false>(prm, blocks, lds_bytes, s);
     return full ? launch_adj_one<T, DY, false, false, true>(prm, blocks, lds_bytes, s)
                 : launch_adj_one<T, DY, false, false, false>(prm, blocks, lds_bytes, s);
 }

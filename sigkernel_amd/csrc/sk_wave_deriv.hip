@@ -36,9 +36,8 @@ struct DerivParams {
 };
 
 // The increments of macro-step t+1 are requested from LDS early in macro-step t and waited for at its end: with
-// one wave per SIMD nothing else hides the LDS round trip.  Issue and wait are separate asm blocks; the wait names
-// the three destination registers as in/out operands, so every use is ordered after it, and it sits in the same loop
-// iteration as the issue, so no loop-carried copy can touch the registers while the reads are in flight.
+// one wave per SIMD nothing else hides the LDS round trip.  Issue and wait are separate asm blocks in the same loop
+// iteration; the issue writes temporaries that nothing reads, the wait hands them over (see lds_read3_wait).
 template <int VM, typename V>
 __device__ __forceinline__ void lds_read3_issue(V (&g)[3], unsigned a) {
     asm volatile("s_waitcnt vmcnt(%4)\n\t"
@@ -47,9 +46,11 @@ __device__ __forceinline__ void lds_read3_issue(V (&g)[3], unsigned a) {
                  "ds_read_b128 %2, %3 offset:2048"
                  : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]) : "v"(a), "n"(VM) : "memory");
 }
+// the wait is the instruction that turns the in-flight temporaries `t` into ordinary values `g` (outputs tied to the
+// temporaries' registers): nothing may read `t` itself (tools/check_async_hazards.py lints the ISA for that)
 template <typename V>
-__device__ __forceinline__ void lds_read3_wait(V (&g)[3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2])::"memory");
+__device__ __forceinline__ void lds_read3_wait(V (&g)[3], V (&t)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "=v"(g[0]), "=v"(g[1]), "=v"(g[2]) : "0"(t[0]), "1"(t[1]), "2"(t[2]) : "memory");
 }
 
 // S consecutive doubles of each of the three states (state stride `ss` bytes): 3*S/2 ds_read_b128, ONE wait, all inside
@@ -225,8 +226,11 @@ __global__ __launch_bounds__(WAVE) void k_deriv_wave(const DerivParams prm) {
     for (int f = 0; f < PF; ++f) issue_fetch();
 
     vec_t gv[3];   // increments of the current macro-step
-    lds_read3_issue<(PF - 1) * 3>(gv, rd_lane + (unsigned)(slot_off + ((u & 7) << 4)));
-    lds_read3_wait(gv);
+    {
+        vec_t g0[3];
+        lds_read3_issue<(PF - 1) * 3>(g0, rd_lane + (unsigned)(slot_off + ((u & 7) << 4)));
+        lds_read3_wait(gv, g0);
+    }
 
     for (int t = 0; t < prm.n_steps; ++t) {
         issue_fetch();   // the line needed at macro-step t + PF
@@ -377,9 +381,7 @@ __global__ __launch_bounds__(WAVE) void k_deriv_wave(const DerivParams prm) {
             }
         }
 
-        lds_read3_wait(gn);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gv[k] = gn[k];
+        lds_read3_wait(gv, gn);
 
         u += 1;
         if ((u & 7) == 0) {

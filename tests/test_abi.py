@@ -66,3 +66,12 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libsk_oracle" not in src, f
+
+
+def test_no_instruction_touches_an_in_flight_asynchronous_load():
+    """sk_wave_adj.hip and sk_wave_deriv.hip issue loads whose wait is a separate inline-asm s_waitcnt; the compiler does not
+    know the destination is still in flight, so the generated ISA is linted for any access in between."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
