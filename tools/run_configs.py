@@ -30,7 +30,7 @@ def sync_time(f):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(); torch.cuda.synchronize(); return r, time.perf_counter() - t0
 
 
-which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
+which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5", "c6"]
 gen = torch.Generator().manual_seed(0)
 if "c1" in which:
     torch.manual_seed(0)
@@ -80,3 +80,21 @@ if "c5" in which:
     K, t = sync_time(lambda: sk.compute_Gram(Xd, Yd))
     print("c5  256x256 len 512 dim 16 RBF d=2 fp32 (grid 2044^2): %.1f ms, %.3e entries/s, %.3e cells/s, "
           "max rel err vs fp64 oracle %.1e (4 pairs)" % (t * 1e3, 256 * 256 / t, 256 * 256 * 2044 * 2044 / t, spot(K.cpu(), X, Y, k, 2, 4)))
+if "c6" in which:
+    # not a BASELINE config: gradients on grids beyond the reference's 1024-thread limit (fused adjoint, multi-band strips)
+    X, Y = walk(gen, 64, 700, 4), walk(gen, 64, 700, 4)
+    k = sigkernel_amd.RBFKernel(1.0); sk = sigkernel_amd.SigKernel(k, 1)
+    Xd, Yd = X.to(dev), Y.to(dev)
+    Xg = Xd.clone().requires_grad_(True)
+    sk.compute_mmd(Xg, Yd).backward()
+    Xg = Xd.clone().requires_grad_(True)
+    mmd, tf = sync_time(lambda: sk.compute_mmd(Xg, Yd))
+    _, tb = sync_time(lambda: mmd.backward())
+    Xs, Ys = X[:2], Y[:3]
+    Xg2 = Xs.to(dev).requires_grad_(True)
+    w = torch.linspace(-1, 1, 6, dtype=torch.float64).reshape(2, 3)
+    (sk.compute_Gram(Xg2, Ys.to(dev)) * w.to(dev)).sum().backward()
+    gp = O.gram_grad_points(Xs, Ys, k, 1, nthreads=8)
+    want = np.einsum("ab,abmd->amd", w.numpy(), gp)
+    print("c6  64x64 len 700 dim 4 RBF d=1 (grid 1398^2, beyond the reference's CUDA limit): mmd fwd %.1f ms + bwd %.1f ms; "
+          "gradient max-norm rel err vs oracle %.1e" % (tf * 1e3, tb * 1e3, np.abs(Xg2.grad.cpu().numpy() - want).max() / np.abs(want).max()))
