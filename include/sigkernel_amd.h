@@ -94,6 +94,15 @@ int sk_static_adjoint_f64(int kind, double param, const double *X, const double 
 int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y, const float *W, int64_t ldw,
                           const float *scale, int64_t A, int64_t B, int M, int N, int D, float *out, void *stream);
 
+/* LinearKernel adjoint from pre-differenced paths (the fast route for path dim <= 8; same contraction as
+ * sk_static_adjoint_* with kind 0): dYt [Bn][8][ldy] fp64 = y[q+1]-y[q], dimension-major, zero-padded -- the array
+ * sk_solve_fwd_linear_* takes; W [P, Mc, ldw]; scale [P] nullable; out [A, Mc, D] = sum_b scale_ab sum_q W[a,b,p,q] dy[b,q,:].
+ * The caller differences `out` along the path (d inc[p,q]/d x[p+1] = +s^2 dy[q], d/d x[p] = -s^2 dy[q]).  B = 0: paired. */
+int sk_linear_adjoint_f64(const double *dYt, int64_t ldy, const double *W, int64_t ldw, const double *scale, int64_t A,
+                          int64_t B, int Mc, int Nc, int D, double *out, void *stream);
+int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_t ldw, const float *scale, int64_t A, int64_t B,
+                          int Mc, int Nc, int D, float *out, void *stream);
+
 /* Transpose of sk_increments_*, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
  * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
  * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference

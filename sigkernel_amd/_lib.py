@@ -36,6 +36,8 @@ SIGNATURES = {
     "sk_static_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _vp, _i64, _vp]),
     "sk_static_adjoint_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "sk_static_adjoint_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "sk_linear_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "sk_linear_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -218,8 +220,16 @@ class HipBackend:
             fn = getattr(load(), "sk_static_adjoint_" + _suffix(X))
             if kind == 0:
                 T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
-                _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(T),
-                          _stream(X)), "sk_static_adjoint")
+                if D <= 8:      # pre-differenced, dimension-major y: every load of the contraction is coalesced
+                    ldy = _padded_ld(N - 1, 8)
+                    dYt = torch.zeros(Y.shape[0], 8, ldy, dtype=torch.float64, device=X.device)
+                    dYt[:, :D, : N - 1] = (Y[:, 1:] - Y[:, :-1]).double().transpose(1, 2)
+                    fl = getattr(load(), "sk_linear_adjoint_" + _suffix(X))
+                    _check(fl(_ptr(dYt), ldy, _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M - 1, N - 1, D, _ptr(T), _stream(X)),
+                           "sk_linear_adjoint")
+                else:
+                    _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D,
+                              _ptr(T), _stream(X)), "sk_static_adjoint")
                 g = torch.zeros(A, M, D, dtype=X.dtype, device=X.device)
                 g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
                 g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]

@@ -145,6 +145,19 @@ int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y
                                         (hipStream_t)stream);
 }
 
+int sk_linear_adjoint_f64(const double *dYt, int64_t ldy, const double *W, int64_t ldw, const double *scale, int64_t A,
+                          int64_t B, int Mc, int Nc, int D, double *out, void *stream) {
+    if (!dYt || !W || !out || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || ldy < Nc || (ldw != 0 && ldw < Nc)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_linear_adjoint_dyt<double>(dYt, ldy, W, ldw ? ldw : Nc, scale, A, B, Mc, Nc, D, out, (hipStream_t)stream);
+}
+int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_t ldw, const float *scale, int64_t A, int64_t B,
+                          int Mc, int Nc, int D, float *out, void *stream) {
+    if (!dYt || !W || !out || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || ldy < Nc || (ldw != 0 && ldw < Nc)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_linear_adjoint_dyt<float>(dYt, ldy, W, ldw ? ldw : Nc, scale, A, B, Mc, Nc, D, out, (hipStream_t)stream);
+}
+
 int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
                               void *stream) {
     if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;

@@ -116,6 +116,10 @@ template <typename T>
 int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                           int64_t B, int M, int N, int D, T *out, hipStream_t s);
 
+template <typename T>
+int launch_linear_adjoint_dyt(const double *dYt, int64_t ldy, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B,
+                              int Mc, int Nc, int D, T *out, hipStream_t s);
+
 inline int check_launch() {
     return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;
 }

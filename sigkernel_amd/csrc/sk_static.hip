@@ -249,13 +249,15 @@ __global__ __launch_bounds__(NT) void k_static_linear_adj(const T *__restrict__ 
 #pragma unroll
             for (int k = 0; k < DMAX; ++k)
                 dy[k] = k < D ? s * ((double)y[(int64_t)(q + 1) * D + k] - (double)y[(int64_t)q * D + k]) : 0.0;
+            double wv[RS];   // unconditional loads from clamped rows: a predicated load gets its own s_waitcnt
 #pragma unroll
-            for (int r = 0; r < RS; ++r)
-                if (p0 + r < Mc) {
-                    const double wv = (double)w[(int64_t)(p0 + r) * ldw + q];
+            for (int r = 0; r < RS; ++r) wv[r] = (double)w[(int64_t)min(p0 + r, Mc - 1) * ldw + q];
 #pragma unroll
-                    for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(wv, dy[k], acc[r][k]);
-                }
+            for (int r = 0; r < RS; ++r) {
+                const double wz = p0 + r < Mc ? wv[r] : 0.0;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(wz, dy[k], acc[r][k]);
+            }
         }
     }
 #pragma unroll
@@ -264,6 +266,72 @@ __global__ __launch_bounds__(NT) void k_static_linear_adj(const T *__restrict__ 
         for (int k = 0; k < DMAX; ++k) {
             const double v = block_sum<NT>(acc[r][k], red);
             if (threadIdx.x == 0 && p0 + r < Mc && k < D) Tout[(a * Mc + p0 + r) * (int64_t)D + k] = (T)v;
+        }
+}
+
+// linear, from pre-differenced paths: T[a][p][k] = sum_b s_ab sum_q W[a,b,p,q] * dYt[b][k][q], with dYt [Bn][DP][ldy]
+// dimension-major and zero-padded (the array sk_solve_fwd_linear_* takes, DP = 8).  Thread = column q: the 8 dy values
+// and the RS rows of W are 16 fully coalesced loads per pair, no per-element predicates; two pairs are in flight per
+// iteration.  (k_static_linear_adj above differences y in the kernel with 8-byte loads strided by the path dimension
+// and a predicate per element: 11.7 ms per headline tile against 3.4 ms of W traffic.)
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void k_linear_adj_dyt(const double *__restrict__ dYt, int64_t ldy, const T *__restrict__ W,
+                                                       int64_t ldw, const T *__restrict__ scale, int64_t B, int Mc, int Nc,
+                                                       int D, int strips, T *__restrict__ Tout) {
+    constexpr int DP = 8, RS = 8;
+    __shared__ double red[NT / 64 + 1];
+    const int64_t a = blockIdx.x / strips;
+    const int p0 = (int)(blockIdx.x % strips) * RS;
+    const int rows = min(RS, Mc - p0);
+    double acc[RS][DP];
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int k = 0; k < DP; ++k) acc[r][k] = 0.0;
+    const int64_t nb = B > 0 ? B : 1;
+    auto one_pair = [&](int64_t bb, int q, double (&dy)[DP], double (&wv)[RS]) {
+        const int64_t b = B > 0 ? bb : a, p = B > 0 ? a * B + bb : a;
+        const double s = scale ? (double)scale[p] : 1.0;
+        const double *y = dYt + b * DP * ldy + q;
+        const T *w = W + (p * Mc + p0) * ldw + q;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) dy[k] = y[k * ldy];
+        // unconditional loads from clamped rows (a predicated load gets its own basic block and its own s_waitcnt)
+#pragma unroll
+        for (int r = 0; r < RS; ++r) wv[r] = (double)w[(int64_t)min(r, rows - 1) * ldw];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) wv[r] *= r < rows ? s : 0.0;
+    };
+    for (int q = threadIdx.x; q < Nc; q += NT) {
+        int64_t bb = 0;
+        for (; bb + 1 < nb; bb += 2) {
+            double dy0[DP], w0[RS], dy1[DP], w1[RS];
+            one_pair(bb, q, dy0, w0);
+            one_pair(bb + 1, q, dy1, w1);
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) acc[r][k] = fma(w0[r], dy0[k], acc[r][k]);
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) acc[r][k] = fma(w1[r], dy1[k], acc[r][k]);
+        }
+        if (bb < nb) {
+            double dy0[DP], w0[RS];
+            one_pair(bb, q, dy0, w0);
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int k = 0; k < DP; ++k) acc[r][k] = fma(w0[r], dy0[k], acc[r][k]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const double v = block_sum<NT>(acc[r][k], red);
+            if (threadIdx.x == 0 && r < rows && k < D) Tout[(a * Mc + p0 + r) * (int64_t)D + k] = (T)v;
         }
 }
 
@@ -310,13 +378,14 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
             const bool lf = n >= 1, rt = n < Nc;
             // t[r] for W rows m0 - 1 + r, r = 0 .. RM (zero outside the matrix)
             double t[RM + 1];
+            const int nl = max(n - 1, 0), nr = min(n, Nc - 1);
 #pragma unroll
-            for (int r = 0; r <= RM; ++r) {
+            for (int r = 0; r <= RM; ++r) {   // unconditional loads from clamped positions, masked afterwards
                 const int wr = m0 - 1 + r;
                 const bool ok = wr >= 0 && wr < Mc;
-                const double wl = (ok && lf) ? (double)w[(int64_t)wr * ldw + n - 1] : 0.0;
-                const double wv = (ok && rt) ? (double)w[(int64_t)wr * ldw + n] : 0.0;
-                t[r] = wv - wl;
+                const int64_t ro = (int64_t)min(max(wr, 0), Mc - 1) * ldw;
+                const double wl = (double)w[ro + nl], wv = (double)w[ro + nr];
+                t[r] = ((ok && rt) ? wv : 0.0) - ((ok && lf) ? wl : 0.0);
             }
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
@@ -456,6 +525,27 @@ int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const 
     if (D <= 32) return launch_static_adj_nt<T, 32>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     return SK_ERR_UNSUPPORTED;
 }
+
+// out: T [A, Mc, D] (the caller differences it along the path and applies scale^2)
+template <typename T>
+int launch_linear_adjoint_dyt(const double *dYt, int64_t ldy, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B,
+                              int Mc, int Nc, int D, T *out, hipStream_t s) {
+    if (D > 8) return SK_ERR_UNSUPPORTED;
+    const int strips = (Mc + 7) / 8;
+    const int64_t blocks = A * strips;
+    if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+    if (Nc <= 80)
+        hipLaunchKernelGGL((k_linear_adj_dyt<T, 64>), dim3((unsigned)blocks), dim3(64), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc, D,
+                           strips, out);
+    else
+        hipLaunchKernelGGL((k_linear_adj_dyt<T, 128>), dim3((unsigned)blocks), dim3(128), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc,
+                           D, strips, out);
+    return check_launch();
+}
+template int launch_linear_adjoint_dyt<double>(const double *, int64_t, const double *, int64_t, const double *, int64_t,
+                                               int64_t, int, int, int, double *, hipStream_t);
+template int launch_linear_adjoint_dyt<float>(const double *, int64_t, const float *, int64_t, const float *, int64_t, int64_t,
+                                              int, int, int, float *, hipStream_t);
 
 template int launch_static_adjoint<double>(int, double, const double *, const double *, const double *, int64_t,
                                            const double *, int64_t, int64_t, int, int, int, double *, hipStream_t);
