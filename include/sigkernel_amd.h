@@ -125,9 +125,9 @@ int sk_increments_adjoint_f32(const float *W, int64_t ldw, const float *scale, i
  *   out_final [P]        K[MM][NN]
  *   out_grid  nullable   [P,MM+1,NN+1] full solution grid (what the reference returns)
  *   out_edges nullable   [P,MM+NN+2]: K[MM][0..NN] followed by K[0..MM][NN] -- the terminal
- *                        row and column, the only forward state the adjoint needs.  (The tiled
- *                        kernel derives the column from zero padding: columns [Nc, ld) of inc_c
- *                        must be zero when out_edges is requested.) */
+ *                        row and column.  Like out_grid it is served by the anti-diagonal kernel
+ *                        (bit-identical to the reference); sk_solve_adj_* obtains the edges it needs
+ *                        from the strip kernel directly, in that kernel's own padded layout. */
 int sk_solve_fwd_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      double *out_final, double *out_grid, double *out_edges, void *stream);
 int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
