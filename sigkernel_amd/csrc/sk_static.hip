@@ -146,7 +146,11 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
         for (int k = 0; k < NS; ++k) vp[c][k] = vpr[c][k] = (TA)0;
 
     for (int i0 = 0; i0 < M; i0 += SK_TPB) {
-        // the extra node column for node rows i0 .. i0+63, lanes = rows
+        // the x rows of this block, lanes = rows: they serve the extra node column, and (narrow paths) every row of the
+        // sweep below reads its x through v_readlane from here -- a scalar load per row and dimension would put one
+        // scalar-cache round trip on the critical path of every iteration
+        constexpr bool XREG = DMAX <= 8;
+        double xr[NV][XREG ? DMAX : 1];
         TA E[NV];
         {
             const int ir = min(i0 + lane, M - 1);
@@ -155,6 +159,10 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
                 double xv[DMAX];
 #pragma unroll
                 for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? (double)xs[v][(int64_t)ir * D + k] : 0.0;
+                if constexpr (XREG) {
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) xr[v][k] = xv[k];
+                }
                 E[v] = (TA)static_node<DMAX, KIND>(xv, ye, yse, inv_sigma);
             }
         }
@@ -166,7 +174,10 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
             for (int v = 0; v < NV; ++v) {
                 double xv[DMAX];
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? (double)xs[v][(int64_t)i * D + k] : 0.0;   // wave-uniform
+                for (int k = 0; k < DMAX; ++k) {
+                    if constexpr (XREG) xv[k] = readlane_f64(xr[v][k], r);                       // wave-uniform
+                    else xv[k] = k < D ? (double)xs[v][(int64_t)i * D + k] : 0.0;
+                }
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND>(xv, yn[c], ys[c], inv_sigma);
             }

@@ -294,12 +294,13 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    if (waves_per_cu > 8) waves_per_cu = 8;
     const int wpc_env = env_int("SK_FUSED_WPC", 0);
-    // persistent waves all carry the same work: an uneven count per SIMD (5, 6, 7 waves on 4 SIMDs) makes the
-    // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4); an explicit override is taken as is
+    // measured on the headline (512 x 512 pairs, len 128, dim 8, d = 1): 8 waves/CU 8.10 ms, 9: 7.3, 10: 6.73, 12: 8.7 --
+    // the third wave on two of the four SIMDs fills issue slots the dependent fp64 chains leave empty, a third wave
+    // everywhere starts to cost more in LDS traffic than it gains.  SK_FUSED_WPC overrides.
+    const int cap = wpc_env > 0 ? 16 : 10;
+    if (waves_per_cu > cap) waves_per_cu = cap;
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
-    else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;

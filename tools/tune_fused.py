@@ -10,6 +10,6 @@ def t(f):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]; ev[0].record()
     for i in range(5): f(); ev[i+1].record()
     torch.cuda.synchronize(); return min(ev[i].elapsed_time(ev[i+1]) for i in range(5))
-for w in (4, 8, 9, 10):
+for w in (8, 9, 10, 8, 10, 9, 12, 10):
     os.environ["SK_FUSED_WPC"] = str(w)
     print("fused WPC=%d : %.3f ms" % (w, t(lambda: be.solve_fwd_fused_linear(X, Y, 1.0, d, False, True))))
