@@ -400,8 +400,10 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
 
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    if (waves_per_cu > 8) waves_per_cu = 8;
     const int wpc_env = env_int("SK_WAVE_WPC", 0);
+    // d = 2 (10 KB of LDS per wave): 16 waves/CU 3.09 ms vs 3.43 ms at 8 on a C4 tile; d = 3 is better off with 8 (2.24 vs 2.36 ms)
+    const int wpc_cap = (wpc_env > 0 || DY == 2) ? 16 : 8;
+    if (waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
     // persistent waves all carry the same work: an uneven count per SIMD (5, 6, 7 waves on 4 SIMDs) makes the
     // fullest SIMD the critical path (measured: 5 waves/CU is 27 % slower than 4); an explicit override is taken as is
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
