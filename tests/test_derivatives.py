@@ -191,6 +191,30 @@ def test_gpu_deriv_solver_default_path(P, Mc, Nc, d):
 
 
 @pytest.mark.gpu
+def test_gpu_deriv_fuzz_random_shapes():
+    """40 random shapes (ragged, tiny, multi-band, partial lane groups) through the fast kernel, fp64 and fp32."""
+    from sigkernel_amd import _lib
+    be = _lib.get_backend()
+    rng = np.random.default_rng(99)
+    for it in range(40):
+        d = int(rng.integers(0, 3))
+        Mc, Nc, P = int(rng.integers(1, 300 >> d)), int(rng.integers(1, 300 >> d)), int(rng.integers(1, 30))
+        inc3 = _rand_inc3(P, Mc, Nc, 1000 + it)
+        ld = (Nc + 15) // 16 * 16
+        padded = torch.zeros(3, P, Mc, ld, dtype=torch.float64, device="cuda")
+        padded[..., :Nc] = inc3.cuda()
+        ref = _oracle_solve(inc3, d)
+        for g, e in zip(be.solve_deriv(padded[..., :Nc], d, flags=_lib.FLAG_FAST_ONLY), ref):
+            assert rel_err(g.cpu().numpy(), e) <= 1e-11, (it, P, Mc, Nc, d)
+        if d <= 1:
+            p32 = torch.zeros(3, P, Mc, (Nc + 31) // 32 * 32, dtype=torch.float32, device="cuda")
+            p32[..., :Nc] = inc3.float().cuda()
+            ref32 = _oracle_solve(inc3.float(), d)
+            for g, e in zip(be.solve_deriv(p32[..., :Nc], d, flags=_lib.FLAG_FAST_ONLY), ref32):
+                assert rel_err(g.cpu().numpy(), e) <= 1e-5, (it, P, Mc, Nc, d)
+
+
+@pytest.mark.gpu
 def test_gpu_deriv_fast_kernel_is_the_one_that_runs():
     """SK_FLAG_FAST_ONLY must succeed on line-padded inputs in the fast kernel's scope (no silent fallback)."""
     from sigkernel_amd import _lib

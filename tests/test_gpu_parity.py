@@ -161,10 +161,10 @@ def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
 
 
 def test_fuzz_random_shapes_against_oracle(be):
-    """60 random shapes (ragged, tiny, multi-band, every dyadic order the tiled kernels cover) through every fast kernel."""
+    """120 random shapes (ragged, tiny, multi-band, every dyadic order the tiled kernels cover) through every fast kernel."""
     rng = np.random.default_rng(2024)
     lin = sigkernel_amd.LinearKernel()
-    for it in range(60):
+    for it in range(120):
         d = int(rng.integers(0, 4))
         Mc = int(rng.integers(1, 330 >> (d // 2)))
         Nc = int(rng.integers(1, 330 >> (d // 2)))
@@ -182,6 +182,8 @@ def test_fuzz_random_shapes_against_oracle(be):
             k, W, res = be.solve_adj(padded(inc), d, naive, return_residual=True)
             assert rel_err(W.cpu().numpy(), ww) <= max(ADJ_TOL, 10 * float(res.max())), (it, P, Mc, Nc, d, naive)
             assert rel_err(k.cpu().numpy(), wk) <= FAST_TOL
+            # tame increments: nothing may need the stored-grid rescue (a wrong terminal edge would show up here)
+            assert float(res.max()) <= 1e-7 * max(1.0, float(np.abs(ww).max())), (it, P, Mc, Nc, d, naive, float(res.max()))
         if d <= 2 and it % 3 == 0:
             A, B, D = int(rng.integers(1, 7)), int(rng.integers(1, 7)), int(rng.integers(1, 9))
             gen = torch.Generator().manual_seed(it)
