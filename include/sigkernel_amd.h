@@ -54,6 +54,8 @@ typedef enum sk_status {
 #define SK_FLAG_EXACT 1  /* FMA-free arithmetic in the reference's operand order: results are
                             bit-identical to the reference's Cython CPU solver (slower path)   */
 #define SK_FLAG_SIMPLE 2 /* force the simple one-wavefront-per-pair anti-diagonal kernels       */
+#define SK_FLAG_EDGES_GIVEN 8 /* sk_solve_adj_* only: `workspace` already holds the strip edges that
+                               * sk_solve_fwd_edges_* wrote for these increments -- skip the forward sweep */
 #define SK_FLAG_FAST_ONLY 4 /* never fall back: SK_ERR_UNSUPPORTED if the tiled kernels do not
                                cover the shape/layout (used by tests and benchmarks)            */
 
@@ -156,9 +158,9 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
  * Two implementations behind one entry point:
  *   fast   -- forward sweep emitting the terminal row/column of K, then ONE fused sweep that runs the reverse
  *             PDE and recomputes K backwards from those edges (no grid is stored; csrc/sk_wave_adj.hip).
- *             Needs dyadic 1..2, increment rows zero-padded to whole 128-byte lines
+ *             Needs dyadic 1..2 (fp32: 1), increment rows zero-padded to whole 128-byte lines
  *             (ld*sizeof(T) % 128 == 0, as sk_increments_* produces when given such an ld), ldw >= that padded
- *             width, MM+NN+2 <= 1024, and out_err != NULL.  out_err[p] receives the self-check residual
+ *             width, and out_err != NULL; any grid size (no 1024-node limit).  out_err[p] receives the self-check residual
  *             max_i |K_recomputed[i][0] - 1| of pair p: the caller re-solves pairs whose residual is too
  *             large with SK_FLAG_SIMPLE (only ever seen when K explodes, |K| >~ 1e4).
  *   simple -- both grids stored in `workspace`, products summed in the reference's order: bit-identical to the
@@ -167,6 +169,18 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
  *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch.
  *   inc_c [P,Mc,ld]; out_final nullable [P]; W [P,Mc,ldw] (ldw = 0: dense); out_err nullable [P] doubles. */
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size);
+
+/* Forward solve that also keeps what the fast adjoint needs -- the terminal row and column of K in the strip kernels'
+ * padded layout -- so that a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN (workspace = `edges`) skips its forward sweep.
+ * The reference keeps the whole solution grid between forward and backward (sigkernel.py:248, :397-399); this is
+ * (MM+NN)/(MM*NN) of that.  sk_strip_edges_bytes: size of `edges` for P pairs, 0 when the strip kernels do not cover the
+ * shape (then sk_solve_fwd_edges_* returns SK_ERR_UNSUPPORTED: use sk_solve_fwd_* and a plain sk_solve_adj_*).
+ * Requires the layout of the fast adjoint (rows zero-padded to whole 128-byte lines). */
+size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size);
+int sk_solve_fwd_edges_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, double *out_final,
+                           double *edges, void *stream);
+int sk_solve_fwd_edges_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, float *out_final,
+                           double *edges, void *stream);
 int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,
                      double *out_final, double *W, int64_t ldw, double *out_err, void *workspace,
                      size_t workspace_bytes, void *stream);

@@ -17,6 +17,7 @@ SCHEME_NAIVE = 1
 FLAG_EXACT = 1
 FLAG_SIMPLE = 2
 FLAG_FAST_ONLY = 4
+FLAG_EDGES_GIVEN = 8
 
 _lib = None
 
@@ -45,6 +46,9 @@ SIGNATURES = {
     "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
+    "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
+    "sk_solve_fwd_edges_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_edges_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_adj_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sk_solve_adj_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sk_deriv_increments_f64": (_int, [_vp, _vp, _vp, ctypes.c_double, _i64, _int, _int, _vp, _vp, _vp, _i64, _vp]),
@@ -272,14 +276,38 @@ class HipBackend:
             return out, grid, edges
         return out
 
+    def solve_fwd_keep_edges(self, inc_c, dyadic, naive=False):
+        """Forward solve that keeps the terminal row/column of every pair for a later solve_adj(..., edges=...):
+        (final [...], edges) -- edges is None when the strip kernels do not cover the shape or layout (then final comes
+        from the ordinary forward solve and the adjoint will run its own forward sweep)."""
+        inc_c, ld = _row_stride(inc_c, "inc_c")
+        Mc, Nc = inc_c.shape[-2:]
+        batch = inc_c.shape[:-2]
+        P = inc_c.numel() // (Mc * Nc)
+        lib = load()
+        nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), inc_c.element_size()))
+        if nbytes and (ld * inc_c.element_size()) % 128 == 0:
+            out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
+            edges = torch.empty(nbytes // 8, dtype=torch.float64, device=inc_c.device)
+            with torch.cuda.device(inc_c.device):
+                fn = getattr(lib, "sk_solve_fwd_edges_" + _suffix(inc_c))
+                rc = fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(out), _ptr(edges),
+                        _stream(inc_c))
+            if rc == SK_OK:
+                return out, edges
+            if rc != 2:
+                _check(rc, "sk_solve_fwd_edges")
+        return self.solve_fwd(inc_c, dyadic, naive), None
+
     # residual of the fast adjoint's self-check above which a pair is re-solved by the stored-grid kernel
     ADJ_RESIDUAL_TOL = 1e-8
 
-    def solve_adj(self, inc_c, dyadic, naive=False, flags=0, return_residual=False):
+    def solve_adj(self, inc_c, dyadic, naive=False, flags=0, return_residual=False, edges=None):
         """inc_c [..., Mc, Nc] -> (final [...], W [..., Mc, Nc] = d final / d inc_c).
 
         The fast kernel recomputes K backwards instead of storing it and reports a per-pair residual; pairs whose
-        residual exceeds ADJ_RESIDUAL_TOL (K exploding beyond ~1e4) are re-solved by the stored-grid kernel."""
+        residual exceeds ADJ_RESIDUAL_TOL (K exploding beyond ~1e4) are re-solved by the stored-grid kernel.
+        `edges` (from solve_fwd_keep_edges on the same increments) skips the forward sweep; `final` is then None."""
         inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
@@ -290,13 +318,19 @@ class HipBackend:
         Wp = torch.empty(batch + (Mc, ldw), dtype=inc_c.dtype, device=dev)
         err = torch.empty(batch, dtype=torch.float64, device=dev)
         lib = load()
-        nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         with torch.cuda.device(dev):
             fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
-            _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags), _ptr(out), _ptr(Wp), ldw, _ptr(err),
-                      _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
+            if edges is not None:
+                _dev(edges, "edges")
+                _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags) | FLAG_EDGES_GIVEN, None, _ptr(Wp), ldw,
+                          _ptr(err), _ptr(edges), edges.numel() * 8, _stream(inc_c)), "sk_solve_adj (edges given)")
+                out = None
+            else:
+                nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags), _ptr(out), _ptr(Wp), ldw, _ptr(err),
+                          _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
             W = Wp[..., :Nc]
             if not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
                 bad = torch.nonzero((err.reshape(-1) > self.ADJ_RESIDUAL_TOL) | torch.isnan(err.reshape(-1))).reshape(-1)
@@ -310,7 +344,8 @@ class HipBackend:
                     _check(fn(_ptr(sub), Nc, n, Mc, Nc, int(dyadic), scheme, FLAG_SIMPLE, _ptr(o2), _ptr(W2), Nc, None,
                               _ptr(ws2), nb2, _stream(inc_c)), "sk_solve_adj (stored-grid re-solve)")
                     Wp.reshape(P, Mc, ldw)[bad, :, :Nc] = W2
-                    out.reshape(-1)[bad] = o2
+                    if out is not None:
+                        out.reshape(-1)[bad] = o2
         # the caching allocator keeps `ws` alive for later work queued on this same stream
         if return_residual:
             return out, W, err

@@ -9,7 +9,8 @@ namespace {
 bool bad_common(const void *inc, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags) {
     if (!inc || P < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return true;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return true;
-    if (flags & ~(SK_FLAG_EXACT | SK_FLAG_SIMPLE | SK_FLAG_FAST_ONLY)) return true;
+    if (flags & ~(SK_FLAG_EXACT | SK_FLAG_SIMPLE | SK_FLAG_FAST_ONLY | SK_FLAG_EDGES_GIVEN)) return true;
+    if ((flags & SK_FLAG_EDGES_GIVEN) && (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE))) return true;
     if ((flags & SK_FLAG_FAST_ONLY) && (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE))) return true;
     if (((int64_t)Mc << dyadic) > (1 << 24) || ((int64_t)Nc << dyadic) > (1 << 24)) return true;
     return false;
@@ -51,6 +52,12 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
     const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // launch_adj_wave's scope
     const size_t fast_ws = fast_shape ? adj_fast_workspace_bytes(g, (int)sizeof(T)) : 0;
+    if (flags & SK_FLAG_EDGES_GIVEN) {
+        // the caller kept the strip edges of its forward pass (sk_solve_fwd_edges_*): only the fused reverse sweep runs
+        const size_t need = fast_shape ? (size_t)P * strip_edge_doubles(g, (int)sizeof(T)) * sizeof(double) : 0;
+        if (!need || !out_err || !ws || ws_bytes < need) return SK_ERR_WORKSPACE;
+        return launch_adj_wave<T>(inc_c, g.ld, g, static_cast<const double *>(ws), W, ldw, out_err, s);
+    }
     if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && fast_ws && out_err && ws && ws_bytes >= fast_ws) {
         // forward sweep that also emits the terminal row/column, then the fused reverse sweep + recompute of K
         double *edges = static_cast<double *>(ws);
@@ -77,6 +84,17 @@ int solve_deriv(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld, int64
         if (rc != SK_ERR_UNSUPPORTED || (flags & SK_FLAG_FAST_ONLY)) return rc;
     }
     return launch_deriv_simple<T>(inc, inc_d, inc_dd, g, out_k, out_kd, out_kdd, (hipStream_t)stream);
+}
+
+template <typename T>
+int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, T *out_final, double *edges,
+                    void *stream) {
+    if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, 0) || !out_final || !edges || (ld != 0 && ld < Nc)) return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
+    const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // what launch_adj_wave will accept later
+    if (!fast_shape || !strip_edge_doubles(g, (int)sizeof(T)) || (g.ld * sizeof(T)) % 128) return SK_ERR_UNSUPPORTED;
+    return launch_fwd_wave<T>(inc_c, g.ld, g, out_final, edges, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -204,6 +222,20 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
     if (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) return simple;
     const size_t fast = adj_fast_workspace_bytes(g, elem_size);
     return fast > simple ? fast : simple;
+}
+
+size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size) {
+    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 1 || dyadic > (elem_size == 8 ? 2 : 1) || (elem_size != 4 && elem_size != 8)) return 0;
+    const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);
+    return (size_t)P * strip_edge_doubles(g, elem_size) * sizeof(double);
+}
+int sk_solve_fwd_edges_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, double *out_final,
+                           double *edges, void *stream) {
+    return solve_fwd_edges<double>(inc_c, ld, P, Mc, Nc, dyadic, scheme, out_final, edges, stream);
+}
+int sk_solve_fwd_edges_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, float *out_final,
+                           double *edges, void *stream) {
+    return solve_fwd_edges<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, out_final, edges, stream);
 }
 
 int sk_solve_adj_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, int flags,

@@ -68,7 +68,7 @@ def _increments(be, static_kernel, Xd, Yd, gram):
     return be.increments(G)
 
 
-def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram):
+def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=None):
     """dL/dX for one tile: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
 
     Fused route (LinearKernel / RBFKernel): sk_static_increments -> sk_solve_adj -> sk_static_adjoint.
@@ -79,14 +79,14 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram):
     if fused is not None and hasattr(be, "static_adjoint"):
         inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
         if inc is not None:
-            _, W = be.solve_adj(inc, dyadic, naive)
+            _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
             del inc
             return be.static_adjoint(fused[0], fused[1], Xt, Yt, W, go, gram)
     Xg = Xt.clone().requires_grad_(True)
     with torch.enable_grad():
         G = static_kernel.Gram_matrix(Xg, Yt) if gram else static_kernel.batch_kernel(Xg, Yt)
     inc = be.increments(G.detach().contiguous())
-    _, W = be.solve_adj(inc, dyadic, naive)
+    _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
     del inc
     dG = be.increments_adjoint(W, go)
     del W
@@ -150,8 +150,15 @@ class _SigKernel(torch.autograd.Function):
 _SYM_TILES = 8   # row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
 
 
-def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes, rows_factor=None):
-    """K[a, b] for every pair of Xd x Yd (no autograd): fused kernel, or increments + solver tiled over rows of Xd."""
+_KEEP_EDGES_FRACTION = 0.5   # of the transient budget: how much may stay allocated between forward and backward
+
+
+def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes, rows_factor=None, keep=None):
+    """K[a, b] for every pair of Xd x Yd (no autograd): fused kernel, or increments + solver tiled over rows of Xd.
+
+    keep (a list, when a gradient is pending): receives one (a0, a1, edges) per tile -- the terminal row/column of every
+    pair, 8(MM+NN) bytes per pair, which lets backward skip its forward sweep.  The reference keeps the whole solution
+    grid for the same purpose (sigkernel.py:248, :397-399)."""
     K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, naive, gram=True)
     if K is not None:
         return K
@@ -160,9 +167,20 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     fused = _fused_static(static_kernel, True) is not None
     # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
     per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
-    for a0, a1 in _tiles(A, per_row, _budget(Xd.device, workspace_bytes)):
+    budget = _budget(Xd.device, workspace_bytes)
+    if keep is not None and hasattr(be, "solve_fwd_keep_edges"):
+        edge_bytes = 8.0 * A * B * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
+        if edge_bytes > _KEEP_EDGES_FRACTION * budget:
+            keep = None
+    else:
+        keep = None
+    for a0, a1 in _tiles(A, per_row, budget):
         inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
-        K[a0:a1] = be.solve_fwd(inc, dyadic_order, naive)                        # :378 / :395
+        if keep is not None:
+            K[a0:a1], edges = be.solve_fwd_keep_edges(inc, dyadic_order, naive)  # :378 / :395, + the edges for backward
+            keep.append((a0, a1, edges))
+        else:
+            K[a0:a1] = be.solve_fwd(inc, dyadic_order, naive)                    # :378 / :395
     return K
 
 
@@ -211,7 +229,8 @@ class _SigKernelGram(torch.autograd.Function):
         fused = _fused_static(static_kernel, True) is not None
         # with a gradient pending, tile like backward will, so that the caching allocator can reuse the same blocks
         rows_factor = (3 if fused else 8) if X.requires_grad else None
-        return _gram_block(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, workspace_bytes, rows_factor)
+        ctx.kept_edges = [] if X.requires_grad else None
+        return _gram_block(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, workspace_bytes, rows_factor, ctx.kept_edges)
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -225,9 +244,15 @@ class _SigKernelGram(torch.autograd.Function):
             go = grad_output.to(X.dtype).contiguous()
             fused = _fused_static(sk, True) is not None
             per_row = (3 if fused else 8) * B * M * N * X.element_size()
-            for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
+            kept = getattr(ctx, "kept_edges", None)
+            if kept:       # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
+                tiles = kept
+                ctx.kept_edges = None
+            else:
+                tiles = [(a0, a1, None) for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes))]
+            for a0, a1, edges in tiles:
                 grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd.contiguous(),
-                                               go[a0:a1].contiguous(), d, naive, gram=True)
+                                               go[a0:a1].contiguous(), d, naive, gram=True, edges=edges)
         # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
         # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
         if ctx.needs_input_grad[1]:

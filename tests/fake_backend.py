@@ -50,7 +50,10 @@ class OracleBackend:
                     torch.from_numpy(edges) if want_edges else None)
         return torch.from_numpy(O.solve_coarse(a, dyadic, naive)).to(inc_c.dtype)
 
-    def solve_adj(self, inc_c, dyadic, naive=False, flags=0):
+    def solve_fwd_keep_edges(self, inc_c, dyadic, naive=False):
+        return self.solve_fwd(inc_c, dyadic, naive), torch.zeros(1)      # a token: the fake adjoint needs no edges
+
+    def solve_adj(self, inc_c, dyadic, naive=False, flags=0, edges=None):
         out, W = O.adjoint_coarse(inc_c.detach().double().numpy(), dyadic, naive)
         return torch.from_numpy(out).to(inc_c.dtype), torch.from_numpy(W).to(inc_c.dtype)
 
