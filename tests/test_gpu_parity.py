@@ -146,6 +146,20 @@ def test_fused_adjoint_without_the_safety_net(be, P, Mc, Nc, d):
     np.testing.assert_allclose(W32.cpu().numpy(), w32, rtol=1e-3, atol=2e-5 * np.abs(w32).max())
 
 
+@pytest.mark.parametrize("P,Mc,Nc,d", [(9, 63, 63, 1), (3, 200, 130, 1), (5, 40, 70, 2), (4, 31, 31, 1)])
+def test_adjoint_from_kept_edges_is_identical(be, P, Mc, Nc, d):
+    """sk_solve_fwd_edges + sk_solve_adj(SK_FLAG_EDGES_GIVEN) == the self-contained sk_solve_adj, bit for bit, and K matches."""
+    inc = padded(_inc(P, Mc, Nc, seed=5 + Mc + Nc, scale=0.6 / np.sqrt(Mc * Nc)))
+    k0, W0, r0 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
+    k1, edges = be.solve_fwd_keep_edges(inc, d)
+    assert edges is not None
+    _, W1, r1 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True, edges=edges)
+    assert torch.equal(W0, W1) and torch.equal(r0, r1) and torch.equal(k0, k1)
+    # shapes outside the strip kernels' adjoint scope: no edges, ordinary forward value
+    k2, e2 = be.solve_fwd_keep_edges(inc, 0)
+    assert e2 is None and rel_err(k2.cpu().numpy(), O.solve_coarse(inc.cpu().numpy(), 0)) <= FAST_TOL
+
+
 def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
     """Exploding kernels (|K| ~ 1e9, far outside where the scheme means anything) break the backward recompute of K;
     the residual must flag those pairs and the re-solve must restore the oracle's answer."""
