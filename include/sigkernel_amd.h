@@ -149,6 +149,11 @@ int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int
 int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                             int dyadic, int scheme, float *out_final, void *stream);
 
+/* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
+ * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 1..2). */
+int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                                  int dyadic, int scheme, double *out_final, double *edges, void *stream);
+
 /* ---- adjoint solve ------------------------------------------------------------------------
  * W[p][a][b] = d K_p[MM][NN] / d inc_c[p][a][b] by the reference's variation-of-parameters
  * formula:  W = 4^-d * sum over the fine cells (i,j) of coarse cell (a,b) of

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "sk_solve_fwd_edges_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
@@ -182,9 +183,11 @@ class HipBackend:
                    "sk_static_increments")
         return out[..., : N - 1]
 
-    def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram):
+    def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram, keep_edges=False):
         """K[MM][NN] for the LINEAR static kernel with the increments formed inside the solver (nothing of size
-        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band)."""
+        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band).
+        keep_edges: returns (K, edges) with the terminal row/column of every pair for solve_adj(..., edges=...)
+        (edges None where that is not available: fp32, dyadic 0)."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -199,14 +202,26 @@ class HipBackend:
         dYt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
         dYt[:, :D, :Nc] = (Y[:, 1:] - Y[:, :-1]).double().transpose(1, 2)
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        lib = load()
         with torch.cuda.device(dev):
-            fn = getattr(load(), "sk_solve_fwd_linear_" + _suffix(X))
-            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic),
-                    SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(out), _stream(X))
+            if keep_edges and X.dtype == torch.float64 and 1 <= dyadic <= 2:
+                P = A * B if gram else A
+                nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
+                if nbytes:
+                    edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+                    rc = lib.sk_solve_fwd_linear_edges_f64(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp,
+                                                           int(dyadic), scheme, _ptr(out), _ptr(edges), _stream(X))
+                    if rc == SK_OK:
+                        return out, edges
+                    if rc != 2:
+                        _check(rc, "sk_solve_fwd_linear_edges")
+            fn = getattr(lib, "sk_solve_fwd_linear_" + _suffix(X))
+            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic), scheme, _ptr(out), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_linear")
-        return out
+        return (out, None) if keep_edges else out
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

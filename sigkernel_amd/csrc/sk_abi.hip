@@ -204,7 +204,7 @@ int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, (hipStream_t)stream);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, nullptr, (hipStream_t)stream);
 }
 int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                             int dyadic, int scheme, float *out_final, void *stream) {
@@ -212,7 +212,16 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, (hipStream_t)stream);
+    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, nullptr, (hipStream_t)stream);
+}
+
+int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                                  int dyadic, int scheme, double *out_final, double *edges, void *stream) {
+    if (!dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 1 || dyadic > 2) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, edges, (hipStream_t)stream);
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {

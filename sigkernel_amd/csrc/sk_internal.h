@@ -90,7 +90,7 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            TO *out, hipStream_t s);
+                            TO *out, double *strip_edges, hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

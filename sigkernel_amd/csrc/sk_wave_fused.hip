@@ -25,6 +25,7 @@ struct FusedParams {
     const double *dXr;   // [A][Mrows][8]: s^2 (x[p+1]-x[p]), zero rows/dims beyond Mc / D
     const double *dYt;   // [Bn][8][Ncp]: y[q+1]-y[q], dimension-major, zero columns/dims beyond Nc / D
     void *out;           // [P] K[MM][NN]
+    double *edges;       // EDGES variant: [P][NUp*S + L*R] terminal row and column in the strip layout (sk_wave.hip)
     int64_t P, B;        // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p)
     int Mrows, Ncp;
     int Mc, Nc, NUp, logL, PPG, n_steps;
@@ -60,7 +61,7 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
                  : "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES>
 __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm) {
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
@@ -143,9 +144,35 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 #pragma unroll
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
 
+    // EDGES: terminal row / column of every pair, register -> global, held one macro-step (see sk_wave.hip)
+    const int EP = EDGES ? (NUp * S + L * R) : 0;
+    double erow[S], ecol[R];
+    int erow_at = -1, ecol_at = -1;
+    int64_t e_pair = 0;
+    const int k_f = (prm.Mc - 1) % RC;
+
     issue_y(0);
     issue_x(0);
     for (int t = 0; t < prm.n_steps; ++t) {
+        if (EDGES) {
+            double *const ep = prm.edges + e_pair * EP;
+            if (erow_at >= 0) {
+#pragma unroll
+                for (int cc = 0; cc < S; cc += 2) {
+                    d2_t v = {erow[cc], erow[cc + 1]};
+                    *reinterpret_cast<d2_t *>(ep + erow_at + cc) = v;
+                }
+            }
+            if (ecol_at >= 0) {
+#pragma unroll
+                for (int rr = 0; rr < R; rr += 2) {
+                    d2_t v = {ecol[rr], ecol[rr + 1]};
+                    *reinterpret_cast<d2_t *>(ep + ecol_at + rr) = v;
+                }
+            }
+            erow_at = -1;
+            ecol_at = -1;
+        }
         if ((t & 7) == 0) {
             // everything issued 8 macro-steps ago has had a whole slab period to land
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -206,6 +233,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
         // -- sweep the R x S block
         double cand[RC][CW];
+        double rowv[RC][S];   // EDGES: K on the last fine row of each coarse row of the block
 #pragma unroll
         for (int cc = 0; cc < S; ++cc) {
             double above = top[cc];
@@ -221,10 +249,30 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
                 above = v;
                 left[rr] = v;
                 if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
+                if (EDGES && (rr & (r - 1)) == r - 1) rowv[rr >> DY][cc] = v;
             }
             bot[cc] = above;
         }
         corner = top[S - 1];
+
+        if (EDGES) {
+            const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
+            if (pair_ok) e_pair = pair0 + ps;
+            if (pair_ok && lam == prm.lam_f) {
+                erow_at = u * S;
+#pragma unroll
+                for (int kk = 0; kk < RC; ++kk)
+                    if (kk == k_f) {
+#pragma unroll
+                        for (int cc = 0; cc < S; ++cc) erow[cc] = rowv[kk][cc];
+                    }
+            }
+            if (pair_ok && u == prm.u_f) {
+                ecol_at = NUp * S + lam * R;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) ecol[rr] = left[rr];
+            }
+        }
 
         // -- K[MM][NN] of a pair
         if (u == my_uf) {
@@ -249,16 +297,36 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
             if (u == NUp) { u = 0; ps += 1; }
         }
     }
+    if (EDGES) {
+        double *const ep = prm.edges + e_pair * EP;
+        if (erow_at >= 0) {
+#pragma unroll
+            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = erow[cc];
+        }
+        if (ecol_at >= 0) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = ecol[rr];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
-int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_linear<TO, DY, NAIVE, FULLWAVE>;
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES>
+int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    auto kern = k_fwd_fused_linear<TO, DY, NAIVE, FULLWAVE, EDGES>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
     return check_launch();
+}
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
+int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    if constexpr (sizeof(TO) == 8 && DY >= 1) {   // the adjoint that consumes the edges exists for fp64, d = 1..2
+        if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true>(prm, blocks, lds_bytes, s);
+    }
+    if (prm.edges) return SK_ERR_UNSUPPORTED;
+    return launch_fused_e<TO, DY, NAIVE, FULLWAVE, false>(prm, blocks, lds_bytes, s);
 }
 
 template <typename TO, int DY>
@@ -276,7 +344,7 @@ int launch_fused_dy(const FusedParams &prm, int blocks, size_t lds_bytes, hipStr
 // dXr [A][Mrows][8], dYt [Bn][8][Ncp] (see FusedParams).  SK_ERR_UNSUPPORTED outside the kernel's scope.
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            TO *out, hipStream_t s) {
+                            TO *out, double *strip_edges, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY > 2) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
@@ -310,7 +378,7 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
 
     FusedParams prm;
-    prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.P = g.P; prm.B = B;
+    prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.edges = strip_edges; prm.P = g.P; prm.B = B;
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.u_f = (g.Nc - 1) / 2;
@@ -326,8 +394,8 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double *,
-                                             hipStream_t);
+                                             double *, hipStream_t);
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, float *,
-                                            hipStream_t);
+                                            double *, hipStream_t);
 
 }  // namespace sk

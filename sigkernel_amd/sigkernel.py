@@ -47,12 +47,14 @@ def _fused_static(static_kernel, gram):
     return None
 
 
-def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram):
+def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=False):
     """Whole forward in one kernel when the static kernel is exactly LinearKernel and the shape fits
-    (sk_solve_fwd_linear_*: increments formed inside the solver); None otherwise."""
+    (sk_solve_fwd_linear_*: increments formed inside the solver); None otherwise.  keep_edges: (K, edges)."""
     if type(static_kernel) is LinearKernel and hasattr(be, "solve_fwd_fused_linear"):
-        return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), 1.0 if gram else float(static_kernel.scale),
-                                         dyadic, naive, gram)
+        scale = 1.0 if gram else float(static_kernel.scale)
+        if keep_edges:
+            return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram, keep_edges=True)
+        return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram)
     return None
 
 
@@ -159,14 +161,7 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     keep (a list, when a gradient is pending): receives one (a0, a1, edges) per tile -- the terminal row/column of every
     pair, 8(MM+NN) bytes per pair, which lets backward skip its forward sweep.  The reference keeps the whole solution
     grid for the same purpose (sigkernel.py:248, :397-399)."""
-    K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, naive, gram=True)
-    if K is not None:
-        return K
     A, B, M, N = Xd.shape[0], Yd.shape[0], Xd.shape[1], Yd.shape[1]
-    K = torch.empty(A, B, dtype=Xd.dtype, device=Xd.device)
-    fused = _fused_static(static_kernel, True) is not None
-    # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
-    per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
     budget = _budget(Xd.device, workspace_bytes)
     if keep is not None and hasattr(be, "solve_fwd_keep_edges"):
         edge_bytes = 8.0 * A * B * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
@@ -174,6 +169,21 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
             keep = None
     else:
         keep = None
+    if keep is not None:
+        res = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, naive, gram=True, keep_edges=True)
+        if res is not None:
+            K, edges = res
+            if edges is not None:
+                keep.append((0, A, edges))      # one block for all rows: backward slices it per tile
+            return K
+    else:
+        K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, naive, gram=True)
+        if K is not None:
+            return K
+    K = torch.empty(A, B, dtype=Xd.dtype, device=Xd.device)
+    fused = _fused_static(static_kernel, True) is not None
+    # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
+    per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
     for a0, a1 in _tiles(A, per_row, budget):
         inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
         if keep is not None:
@@ -245,11 +255,14 @@ class _SigKernelGram(torch.autograd.Function):
             fused = _fused_static(sk, True) is not None
             per_row = (3 if fused else 8) * B * M * N * X.element_size()
             kept = getattr(ctx, "kept_edges", None)
-            if kept:       # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
+            tiles = [(a0, a1, None) for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes))]
+            if kept and len(kept) == 1 and kept[0][:2] == (0, A) and kept[0][2] is not None and len(tiles) > 1:
+                full = kept[0][2]              # the fused forward kept one block for all rows: slice it per tile
+                per = full.numel() // A
+                tiles = [(a0, a1, full[a0 * per:a1 * per]) for a0, a1, _ in tiles]
+            elif kept:     # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
                 tiles = kept
-                ctx.kept_edges = None
-            else:
-                tiles = [(a0, a1, None) for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes))]
+            ctx.kept_edges = None
             for a0, a1, edges in tiles:
                 grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd.contiguous(),
                                                go[a0:a1].contiguous(), d, naive, gram=True, edges=edges)

@@ -160,6 +160,20 @@ def test_adjoint_from_kept_edges_is_identical(be, P, Mc, Nc, d):
     assert e2 is None and rel_err(k2.cpu().numpy(), O.solve_coarse(inc.cpu().numpy(), 0)) <= FAST_TOL
 
 
+@pytest.mark.parametrize("A,B,M,N,D,d", [(6, 5, 64, 64, 4, 1), (3, 4, 128, 100, 8, 1), (4, 4, 40, 64, 3, 2), (2, 9, 20, 24, 8, 1)])
+def test_fused_linear_forward_keeps_usable_edges(be, A, B, M, N, D, d):
+    """The fused linear forward's edges feed the fused adjoint of the (separately formed) increments: same W to 1e-10."""
+    gen = torch.Generator().manual_seed(A * 7 + M + N)
+    X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+    K, edges = be.solve_fwd_fused_linear(X, Y, 1.0, d, False, gram=True, keep_edges=True)
+    assert edges is not None
+    inc = be.static_increments(0, 1.0, X, Y, gram=True)
+    k0, W0, r0 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
+    _, W1, r1 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True, edges=edges)
+    assert rel_err(K.cpu().numpy(), k0.cpu().numpy()) <= FAST_TOL
+    assert float(r1.max()) <= 1e-9 and rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= ADJ_TOL
+
+
 def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
     """Exploding kernels (|K| ~ 1e9, far outside where the scheme means anything) break the backward recompute of K;
     the residual must flag those pairs and the re-solve must restore the oracle's answer."""
