@@ -530,8 +530,8 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     const int wpc_env = env_int("SK_ADJ_WPC", 0);
     const int wpc_cap = (wpc_env > 0 || DY == 2) ? 16 : 8;   // d = 2 (10 KB per wave): 13.1 ms at 16 (VGPRs allow 12) vs 13.6 at 8
     if (waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
-    // this kernel waits on memory every macro-step, so every extra resident wave helps, also an uneven count per SIMD
-    // (7 waves/CU at d = 1); SK_ADJ_WPC overrides
+    // this kernel waits on memory every macro-step, so every resident wave the LDS ring allows is taken (8 at d = 1, up to
+    // 16 at d = 2); SK_ADJ_WPC overrides
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
