@@ -78,16 +78,22 @@ __device__ __forceinline__ float readlane_f64(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
+// static kernel at one node: x (wave-uniform), its squared norm xs, y node (per lane) and its squared norm ys
 template <int DMAX, int KIND>
-__device__ __forceinline__ double static_node(const double (&xv)[DMAX], const double (&yv)[DMAX], double ys, double inv_sigma) {
-    double sq = 0.0, xy = 0.0;
+__device__ __forceinline__ double static_node(const double (&xv)[DMAX], double xs, const double (&yv)[DMAX], double ys,
+                                               double inv_sigma) {
+    double xy = 0.0;
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        sq = fma(xv[k], xv[k], sq);
-        xy = fma(xv[k], yv[k], xy);
-    }
+    for (int k = 0; k < DMAX; ++k) xy = fma(xv[k], yv[k], xy);
     // rbf: dist = -2 xy + (xs + ys);  G = exp(-dist / sigma)          (static_kernels.py:53-56, :70-73)
-    return KIND == 0 ? xy : exp(-(fma(-2.0, xy, sq + ys)) * inv_sigma);
+    return KIND == 0 ? xy : exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+}
+template <int DMAX>
+__device__ __forceinline__ double sqnorm(const double (&v)[DMAX]) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) s = fma(v[k], v[k], s);
+    return s;
 }
 
 template <typename T, int DMAX, int KIND, int NV, int CPT>
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
         // sweep below reads its x through v_readlane from here -- a scalar load per row and dimension would put one
         // scalar-cache round trip on the critical path of every iteration
         constexpr bool XREG = DMAX <= 8;
-        double xr[NV][XREG ? DMAX : 1];
+        double xr[NV][XREG ? DMAX : 1], xsq[NV];   // xsq: |x_row|^2, computed once per row here instead of once per node
         TA E[NV];
         {
             const int ir = min(i0 + lane, M - 1);
@@ -163,7 +169,8 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) xr[v][k] = xv[k];
                 }
-                E[v] = (TA)static_node<DMAX, KIND>(xv, ye, yse, inv_sigma);
+                xsq[v] = sqnorm<DMAX>(xv);
+                E[v] = (TA)static_node<DMAX, KIND>(xv, xsq[v], ye, yse, inv_sigma);
             }
         }
         const int rows = min(SK_TPB, M - i0);
@@ -176,10 +183,15 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
 #pragma unroll
                 for (int k = 0; k < DMAX; ++k) {
                     if constexpr (XREG) xv[k] = readlane_f64(xr[v][k], r);                       // wave-uniform
-                    else xv[k] = k < D ? (double)xs[v][(int64_t)i * D + k] : 0.0;
+                    else xv[k] = (double)xs[v][(int64_t)i * D + min(k, D - 1)];   // unconditional (mergeable) scalar loads
                 }
+                if constexpr (!XREG) {
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND>(xv, yn[c], ys[c], inv_sigma);
+                    for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? xv[k] : 0.0;
+                }
+                const double xs_row = readlane_f64(xsq[v], r);
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND>(xv, xs_row, yn[c], ys[c], inv_sigma);
             }
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
