@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +116,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:              # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     A, B, M, N, D, kname, dyadic, dtype, desc = CONFIGS[args.config]
@@ -128,14 +133,14 @@ def main():
 
     def step():
         Kloc = sk.compute_Gram(X, Y)                     # this rank's (A x B) block
-        if world > 1:
+        if use_dist:
             out = torch.empty((world * A, B), dtype=Kloc.dtype, device=dev)
             dist.all_gather_into_tensor(out, Kloc)       # the one collective of the path
             return out
         return Kloc
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +152,7 @@ def main():
         K = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -277,7 +282,7 @@ def main():
         print(json.dumps(result))
         sys.stdout.flush()
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -75,3 +75,38 @@ def test_row_range_partitions_all_rows():
                 assert hi - lo <= chunk
                 rows += list(range(lo, hi))
             assert rows == list(range(n))
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import sigkernel_amd
+        c = golden("gram_c3mini_lin_d1")
+        X, Y, w = (torch.from_numpy(c[k]).cuda() for k in ("X", "Y", "w"))
+        sk = sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"]), process_group=dist.group.WORLD)
+        Xg = X.clone().requires_grad_(True)
+        K = sk.compute_Gram(Xg, Y)
+        (K * w).sum().backward()
+        g = torch.randn(X.shape, dtype=X.dtype, generator=torch.Generator().manual_seed(1)).cuda()
+        kk = sk.compute_kernel_and_derivatives_Gram(X, Y, g)
+        k1 = sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"])).compute_kernel_and_derivatives_Gram(X, Y, g)
+        np.savez(os.path.join(out_dir, "nccl.npz"), gram=K.detach().cpu().numpy(), grad_w=Xg.grad.cpu().numpy(),
+                 kd_err=float(max((a - b).abs().max() for a, b in zip(kk, k1))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_gram_over_rccl_single_rank(tmp_path):
+    """The RCCL path of sigkernel_amd.distributed on a real GPU (one rank is all a 1-GPU box offers): process-group init,
+    all_gather_into_tensor of the value and gradient blocks, and the sharded derivative Gram."""
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    c = golden("gram_c3mini_lin_d1")
+    got = dict(np.load(tmp_path / "nccl.npz"))
+    assert rel_err(got["gram"], c["gram"]) <= 1e-12
+    assert rel_err(got["grad_w"], c["grad_w"]) <= 2e-5
+    assert float(got["kd_err"]) == 0.0
