@@ -101,36 +101,53 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
     // ---- producers (uniform control; per-lane source offsets) ------------------------------------------------
     // y slab s = virtual units [8s, 8s+8) of every lane group: dims k = lane/8, unit x = lane%8
-    auto issue_y = [&](int s) {
-        const int v0 = s * 8;
-        const int pi = v0 / NUp, u0 = v0 - pi * NUp;   // pair-in-group and first unit (NUp % 8 == 0: no straddling)
+    // The producers run once per 8 macro-steps with wave-uniform control.  Their cursors advance incrementally (no division
+    // by NUp), and the pair -> (a, b) split uses 32-bit arithmetic whenever the pair count allows: the 64-bit division
+    // sequence is ~150 scalar instructions, and there are G of them per call.
+    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
+    auto split_b = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+    };
+    auto split_a = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+    };
+    int y_pi = 0, y_u0 = 0, y_slot = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling), ring slot
+    auto issue_y = [&]() {
         for (int g = 0; g < G; ++g) {
-            int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
-            if (pi >= prm.PPG || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
-            const int64_t b = prm.B > 0 ? p % prm.B : p;
-            const double *src = prm.dYt + ((b * FD + (lane >> 3)) * (int64_t)prm.Ncp + (int64_t)(u0 + (lane & 7)) * 2);
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + (s % NSLAB) * Y_SLAB_PITCH), 16, 0, 0);
+            int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + y_pi;
+            if (y_pi >= prm.PPG || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
+            const int64_t b = split_b(p);
+            const double *src = prm.dYt + ((b * FD + (lane >> 3)) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + y_slot * Y_SLAB_PITCH), 16, 0, 0);
         }
+        y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
+        y_u0 += 8;
+        if (y_u0 == NUp) { y_u0 = 0; y_pi += 1; }
     };
     // x slabs for the lanes that start a pair during macro-steps [t0, t0+8): lanes lam0 + j*NUp .. +7 start pair
     // t0/NUp - j, rows (lam0 + j*NUp .. +7)*RC of its x
-    auto issue_x = [&](int t0) {
-        const int q0 = t0 / NUp, lam0 = t0 - q0 * NUp;
+    int x_q0 = 0, x_lam0 = 0, x_slot = 0;   // next window: t0 / NUp, t0 % NUp, ring slot
+    auto issue_x = [&]() {
         for (int j = 0; j < JMAX; ++j) {
-            const int lamj = lam0 + j * NUp, pi = q0 - j;
+            const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
                 int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
                 if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
-                const int64_t a = prm.B > 0 ? p / prm.B : p;
+                const int64_t a = split_a(p);
                 const char *src = reinterpret_cast<const char *>(prm.dXr + (a * prm.Mrows + (int64_t)lamj * RC) * FD);
-                char *dst = lds + x_base0 + ((g * X_SLOTS + (t0 >> 3) % X_SLOTS) * JMAX + j) * XSLAB;
+                char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
 #pragma unroll
                 for (int c = 0; c < (XSLAB + 1023) / 1024; ++c)
                     if (c * 1024 + lane * 16 < XSLAB)
                         __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, (lds_void *)(dst + c * 1024), 16, 0, 0);
             }
         }
+        x_slot = x_slot + 1 == X_SLOTS ? 0 : x_slot + 1;
+        x_lam0 += 8;
+        if (x_lam0 == NUp) { x_lam0 = 0; x_q0 += 1; }
     };
 
     double dxr[RC][FD];
@@ -151,8 +168,8 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
     int64_t e_pair = 0;
     const int k_f = (prm.Mc - 1) % RC;
 
-    issue_y(0);
-    issue_x(0);
+    issue_y();
+    issue_x();
     for (int t = 0; t < prm.n_steps; ++t) {
         if (EDGES) {
             double *const ep = prm.edges + e_pair * EP;
@@ -176,8 +193,8 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
         if ((t & 7) == 0) {
             // everything issued 8 macro-steps ago has had a whole slab period to land
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            issue_y((t >> 3) + 1);
-            issue_x(t + 8);
+            issue_y();       // slab (t >> 3) + 1
+            issue_x();       // window t + 8
         }
 
         // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows
