@@ -85,9 +85,13 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     // step's DMA wait, so that the stores have a whole step to be acknowledged before the following wait (loads and
     // stores share vmcnt on gfx9: a store still in flight at the wait costs a step of prefetch distance).
     const int EP = EDGES ? (NUp * S + nb * L * R) : 0;   // doubles per pair
-    double erow[S], ecol[R];
-    int erow_at = -1, ecol_at = -1;                       // element offsets inside the pair's block, -1 = nothing held
+    // The column values are this lane's `left` state and, when the pair's last coarse row is the last row of the lane's
+    // block, the row values are its `bot` state: both survive untouched until the next step's sweep, so they are stored
+    // from there.  Only when the last row sits higher in the block (k_f < RC-1) is a copy held in `erow`.
+    double erow[S];
+    int erow_at = -1, ecol_at = -1;                       // element offsets inside the pair's block, -1 = nothing to store
     int64_t e_pair = 0;
+    const bool row_in_bot = prm.k_f == RC - 1;             // uniform
 
     // ---- producer (DMA) state ---------------------------------------------------------------------------
     // Fetch step f = 8q + j serves the 8 consumer lanes lc = j + 8*(lane/8); all of them are about to start
@@ -162,24 +166,22 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         vec_t gv[RC];
         lds_read_rows<PF * RC>(gv, rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4)));
 
-        if (EDGES) {   // the edge values produced in the previous macro-step
+        if (EDGES) {   // the edge values produced in the previous macro-step (before anything touches left / bot)
             double *const ep = prm.edges + e_pair * EP;
             if (erow_at >= 0) {
 #pragma unroll
                 for (int cc = 0; cc < S; cc += 2) {
-                    d2_t v = {erow[cc], erow[cc + 1]};
+                    d2_t v = {row_in_bot ? bot[cc] : erow[cc], row_in_bot ? bot[cc + 1] : erow[cc + 1]};
                     *reinterpret_cast<d2_t *>(ep + erow_at + cc) = v;
                 }
             }
             if (ecol_at >= 0) {
 #pragma unroll
                 for (int rr = 0; rr < R; rr += 2) {
-                    d2_t v = {ecol[rr], ecol[rr + 1]};
+                    d2_t v = {left[rr], left[rr + 1]};
                     *reinterpret_cast<d2_t *>(ep + ecol_at + rr) = v;
                 }
             }
-            erow_at = -1;
-            ecol_at = -1;
         }
 
         // -- row-unit start: left boundary K[i][0] = 1
@@ -269,24 +271,20 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
             }
         }
 
-        // -- terminal row and column of the pair: hold them, the next macro-step stores them (see above).  The column
-        //    relies on the padding columns of the last unit being zero (K is constant along zero increments).
+        // -- terminal row and column of the pair: note where they go, the next macro-step stores them (see above).  The
+        //    column relies on the padding columns of the last unit being zero (K is constant along zero increments).
         if (EDGES) {
             const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
-            if (pair_ok) e_pair = pair0 + ps;
-            if (pair_ok && lam == prm.lam_f && band == nb - 1) {
-                erow_at = u * S;
+            e_pair = pair0 + ps;                       // only read where one of the offsets below is set
+            erow_at = (pair_ok && lam == prm.lam_f && band == nb - 1) ? u * S : -1;
+            ecol_at = (pair_ok && u == prm.u_f) ? NUp * S + (band * L + lam) * R : -1;
+            if (!row_in_bot) {                         // uniform branch, unconditional copies
 #pragma unroll
-                for (int kk = 0; kk < RC; ++kk)
-                    if (kk == prm.k_f) {   // uniform: which coarse row of the block is the pair's last row
+                for (int kk = 0; kk < RC - 1; ++kk)
+                    if (kk == prm.k_f) {
 #pragma unroll
                         for (int cc = 0; cc < S; ++cc) erow[cc] = rowv[kk][cc];
                     }
-            }
-            if (pair_ok && u == prm.u_f) {
-                ecol_at = NUp * S + (band * L + lam) * R;
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr) ecol[rr] = left[rr];
             }
         }
 
@@ -325,11 +323,11 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         double *const ep = prm.edges + e_pair * EP;
         if (erow_at >= 0) {
 #pragma unroll
-            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = erow[cc];
+            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = row_in_bot ? bot[cc] : erow[cc];
         }
         if (ecol_at >= 0) {
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = ecol[rr];
+            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = left[rr];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -163,32 +163,31 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
     // EDGES: terminal row / column of every pair, register -> global, held one macro-step (see sk_wave.hip)
     const int EP = EDGES ? (NUp * S + L * R) : 0;
-    double erow[S], ecol[R];
+    double erow[S];
     int erow_at = -1, ecol_at = -1;
     int64_t e_pair = 0;
     const int k_f = (prm.Mc - 1) % RC;
+    const bool row_in_bot = k_f == RC - 1;   // then the row values are the `bot` state (see sk_wave.hip)
 
     issue_y();
     issue_x();
     for (int t = 0; t < prm.n_steps; ++t) {
-        if (EDGES) {
+        if (EDGES) {   // the edge values of the previous macro-step, straight from the state registers
             double *const ep = prm.edges + e_pair * EP;
             if (erow_at >= 0) {
 #pragma unroll
                 for (int cc = 0; cc < S; cc += 2) {
-                    d2_t v = {erow[cc], erow[cc + 1]};
+                    d2_t v = {row_in_bot ? bot[cc] : erow[cc], row_in_bot ? bot[cc + 1] : erow[cc + 1]};
                     *reinterpret_cast<d2_t *>(ep + erow_at + cc) = v;
                 }
             }
             if (ecol_at >= 0) {
 #pragma unroll
                 for (int rr = 0; rr < R; rr += 2) {
-                    d2_t v = {ecol[rr], ecol[rr + 1]};
+                    d2_t v = {left[rr], left[rr + 1]};
                     *reinterpret_cast<d2_t *>(ep + ecol_at + rr) = v;
                 }
             }
-            erow_at = -1;
-            ecol_at = -1;
         }
         if ((t & 7) == 0) {
             // everything issued 8 macro-steps ago has had a whole slab period to land
@@ -274,20 +273,16 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
         if (EDGES) {
             const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
-            if (pair_ok) e_pair = pair0 + ps;
-            if (pair_ok && lam == prm.lam_f) {
-                erow_at = u * S;
+            e_pair = pair0 + ps;
+            erow_at = (pair_ok && lam == prm.lam_f) ? u * S : -1;
+            ecol_at = (pair_ok && u == prm.u_f) ? NUp * S + lam * R : -1;
+            if (!row_in_bot) {
 #pragma unroll
-                for (int kk = 0; kk < RC; ++kk)
+                for (int kk = 0; kk < RC - 1; ++kk)
                     if (kk == k_f) {
 #pragma unroll
                         for (int cc = 0; cc < S; ++cc) erow[cc] = rowv[kk][cc];
                     }
-            }
-            if (pair_ok && u == prm.u_f) {
-                ecol_at = NUp * S + lam * R;
-#pragma unroll
-                for (int rr = 0; rr < R; ++rr) ecol[rr] = left[rr];
             }
         }
 
@@ -318,11 +313,11 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
         double *const ep = prm.edges + e_pair * EP;
         if (erow_at >= 0) {
 #pragma unroll
-            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = erow[cc];
+            for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = row_in_bot ? bot[cc] : erow[cc];
         }
         if (ecol_at >= 0) {
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = ecol[rr];
+            for (int rr = 0; rr < R; ++rr) ep[ecol_at + rr] = left[rr];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
