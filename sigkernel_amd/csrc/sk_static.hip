@@ -386,40 +386,57 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
         }
     }
     const int64_t nb = B > 0 ? B : 1;
-    for (int64_t bb = 0; bb < nb; ++bb) {
+    // everything one (pair, column) needs from memory, loaded without using it: two pairs are in flight per iteration
+    auto fetch = [&](int64_t bb, int n, double (&yn)[DMAX], double (&wl)[RM + 1], double (&wv)[RM + 1], double &s) {
         const int64_t b = B > 0 ? bb : a, p = B > 0 ? a * B + bb : a;
-        const double s = scale ? (double)scale[p] : 1.0;
+        s = scale ? (double)scale[p] : 1.0;
         const T *y = Y + b * (int64_t)N * D;
         const T *w = W + p * (int64_t)Mc * ldw;
-        for (int n = threadIdx.x; n < N; n += NT) {
-            double yn[DMAX], ys = 0.0;
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) {
-                yn[k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
-                ys = fma(yn[k], yn[k], ys);
-            }
-            const bool lf = n >= 1, rt = n < Nc;
-            // t[r] for W rows m0 - 1 + r, r = 0 .. RM (zero outside the matrix)
-            double t[RM + 1];
-            const int nl = max(n - 1, 0), nr = min(n, Nc - 1);
+        for (int k = 0; k < DMAX; ++k) yn[k] = k < D ? (double)y[(int64_t)n * D + k] : 0.0;
+        const int nl = max(n - 1, 0), nr = min(n, Nc - 1);
 #pragma unroll
-            for (int r = 0; r <= RM; ++r) {   // unconditional loads from clamped positions, masked afterwards
-                const int wr = m0 - 1 + r;
-                const bool ok = wr >= 0 && wr < Mc;
-                const int64_t ro = (int64_t)min(max(wr, 0), Mc - 1) * ldw;
-                const double wl = (double)w[ro + nl], wv = (double)w[ro + nr];
-                t[r] = ((ok && rt) ? wv : 0.0) - ((ok && lf) ? wl : 0.0);
-            }
+        for (int r = 0; r <= RM; ++r) {   // unconditional loads from clamped positions, masked in use()
+            const int64_t ro = (int64_t)min(max(m0 - 1 + r, 0), Mc - 1) * ldw;
+            wl[r] = (double)w[ro + nl];
+            wv[r] = (double)w[ro + nr];
+        }
+    };
+    auto use = [&](int n, const double (&yn)[DMAX], const double (&wl)[RM + 1], const double (&wv)[RM + 1], double s) {
+        const bool lf = n >= 1, rt = n < Nc;
+        double ys = 0.0, t[RM + 1];   // t[r] = W[r][n] - W[r][n-1] for W rows m0 - 1 + r (zero outside the matrix)
 #pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                double xy = 0.0;
+        for (int k = 0; k < DMAX; ++k) ys = fma(yn[k], yn[k], ys);
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k) xy = fma(xm[r][k], yn[k], xy);
-                const double g = exp(-(fma(-2.0, xy, xs[r] + ys)) * inv_sigma);
-                const double c = (m0 + r < M ? s : 0.0) * (t[r + 1] - t[r]) * g;
+        for (int r = 0; r <= RM; ++r) {
+            const int wr = m0 - 1 + r;
+            const bool ok = wr >= 0 && wr < Mc;
+            t[r] = ((ok && rt) ? wv[r] : 0.0) - ((ok && lf) ? wl[r] : 0.0);
+        }
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(c, xm[r][k] - yn[k], acc[r][k]);
-            }
+        for (int r = 0; r < RM; ++r) {
+            double xy = 0.0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) xy = fma(xm[r][k], yn[k], xy);
+            const double g = exp(-(fma(-2.0, xy, xs[r] + ys)) * inv_sigma);
+            const double c = (m0 + r < M ? s : 0.0) * (t[r + 1] - t[r]) * g;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(c, xm[r][k] - yn[k], acc[r][k]);
+        }
+    };
+    for (int n = threadIdx.x; n < N; n += NT) {
+        int64_t bb = 0;
+        for (; bb + 1 < nb; bb += 2) {
+            double y0[DMAX], l0[RM + 1], v0[RM + 1], s0, y1[DMAX], l1[RM + 1], v1[RM + 1], s1;
+            fetch(bb, n, y0, l0, v0, s0);
+            fetch(bb + 1, n, y1, l1, v1, s1);
+            use(n, y0, l0, v0, s0);
+            use(n, y1, l1, v1, s1);
+        }
+        if (bb < nb) {
+            double y0[DMAX], l0[RM + 1], v0[RM + 1], s0;
+            fetch(bb, n, y0, l0, v0, s0);
+            use(n, y0, l0, v0, s0);
         }
     }
 #pragma unroll
