@@ -59,6 +59,24 @@ __device__ __forceinline__ void async_begin(double &t) { asm volatile("" : "=v"(
 __device__ __forceinline__ void load_async(double &dst, const double *p) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+template <int BYTE_OFF>   // immediate offset (13-bit signed): one address register pair serves a run of loads
+__device__ __forceinline__ void load_async_at(double &dst, const double *p) {
+    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(BYTE_OFF) : "memory");
+}
+// dst[i] <- p[-i], i = 0 .. N-1
+template <int N, int M>
+__device__ __forceinline__ void load_run(double (&dst)[M], const double *p) {
+    static_assert(N <= M && N <= 8, "");
+    if constexpr (N > 0) load_async_at<0>(dst[0], p);
+    if constexpr (N > 1) load_async_at<-8>(dst[1], p);
+    if constexpr (N > 2) load_async_at<-16>(dst[2], p);
+    if constexpr (N > 3) load_async_at<-24>(dst[3], p);
+    if constexpr (N > 4) load_async_at<-32>(dst[4], p);
+    if constexpr (N > 5) load_async_at<-40>(dst[5], p);
+    if constexpr (N > 6) load_async_at<-48>(dst[6], p);
+    if constexpr (N > 7) load_async_at<-56>(dst[7], p);
+}
+
 template <int VM>
 __device__ __forceinline__ void async_wait(double (&o)[4], double (&t)[4]) {
     asm volatile("s_waitcnt vmcnt(%8)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3])
@@ -255,8 +273,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
             // Kf[0][j'] = K[MM][NNp - j'], j' = nu*S + i + 1, stored at [NNp - j' - 1]; only the very last element of a row
             // (nu = NUp-1, i = S-1) asks for K[MM][0] = 1, which is not stored: clamped here, fixed up after the wait
             const double *q = e + (NNp - nu * S - 2);
-#pragma unroll
-            for (int i = 0; i < S - 1; ++i) load_async(prow[i], q - i);
+            load_run<S - 1>(prow, q);
             load_async(prow[S - 1], nu == NUp - 1 ? e : q - (S - 1));
         }
         if (nu == 0) {
