@@ -49,15 +49,16 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
     if (ldw == 0) ldw = Nc;
     hipStream_t s = (hipStream_t)stream;
-    if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
     const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // launch_adj_wave's scope
     const size_t fast_ws = fast_shape ? adj_fast_workspace_bytes(g, (int)sizeof(T)) : 0;
-    if (flags & SK_FLAG_EDGES_GIVEN) {
-        // the caller kept the strip edges of its forward pass (sk_solve_fwd_edges_*): only the fused reverse sweep runs
+    if (flags & SK_FLAG_EDGES_GIVEN) {   // argument checks before any HIP call
         const size_t need = fast_shape ? (size_t)P * strip_edge_doubles(g, (int)sizeof(T)) * sizeof(double) : 0;
         if (!need || !out_err || !ws || ws_bytes < need) return SK_ERR_WORKSPACE;
-        return launch_adj_wave<T>(inc_c, g.ld, g, static_cast<const double *>(ws), W, ldw, out_err, s);
     }
+    if (out_err && hipMemsetAsync(out_err, 0, sizeof(double) * (size_t)P, s) != hipSuccess) return SK_ERR_LAUNCH;
+    if (flags & SK_FLAG_EDGES_GIVEN)
+        // the caller kept the strip edges of its forward pass (sk_solve_fwd_edges_*): only the fused reverse sweep runs
+        return launch_adj_wave<T>(inc_c, g.ld, g, static_cast<const double *>(ws), W, ldw, out_err, s);
     if (!(flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) && fast_ws && out_err && ws && ws_bytes >= fast_ws) {
         // forward sweep that also emits the terminal row/column, then the fused reverse sweep + recompute of K
         double *edges = static_cast<double *>(ws);

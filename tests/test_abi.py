@@ -45,6 +45,17 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_fwd_f64(ctypes.c_void_p(16), 3, 1, 4, 4, 0, 0, 0, ctypes.c_void_p(16), None, None, None) == 1   # ld < Nc
     assert lib.sk_increments_f64(None, 1, 4, 4, None, 0, None) == 1
     assert lib.sk_solve_adj_f64(ctypes.c_void_p(16), 0, 1, 4, 4, 0, 0, 0, None, None, 0, None, None, 0, None) == 1
+    p = ctypes.c_void_p(16)
+    # EDGES_GIVEN (8) cannot be combined with the exact / simple kernels, and needs a workspace
+    assert lib.sk_solve_adj_f64(p, 0, 1, 4, 4, 1, 0, 8 | 2, None, p, 0, p, p, 64, None) == 1
+    assert lib.sk_solve_adj_f64(p, 16, 1, 4, 4, 1, 0, 8, None, p, 16, p, None, 0, None) == 4     # SK_ERR_WORKSPACE
+    assert lib.sk_solve_fwd_edges_f64(p, 16, 1, 4, 4, 1, 0, None, p, None) == 1                # no output vector
+    assert lib.sk_solve_fwd_edges_f64(p, 16, 1, 4, 4, 0, 0, p, p, None) == 2                   # dyadic 0: not covered
+    assert lib.sk_strip_edges_bytes(10, 63, 63, 1, 8) == 10 * (128 + 128) * 8                  # NNp = 32 units * 4, MMp = 32 lanes * 4
+    assert lib.sk_strip_edges_bytes(10, 63, 63, 0, 8) == 0 and lib.sk_strip_edges_bytes(10, 63, 63, 2, 4) == 0
+    assert lib.sk_solve_deriv_f64(p, None, p, 0, 1, 4, 4, 0, 0, p, p, p, None) == 1
+    assert lib.sk_deriv_increments_f64(p, p, p, 0.0, 1, 4, 4, p, p, p, 0, None) == 1              # eps must be positive
+    assert lib.sk_linear_adjoint_f64(p, 2, p, 0, None, 1, 1, 4, 4, 2, p, None) == 1               # ldy < Nc
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
@@ -75,3 +86,17 @@ def test_no_instruction_touches_an_in_flight_asynchronous_load():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_hazards.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_the_hazard_lint_recognises_a_hazard():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_async_hazards as lint
+    bad = """_Zbad: ; @_Zbad
+\tglobal_load_dwordx2 v[10:11], v[4:5], off
+\tv_mov_b64_e32 v[2:3], v[10:11]
+\ts_waitcnt vmcnt(0)
+.Lfunc_end0:
+"""
+    good = bad.replace("\tv_mov_b64_e32 v[2:3], v[10:11]\n\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\tv_mov_b64_e32 v[2:3], v[10:11]")
+    assert len(lint.scan(bad)) == 1 and len(lint.scan(good)) == 0
