@@ -105,6 +105,21 @@ int sk_linear_adjoint_f64(const double *dYt, int64_t ldy, const double *W, int64
 int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_t ldw, const float *scale, int64_t A, int64_t B,
                           int Mc, int Nc, int D, float *out, void *stream);
 
+/* Second-argument adjoint (Gram only): dL/dY from W for the pairs (a, b), b >= b0 -- the counterpart of sk_static_adjoint_*
+ * that the reference never needs (it returns no gradient for its second argument, sigkernel.py:343, :412).  It exists for
+ * compute_Gram(X, X, sym=True) with a gradient: only the blocks on and above the diagonal are solved, and a pair (a, b)
+ * above the diagonal also stands for (b, a), whose first-argument gradient is this pair's second-argument one.
+ *   W [A*B, M-1, ldw], scale [A*B] nullable (the caller passes the TRANSPOSED upstream gradient block).
+ *   kind 0 (linear, D <= 8): dXr [A][Mrows][8] fp64 = param^2 (x[p+1]-x[p]) zero-padded (the array sk_solve_fwd_linear_* takes),
+ *                    X, Y unused; out = T2 [B-b0, N-1, D], the caller forms dL/dy[b][n] = T2[b][n-1] - T2[b][n].
+ *   kind 1 (rbf):    dXr unused; out = dL/dY [B-b0, N, D]. */
+int sk_static_adjoint2_f64(int kind, double param, const double *X, const double *Y, const double *dXr, int Mrows,
+                           const double *W, int64_t ldw, const double *scale, int64_t A, int64_t B, int b0, int M, int N, int D,
+                           double *out, void *stream);
+int sk_static_adjoint2_f32(int kind, double param, const float *X, const float *Y, const double *dXr, int Mrows, const float *W,
+                           int64_t ldw, const float *scale, int64_t A, int64_t B, int b0, int M, int N, int D, float *out,
+                           void *stream);
+
 /* Transpose of sk_increments_*, used by the adjoint: dG[p][m][n] = s_p * (W[m-1][n-1] + W[m][n]
  * - W[m-1][n] - W[m][n-1]) with out-of-range W = 0 and s_p = scale[p] (or 1 if scale == NULL).
  * Replaces the finite-difference contraction at sigkernel.py:313-341 / :472-500 (the reference

@@ -39,6 +39,10 @@ SIGNATURES = {
     "sk_static_adjoint_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "sk_linear_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "sk_linear_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "sk_static_adjoint2_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _int, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _int,
+                                      _vp, _vp]),
+    "sk_static_adjoint2_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _int, _vp, _i64, _vp, _i64, _i64, _int, _int, _int, _int,
+                                      _vp, _vp]),
     "sk_increments_adjoint_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
@@ -256,6 +260,38 @@ class HipBackend:
             g = torch.empty(A, M, D, dtype=X.dtype, device=X.device)
             _check(fn(1, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(g),
                       _stream(X)), "sk_static_adjoint")
+            return g
+
+    def static_adjoint2(self, kind, param, X, Y, W, scale, b0=0):
+        """dL/dY[b0:] (B-b0, N, D) from W = dL/d inc_c of the Gram pairs (a, b) and the per-pair upstream gradient `scale`
+        (A, B): the second-argument counterpart of static_adjoint (Gram only).  None outside its scope (linear: D > 8)."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        W, ldw = _row_stride(W, "W")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        if (kind == 0 and D > 8) or D > self.MAX_FUSED_DIM:
+            return None
+        if scale is not None:
+            _dev(scale, "scale")
+            if scale.dtype != W.dtype or scale.numel() != A * B:
+                raise ValueError("scale must be (A, B) with W's dtype")
+        dev = X.device
+        with torch.cuda.device(dev):
+            fn = getattr(load(), "sk_static_adjoint2_" + _suffix(X))
+            if kind == 0:
+                dXr = torch.zeros(A, M - 1, 8, dtype=torch.float64, device=dev)
+                dXr[:, :, :D] = (X[:, 1:] - X[:, :-1]).double() * (float(param) ** 2)
+                T2 = torch.empty(B - b0, N - 1, D, dtype=X.dtype, device=dev)
+                _check(fn(0, float(param), None, None, _ptr(dXr), M - 1, _ptr(W), ldw, _ptr(scale), A, B, int(b0), M, N, D,
+                          _ptr(T2), _stream(X)), "sk_static_adjoint2")
+                g = torch.zeros(B - b0, N, D, dtype=X.dtype, device=dev)
+                g[:, 1:] += T2
+                g[:, :-1] -= T2
+                return g
+            g = torch.empty(B - b0, N, D, dtype=X.dtype, device=dev)
+            _check(fn(1, float(param), _ptr(X), _ptr(Y), None, 0, _ptr(W), ldw, _ptr(scale), A, B, int(b0), M, N, D, _ptr(g),
+                      _stream(X)), "sk_static_adjoint2")
             return g
 
     def increments_adjoint(self, W, scale=None):

@@ -177,6 +177,27 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
     return launch_linear_adjoint_dyt<float>(dYt, ldy, W, ldw ? ldw : Nc, scale, A, B, Mc, Nc, D, out, (hipStream_t)stream);
 }
 
+int sk_static_adjoint2_f64(int kind, double param, const double *X, const double *Y, const double *dXr, int Mrows,
+                           const double *W, int64_t ldw, const double *scale, int64_t A, int64_t B, int b0, int M, int N, int D,
+                           double *out, void *stream) {
+    if (!W || !out || A < 0 || B < 1 || b0 < 0 || b0 > B || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ldw != 0 && ldw < N - 1) || (kind == 1 && (!(param > 0) || !X || !Y)) || (kind == 0 && (!dXr || Mrows < M - 1)))
+        return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_adjoint2<double>(kind, param, X, Y, dXr, Mrows, W, ldw ? ldw : N - 1, scale, A, B, b0, M, N, D, out,
+                                          (hipStream_t)stream);
+}
+int sk_static_adjoint2_f32(int kind, double param, const float *X, const float *Y, const double *dXr, int Mrows, const float *W,
+                           int64_t ldw, const float *scale, int64_t A, int64_t B, int b0, int M, int N, int D, float *out,
+                           void *stream) {
+    if (!W || !out || A < 0 || B < 1 || b0 < 0 || b0 > B || M < 2 || N < 2 || D < 1 || (kind != 0 && kind != 1)) return SK_ERR_BAD_ARG;
+    if ((ldw != 0 && ldw < N - 1) || (kind == 1 && (!(param > 0) || !X || !Y)) || (kind == 0 && (!dXr || Mrows < M - 1)))
+        return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_static_adjoint2<float>(kind, param, X, Y, dXr, Mrows, W, ldw ? ldw : N - 1, scale, A, B, b0, M, N, D, out,
+                                         (hipStream_t)stream);
+}
+
 int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale, int64_t P, int M, int N, double *dG,
                               void *stream) {
     if (!W || !dG || P < 0 || M < 2 || N < 2 || (ldw != 0 && ldw < N - 1)) return SK_ERR_BAD_ARG;

@@ -120,6 +120,10 @@ template <typename T>
 int launch_linear_adjoint_dyt(const double *dYt, int64_t ldy, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B,
                               int Mc, int Nc, int D, T *out, hipStream_t s);
 
+template <typename T>
+int launch_static_adjoint2(int kind, double param, const T *X, const T *Y, const double *dXr, int Mrows, const T *W, int64_t ldw,
+                           const T *scale, int64_t A, int64_t B, int b0, int M, int N, int D, T *out, hipStream_t s);
+
 inline int check_launch() {
     return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;
 }

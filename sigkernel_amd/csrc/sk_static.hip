@@ -448,6 +448,106 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
         }
 }
 
+// ---- second-argument adjoints (Gram only): dL/dY from W, for the pairs (a, b) with b >= b0 ---------------------------
+// Used for compute_Gram(X, X, sym=True) with a gradient: only the blocks on and above the diagonal are solved, and a pair
+// (a, b) above the diagonal also stands for (b, a) -- whose first-argument gradient is this pair's second-argument one.
+// The reference never differentiates its second argument (sigkernel.py:343, :412); these kernels exist for that shortcut.
+// Thread = column (q or n), so the reads of W are coalesced along rows as in the first-argument kernels.
+
+// linear: T2[b][q][k] = sum_a s_ab sum_p W[a,b,p,q] * dXr[a][p][k]   (dXr [A][Mrows][8]: scaled row differences, as the
+// fused forward takes them);  the caller forms dL/dy[b][n] = T2[b][n-1] - T2[b][n].
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void k_linear_adj2(const double *__restrict__ dXr, int Mrows, const T *__restrict__ W,
+                                                    int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0,
+                                                    int Mc, int Nc, int D, int col_tiles, T *__restrict__ Tout) {
+    constexpr int DP = 8;
+    const int64_t b = b0 + blockIdx.x / col_tiles;
+    const int q = (int)(blockIdx.x % col_tiles) * NT + threadIdx.x;
+    const int qc = min(q, Nc - 1);
+    double acc[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) acc[k] = 0.0;
+    for (int64_t a = 0; a < A; ++a) {
+        const int64_t p = a * B + b;
+        const double s = scale ? (double)scale[p] : 1.0;
+        const T *w = W + p * Mc * ldw + qc;
+        const double *dx = dXr + a * (int64_t)Mrows * DP;
+        int i = 0;
+        for (; i + 4 <= Mc; i += 4) {   // four rows in flight
+            double wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = (double)w[(int64_t)(i + j) * ldw];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double c = s * wv[j];
+#pragma unroll
+                for (int k = 0; k < DP; ++k) acc[k] = fma(c, dx[(i + j) * DP + k], acc[k]);   // dx: wave-uniform
+            }
+        }
+        for (; i < Mc; ++i) {
+            const double c = s * (double)w[(int64_t)i * ldw];
+#pragma unroll
+            for (int k = 0; k < DP; ++k) acc[k] = fma(c, dx[i * DP + k], acc[k]);
+        }
+    }
+    if (q < Nc) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < D) Tout[((b - b0) * Nc + q) * (int64_t)D + k] = (T)acc[k];
+    }
+}
+
+// rbf: dL/dy[b][n][k] = (2/sigma) sum_a s_ab sum_m dG[m][n] G[m][n] (x[a][m][k] - y[b][n][k]),
+//      dG[m][n] = t_m - t_{m-1},  t_m = W[m][n] - W[m][n-1] (zero outside the matrix)
+template <typename T, int DMAX, int NT>
+__global__ __launch_bounds__(NT) void k_rbf_adj2(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W,
+                                                 int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0, int M,
+                                                 int N, int D, double inv_sigma, int col_tiles, T *__restrict__ gY) {
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t b = b0 + blockIdx.x / col_tiles;
+    const int n = (int)(blockIdx.x % col_tiles) * NT + threadIdx.x;
+    const int nn = min(n, N - 1);
+    const bool lf = nn >= 1, rt = nn < Nc;
+    const int nl = max(nn - 1, 0), nr = min(nn, Nc - 1);
+    double yn[DMAX], ys = 0.0, acc[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        yn[k] = k < D ? (double)Y[(b * N + nn) * (int64_t)D + k] : 0.0;
+        ys = fma(yn[k], yn[k], ys);
+        acc[k] = 0.0;
+    }
+    for (int64_t a = 0; a < A; ++a) {
+        const int64_t p = a * B + b;
+        const double s = scale ? (double)scale[p] : 1.0;
+        const T *w = W + p * Mc * ldw;
+        const T *x = X + a * (int64_t)M * D;
+        double tprev = 0.0;
+        for (int m = 0; m < M; ++m) {
+            const int64_t ro = (int64_t)min(m, Mc - 1) * ldw;
+            const double wl = (double)w[ro + nl], wv = (double)w[ro + nr];   // unconditional, masked below
+            const double tcur = m < Mc ? ((rt ? wv : 0.0) - (lf ? wl : 0.0)) : 0.0;
+            double xv[DMAX], xs = 0.0, xy = 0.0;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                xv[k] = (double)x[(int64_t)m * D + min(k, D - 1)];   // wave-uniform
+                xv[k] = k < D ? xv[k] : 0.0;
+                xs = fma(xv[k], xv[k], xs);
+                xy = fma(xv[k], yn[k], xy);
+            }
+            const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+            const double c = s * (tcur - tprev) * g;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xv[k] - yn[k], acc[k]);
+            tprev = tcur;
+        }
+    }
+    if (n < N) {
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k)
+            if (k < D) gY[((b - b0) * N + n) * (int64_t)D + k] = (T)(2.0 * inv_sigma * acc[k]);
+    }
+}
+
 template <typename T, int DMAX, int NT>
 int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
@@ -586,6 +686,39 @@ template int launch_linear_adjoint_dyt<double>(const double *, int64_t, const do
                                                int64_t, int, int, int, double *, hipStream_t);
 template int launch_linear_adjoint_dyt<float>(const double *, int64_t, const float *, int64_t, const float *, int64_t, int64_t,
                                               int, int, int, float *, hipStream_t);
+
+// kind 0: out = T2 [B - b0, Nc, D] from dXr (aux); kind 1: out = dL/dY [B - b0, N, D]
+template <typename T>
+int launch_static_adjoint2(int kind, double param, const T *X, const T *Y, const double *dXr, int Mrows, const T *W, int64_t ldw,
+                           const T *scale, int64_t A, int64_t B, int b0, int M, int N, int D, T *out, hipStream_t s) {
+    const int64_t nbk = B - b0;
+    if (nbk <= 0) return SK_OK;
+    if (kind == 0) {
+        if (D > 8 || !dXr) return SK_ERR_UNSUPPORTED;
+        const int Nc = N - 1;
+        const int col_tiles = (Nc + 63) / 64;
+        if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_linear_adj2<T, 64>), dim3((unsigned)(nbk * col_tiles)), dim3(64), 0, s, dXr, Mrows, W, ldw, scale, A,
+                           B, b0, M - 1, Nc, D, col_tiles, out);
+        return check_launch();
+    }
+    const int col_tiles = (N + 63) / 64;
+    if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+#define SK_RBF2(DM)                                                                                                     \
+    hipLaunchKernelGGL((k_rbf_adj2<T, DM, 64>), dim3((unsigned)(nbk * col_tiles)), dim3(64), 0, s, X, Y, W, ldw, scale, A, B, \
+                       b0, M, N, D, 1.0 / param, col_tiles, out)
+    if (D <= 4) SK_RBF2(4);
+    else if (D <= 8) SK_RBF2(8);
+    else if (D <= 16) SK_RBF2(16);
+    else if (D <= 32) SK_RBF2(32);
+    else return SK_ERR_UNSUPPORTED;
+#undef SK_RBF2
+    return check_launch();
+}
+template int launch_static_adjoint2<double>(int, double, const double *, const double *, const double *, int, const double *,
+                                            int64_t, const double *, int64_t, int64_t, int, int, int, int, double *, hipStream_t);
+template int launch_static_adjoint2<float>(int, double, const float *, const float *, const double *, int, const float *, int64_t,
+                                           const float *, int64_t, int64_t, int, int, int, int, float *, hipStream_t);
 
 template int launch_static_adjoint<double>(int, double, const double *, const double *, const double *, int64_t,
                                            const double *, int64_t, int64_t, int, int, int, double *, hipStream_t);

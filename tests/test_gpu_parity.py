@@ -290,6 +290,34 @@ def test_fused_static_adjoint_matches_autograd_through_the_static_kernel(be, kin
             assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
 
 
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+@pytest.mark.parametrize("A,B,M,N,D,b0", [(3, 4, 10, 20, 2, 0), (2, 5, 64, 70, 8, 2), (5, 3, 33, 64, 4, 1), (2, 2, 9, 131, 17, 0), (1, 1, 2, 2, 1, 0)])
+def test_second_argument_static_adjoint_matches_autograd(be, kind, A, B, M, N, D, b0):
+    """sk_static_adjoint2_*: dL/dY for the pairs (a, b >= b0), against torch autograd through the static kernel."""
+    gen = torch.Generator().manual_seed(11 + A * 100 + M + N + D)
+    X = (walk(gen, A, M, D) * 3).to(DEV)
+    Y = (walk(gen, B, N, D) * 3).to(DEV)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.7)
+    code, param = (0, 1.0) if kind == "linear" else (1, 0.7)
+    W = padded(np.random.default_rng(4).normal(size=(A, B, M - 1, N - 1)))
+    go = torch.randn(A, B, generator=gen, dtype=torch.float64).to(DEV)
+    got = be.static_adjoint2(code, param, X, Y, W, go, b0)
+    if kind == "linear" and D > 8:
+        assert got is None
+        return
+    Yg = Y.clone().requires_grad_(True)
+    G = k.Gram_matrix(X, Yg)
+    (want,) = torch.autograd.grad(G, Yg, be.increments_adjoint(W, go))
+    # pairs with b < b0 are excluded: compare rows b >= b0 of a run that zeroes their upstream gradient
+    go0 = go.clone()
+    go0[:, :b0] = 0
+    (want0,) = torch.autograd.grad(k.Gram_matrix(X, Yg), Yg, be.increments_adjoint(W, go0))
+    assert got.shape == (B - b0, N, D)
+    assert rel_err(got.cpu().numpy(), want0[b0:].cpu().numpy()) <= 1e-12
+    if b0 == 0:
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
+
+
 @pytest.mark.parametrize("A,B,M,N,D,d", [(3, 4, 10, 20, 2, 1), (2, 3, 128, 128, 8, 1), (70, 9, 64, 64, 4, 2), (5, 130, 33, 17, 3, 0),
                                             (1, 1, 2, 2, 1, 0), (9, 7, 128, 40, 8, 1), (4, 4, 65, 128, 5, 2), (300, 300, 20, 24, 8, 1),
                                             (2, 2, 257, 30, 6, 0)])
