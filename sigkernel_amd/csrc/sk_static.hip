@@ -516,29 +516,51 @@ __global__ __launch_bounds__(NT) void k_rbf_adj2(const T *__restrict__ X, const 
         ys = fma(yn[k], yn[k], ys);
         acc[k] = 0.0;
     }
-    for (int64_t a = 0; a < A; ++a) {
-        const int64_t p = a * B + b;
-        const double s = scale ? (double)scale[p] : 1.0;
-        const T *w = W + p * Mc * ldw;
-        const T *x = X + a * (int64_t)M * D;
-        double tprev = 0.0;
-        for (int m = 0; m < M; ++m) {
-            const int64_t ro = (int64_t)min(m, Mc - 1) * ldw;
-            const double wl = (double)w[ro + nl], wv = (double)w[ro + nr];   // unconditional, masked below
-            const double tcur = m < Mc ? ((rt ? wv : 0.0) - (lf ? wl : 0.0)) : 0.0;
-            double xv[DMAX], xs = 0.0, xy = 0.0;
+    constexpr int MR = 4;   // node rows per iteration and path: their loads of W are issued before any is used
+    constexpr int AU = 2;   // paths x_a in flight: independent exp chains (one wave per block leaves the SIMD little else)
+    for (int64_t a0 = 0; a0 < A; a0 += AU) {
+        double s[AU], tprev[AU];
+        const T *w[AU], *x[AU];
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) {
-                xv[k] = (double)x[(int64_t)m * D + min(k, D - 1)];   // wave-uniform
-                xv[k] = k < D ? xv[k] : 0.0;
-                xs = fma(xv[k], xv[k], xs);
-                xy = fma(xv[k], yn[k], xy);
+        for (int u = 0; u < AU; ++u) {
+            const int64_t aa = a0 + u < A ? a0 + u : A - 1;
+            const int64_t p = aa * B + b;
+            s[u] = a0 + u < A ? (scale ? (double)scale[p] : 1.0) : 0.0;
+            w[u] = W + p * Mc * ldw;
+            x[u] = X + aa * (int64_t)M * D;
+            tprev[u] = 0.0;
+        }
+        for (int m0 = 0; m0 < M; m0 += MR) {
+            double wl[AU][MR], wv[AU][MR];
+#pragma unroll
+            for (int u = 0; u < AU; ++u)
+#pragma unroll
+                for (int j = 0; j < MR; ++j) {   // unconditional loads from clamped rows, masked below
+                    const int64_t ro = (int64_t)min(m0 + j, Mc - 1) * ldw;
+                    wl[u][j] = (double)w[u][ro + nl];
+                    wv[u][j] = (double)w[u][ro + nr];
+                }
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                const int m = m0 + j, mm = min(m, M - 1);
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const double tcur = m < Mc ? ((rt ? wv[u][j] : 0.0) - (lf ? wl[u][j] : 0.0)) : 0.0;
+                    double xv[DMAX], xs = 0.0, xy = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        xv[k] = (double)x[u][(int64_t)mm * D + min(k, D - 1)];   // wave-uniform
+                        xv[k] = k < D ? xv[k] : 0.0;
+                        xs = fma(xv[k], xv[k], xs);
+                        xy = fma(xv[k], yn[k], xy);
+                    }
+                    const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+                    const double c = (m < M ? s[u] : 0.0) * (tcur - tprev[u]) * g;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xv[k] - yn[k], acc[k]);
+                    tprev[u] = m < M ? tcur : tprev[u];
+                }
             }
-            const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
-            const double c = s * (tcur - tprev) * g;
-#pragma unroll
-            for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xv[k] - yn[k], acc[k]);
-            tprev = tcur;
         }
     }
     if (n < N) {

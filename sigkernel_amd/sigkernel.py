@@ -150,6 +150,7 @@ class _SigKernel(torch.autograd.Function):
 
 
 _SYM_TILES = 8   # row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
+_SYM_MIN_CELLS = 5e9   # below this the extra launches cost more than the saved solves
 
 
 _KEEP_EDGES_FRACTION = 0.5   # of the transient budget: how much may stay allocated between forward and backward
@@ -194,20 +195,25 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     return K
 
 
-def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes):
-    """compute_Gram(X, X, sym=True) without a gradient: only the blocks on and above the diagonal of a T x T tiling are
-    solved and mirrored, like the reference's CPU solver does pair by pair (cython_backend.pyx:74-97; its GPU path
-    ignores `sym`).  The result is exactly symmetric."""
+def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes, keep_blocks=None):
+    """compute_Gram(X, X, sym=True): only the blocks on and above the diagonal of a T x T tiling are solved and
+    mirrored, like the reference's CPU solver does pair by pair (cython_backend.pyx:74-97; its GPU path ignores `sym`).
+    The result is exactly symmetric.  keep_blocks (a list, when a gradient is pending) receives (r0, r1, kept edges) per
+    row block for _SigKernelGram.backward's triangular adjoint."""
     A = Xd.shape[0]
     K = torch.empty(A, A, dtype=Xd.dtype, device=Xd.device)
     cells = float(A) * A * ((Xd.shape[1] - 1) << dyadic_order) ** 2
     # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of
     # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
-    T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= 5e9) else 1
+    T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= _SYM_MIN_CELLS) else 1
     step = -(-A // T)
     for r0 in range(0, A, step):
         r1 = min(r0 + step, A)
-        blk = _gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes)
+        kept = [] if keep_blocks is not None else None
+        blk = _gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes,
+                          3 if keep_blocks is not None else None, kept)
+        if keep_blocks is not None:
+            keep_blocks.append((r0, r1, kept))
         K[r0:r1, r0:] = blk
         if r1 < A:
             K[r1:, r0:r1] = blk[:, r1 - r0:].t()
@@ -215,6 +221,22 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes)
     iu = torch.triu_indices(A, A, offset=1, device=Xd.device)
     K[iu[1], iu[0]] = K[iu[0], iu[1]]
     return K
+
+
+def _edge_tiles(kept, n_rows, per_row, budget):
+    """Row tiles of a backward pass with the terminal edges forward kept for them: [(a0, a1, edges or None)]."""
+    tiles = [(a0, a1, None) for a0, a1 in _tiles(n_rows, per_row, budget)]
+    if kept and len(kept) == 1 and kept[0][:2] == (0, n_rows) and kept[0][2] is not None and len(tiles) > 1:
+        full = kept[0][2]              # the fused forward kept one block for all rows: slice it per tile
+        per = full.numel() // n_rows
+        return [(a0, a1, full[a0 * per:a1 * per]) for a0, a1, _ in tiles]
+    if kept:                           # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
+        return kept
+    return tiles
+
+
+def _same_storage(Xd, Yd):
+    return Xd.shape == Yd.shape and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()
 
 
 class _SigKernelGram(torch.autograd.Function):
@@ -233,9 +255,17 @@ class _SigKernelGram(torch.autograd.Function):
         Xd, Yd = X.detach(), Y.detach()
         # `sym`: the reference's GPU path ignores it (sigkernel.py:366-382) and its CPU path silently assumes X is Y.
         # Here it halves the work when that assumption can be checked (same storage) and no gradient is needed.
-        if (sym and not X.requires_grad and not Y.requires_grad and Xd.shape == Yd.shape
-                and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()):
-            return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes)
+        ctx.sym_blocks = None
+        if sym and _same_storage(Xd, Yd):
+            if not X.requires_grad and not Y.requires_grad:
+                return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes)
+            # with a gradient: the triangular forward AND a triangular adjoint (a pair above the diagonal also stands for
+            # its mirror image, through the second-argument contraction of the same W) -- fused static kernels only
+            if (X.requires_grad and Y.requires_grad and _fused_static(static_kernel, True) is not None
+                    and hasattr(be, "static_adjoint2") and X.shape[2] <= (8 if type(static_kernel) is LinearKernel else 32)):
+                ctx.sym_blocks = []
+                return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes,
+                                       ctx.sym_blocks)
         fused = _fused_static(static_kernel, True) is not None
         # with a gradient pending, tile like backward will, so that the caching allocator can reuse the same blocks
         rows_factor = (3 if fused else 8) if X.requires_grad else None
@@ -249,19 +279,36 @@ class _SigKernelGram(torch.autograd.Function):
         be = _lib.get_backend()
         A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
         grad_X = torch.zeros_like(X)
-        if M >= 2 and N >= 2:
+        if M >= 2 and N >= 2 and getattr(ctx, "sym_blocks", None):
+            # compute_Gram(X, X, sym=True): per row block r0:r1 the pairs (a, b >= r0) were solved.  Their first-argument
+            # contraction gives rows r0:r1; the second-argument contraction of the SAME W, weighted by the transposed
+            # upstream gradient, gives what the unsolved mirror pairs (b, a), b >= r1, owe to rows r1: (K is symmetric, so
+            # d1 K(x_b, x_a) = d2 K(x_a, x_b)).  The reference's 2x rule (sigkernel.py:410-412) is applied below as usual.
+            Xd = X.detach().contiguous()
+            go = grad_output.to(X.dtype).contiguous()
+            kind, param = _fused_static(sk, True)
+            budget = _budget(X.device, ctx.workspace_bytes)
+            for r0, r1, kept in ctx.sym_blocks:
+                Xr, Xc = Xd[r0:r1].contiguous(), Xd[r0:].contiguous()
+                go_blk = go[r0:r1, r0:].contiguous()
+                go_t = go[r0:, r0:r1].t().contiguous()         # [a, b] -> upstream gradient of the mirror pair (b, a)
+                per_row = 3 * Xc.shape[0] * M * N * X.element_size()
+                for a0, a1, edges in _edge_tiles(kept, r1 - r0, per_row, budget):
+                    Xt = Xr[a0:a1].contiguous()
+                    inc = be.static_increments(kind, param, Xt, Xc, True)
+                    _, W = be.solve_adj(inc, d, naive, edges=edges) if edges is not None else be.solve_adj(inc, d, naive)
+                    del inc
+                    grad_X[r0 + a0:r0 + a1] += be.static_adjoint(kind, param, Xt, Xc, W, go_blk[a0:a1].contiguous(), True)
+                    if r1 < A:
+                        grad_X[r1:] += be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
+                    del W
+            ctx.sym_blocks = None
+        elif M >= 2 and N >= 2:
             Yd = Y.detach()
             go = grad_output.to(X.dtype).contiguous()
             fused = _fused_static(sk, True) is not None
             per_row = (3 if fused else 8) * B * M * N * X.element_size()
-            kept = getattr(ctx, "kept_edges", None)
-            tiles = [(a0, a1, None) for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes))]
-            if kept and len(kept) == 1 and kept[0][:2] == (0, A) and kept[0][2] is not None and len(tiles) > 1:
-                full = kept[0][2]              # the fused forward kept one block for all rows: slice it per tile
-                per = full.numel() // A
-                tiles = [(a0, a1, full[a0 * per:a1 * per]) for a0, a1, _ in tiles]
-            elif kept:     # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
-                tiles = kept
+            tiles = _edge_tiles(getattr(ctx, "kept_edges", None), A, per_row, _budget(X.device, ctx.workspace_bytes))
             ctx.kept_edges = None
             for a0, a1, edges in tiles:
                 grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd.contiguous(),

@@ -174,6 +174,29 @@ def test_fused_linear_forward_keeps_usable_edges(be, A, B, M, N, D, d):
     assert float(r1.max()) <= 1e-9 and rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= ADJ_TOL
 
 
+@pytest.mark.parametrize("kind,D,d", [("rbf", 3, 1), ("linear", 8, 1), ("rbf", 4, 2), ("linear", 2, 2)])
+def test_symmetric_gram_with_gradient_uses_the_triangle(be, kind, D, d, monkeypatch):
+    """compute_Gram(X, X, sym=True) with a gradient solves only the blocks on and above the diagonal; values, gradient of a
+    non-symmetric loss and the reference's 2x rule must match the full (sym=False) computation."""
+    from sigkernel_amd import sigkernel as S
+    monkeypatch.setattr(S, "_SYM_TILES", 3)
+    monkeypatch.setattr(S, "_SYM_MIN_CELLS", 0.0)
+    gen = torch.Generator().manual_seed(17 + D + d)
+    X = (walk(gen, 29, 20, D) * 2).to(DEV)
+    w = torch.randn(29, 29, generator=gen, dtype=torch.float64).to(DEV)      # NOT symmetric on purpose
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.9)
+    sk = sigkernel_amd.SigKernel(k, d)
+    X1 = X.clone().requires_grad_(True)
+    K1 = sk.compute_Gram(X1, X1, sym=True)
+    (K1 * w).sum().backward()
+    X2 = X.clone().requires_grad_(True)
+    K2 = sk.compute_Gram(X2, X2, sym=False)
+    (K2 * w).sum().backward()
+    assert torch.equal(K1, K1.t())
+    assert rel_err(K1.detach().cpu().numpy(), K2.detach().cpu().numpy()) <= 1e-12
+    assert rel_err(X1.grad.cpu().numpy(), X2.grad.cpu().numpy()) <= 1e-10
+
+
 def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
     """Exploding kernels (|K| ~ 1e9, far outside where the scheme means anything) break the backward recompute of K;
     the residual must flag those pairs and the re-solve must restore the oracle's answer."""
