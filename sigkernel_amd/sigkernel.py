@@ -151,6 +151,7 @@ class _SigKernel(torch.autograd.Function):
 
 _SYM_TILES = 8   # row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
 _SYM_MIN_CELLS = 5e9   # below this the extra launches cost more than the saved solves
+_SYM_MIN_ROWS = 32     # rows per block of the triangular adjoint
 
 
 _KEEP_EDGES_FRACTION = 0.5   # of the transient budget: how much may stay allocated between forward and backward
@@ -206,6 +207,10 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of
     # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
     T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= _SYM_MIN_CELLS) else 1
+    if keep_blocks is not None and T > 1:
+        # with the adjoint in the blocks too, small blocks lose more to launches and pipeline fill than the triangle saves
+        # (measured: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms): at least _SYM_MIN_ROWS rows each
+        T = max(1, min(T, A // _SYM_MIN_ROWS))
     step = -(-A // T)
     for r0 in range(0, A, step):
         r1 = min(r0 + step, A)

@@ -181,6 +181,7 @@ def test_symmetric_gram_with_gradient_uses_the_triangle(be, kind, D, d, monkeypa
     from sigkernel_amd import sigkernel as S
     monkeypatch.setattr(S, "_SYM_TILES", 3)
     monkeypatch.setattr(S, "_SYM_MIN_CELLS", 0.0)
+    monkeypatch.setattr(S, "_SYM_MIN_ROWS", 4)
     gen = torch.Generator().manual_seed(17 + D + d)
     X = (walk(gen, 29, 20, D) * 2).to(DEV)
     w = torch.randn(29, 29, generator=gen, dtype=torch.float64).to(DEV)      # NOT symmetric on purpose
