@@ -359,6 +359,10 @@ class HipBackend:
         The fast kernel recomputes K backwards instead of storing it and reports a per-pair residual; pairs whose
         residual exceeds ADJ_RESIDUAL_TOL (K exploding beyond ~1e4) are re-solved by the stored-grid kernel.
         `edges` (from solve_fwd_keep_edges on the same increments) skips the forward sweep; `final` is then None."""
+        if (inc_c.dtype == torch.float32 and dyadic == 2 and edges is None and not (flags & (FLAG_SIMPLE | FLAG_EXACT))):
+            # the fused adjoint has no fp32 variant at dyadic 2 (16-column blocks do not fit the register file) and the
+            # stored-grid kernel is ~100x slower: run the fp64 kernel on up-cast increments, in pair chunks of bounded size
+            return self._solve_adj_upcast(inc_c, dyadic, naive, flags, return_residual)
         inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
@@ -450,6 +454,32 @@ class HipBackend:
             _check(fn(_ptr(inc3[0]), _ptr(inc3[1]), _ptr(inc3[2]), ld, P, Mc, Nc, int(dyadic), int(flags), _ptr(out[0]),
                       _ptr(out[1]), _ptr(out[2]), _stream(inc3)), "sk_solve_deriv")
         return out[0], out[1], out[2]
+
+    UPCAST_CHUNK_BYTES = 4 << 30   # fp64 copy of the increments handled at a time by _solve_adj_upcast
+
+    def _solve_adj_upcast(self, inc_c, dyadic, naive, flags, return_residual):
+        Mc, Nc = inc_c.shape[-2:]
+        batch = inc_c.shape[:-2]
+        P = inc_c.numel() // (Mc * Nc)
+        dev = inc_c.device
+        flat = inc_c.reshape(P, Mc, Nc)
+        ld64 = _padded_ld(Nc, 8)
+        ldw = _padded_ld(Nc, 4)
+        out = torch.empty(P, dtype=torch.float32, device=dev)
+        Wp = torch.empty(P, Mc, ldw, dtype=torch.float32, device=dev)
+        err = torch.empty(P, dtype=torch.float64, device=dev)
+        step = max(1, int(self.UPCAST_CHUNK_BYTES // (Mc * ld64 * 8)))
+        for p0 in range(0, P, step):
+            p1 = min(P, p0 + step)
+            buf = torch.zeros(p1 - p0, Mc, ld64, dtype=torch.float64, device=dev)
+            buf[..., :Nc] = flat[p0:p1]
+            o, W, e = self.solve_adj(buf[..., :Nc], dyadic, naive, flags, return_residual=True)
+            out[p0:p1] = o
+            Wp[p0:p1, :, :Nc] = W
+            err[p0:p1] = e
+            del buf, W
+        res = (out.reshape(batch), Wp.reshape(batch + (Mc, ldw))[..., :Nc])
+        return res + (err.reshape(batch),) if return_residual else res
 
 
 _backend = HipBackend()

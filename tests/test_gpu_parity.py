@@ -141,8 +141,10 @@ def test_fused_adjoint_without_the_safety_net(be, P, Mc, Nc, d):
     k, W, res = be.solve_adj(padded(inc), d, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
     assert float(res.max()) < 1e-10
     assert rel_err(W.cpu().numpy(), want_w) <= ADJ_TOL and rel_err(k.cpu().numpy(), want_k) <= FAST_TOL
-    k32, W32, _ = be.solve_adj(padded(inc.astype(np.float32)), 1 if d == 2 else d, flags=0, return_residual=True)
-    w32 = O.adjoint_coarse(inc.astype(np.float32).astype(np.float64), 1 if d == 2 else d, nthreads=8)[1]
+    # fp32 I/O: the fp32 fused adjoint at d = 1, the fp64 one on up-cast increments at d = 2 (never the stored-grid kernel)
+    k32, W32, r32 = be.solve_adj(padded(inc.astype(np.float32)), d, flags=0, return_residual=True)
+    w32 = O.adjoint_coarse(inc.astype(np.float32).astype(np.float64), d, nthreads=8)[1]
+    assert W32.dtype == torch.float32 and float(r32.max()) < 1e-6
     np.testing.assert_allclose(W32.cpu().numpy(), w32, rtol=1e-3, atol=2e-5 * np.abs(w32).max())
 
 
