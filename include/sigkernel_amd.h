@@ -165,7 +165,7 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
                             int dyadic, int scheme, float *out_final, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
- * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 1..2). */
+ * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 0..2). */
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                   int dyadic, int scheme, double *out_final, double *edges, void *stream);
 
@@ -178,7 +178,7 @@ int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t 
  * Two implementations behind one entry point:
  *   fast   -- forward sweep emitting the terminal row/column of K, then ONE fused sweep that runs the reverse
  *             PDE and recomputes K backwards from those edges (no grid is stored; csrc/sk_wave_adj.hip).
- *             Needs dyadic 1..2 (fp32: 1), increment rows zero-padded to whole 128-byte lines
+ *             Needs dyadic 0..2 (fp32: 0..1), increment rows zero-padded to whole 128-byte lines
  *             (ld*sizeof(T) % 128 == 0, as sk_increments_* produces when given such an ld), ldw >= that padded
  *             width, and out_err != NULL; any grid size (no 1024-node limit).  out_err[p] receives the self-check residual
  *             max_i |K_recomputed[i][0] - 1| of pair p: the caller re-solves pairs whose residual is too

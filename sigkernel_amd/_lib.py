@@ -209,7 +209,7 @@ class HipBackend:
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with torch.cuda.device(dev):
-            if keep_edges and X.dtype == torch.float64 and 1 <= dyadic <= 2:
+            if keep_edges and X.dtype == torch.float64 and 0 <= dyadic <= 2:
                 P = A * B if gram else A
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
                 if nbytes:

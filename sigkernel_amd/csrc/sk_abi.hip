@@ -49,7 +49,7 @@ int solve_adj(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic,
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
     if (ldw == 0) ldw = Nc;
     hipStream_t s = (hipStream_t)stream;
-    const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // launch_adj_wave's scope
+    const bool fast_shape = dyadic >= 0 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // launch_adj_wave's scope
     const size_t fast_ws = fast_shape ? adj_fast_workspace_bytes(g, (int)sizeof(T)) : 0;
     if (flags & SK_FLAG_EDGES_GIVEN) {   // argument checks before any HIP call
         const size_t need = fast_shape ? (size_t)P * strip_edge_doubles(g, (int)sizeof(T)) * sizeof(double) : 0;
@@ -93,7 +93,7 @@ int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d
     if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, 0) || !out_final || !edges || (ld != 0 && ld < Nc)) return SK_ERR_BAD_ARG;
     if (P == 0) return SK_OK;
     const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
-    const bool fast_shape = dyadic >= 1 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // what launch_adj_wave will accept later
+    const bool fast_shape = dyadic >= 0 && dyadic <= (sizeof(T) == 8 ? 2 : 1);   // what launch_adj_wave will accept later
     if (!fast_shape || !strip_edge_doubles(g, (int)sizeof(T)) || (g.ld * sizeof(T)) % 128) return SK_ERR_UNSUPPORTED;
     return launch_fwd_wave<T>(inc_c, g.ld, g, out_final, edges, (hipStream_t)stream);
 }
@@ -239,7 +239,7 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
 
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                   int dyadic, int scheme, double *out_final, double *edges, void *stream) {
-    if (!dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 1 || dyadic > 2) return SK_ERR_BAD_ARG;
+    if (!dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
@@ -256,7 +256,7 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
 }
 
 size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size) {
-    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 1 || dyadic > (elem_size == 8 ? 2 : 1) || (elem_size != 4 && elem_size != 8)) return 0;
+    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > (elem_size == 8 ? 2 : 1) || (elem_size != 4 && elem_size != 8)) return 0;
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);
     return (size_t)P * strip_edge_doubles(g, elem_size) * sizeof(double);
 }

@@ -358,8 +358,16 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
             for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
             if (MULTIBAND) {
                 if (is_top && band > 0) {
-                    lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
-                    lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
+                    if constexpr (S % 4 == 0) {
+                        lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
+                        lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            tbR[i] = lds_read_f64(bnd_r + (unsigned)(u * S + i) * 8u);
+                            tbF[i] = lds_read_f64(bnd_f + (unsigned)(u * S + i) * 8u);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -520,7 +528,7 @@ int launch_adj_dy(const AdjParams &prm, bool multiband, int blocks, size_t lds_b
 }  // namespace
 
 // SK_ERR_UNSUPPORTED when the shape / layout is not covered (the caller falls back to the stored-grid kernel).
-// Requirements: dyadic 1..2 (a lane block must cover whole coarse cells; d = 3 would spill), increment rows padded with ZEROS to whole
+// Requirements: dyadic 0..2 (d = 3 would spill), increment rows padded with ZEROS to whole
 // 128-byte lines (ld*sizeof(T) % 128 == 0 and ld >= the padded width), W with the same row stride rule.
 template <typename T>
 int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edges, T *W, int64_t ldw, double *err,
@@ -528,7 +536,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     constexpr int CW = Unit<T>::CW;
     const int DY = g.dyadic;
     // d = 3 (and d = 2 with 4-column fp32 units) needs > 256 VGPRs for the two states: stored-grid kernel
-    if (DY < 1 || DY > (sizeof(T) == 8 ? 2 : 1)) return SK_ERR_UNSUPPORTED;
+    if (DY < 0 || DY > (sizeof(T) == 8 ? 2 : 1)) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || (reinterpret_cast<uintptr_t>(W) & 15)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, (int)sizeof(T));   // the same decomposition as the forward kernel (it wrote `edges`)
     if (!st.ok) return SK_ERR_UNSUPPORTED;
@@ -572,6 +580,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
     prm.naive = g.naive;
 
+    if (DY == 0) return launch_adj_dy<T, 0>(prm, multiband, (int)waves, lds_bytes, s);
     if (DY == 1) return launch_adj_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
     if constexpr (sizeof(T) == 8) return launch_adj_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
     return SK_ERR_UNSUPPORTED;

@@ -334,7 +334,7 @@ int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStre
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
 int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    if constexpr (sizeof(TO) == 8 && DY >= 1) {   // the adjoint that consumes the edges exists for fp64, d = 1..2
+    if constexpr (sizeof(TO) == 8) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
         if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true>(prm, blocks, lds_bytes, s);
     }
     if (prm.edges) return SK_ERR_UNSUPPORTED;

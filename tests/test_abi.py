@@ -50,9 +50,9 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_adj_f64(p, 0, 1, 4, 4, 1, 0, 8 | 2, None, p, 0, p, p, 64, None) == 1
     assert lib.sk_solve_adj_f64(p, 16, 1, 4, 4, 1, 0, 8, None, p, 16, p, None, 0, None) == 4     # SK_ERR_WORKSPACE
     assert lib.sk_solve_fwd_edges_f64(p, 16, 1, 4, 4, 1, 0, None, p, None) == 1                # no output vector
-    assert lib.sk_solve_fwd_edges_f64(p, 16, 1, 4, 4, 0, 0, p, p, None) == 2                   # dyadic 0: not covered
+    assert lib.sk_solve_fwd_edges_f64(p, 16, 1, 4, 4, 3, 0, p, p, None) == 2                   # dyadic 3: not covered
     assert lib.sk_strip_edges_bytes(10, 63, 63, 1, 8) == 10 * (128 + 128) * 8                  # NNp = 32 units * 4, MMp = 32 lanes * 4
-    assert lib.sk_strip_edges_bytes(10, 63, 63, 0, 8) == 0 and lib.sk_strip_edges_bytes(10, 63, 63, 2, 4) == 0
+    assert lib.sk_strip_edges_bytes(10, 63, 63, 3, 8) == 0 and lib.sk_strip_edges_bytes(10, 63, 63, 2, 4) == 0
     assert lib.sk_solve_deriv_f64(p, None, p, 0, 1, 4, 4, 0, 0, p, p, p, None) == 1
     assert lib.sk_deriv_increments_f64(p, p, p, 0.0, 1, 4, 4, p, p, p, 0, None) == 1              # eps must be positive
     assert lib.sk_linear_adjoint_f64(p, 2, p, 0, None, 1, 1, 4, 4, 2, p, None) == 1               # ldy < Nc
