@@ -444,6 +444,23 @@ class HipBackend:
         """inc3 [3, ..., Mc, Nc] (increments of k, d/dgamma, d2/dgamma2) -> (k, k_gamma, k_gamma_gamma), [...] each."""
         if inc3.shape[0] != 3:
             raise ValueError("inc3 must stack the three increment arrays on dim 0")
+        if inc3.dtype == torch.float32 and dyadic == 2 and not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+            # no fp32 fast kernel at dyadic 2 (register file): the fp64 one on up-cast increments, in bounded chunks
+            Mc, Nc = inc3.shape[-2:]
+            batch = inc3.shape[1:-2]
+            P = inc3[0].numel() // (Mc * Nc)
+            flat = inc3.reshape(3, P, Mc, Nc)
+            ld64 = _padded_ld(Nc, 8)
+            out = torch.empty(3, P, dtype=torch.float32, device=inc3.device)
+            step = max(1, int(self.UPCAST_CHUNK_BYTES // (3 * Mc * ld64 * 8)))
+            for p0 in range(0, P, step):
+                p1 = min(P, p0 + step)
+                buf = torch.zeros(3, p1 - p0, Mc, ld64, dtype=torch.float64, device=inc3.device)
+                buf[..., :Nc] = flat[:, p0:p1]
+                k, kd, kdd = self.solve_deriv(buf[..., :Nc], dyadic, flags)
+                out[0, p0:p1], out[1, p0:p1], out[2, p0:p1] = k, kd, kdd
+                del buf
+            return out[0].reshape(batch), out[1].reshape(batch), out[2].reshape(batch)
         inc3, ld = _row_stride(inc3, "inc3")
         Mc, Nc = inc3.shape[-2:]
         batch = inc3.shape[1:-2]
