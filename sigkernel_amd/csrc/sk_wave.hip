@@ -42,7 +42,6 @@ struct WaveParams {
     int naive;
     double *edges;     // nullable [P, NNp + MMp]: K[MM][1..NNp] then K[1..MMp][NN] (EDGES variant; padded strip sizes)
     int k_f;           // coarse row inside the lane's block that holds the pair's last row
-    int nt;            // non-temporal cache policy on the increment loads
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -128,13 +127,9 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
 
     auto issue_fetch = [&]() {
 #pragma unroll
-        for (int k = 0; k < RC; ++k)
-            if (prm.nt)   // streaming hint: the line is read exactly once
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
-                                                         st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
-                                                         st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 0);
+        for (int k = 0; k < RC; ++k)   // aux = 2, non-temporal: the line is read exactly once
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + fslot * SLOT_BYTES + k * 1024), 16,
+                                                     st_off + (unsigned)((fj * RC + k) * ldb), 0, 0, 2);
         fslot = fslot + 1 == NSLOT ? 0 : fslot + 1;
         fj += 1;
         if (fj == LINE_UNITS) {   // all 8 classes have their line number n: move the cursor to n + 1
@@ -432,7 +427,6 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     prm.naive = g.naive;
     prm.edges = strip_edges;
     prm.k_f = (g.Mc - 1) % RC;
-    prm.nt = env_int("SK_WAVE_NT", 1);
 
     switch (DY) {
         case 0: return launch_dy<T, 0>(prm, multiband, PF, (int)waves, lds_bytes, s);
