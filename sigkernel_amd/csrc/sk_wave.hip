@@ -145,11 +145,11 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         }
     };
 
-    double left[R], bot[S], corner = 1.0;
+    double left[R], bot[S], ktop[S], corner = 1.0;
 #pragma unroll
     for (int i = 0; i < R; ++i) left[i] = 1.0;
 #pragma unroll
-    for (int i = 0; i < S; ++i) bot[i] = 1.0;
+    for (int i = 0; i < S; ++i) { bot[i] = 1.0; ktop[i] = 1.0; }
 
     // prologue: the lines needed at macro-steps 0 .. PF-1
 #pragma unroll
@@ -207,9 +207,14 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
                 top[i] = is_top ? tb[i] : sh;
             }
         } else if (FULLWAVE) {
-            // one pair per wave: lane 0 is the only top lane and wave_shr leaves its `old` operand (1.0) in place
+            // one pair per wave: lane 0 is the only top lane and wave_shr leaves its `old` operand in place there.  The
+            // old operand is the persistent register ktop[i], which nothing else writes: lane 0 keeps the 1.0 it was
+            // initialised with, and no constant has to be re-materialised in the destination every macro-step.
 #pragma unroll
-            for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
+            for (int i = 0; i < S; ++i) {
+                ktop[i] = dpp_shr1(bot[i], ktop[i]);
+                top[i] = ktop[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < S; ++i) {

@@ -292,6 +292,9 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         if (nu == 0 && (nband * L + lam) * RC * r + R == MMp) pcol[R] = 1.0;
     };
 
+    double ktopR[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) ktopR[i] = 1.0;
     double leftR[R], botR[S], cornerR = 1.0;
     double leftF[R], botF[S], cornerF = 1.0;
 #pragma unroll
@@ -373,7 +376,12 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 if (FULLWAVE) {   // lane 0 is the only top lane: wave_shr leaves its `old` operand in place there
-                    topR[i] = MULTIBAND ? dpp_shr1(botR[i], tbR[i]) : dpp_shr1(botR[i], 1.0);
+                    if (MULTIBAND) {
+                        topR[i] = dpp_shr1(botR[i], tbR[i]);
+                    } else {   // lane 0 keeps the 1.0 of the persistent `old` register (see sk_wave.hip)
+                        ktopR[i] = dpp_shr1(botR[i], ktopR[i]);
+                        topR[i] = ktopR[i];
+                    }
                     topF[i] = dpp_shr1(botF[i], tbF[i]);
                 } else {
                     const double shR = dpp_shr1(botR[i], 1.0);

@@ -155,11 +155,11 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
     for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int j = 0; j < FD; ++j) dxr[k][j] = 0.0;
-    double left[R], bot[S], corner = 1.0;
+    double left[R], bot[S], ktop[S], corner = 1.0;
 #pragma unroll
     for (int i = 0; i < R; ++i) left[i] = 1.0;
 #pragma unroll
-    for (int i = 0; i < S; ++i) bot[i] = 1.0;
+    for (int i = 0; i < S; ++i) { bot[i] = 1.0; ktop[i] = 1.0; }
 
     // EDGES: terminal row / column of every pair, register -> global, held one macro-step (see sk_wave.hip)
     const int EP = EDGES ? (NUp * S + L * R) : 0;
@@ -217,9 +217,12 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
         // -- top row of the block from the lane above
         double top[S];
-        if (FULLWAVE) {
+        if (FULLWAVE) {   // lane 0 keeps the 1.0 of the persistent `old` register ktop[i] (see sk_wave.hip)
 #pragma unroll
-            for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], 1.0);
+            for (int i = 0; i < S; ++i) {
+                ktop[i] = dpp_shr1(bot[i], ktop[i]);
+                top[i] = ktop[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < S; ++i) {
