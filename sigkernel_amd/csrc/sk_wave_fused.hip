@@ -19,7 +19,7 @@ namespace {
 
 constexpr int FD = 8;              // dims carried (inputs are zero-padded to 8)
 constexpr int Y_SLAB_PITCH = FD * 128 + 128;
-constexpr int X_SLOTS = 3;
+constexpr int X_SLOTS = 2;   // the window being consumed + the one in flight
 
 struct FusedParams {
     const double *dXr;   // [A][Mrows][8]: s^2 (x[p+1]-x[p]), zero rows/dims beyond Mc / D
@@ -381,7 +381,7 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     // measured on the headline (512 x 512 pairs, len 128, dim 8, d = 1): 8 waves/CU 8.10 ms, 9: 7.3, 10: 6.73, 12: 8.7 --
     // the third wave on two of the four SIMDs fills issue slots the dependent fp64 chains leave empty, a third wave
     // everywhere starts to cost more in LDS traffic than it gains.  SK_FUSED_WPC overrides.
-    const int cap = wpc_env > 0 ? 16 : 10;
+    const int cap = wpc_env > 0 ? 16 : (DY == 0 ? 6 : 10);   // d = 0 (four coarse rows per lane): 6: 4.50 ms, 8-11: 5.1-5.2 ms
     if (waves_per_cu > cap) waves_per_cu = cap;
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     if (waves_per_cu < 1) waves_per_cu = 1;
