@@ -49,6 +49,21 @@ __device__ __forceinline__ void lds_read_units<8>(d2_t (&v)[8], unsigned a) {
                  : "v"(a)
                  : "memory");
 }
+// 128 contiguous bytes (two coarse rows of x differences), one wait
+__device__ __forceinline__ void lds_read_line(d2_t (&v)[8], unsigned a) {
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %8 offset:16\n\t"
+                 "ds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\t"
+                 "ds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\t"
+                 "ds_read_b128 %7, %8 offset:112\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a)
+                 : "memory");
+}
 template <>
 __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
     asm volatile("ds_read_b128 %0, %4\n\t"
@@ -202,12 +217,25 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 #pragma unroll
             for (int i = 0; i < R; ++i) left[i] = 1.0;
             const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
+            if constexpr (RC % 2 == 0) {   // two rows per LDS round trip (every wave takes this branch every step: some
+#pragma unroll                             // lane always starts a pair)
+                for (int k = 0; k < RC; k += 2) {
+                    d2_t xv[8];
+                    lds_read_line(xv, xa + k * 64u);
 #pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                d2_t xv[4];
-                lds_read_units<4>(xv, xa + k * 64u);
+                    for (int j = 0; j < 4; ++j) {
+                        dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1];
+                        dxr[k + 1][2 * j] = xv[4 + j][0]; dxr[k + 1][2 * j + 1] = xv[4 + j][1];
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+                for (int k = 0; k < RC; ++k) {
+                    d2_t xv[4];
+                    lds_read_units<4>(xv, xa + k * 64u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+                }
             }
         }
 
