@@ -191,12 +191,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         if (MULTIBAND) {
             double tb[S];
             if (is_top && band > 0) {
-                if constexpr (S % 4 == 0) {
-                    lds_read_row<S>(tb, my_bnd + (unsigned)(u * S) * 8u);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < S; ++i) tb[i] = lds_read_f64(my_bnd + (unsigned)(u * S + i) * 8u);
-                }
+                lds_read_row1<S>(tb, my_bnd + (unsigned)(u * S) * 8u);   // one LDS round trip
             } else {
 #pragma unroll
                 for (int i = 0; i < S; ++i) tb[i] = 1.0;
@@ -267,7 +262,10 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         if (MULTIBAND) {
             if (is_bot) {
 #pragma unroll
-                for (int i = 0; i < S; ++i) lds_write_f64(my_bnd + (unsigned)(u * S + i) * 8u, bot[i]);
+                for (int i = 0; i < S; i += 2) {
+                    d2_t v = {bot[i], bot[i + 1]};
+                    lds_write_b128(my_bnd + (unsigned)(u * S + i) * 8u, v);
+                }
             }
         }
 

@@ -361,16 +361,8 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
             for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
             if (MULTIBAND) {
                 if (is_top && band > 0) {
-                    if constexpr (S % 4 == 0) {
-                        lds_read_row<S>(tbR, bnd_r + (unsigned)(u * S) * 8u);
-                        lds_read_row<S>(tbF, bnd_f + (unsigned)(u * S) * 8u);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < S; ++i) {
-                            tbR[i] = lds_read_f64(bnd_r + (unsigned)(u * S + i) * 8u);
-                            tbF[i] = lds_read_f64(bnd_f + (unsigned)(u * S + i) * 8u);
-                        }
-                    }
+                    // both boundary rows in one LDS round trip (a top lane exists in every wave, every macro-step)
+                    lds_read_2rows<S>(tbR, tbF, bnd_r + (unsigned)(u * S) * 8u, bnd_f + (unsigned)(u * S) * 8u);
                 }
             }
 #pragma unroll
@@ -462,9 +454,10 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         if (MULTIBAND) {
             if (is_bot) {
 #pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    lds_write_f64(bnd_r + (unsigned)(u * S + i) * 8u, botR[i]);
-                    lds_write_f64(bnd_f + (unsigned)(u * S + i) * 8u, botF[i]);
+                for (int i = 0; i < S; i += 2) {
+                    d2_t vr = {botR[i], botR[i + 1]}, vf = {botF[i], botF[i + 1]};
+                    lds_write_b128(bnd_r + (unsigned)(u * S + i) * 8u, vr);
+                    lds_write_b128(bnd_f + (unsigned)(u * S + i) * 8u, vf);
                 }
             }
         }

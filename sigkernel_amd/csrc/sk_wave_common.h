@@ -90,6 +90,83 @@ __device__ __forceinline__ void lds_read_row(double (&v)[N], unsigned addr) {
         lds_read_f64x4(v[i], v[i + 1], v[i + 2], v[i + 3], addr + i * 8u, addr + (i + 1) * 8u, addr + (i + 2) * 8u,
                        addr + (i + 3) * 8u);
 }
+// N consecutive doubles (16-byte aligned) with N/2 ds_read_b128 and ONE wait
+template <int N>
+__device__ __forceinline__ void lds_read_row1(double (&v)[N], unsigned addr);
+template <>
+__device__ __forceinline__ void lds_read_row1<2>(double (&v)[2], unsigned p) {
+    d2_t t;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"(p) : "memory");
+    v[0] = t[0]; v[1] = t[1];
+}
+template <>
+__device__ __forceinline__ void lds_read_row1<4>(double (&v)[4], unsigned p) {
+    d2_t t[2];
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]) : "v"(p) : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { v[2 * i] = t[i][0]; v[2 * i + 1] = t[i][1]; }
+}
+template <>
+__device__ __forceinline__ void lds_read_row1<8>(double (&v)[8], unsigned p) {
+    d2_t t[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(p) : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = t[i][0]; v[2 * i + 1] = t[i][1]; }
+}
+template <>
+__device__ __forceinline__ void lds_read_row1<16>(double (&v)[16], unsigned p) {
+    d2_t t[8];
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                 : "v"(p) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[2 * i] = t[i][0]; v[2 * i + 1] = t[i][1]; }
+}
+template <>
+__device__ __forceinline__ void lds_read_row1<32>(double (&v)[32], unsigned p) {
+    double lo[16], hi[16];
+    lds_read_row1<16>(lo, p);
+    lds_read_row1<16>(hi, p + 128u);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = lo[i]; v[16 + i] = hi[i]; }
+}
+
+// two rows of N consecutive doubles each (the Kr / Kf band boundaries of the adjoint), all reads issued before ONE wait
+template <int N>
+__device__ __forceinline__ void lds_read_2rows(double (&a)[N], double (&b)[N], unsigned addr_a, unsigned addr_b);
+template <>
+__device__ __forceinline__ void lds_read_2rows<2>(double (&a)[2], double (&b)[2], unsigned pa, unsigned pb) {
+    d2_t t[2];
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]) : "v"(pa), "v"(pb) : "memory");
+    a[0] = t[0][0]; a[1] = t[0][1]; b[0] = t[1][0]; b[1] = t[1][1];
+}
+template <>
+__device__ __forceinline__ void lds_read_2rows<4>(double (&a)[4], double (&b)[4], unsigned pa, unsigned pb) {
+    d2_t t[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(pa), "v"(pb) : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { a[2 * i] = t[i][0]; a[2 * i + 1] = t[i][1]; b[2 * i] = t[2 + i][0]; b[2 * i + 1] = t[2 + i][1]; }
+}
+template <>
+__device__ __forceinline__ void lds_read_2rows<8>(double (&a)[8], double (&b)[8], unsigned pa, unsigned pb) {
+    d2_t t[8];
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\t"
+                 "ds_read_b128 %6, %9 offset:32\n\tds_read_b128 %7, %9 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                 : "v"(pa), "v"(pb) : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[2 * i] = t[i][0]; a[2 * i + 1] = t[i][1]; b[2 * i] = t[4 + i][0]; b[2 * i + 1] = t[4 + i][1]; }
+}
+
 __device__ __forceinline__ void lds_write_f64(unsigned addr, double v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
