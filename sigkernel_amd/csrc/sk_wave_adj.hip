@@ -231,9 +231,8 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     char *const w_wave = static_cast<char *>(prm.W) + first_pair * pairw_bytes;
     int wj = 0, wslot = 0;
     // write the finished line of class wj (8 lanes x RC rows per instruction, 128 contiguous bytes per row)
-    auto store_lines = [&]() {
-        vec_t wv[RC];
-        lds_read_rows<63>(wv, lds0 + (unsigned)(wslot * SLOT_BYTES + lane * 16));
+    // wv: the finished line, read from lds0 + wslot * SLOT_BYTES + lane * 16 by the caller
+    auto store_lines = [&](const vec_t (&wv)[RC]) {
         const bool pair_ok = wt_ps >= 0 && wt_ps < prm.PPG && first_pair + (int64_t)wt_gc * prm.PPG + wt_ps < prm.P;
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
@@ -328,8 +327,12 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     for (int t = 0; t < prm.n_steps; ++t) {
         vec_t gv[RC];
         const unsigned my_unit = rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4));
-        lds_read_rows<63>(gv, my_unit);       // its line arrived before the previous step's closing wait
-        if (t >= LINE_UNITS) store_lines();   // the lines whose last unit was written in the previous macro-step
+        {   // the increments (their line arrived before the previous step's closing wait) and the W line whose last
+            // unit was written in the previous macro-step: one LDS round trip for both
+            vec_t wv[RC];
+            lds_read_rows_pair(gv, my_unit, wv, lds0 + (unsigned)(wslot * SLOT_BYTES + lane * 16));
+            if (t >= LINE_UNITS) store_lines(wv);
+        }
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
             chk_pair = -1;
@@ -496,7 +499,11 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         }
         u = nu; band = nband; ps = nps;
     }
-    for (int t = 0; t < LINE_UNITS; ++t) store_lines();   // the lines completed in the last 8 macro-steps
+    for (int t = 0; t < LINE_UNITS; ++t) {   // the lines completed in the last 8 macro-steps
+        vec_t wv[RC];
+        lds_read_rows<63>(wv, lds0 + (unsigned)(wslot * SLOT_BYTES + lane * 16));
+        store_lines(wv);
+    }
     if (chk_pair >= 0)
         atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

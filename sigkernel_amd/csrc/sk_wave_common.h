@@ -64,6 +64,26 @@ __device__ __forceinline__ void lds_read_rows(V (&g)[4], unsigned a) {
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]) : "v"(a), "n"(VM) : "memory");
 }
+// two independent row sets (the increments of this macro-step and a finished W line), one wait
+template <typename V>
+__device__ __forceinline__ void lds_read_rows_pair(V (&g)[1], unsigned a, V (&w)[1], unsigned b) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(w[0]) : "v"(a), "v"(b) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void lds_read_rows_pair(V (&g)[2], unsigned a, V (&w)[2], unsigned b) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                 "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(w[0]), "=&v"(w[1]) : "v"(a), "v"(b) : "memory");
+}
+template <typename V>
+__device__ __forceinline__ void lds_read_rows_pair(V (&g)[4], unsigned a, V (&w)[4], unsigned b) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
+                 "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:1024\n\t"
+                 "ds_read_b128 %6, %9 offset:2048\n\tds_read_b128 %7, %9 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(a), "v"(b) : "memory");
+}
 __device__ __forceinline__ double lds_read_f64(unsigned addr) {
     double v;
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
