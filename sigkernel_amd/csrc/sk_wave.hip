@@ -42,20 +42,24 @@ struct WaveParams {
     int naive;
     double *edges;     // nullable [P, NNp + MMp]: K[MM][1..NNp] then K[1..MMp][NN] (EDGES variant; padded strip sizes)
     int k_f;           // coarse row inside the lane's block that holds the pair's last row
+    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
 };
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE, bool EDGES, int PF>
-__global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
+__global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     constexpr int NSLOT = LINE_UNITS + PF;    // ring slots; one slot = the next line of 8 lanes' rows
     constexpr int SLOT_BYTES = RC * 1024;     // [k][lane/8][128 B]
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
     const unsigned lds0 = lds_offset(lds);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int L = 1 << prm.logL, G = WAVE >> prm.logL;
     const int lam = lane & (L - 1);
     const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
         band = sig - ps * nb;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;   // the unit at which this lane holds K[MM][NN] (if ever)
-    const int64_t pair0 = ((int64_t)blockIdx.x * G + (lane >> prm.logL)) * prm.PPG;
+    const int64_t pair0 = (wave_id * G + (lane >> prm.logL)) * prm.PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     // ring slot of the line this lane is reading: the line it started at macro-step ts sits in slot ts % NSLOT
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_wave(const WaveParams prm) {
     // the end of a pair, pairs past P and the not-yet-started lanes of the pipeline fall outside num_records
     // (or into a neighbouring pair) and the bounds-checked buffer load returns without touching memory.
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
+    const int64_t first_pair = wave_id * G * prm.PPG;
     int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
     const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
@@ -336,7 +340,7 @@ int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t 
     auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, EDGES, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 
@@ -431,11 +435,16 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     prm.edges = strip_edges;
     prm.k_f = (g.Mc - 1) % RC;
 
+    // the HBM-bound streaming sweep gains nothing from even SIMD loads and is a few per cent faster with single-wave
+    // workgroups (per 131072 pairs of 127 x 127: d = 0 2.70 vs 2.80 ms, with strip edges at d = 1 3.77 vs 3.98 ms)
+    prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 1);
+    const int blocks = wave_group_blocks(prm.wg);
+    const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
-        case 0: return launch_dy<T, 0>(prm, multiband, PF, (int)waves, lds_bytes, s);
-        case 1: return launch_dy<T, 1>(prm, multiband, PF, (int)waves, lds_bytes, s);
-        case 2: return launch_dy<T, 2>(prm, multiband, PF, (int)waves, lds_bytes, s);
-        default: return launch_dy<T, 3>(prm, multiband, PF, (int)waves, lds_bytes, s);
+        case 0: return launch_dy<T, 0>(prm, multiband, PF, blocks, lds_block, s);
+        case 1: return launch_dy<T, 1>(prm, multiband, PF, blocks, lds_block, s);
+        case 2: return launch_dy<T, 2>(prm, multiband, PF, blocks, lds_block, s);
+        default: return launch_dy<T, 3>(prm, multiband, PF, blocks, lds_block, s);
     }
 }
 

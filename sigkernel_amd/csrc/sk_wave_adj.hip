@@ -37,6 +37,7 @@ struct AdjParams {
     int64_t ldb, ldwb;     // row strides in bytes
     int Mc, Nc;
     int NUp, nb, logL, PPG, n_steps, naive;
+    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
 };
 
 // Prefetch distance of the increment lines, in macro-steps.  Memory operations of a macro-step are issued at its top in
@@ -125,7 +126,7 @@ __device__ __forceinline__ void store_unit(float *dst, double a, double b, doubl
 }
 
 template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE>
-__global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
+__global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     constexpr int PF = ADJ_PF;
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
@@ -134,10 +135,13 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
     // the W units of the same positions, and written out as whole lines on the 9th step
     constexpr int NSLOT = LINE_UNITS + 1 + PF;
     constexpr int SLOT_BYTES = RC * 1024;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
     const unsigned lds0 = lds_offset(lds);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int L = 1 << prm.logL, G = WAVE >> prm.logL;
     const int lam = lane & (L - 1), grp = lane >> prm.logL;
     const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
         ps = floor_div(sig, nb);
         band = sig - ps * nb;
     }
-    const int64_t pair0 = ((int64_t)blockIdx.x * G + grp) * prm.PPG;
+    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_wave(const AdjParams prm) {
 
     // ---- producer: increments, whole lines, back to front (see sk_wave.hip for the forward-order twin) ----
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
+    const int64_t first_pair = wave_id * G * prm.PPG;
     int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
     const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
@@ -514,7 +518,7 @@ int launch_adj_one(const AdjParams &prm, int blocks, size_t lds_bytes, hipStream
     auto kern = k_adj_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 
@@ -566,6 +570,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     // this kernel waits on memory every macro-step, so every resident wave the LDS ring allows is taken (8 at d = 1, up to
     // 16 at d = 2); SK_ADJ_WPC overrides
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
+    else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups: the same number of waves on every SIMD
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
@@ -588,9 +593,12 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
     prm.naive = g.naive;
 
-    if (DY == 0) return launch_adj_dy<T, 0>(prm, multiband, (int)waves, lds_bytes, s);
-    if (DY == 1) return launch_adj_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
-    if constexpr (sizeof(T) == 8) return launch_adj_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
+    prm.wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
+    const int blocks = wave_group_blocks(prm.wg);
+    const size_t lds_block = wave_group_lds(prm.wg);
+    if (DY == 0) return launch_adj_dy<T, 0>(prm, multiband, blocks, lds_block, s);
+    if (DY == 1) return launch_adj_dy<T, 1>(prm, multiband, blocks, lds_block, s);
+    if constexpr (sizeof(T) == 8) return launch_adj_dy<T, 2>(prm, multiband, blocks, lds_block, s);
     return SK_ERR_UNSUPPORTED;
 }
 

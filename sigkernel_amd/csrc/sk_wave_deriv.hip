@@ -33,6 +33,7 @@ struct DerivParams {
     int NUp, nb, logL, PPG, n_steps;
     int u_f, lam_f, sel_f;
     int pf;              // prefetch distance in macro-steps (3 or 5)
+    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
 };
 
 // The increments of macro-step t+1 are requested from LDS early in macro-step t and waited for at its end: with
@@ -125,16 +126,19 @@ __device__ __forceinline__ void lds_read_states<8>(double (&v)[3][8], unsigned a
 }
 
 template <typename T, int DY, bool MULTIBAND, bool FULLWAVE, int PF>
-__global__ __launch_bounds__(WAVE) void k_deriv_wave(const DerivParams prm) {
+__global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) {
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
     constexpr int R = 1 << DY, S = CW << DY, r = 1 << DY;
     constexpr int NSLOT = LINE_UNITS + PF;
     constexpr int SLOT_BYTES = 3 * 1024;   // [array][lane/8][128 B]
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
     const unsigned lds0 = lds_offset(lds);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int L = 1 << prm.logL, G = WAVE >> prm.logL;
     const int lam = lane & (L - 1);
     const int NUp = prm.NUp, nb = prm.nb, NLp = NUp / LINE_UNITS;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(WAVE) void k_deriv_wave(const DerivParams prm) {
         band = sig - ps * nb;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
-    const int64_t pair0 = ((int64_t)blockIdx.x * G + (lane >> prm.logL)) * prm.PPG;
+    const int64_t pair0 = (wave_id * G + (lane >> prm.logL)) * prm.PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot_off = ((((-(u & 7)) % NSLOT) + NSLOT) % NSLOT) * SLOT_BYTES;   // ring slot (byte offset) of the line being read
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(WAVE) void k_deriv_wave(const DerivParams prm) {
 
     // ---- producer (DMA) state: one cursor, three buffer resources ----------------------------------------
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = (int64_t)blockIdx.x * G * prm.PPG;
+    const int64_t first_pair = wave_id * G * prm.PPG;
     int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
     const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
@@ -405,7 +409,7 @@ int launch_pf(const DerivParams &prm, int blocks, size_t lds_bytes, hipStream_t 
     auto kern = k_deriv_wave<T, DY, MULTIBAND, FULLWAVE, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 
@@ -489,11 +493,14 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
     prm.sel_f = (g.Nc - 1) % CW;
     prm.pf = PF;
 
+    prm.wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
+    const int blocks = wave_group_blocks(prm.wg);
+    const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
-        case 0: return launch_dy<T, 0>(prm, multiband, (int)waves, lds_bytes, s);
-        case 1: return launch_dy<T, 1>(prm, multiband, (int)waves, lds_bytes, s);
+        case 0: return launch_dy<T, 0>(prm, multiband, blocks, lds_block, s);
+        case 1: return launch_dy<T, 1>(prm, multiband, blocks, lds_block, s);
         default:
-            if constexpr (sizeof(T) == 8) return launch_dy<T, 2>(prm, multiband, (int)waves, lds_bytes, s);
+            if constexpr (sizeof(T) == 8) return launch_dy<T, 2>(prm, multiband, blocks, lds_block, s);
             return SK_ERR_UNSUPPORTED;
     }
 }

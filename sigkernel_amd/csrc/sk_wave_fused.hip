@@ -7,8 +7,9 @@
 //     from a small LDS ring that the wave fills 8 lanes at a time, one macro-step ahead of the first lane that needs it;
 //   * the y differences of the 2 coarse columns of the macro-step, dy[8][2], are read from an LDS ring over the lane
 //     group's virtual column stream: slabs of 8 units x 8 dims (1 KiB, one LDS-DMA instruction every 8 macro-steps,
-//     fetched a whole slab ahead), slab pitch 1152 B so that lanes 8 apart -- same unit, neighbouring slabs -- hit
-//     different halves of the 256-byte bank row;
+//     fetched a whole slab ahead).  Lanes 8 apart read the same unit of neighbouring slabs; so that they hit different
+//     halves of the 256-byte bank row without padding, odd slabs are stored with each pair of dimension rows swapped
+//     (the DMA lanes simply fetch the other row) and the reader addresses even and odd dimensions separately;
 //   * 32 extra FMAs per macro-step (RC*2 coarse cells x 8 dims) replace the increment read.
 // HBM traffic: the paths (MBs).  The kernel is bound by fp64 issue.  Scope: dim <= 8 (zero-padded), one band per
 // pair (M-1 <= 64*RC), dyadic <= 2; everything else takes sk_static_increments + sk_solve_fwd.
@@ -18,7 +19,7 @@ namespace sk {
 namespace {
 
 constexpr int FD = 8;              // dims carried (inputs are zero-padded to 8)
-constexpr int Y_SLAB_PITCH = FD * 128 + 128;
+constexpr int Y_SLAB_PITCH = FD * 128;   // 8 dimension rows of 8 units; no padding (parity swizzle, see above)
 constexpr int X_SLOTS = 2;   // the window being consumed + the one in flight
 
 struct FusedParams {
@@ -30,23 +31,24 @@ struct FusedParams {
     int Mrows, Ncp;
     int Mc, Nc, NUp, logL, PPG, n_steps;
     int u_f, lam_f, sel_f, naive;
+    WaveGroup wg;
 };
 
 template <int N>
 __device__ __forceinline__ void lds_read_units(d2_t (&v)[N], unsigned addr);
-template <>
-__device__ __forceinline__ void lds_read_units<8>(d2_t (&v)[8], unsigned a) {
+// even dimensions from a_even + {0, 256, 512, 768}, odd ones from a_odd + the same: the two addresses differ by +-128
+__device__ __forceinline__ void lds_read_dims(d2_t (&v)[8], unsigned a_even, unsigned a_odd) {
     asm volatile("ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %8 offset:128\n\t"
+                 "ds_read_b128 %1, %9\n\t"
                  "ds_read_b128 %2, %8 offset:256\n\t"
-                 "ds_read_b128 %3, %8 offset:384\n\t"
+                 "ds_read_b128 %3, %9 offset:256\n\t"
                  "ds_read_b128 %4, %8 offset:512\n\t"
-                 "ds_read_b128 %5, %8 offset:640\n\t"
+                 "ds_read_b128 %5, %9 offset:512\n\t"
                  "ds_read_b128 %6, %8 offset:768\n\t"
-                 "ds_read_b128 %7, %8 offset:896\n\t"
+                 "ds_read_b128 %7, %9 offset:768\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(a)
+                 : "v"(a_even), "v"(a_odd)
                  : "memory");
 }
 // 128 contiguous bytes (two coarse rows of x differences), one wait
@@ -77,14 +79,17 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES>
-__global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm) {
+__global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams prm) {
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     constexpr int XSLAB = RC * 512;   // 8 lanes x RC rows x 64 B
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);   // independent waves, see sk_wave_common.h
+    if (wave_id < 0) return;
     const unsigned lds0 = lds_offset(lds);
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int L = 1 << prm.logL, G = WAVE >> prm.logL;
     const int lam = lane & (L - 1), grp = lane >> prm.logL;
     const int NUp = prm.NUp;
@@ -100,13 +105,14 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
         ps = floor_div(-lam, NUp);
         u = -lam - ps * NUp;
     }
-    int yslab;   // slab of the y ring holding virtual unit v
+    int yslab, ypar;   // slab of the y ring holding virtual unit v, and that slab's storage parity
     {
         const int s0 = floor_div(-lam, 8);
         yslab = ((s0 % NSLAB) + NSLAB) % NSLAB;
+        ypar = (s0 + grp) & 1;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
-    const int64_t pair0 = ((int64_t)blockIdx.x * G + grp) * prm.PPG;
+    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
     // lanes NUp apart start (different) pairs at the same macro-step: one x slab per such "lap" j = lam / NUp
@@ -128,16 +134,18 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
         if (prm.B <= 0) return p;
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
     };
-    int y_pi = 0, y_u0 = 0, y_slot = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling), ring slot
-    auto issue_y = [&]() {
+    int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
+    auto issue_y = [&]() {                            // ring slot, parity of the virtual slab number
         for (int g = 0; g < G; ++g) {
-            int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + y_pi;
+            int64_t p = (wave_id * G + g) * prm.PPG + y_pi;
             if (y_pi >= prm.PPG || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
             const int64_t b = split_b(p);
-            const double *src = prm.dYt + ((b * FD + (lane >> 3)) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
+            const int krow = (lane >> 3) ^ ((y_par + g) & 1);   // odd slabs (per group): dimension rows swapped in pairs
+            const double *src = prm.dYt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
             __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + y_slot * Y_SLAB_PITCH), 16, 0, 0);
         }
         y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
+        y_par ^= 1;
         y_u0 += 8;
         if (y_u0 == NUp) { y_u0 = 0; y_pi += 1; }
     };
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = ((int64_t)blockIdx.x * G + g) * prm.PPG + pi;
+                int64_t p = (wave_id * G + g) * prm.PPG + pi;
                 if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
                 const int64_t a = split_a(p);
                 const char *src = reinterpret_cast<const char *>(prm.dXr + (a * prm.Mrows + (int64_t)lamj * RC) * FD);
@@ -241,7 +249,10 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
 
         // -- y differences of the two coarse columns of this macro-step, all 8 dims
         d2_t dyv[FD];
-        lds_read_units<8>(dyv, my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4)));
+        {
+            const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
+            lds_read_dims(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        }
 
         // -- top row of the block from the lane above
         double top[S];
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(WAVE) void k_fwd_fused_linear(const FusedParams prm
         u += 1;
         if ((u & 7) == 0) {
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
+            ypar ^= 1;
             if (u == NUp) { u = 0; ps += 1; }
         }
     }
@@ -359,7 +371,7 @@ int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStre
     auto kern = k_fwd_fused_linear<TO, DY, NAIVE, FULLWAVE, EDGES>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE), lds_bytes, s, prm);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 
@@ -406,12 +418,14 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     const int wpc_env = env_int("SK_FUSED_WPC", 0);
-    // measured on the headline (512 x 512 pairs, len 128, dim 8, d = 1): 8 waves/CU 8.10 ms, 9: 7.3, 10: 6.73, 12: 8.7 --
-    // the third wave on two of the four SIMDs fills issue slots the dependent fp64 chains leave empty, a third wave
-    // everywhere starts to cost more in LDS traffic than it gains.  SK_FUSED_WPC overrides.
-    const int cap = wpc_env > 0 ? 16 : (DY == 0 ? 6 : 10);   // d = 0 (four coarse rows per lane): 6: 4.50 ms, 8-11: 5.1-5.2 ms
+    // measured on the headline (512 x 512 pairs, len 128, dim 8, d = 1) with four-wave workgroups, i.e. the same number of
+    // waves on every SIMD: 8 waves/CU 5.66 ms, 12: 5.30, 13: 6.65 (single-wave workgroups, whose placement is uneven:
+    // 8: 7.58, 10: 6.31, 12: 6.77).  d = 0 (four coarse rows per lane): 4: 4.60 ms, 8: 3.33, 12: 3.32; d = 2: 8: 3.31,
+    // 12: 3.07 on 512 x 512 pairs of length 64.  SK_FUSED_WPC overrides.
+    const int cap = wpc_env > 0 ? 16 : (DY == 0 ? 8 : 12);
     if (waves_per_cu > cap) waves_per_cu = cap;
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
+    else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
@@ -429,10 +443,13 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     prm.sel_f = ((g.Mc - 1) % RC) * 2 + (g.Nc - 1) % 2;
     prm.naive = g.naive;
     (void)A;
+    prm.wg = wave_group(lds_bytes, waves, "SK_FUSED_WPB");
+    const int blocks = wave_group_blocks(prm.wg);
+    const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
-        case 0: return launch_fused_dy<TO, 0>(prm, (int)waves, lds_bytes, s);
-        case 1: return launch_fused_dy<TO, 1>(prm, (int)waves, lds_bytes, s);
-        default: return launch_fused_dy<TO, 2>(prm, (int)waves, lds_bytes, s);
+        case 0: return launch_fused_dy<TO, 0>(prm, blocks, lds_block, s);
+        case 1: return launch_fused_dy<TO, 1>(prm, blocks, lds_block, s);
+        default: return launch_fused_dy<TO, 2>(prm, blocks, lds_block, s);
     }
 }
 
