@@ -51,6 +51,28 @@ __device__ __forceinline__ void lds_read_dims(d2_t (&v)[8], unsigned a_even, uns
                  : "v"(a_even), "v"(a_odd)
                  : "memory");
 }
+// The same reads without the wait: they are issued at the end of a macro-step for the next one, so that their round trip
+// overlaps this wave's own block sweep.  `t` is written by the LDS and read by nothing until lds_dims_wait hands it
+// over (outputs tied to the temporaries' registers; tools/check_async_hazards.py lints the ISA for early uses).
+__device__ __forceinline__ void lds_read_dims_issue(d2_t (&t)[8], unsigned a_even, unsigned a_odd) {
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %8 offset:256\n\t"
+                 "ds_read_b128 %3, %9 offset:256\n\t"
+                 "ds_read_b128 %4, %8 offset:512\n\t"
+                 "ds_read_b128 %5, %9 offset:512\n\t"
+                 "ds_read_b128 %6, %8 offset:768\n\t"
+                 "ds_read_b128 %7, %9 offset:768"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                 : "v"(a_even), "v"(a_odd)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dims_wait(d2_t (&v)[8], d2_t (&t)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "5"(t[5]), "6"(t[6]), "7"(t[7])
+                 : "memory");
+}
 // 128 contiguous bytes (two coarse rows of x differences), one wait
 __device__ __forceinline__ void lds_read_line(d2_t (&v)[8], unsigned a) {
     asm volatile("ds_read_b128 %0, %8\n\t"
@@ -192,8 +214,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
     const int k_f = (prm.Mc - 1) % RC;
     const bool row_in_bot = k_f == RC - 1;   // then the row values are the `bot` state (see sk_wave.hip)
 
+    // DMA: slab / window n+1 is issued when the steps of slab / window n begin, and waited for when they end.  The y
+    // differences of a macro-step are read from LDS at the end of the previous one.
+    d2_t dyn[FD];
+    auto read_y = [&]() {
+        const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
+        lds_read_dims_issue(dyn, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+    };
     issue_y();
     issue_x();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_y();
+    issue_x();
+    read_y();
     for (int t = 0; t < prm.n_steps; ++t) {
         if (EDGES) {   // the edge values of the previous macro-step, straight from the state registers
             double *const ep = prm.edges + e_pair * EP;
@@ -211,12 +244,6 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
                     *reinterpret_cast<d2_t *>(ep + ecol_at + rr) = v;
                 }
             }
-        }
-        if ((t & 7) == 0) {
-            // everything issued 8 macro-steps ago has had a whole slab period to land
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            issue_y();       // slab (t >> 3) + 1
-            issue_x();       // window t + 8
         }
 
         // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows
@@ -249,10 +276,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
 
         // -- y differences of the two coarse columns of this macro-step, all 8 dims
         d2_t dyv[FD];
-        {
-            const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
-            lds_read_dims(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
-        }
+        lds_dims_wait(dyv, dyn);
 
         // -- top row of the block from the lane above
         double top[S];
@@ -351,6 +375,17 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
             ypar ^= 1;
             if (u == NUp) { u = 0; ps += 1; }
         }
+        if (((t + 1) & 7) == 0) {
+            // everything issued 8 macro-steps ago has had a whole slab period to land
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue_y();       // slab ((t + 1) >> 3) + 1
+            issue_x();       // window t + 9 .. t + 16
+        }
+        read_y();            // for macro-step t + 1
+    }
+    {   // the last read-ahead is never used, but its registers are not free before it has landed
+        d2_t drain[FD];
+        lds_dims_wait(drain, dyn);
     }
     if (EDGES) {
         double *const ep = prm.edges + e_pair * EP;

@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sigkernel_amd", "csrc")
-DEFAULT = ["sk_wave_adj.hip", "sk_wave_deriv.hip"]
+DEFAULT = ["sk_wave_adj.hip", "sk_wave_deriv.hip", "sk_wave_fused.hip"]
 
 
 def regs(tok):
@@ -65,7 +65,7 @@ def scan(asm_text):
             for dest, text in vm + lgkm:
                 if touched & dest:
                     hazards.append((name, text, l))
-            is_lds_dma = " lds" in l and op.startswith("buffer_load")
+            is_lds_dma = (" lds" in l and op.startswith("buffer_load")) or op.startswith("global_load_lds")
             if (op.startswith("global_load") or op.startswith("buffer_load") or op.startswith("flat_load")) and not is_lds_dma:
                 vm.append((regs(l.split()[1].rstrip(",")), l))
             elif is_lds_dma or op.startswith("global_store") or op.startswith("buffer_store") or "atomic" in op:

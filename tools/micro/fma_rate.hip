@@ -1,0 +1,44 @@
+// fp64 VALU issue-rate probe: waves of independent v_fma_f64 / v_mul_f64 / v_add_f64 chains (build: hipcc --offload-arch=gfx950)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+template <int OP>
+__global__ __launch_bounds__(256) void k(double *out, int iters, double a, double b) {
+    double v[16];
+    for (int i = 0; i < 16; ++i) v[i] = threadIdx.x + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (OP == 0) v[i] = __builtin_fma(v[i], a, b);
+                else if (OP == 1) v[i] = v[i] * a;
+                else if (OP == 2) v[i] = v[i] + b;
+                else { float f = (float)v[i]; f = __builtin_fmaf(f, (float)a, (float)b); v[i] = f; }
+            }
+    }
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678) out[0] = s;
+}
+template <int OP>
+void run(const char *name, int wpc, double *d) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int blocks = 256 * wpc / 4;
+    k<OP><<<blocks, 256>>>(d, 16, 1.0000001, 1e-9);
+    hipEventRecord(e0);
+    k<OP><<<blocks, 256>>>(d, iters, 1.0000001, 1e-9);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double inst = (double)blocks * 4 * iters * 64;   // wave instructions
+    printf("%-8s %2d waves/CU: %.3f ms, %.2f cycles per wave-instruction per SIMD at 2.4 GHz, %.1f T lane-ops/s\n", name, wpc, ms,
+           ms * 1e-3 * 2.4e9 / (inst / 1024), inst * 64 / ms / 1e9);
+}
+int main() {
+    double *d; hipMalloc(&d, 8);
+    for (int wpc : {4, 8, 12}) { run<0>("fma_f64", wpc, d); run<1>("mul_f64", wpc, d); run<2>("add_f64", wpc, d); }
+    return 0;
+}
