@@ -164,6 +164,22 @@ int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int
 int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                             int dyadic, int scheme, float *out_final, void *stream);
 
+/* Forward solve with the RBF static kernel fused in (csrc/sk_wave_fused.hip, KIND 1): the nodes
+ * G[p][q] = exp(-|x_p - y_q|^2 / sigma) are evaluated inside the sweep (one exp per coarse cell; a lane takes the node row
+ * under its last coarse row from the lane below by DPP) and differenced in the reference's order
+ * ((G11 + G00) - G10) - G01; neither G_static nor the increments exist in HBM.  Replaces, for RBFKernel,
+ * static_kernels.py:58-73 + sigkernel.py:362-382 (Gram) / static_kernels.py:43-56 + sigkernel.py:216-234 (paired).
+ * |x - y|^2 is summed directly over the dimensions, not as |x|^2 + |y|^2 - 2<x,y>.
+ *   Xr [A][Mrows][8] fp64: the path POINTS x_p, p < M = Mc + 1, zero padding rows / dims (path dim <= 8);
+ *   Yt [Bn][8][Ncp] fp64: y_q, q < N = Nc + 1, dimension-major, zero-padded; Ncp = N rounded up to a multiple of 16;
+ *   inv_sigma = 1 / sigma;  B > 0: Gram, B == 0: paired;  out_final [P].
+ * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M > 256/128/64 for dyadic 0/1/2):
+ * use sk_static_increments_* + sk_solve_fwd_*. */
+int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                         int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
+int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                         int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
+
 /* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
  * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 0..2). */
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,

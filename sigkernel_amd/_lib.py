@@ -49,6 +49,8 @@ SIGNATURES = {
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
@@ -226,6 +228,34 @@ class HipBackend:
             return None
         _check(rc, "sk_solve_fwd_linear")
         return (out, None) if keep_edges else out
+
+    def solve_fwd_fused_rbf(self, X, Y, sigma, dyadic, naive, gram):
+        """K[MM][NN] for the RBF static kernel with nodes and increments formed inside the solver (nothing of size
+        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band)."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if D > 8 or dyadic > 2 or Mc < 1 or Nc < 1 or M > 64 * (4 >> min(dyadic, 2)) or not float(sigma) > 0:
+            return None
+        Mrows, Ncp = 256, (N + 15) // 16 * 16
+        dev = X.device
+        Xr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
+        Xr[:, :M, :D] = X.double()
+        Yt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
+        Yt[:, :D, :N] = Y.double().transpose(1, 2)
+        out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        lib = load()
+        with torch.cuda.device(dev):
+            fn = getattr(lib, "sk_solve_fwd_rbf_" + _suffix(X))
+            rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic), scheme, 1.0 / float(sigma),
+                    _ptr(out), _stream(X))
+        if rc == 2:
+            return None
+        _check(rc, "sk_solve_fwd_rbf")
+        return out
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

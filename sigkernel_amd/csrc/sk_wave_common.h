@@ -21,6 +21,14 @@ __device__ __forceinline__ double dpp_shr1(double v, double fill) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double dpp_shl1(double v, double fill) {
+    // lane l receives lane l+1's value; lane 63 keeps `fill`
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ int floor_div(int a, int b) {  // b > 0
     int q = a / b;
     return (a % b < 0) ? q - 1 : q;

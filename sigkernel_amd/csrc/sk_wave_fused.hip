@@ -31,6 +31,7 @@ struct FusedParams {
     int Mrows, Ncp;
     int Mc, Nc, NUp, logL, PPG, n_steps;
     int u_f, lam_f, sel_f, naive;
+    double inv_sigma;    // RBF: G = exp(-|x - y|^2 * inv_sigma)
     WaveGroup wg;
 };
 
@@ -100,8 +101,40 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
                  : "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES>
-__global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams prm) {
+// exp(x) for finite x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-term ln 2), Taylor polynomial of
+// degree 13 in |r| <= ln2 / 2 (truncation 4e-18), result scaled by 2^n; underflow goes through v_ldexp to 0.  Without the
+// range checks and special cases of the library exp this is 19 VALU instructions.
+// The 11 polynomial coefficients that are not inline constants live in VGPRs: as SGPR pairs they push the kernel's scalar
+// state into spills (v_readlane in the hot loop).
+struct ExpCoef {
+    double c[11];   // 1/13!, 1/12!, ..., 1/3!
+    __device__ __forceinline__ void init() {
+        const double k[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            c[i] = k[i];
+            asm volatile("" : "+v"(c[i]));
+        }
+    }
+};
+__device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = e.c[0];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) p = fma(p, r, e.c[i]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
+__global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
+    constexpr bool RBF = KIND == 1;
+    constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     constexpr int XSLAB = RC * 512;   // 8 lanes x RC rows x 64 B
@@ -126,6 +159,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
     {
         ps = floor_div(-lam, NUp);
         u = -lam - ps * NUp;
+    }
+    int uk = u, psk = ps;   // RBF: the unit / pair the block sweep is at (LAG steps behind); linear: the same as (u, ps)
+    if (RBF) {
+        psk = floor_div(-lam - LAG, NUp);
+        uk = -lam - LAG - psk * NUp;
     }
     int yslab, ypar;   // slab of the y ring holding virtual unit v, and that slab's storage parity
     {
@@ -200,6 +238,17 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
     for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int j = 0; j < FD; ++j) dxr[k][j] = 0.0;
+    // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
+    // of the first row of the lane below at the columns of units uk and uk + 1
+    double own[RBF ? RC : 1][6], bel[4];
+    ExpCoef expc;
+    if (RBF) expc.init();
+#pragma unroll
+    for (int k = 0; k < (RBF ? RC : 1); ++k)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) own[k][c] = 1.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bel[c] = 1.0;
     double left[R], bot[S], ktop[S], corner = 1.0;
 #pragma unroll
     for (int i = 0; i < R; ++i) left[i] = 1.0;
@@ -247,10 +296,17 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
         }
 
         // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows
-        if (u == 0) {
+        if (RBF && uk == 0) {
             corner = 1.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) left[i] = 1.0;
+        }
+        if (u == 0) {
+            if (!RBF) {
+                corner = 1.0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) left[i] = 1.0;
+            }
             const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
             if constexpr (RC % 2 == 0) {   // two rows per LDS round trip (every wave takes this branch every step: some
 #pragma unroll                             // lane always starts a pair)
@@ -296,13 +352,57 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
 
         // -- increments and coefficients per coarse cell
         double ca[RC][CW], cbm[RC][CW];
+        double ginc[RC][CW];
+        if constexpr (RBF) {
+            // nodes G[p][q] = exp(-|x_p - y_q|^2 / sigma) of this lane's RC top node rows at the two columns of unit u
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) {
+                        const double df = dxr[k][j] - dyv[j][q];
+                        d2 = fma(df, df, d2);
+                    }
+                    own[k][4 + q] = exp_nonpos(-d2 * prm.inv_sigma, expc);
+                }
+            // the node row below this lane's last coarse row is the first row of the lane below, which is one macro-step
+            // behind: what it has just evaluated are the columns of unit u - 1 = uk + 1
+            bel[2] = dpp_shl1(own[0][4], bel[2]);
+            bel[3] = dpp_shl1(own[0][5], bel[3]);
+            // 4-corner differences in the reference's order (sigkernel.py:362-363): G11 + G00 - G10 - G01
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    const double t0 = own[k][q], t1 = own[k][q + 1];
+                    const double b0 = k + 1 < RC ? own[(k + 1) % RC][q] : bel[q];
+                    const double b1 = k + 1 < RC ? own[(k + 1) % RC][q + 1] : bel[q + 1];
+                    ginc[k][q] = ((b1 + t0) - b0) - t1;
+                }
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) own[k][c] = own[k][c + 2];
+            bel[0] = bel[2];
+            bel[1] = bel[3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    double g = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                    ginc[k][q] = g;
+                }
+        }
 #pragma unroll
         for (int k = 0; k < RC; ++k)
 #pragma unroll
             for (int q = 0; q < CW; ++q) {
-                double g = 0.0;
-#pragma unroll
-                for (int j = 0; j < FD; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                const double g = ginc[k][q];
                 if (NAIVE) {
                     ca[k][q] = fma(g, c_half, 1.0);
                     cbm[k][q] = 1.0;
@@ -338,10 +438,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
         corner = top[S - 1];
 
         if (EDGES) {
-            const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
-            e_pair = pair0 + ps;
-            erow_at = (pair_ok && lam == prm.lam_f) ? u * S : -1;
-            ecol_at = (pair_ok && u == prm.u_f) ? NUp * S + lam * R : -1;
+            const bool pair_ok = psk >= 0 && psk < prm.PPG && pair0 + psk < prm.P;
+            e_pair = pair0 + psk;
+            erow_at = (pair_ok && lam == prm.lam_f) ? uk * S : -1;
+            ecol_at = (pair_ok && uk == prm.u_f) ? NUp * S + lam * R : -1;
             if (!row_in_bot) {
 #pragma unroll
                 for (int kk = 0; kk < RC - 1; ++kk)
@@ -353,8 +453,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
         }
 
         // -- K[MM][NN] of a pair
-        if (u == my_uf) {
-            if (ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+        if (uk == my_uf) {
+            if (psk >= 0 && psk < prm.PPG && pair0 + psk < prm.P) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -364,17 +464,22 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                static_cast<TO *>(prm.out)[pair0 + ps] = (TO)v;
+                static_cast<TO *>(prm.out)[pair0 + psk] = (TO)v;
             }
         }
 
         // -- advance
+        if (RBF) {
+            uk += 1;
+            if (uk == NUp) { uk = 0; psk += 1; }
+        }
         u += 1;
         if ((u & 7) == 0) {
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
             if (u == NUp) { u = 0; ps += 1; }
         }
+        if (!RBF) { uk = u; psk = ps; }
         if (((t + 1) & 7) == 0) {
             // everything issued 8 macro-steps ago has had a whole slab period to land
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -401,50 +506,53 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_linear(const FusedParams
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES>
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
 int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_linear<TO, DY, NAIVE, FULLWAVE, EDGES>;
+    auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE>
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
 int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    if constexpr (sizeof(TO) == 8) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
-        if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true>(prm, blocks, lds_bytes, s);
+    if constexpr (sizeof(TO) == 8 && KIND == 0) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
+        if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true, KIND>(prm, blocks, lds_bytes, s);
     }
     if (prm.edges) return SK_ERR_UNSUPPORTED;
-    return launch_fused_e<TO, DY, NAIVE, FULLWAVE, false>(prm, blocks, lds_bytes, s);
+    return launch_fused_e<TO, DY, NAIVE, FULLWAVE, false, KIND>(prm, blocks, lds_bytes, s);
 }
 
-template <typename TO, int DY>
+template <typename TO, int DY, int KIND>
 int launch_fused_dy(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
     const bool full = prm.logL == 6;
     if (prm.naive)
-        return full ? launch_fused_one<TO, DY, true, true>(prm, blocks, lds_bytes, s)
-                    : launch_fused_one<TO, DY, true, false>(prm, blocks, lds_bytes, s);
-    return full ? launch_fused_one<TO, DY, false, true>(prm, blocks, lds_bytes, s)
-                : launch_fused_one<TO, DY, false, false>(prm, blocks, lds_bytes, s);
+        return full ? launch_fused_one<TO, DY, true, true, KIND>(prm, blocks, lds_bytes, s)
+                    : launch_fused_one<TO, DY, true, false, KIND>(prm, blocks, lds_bytes, s);
+    return full ? launch_fused_one<TO, DY, false, true, KIND>(prm, blocks, lds_bytes, s)
+                : launch_fused_one<TO, DY, false, false, KIND>(prm, blocks, lds_bytes, s);
 }
 
-}  // namespace
-
-// dXr [A][Mrows][8], dYt [Bn][8][Ncp] (see FusedParams).  SK_ERR_UNSUPPORTED outside the kernel's scope.
-template <typename TO>
-int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            TO *out, double *strip_edges, hipStream_t s) {
+// KIND 0: dXr [A][Mrows][8] / dYt [Bn][8][Ncp] are path differences; KIND 1: the same layouts hold the path points.
+// SK_ERR_UNSUPPORTED outside the kernel's scope.
+template <typename TO, int KIND>
+int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                     double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY > 2) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
-    const int NU = (g.Nc + 1) / 2;
+    // linear: one unit = two increment columns.  RBF: one unit = two NODE columns, and the sweep of a pair's last unit
+    // reads one node column of the following unit, which therefore has to exist as padding inside the pair's stream;
+    // likewise the lanes of a pair must cover M node rows, not M - 1 increment rows
+    const int NU = KIND == 1 ? (g.Nc + 2) / 2 : (g.Nc + 1) / 2;
+    const int rows = KIND == 1 ? g.Mc + 1 : g.Mc;
     const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (Ncp < NUp * 2 || (Ncp & 1)) return SK_ERR_UNSUPPORTED;
     int logL = 3;
-    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
+    while (logL < 6 && (RC << logL) < rows) ++logL;
     const int L = 1 << logL;
-    if (L * RC < g.Mc) return SK_ERR_UNSUPPORTED;   // more than one band per pair
+    if (L * RC < rows) return SK_ERR_UNSUPPORTED;   // more than one band per pair
     if (Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int G = WAVE / L;
     const int JMAX = (L + NUp - 1) / NUp;
@@ -472,7 +580,8 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     FusedParams prm;
     prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.edges = strip_edges; prm.P = g.P; prm.B = B;
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
-    prm.n_steps = (int)(PPG * NUp + (L - 1));
+    prm.n_steps = (int)(PPG * NUp + (L - 1)) + (KIND == 1 ? 2 : 0);
+    prm.inv_sigma = inv_sigma;
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = ((g.Mc - 1) / RC) % L;
     prm.sel_f = ((g.Mc - 1) % RC) * 2 + (g.Nc - 1) % 2;
@@ -482,15 +591,33 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     const int blocks = wave_group_blocks(prm.wg);
     const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
-        case 0: return launch_fused_dy<TO, 0>(prm, blocks, lds_block, s);
-        case 1: return launch_fused_dy<TO, 1>(prm, blocks, lds_block, s);
-        default: return launch_fused_dy<TO, 2>(prm, blocks, lds_block, s);
+        case 0: return launch_fused_dy<TO, 0, KIND>(prm, blocks, lds_block, s);
+        case 1: return launch_fused_dy<TO, 1, KIND>(prm, blocks, lds_block, s);
+        default: return launch_fused_dy<TO, 2, KIND>(prm, blocks, lds_block, s);
     }
+}
+
+}  // namespace
+
+template <typename TO>
+int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            TO *out, double *strip_edges, hipStream_t s) {
+    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, g, 0.0, out, strip_edges, s);
+}
+// Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
+template <typename TO>
+int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                         double inv_sigma, TO *out, hipStream_t s) {
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out, nullptr, s);
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double *,
                                              double *, hipStream_t);
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, float *,
                                             double *, hipStream_t);
+template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, double *,
+                                          hipStream_t);
+template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, float *,
+                                         hipStream_t);
 
 }  // namespace sk

@@ -375,6 +375,51 @@ def test_fused_linear_forward_scope(be):
     assert be.solve_fwd_fused_linear(X9, X9, 1.0, 1, False, True) is None        # dim 9
 
 
+@pytest.mark.parametrize("A,B,M,N,D,d", [(3, 4, 10, 20, 2, 1), (2, 3, 128, 128, 8, 1), (70, 9, 64, 64, 4, 2), (5, 130, 33, 17, 3, 0),
+                                            (1, 1, 2, 2, 1, 0), (9, 7, 128, 41, 8, 1), (4, 4, 64, 127, 5, 2), (300, 300, 20, 24, 8, 1),
+                                            (2, 2, 256, 30, 6, 0), (3, 3, 127, 129, 7, 1), (5, 5, 17, 65, 1, 2)])
+@pytest.mark.parametrize("naive", [False, True])
+def test_fused_rbf_forward_matches_oracle(be, A, B, M, N, D, d, naive):
+    """sk_solve_fwd_rbf_*: nodes, increments and PDE in one kernel, against the oracle's RBF Gram (odd and even lengths: the
+    node stream of a pair is one column longer than its increments; M up to the last lane's padding row)."""
+    gen = torch.Generator().manual_seed(A + B + M + N + D + d)
+    Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
+    X, Y = Xc.to(DEV), Yc.to(DEV)
+    sigma = 0.7
+    K = be.solve_fwd_fused_rbf(X, Y, sigma, d, naive, gram=True)
+    assert K is not None, "shape is inside the fused kernel's scope"
+    want = O.gram_forward(Xc, Yc, sigkernel_amd.RBFKernel(sigma), d, naive=naive, nthreads=8)
+    assert rel_err(K.cpu().numpy(), want) <= 1e-12
+    n = min(A, B)
+    Kp = be.solve_fwd_fused_rbf(X[:n].contiguous(), Y[:n].contiguous(), sigma, d, naive, gram=False)
+    assert rel_err(Kp.cpu().numpy(), np.diag(want)[:n]) <= 1e-12
+    K32 = be.solve_fwd_fused_rbf(X.float(), Y.float(), sigma, d, naive, gram=True)
+    np.testing.assert_allclose(K32.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_fused_rbf_forward_scope_and_route(be, monkeypatch):
+    X = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
+    assert be.solve_fwd_fused_rbf(X, X, 1.0, 1, False, True) is None            # 300 node rows > 128: two bands
+    Xs = X[:, :20].contiguous()
+    assert be.solve_fwd_fused_rbf(Xs, Xs, 1.0, 3, False, True) is None          # dyadic 3
+    X9 = torch.zeros(2, 20, 9, dtype=torch.float64, device=DEV)
+    assert be.solve_fwd_fused_rbf(X9, X9, 1.0, 1, False, True) is None          # dim 9
+    X65 = torch.zeros(2, 65, 2, dtype=torch.float64, device=DEV)
+    assert be.solve_fwd_fused_rbf(X65, X65, 1.0, 2, False, True) is None        # 65 node rows at dyadic 2: one more than 64 lanes
+    # compute_Gram without a gradient takes the fused kernel and agrees with the increments-in-HBM route
+    gen = torch.Generator().manual_seed(5)
+    Xw, Yw = walk(gen, 9, 50, 3).to(DEV), walk(gen, 7, 41, 3).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.6), 1)
+    calls = []
+    orig = type(be).solve_fwd_fused_rbf
+    monkeypatch.setattr(type(be), "solve_fwd_fused_rbf", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    K1 = sk.compute_Gram(Xw, Yw)
+    assert calls, "RBFKernel forward without gradient did not use the fused kernel"
+    monkeypatch.setenv("SK_NO_FUSED_RBF", "1")
+    K2 = sk.compute_Gram(Xw, Yw)
+    assert rel_err(K1.cpu().numpy(), K2.cpu().numpy()) <= 1e-12
+
+
 class _SubclassedLinear(sigkernel_amd.LinearKernel):
     """Not `type(...) is LinearKernel`: must take the generic Gram_matrix / autograd route."""
 
