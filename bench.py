@@ -212,7 +212,7 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "achieved": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "sk_solve_fwd_linear_f64 (k_fwd_fused_linear: static kernel + increments + PDE in one launch)",
+                "kernel": "sk_solve_fwd_linear_f64 (k_fwd_fused: static kernel + increments + PDE in one launch)",
                 "pairs_per_launch": pairs_f, "algorithmic_bytes_per_launch": pairs_f * alg_per_pair, "avg_launch_ms": avg,
                 "min_launch_ms": float(np.min(ms)),
                 "note": "HBM-equivalent rate: the increment matrix is never materialised, actual HBM traffic is the paths "

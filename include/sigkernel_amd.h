@@ -179,6 +179,10 @@ int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t 
                          int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                          int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
+/* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
+ * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */
+int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
  * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 0..2). */

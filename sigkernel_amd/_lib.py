@@ -51,6 +51,7 @@ SIGNATURES = {
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
     "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
@@ -229,9 +230,10 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_linear")
         return (out, None) if keep_edges else out
 
-    def solve_fwd_fused_rbf(self, X, Y, sigma, dyadic, naive, gram):
+    def solve_fwd_fused_rbf(self, X, Y, sigma, dyadic, naive, gram, keep_edges=False):
         """K[MM][NN] for the RBF static kernel with nodes and increments formed inside the solver (nothing of size
-        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band)."""
+        pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band).
+        keep_edges: (K, edges) as solve_fwd_fused_linear."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -249,13 +251,24 @@ class HipBackend:
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with torch.cuda.device(dev):
+            if keep_edges and X.dtype == torch.float64:
+                P = A * B if gram else A
+                nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
+                if nbytes:
+                    edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+                    rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic),
+                                                        scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _stream(X))
+                    if rc == SK_OK:
+                        return out, edges
+                    if rc != 2:
+                        _check(rc, "sk_solve_fwd_rbf_edges")
             fn = getattr(lib, "sk_solve_fwd_rbf_" + _suffix(X))
             rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic), scheme, 1.0 / float(sigma),
                     _ptr(out), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_rbf")
-        return out
+        return (out, None) if keep_edges else out
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

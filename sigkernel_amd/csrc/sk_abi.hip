@@ -244,7 +244,7 @@ int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t 
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
 }
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int dyadic,
                          int scheme, double inv_sigma, float *out_final, void *stream) {
@@ -253,7 +253,17 @@ int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t 
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+}
+
+int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream) {
+    if (!Xr || !Yt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, edges, (hipStream_t)stream);
 }
 
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,

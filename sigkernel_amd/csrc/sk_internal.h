@@ -94,7 +94,7 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
 
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                         double inv_sigma, TO *out, hipStream_t s);
+                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

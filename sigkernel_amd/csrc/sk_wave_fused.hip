@@ -32,6 +32,7 @@ struct FusedParams {
     int Mc, Nc, NUp, logL, PPG, n_steps;
     int u_f, lam_f, sel_f, naive;
     double inv_sigma;    // RBF: G = exp(-|x - y|^2 * inv_sigma)
+    int e_NUp, e_L;      // EDGES: units per row / lanes per pair of the strip layout the adjoint reads (strip_geom)
     WaveGroup wg;
 };
 
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     for (int i = 0; i < S; ++i) { bot[i] = 1.0; ktop[i] = 1.0; }
 
     // EDGES: terminal row / column of every pair, register -> global, held one macro-step (see sk_wave.hip)
-    const int EP = EDGES ? (NUp * S + L * R) : 0;
+    const int EP = EDGES ? (prm.e_NUp * S + prm.e_L * R) : 0;
     double erow[S];
     int erow_at = -1, ecol_at = -1;
     int64_t e_pair = 0;
@@ -381,6 +382,15 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                     const double b1 = k + 1 < RC ? own[(k + 1) % RC][q + 1] : bel[q + 1];
                     ginc[k][q] = ((b1 + t0) - b0) - t1;
                 }
+            if (EDGES) {
+                // the adjoint sweeps the padded strip with zero increments in the padding: the edges must come from the same
+                // grid, so the (meaningless) node differences of padding rows / columns are dropped here
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+                        if (lam * RC + k >= prm.Mc || uk * CW + q >= prm.Nc) ginc[k][q] = 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < RC; ++k)
 #pragma unroll
@@ -440,8 +450,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (EDGES) {
             const bool pair_ok = psk >= 0 && psk < prm.PPG && pair0 + psk < prm.P;
             e_pair = pair0 + psk;
-            erow_at = (pair_ok && lam == prm.lam_f) ? uk * S : -1;
-            ecol_at = (pair_ok && uk == prm.u_f) ? NUp * S + lam * R : -1;
+            erow_at = (pair_ok && lam == prm.lam_f && uk < prm.e_NUp) ? uk * S : -1;
+            ecol_at = (pair_ok && uk == prm.u_f && lam < prm.e_L) ? prm.e_NUp * S + lam * R : -1;
             if (!row_in_bot) {
 #pragma unroll
                 for (int kk = 0; kk < RC - 1; ++kk)
@@ -517,7 +527,7 @@ int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStre
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
 int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    if constexpr (sizeof(TO) == 8 && KIND == 0) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
+    if constexpr (sizeof(TO) == 8) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
         if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true, KIND>(prm, blocks, lds_bytes, s);
     }
     if (prm.edges) return SK_ERR_UNSUPPORTED;
@@ -582,6 +592,14 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + (KIND == 1 ? 2 : 0);
     prm.inv_sigma = inv_sigma;
+    prm.e_NUp = NUp;
+    prm.e_L = L;
+    if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
+        const Strip st = strip_geom(g, 8);
+        if (!st.ok || st.nb != 1 || st.RC != RC) return SK_ERR_UNSUPPORTED;
+        prm.e_NUp = st.NUp;
+        prm.e_L = 1 << st.logL;
+    }
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = ((g.Mc - 1) / RC) % L;
     prm.sel_f = ((g.Mc - 1) % RC) * 2 + (g.Nc - 1) % 2;
@@ -607,8 +625,8 @@ int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int
 // Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                         double inv_sigma, TO *out, hipStream_t s) {
-    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out, nullptr, s);
+                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out, strip_edges, s);
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double *,
@@ -616,8 +634,8 @@ template int launch_fwd_fused_linear<double>(const double *, const double *, int
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, float *,
                                             double *, hipStream_t);
 template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, double *,
-                                          hipStream_t);
+                                          double *, hipStream_t);
 template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, float *,
-                                         hipStream_t);
+                                         double *, hipStream_t);
 
 }  // namespace sk

@@ -50,16 +50,19 @@ def _fused_static(static_kernel, gram):
 
 
 def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=False):
-    """Whole forward in one kernel when the static kernel is exactly LinearKernel (sk_solve_fwd_linear_*) or, when no
-    strip edges are wanted for a backward pass, exactly RBFKernel (sk_solve_fwd_rbf_*), and the shape fits: the
-    increments are formed inside the solver.  None otherwise.  keep_edges: (K, edges)."""
+    """Whole forward in one kernel when the static kernel is exactly LinearKernel (sk_solve_fwd_linear_*) or exactly
+    RBFKernel (sk_solve_fwd_rbf_*) and the shape fits: the increments are formed inside the solver.  None otherwise.
+    keep_edges: (K, edges)."""
     if type(static_kernel) is LinearKernel and hasattr(be, "solve_fwd_fused_linear"):
         scale = 1.0 if gram else float(static_kernel.scale)
         if keep_edges:
             return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram, keep_edges=True)
         return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram)
-    if (type(static_kernel) is RBFKernel and not keep_edges and hasattr(be, "solve_fwd_fused_rbf")
-            and float(static_kernel.sigma) > 0 and not os.environ.get("SK_NO_FUSED_RBF")):
+    if (type(static_kernel) is RBFKernel and hasattr(be, "solve_fwd_fused_rbf") and float(static_kernel.sigma) > 0
+            and not os.environ.get("SK_NO_FUSED_RBF")):
+        if keep_edges:
+            return be.solve_fwd_fused_rbf(Xd.contiguous(), Yd.contiguous(), float(static_kernel.sigma), dyadic, naive, gram,
+                                          keep_edges=True)
         return be.solve_fwd_fused_rbf(Xd.contiguous(), Yd.contiguous(), float(static_kernel.sigma), dyadic, naive, gram)
     return None
 

@@ -397,6 +397,22 @@ def test_fused_rbf_forward_matches_oracle(be, A, B, M, N, D, d, naive):
     np.testing.assert_allclose(K32.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("A,B,M,N,D,d", [(6, 5, 64, 64, 4, 1), (3, 4, 128, 100, 8, 1), (4, 4, 33, 65, 3, 2), (2, 9, 20, 24, 8, 1),
+                                            (3, 3, 17, 129, 2, 0), (5, 4, 64, 17, 4, 2)])
+def test_fused_rbf_forward_keeps_usable_edges(be, A, B, M, N, D, d):
+    """The fused RBF forward's edges (written in the adjoint's strip layout, whose lane / unit counts can be smaller than
+    the node stream's) feed the fused adjoint of the separately formed increments: same W to 1e-10."""
+    gen = torch.Generator().manual_seed(A * 7 + M + N)
+    X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+    K, edges = be.solve_fwd_fused_rbf(X, Y, 0.8, d, False, gram=True, keep_edges=True)
+    assert edges is not None
+    inc = be.static_increments(1, 0.8, X, Y, gram=True)
+    k0, W0, r0 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
+    _, W1, r1 = be.solve_adj(inc, d, flags=_lib.FLAG_FAST_ONLY, return_residual=True, edges=edges)
+    assert rel_err(K.cpu().numpy(), k0.cpu().numpy()) <= FAST_TOL
+    assert float(r1.max()) <= 1e-9 and rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= ADJ_TOL
+
+
 def test_fused_rbf_forward_scope_and_route(be, monkeypatch):
     X = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
     assert be.solve_fwd_fused_rbf(X, X, 1.0, 1, False, True) is None            # 300 node rows > 128: two bands

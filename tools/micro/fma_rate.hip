@@ -14,7 +14,10 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
                 if (OP == 0) v[i] = __builtin_fma(v[i], a, b);
                 else if (OP == 1) v[i] = v[i] * a;
                 else if (OP == 2) v[i] = v[i] + b;
-                else { float f = (float)v[i]; f = __builtin_fmaf(f, (float)a, (float)b); v[i] = f; }
+                else if (OP == 3) v[i] = __builtin_rint(v[i]);
+                else if (OP == 4) v[i] = __builtin_ldexp(v[i], (int)threadIdx.x & 1);
+                else if (OP == 5) v[i] = (double)((int)v[i]);          // cvt_i32_f64 + cvt_f64_i32
+                else v[i] = v[i] - b;
             }
     }
     double s = 0;
@@ -39,6 +42,9 @@ void run(const char *name, int wpc, double *d) {
 }
 int main() {
     double *d; hipMalloc(&d, 8);
-    for (int wpc : {4, 8, 12}) { run<0>("fma_f64", wpc, d); run<1>("mul_f64", wpc, d); run<2>("add_f64", wpc, d); }
+    for (int wpc : {8, 12}) {
+        run<0>("fma_f64", wpc, d); run<1>("mul_f64", wpc, d); run<2>("add_f64", wpc, d); run<3>("rndne_f64", wpc, d);
+        run<4>("ldexp_f64", wpc, d); run<5>("cvt_pair", wpc, d);
+    }
     return 0;
 }

@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key in ("k_fwd_fused_linear", "k_fwd_wave", "k_fwd_simple", "k_adj_simple", "k_adj_wave", "k_static_linear_adj", "k_static_rbf_adj",
+    for key in ("k_fwd_fused", "k_fwd_wave", "k_fwd_simple", "k_adj_simple", "k_adj_wave", "k_static_linear_adj", "k_static_rbf_adj",
                 "k_static_linear", "k_static_rbf", "k_increments_adjoint", "k_increments"):
         if key in name:
             rest = name.split(key)[1]
