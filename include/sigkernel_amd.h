@@ -157,11 +157,12 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
  *                           and padding dims (path dim <= 8);
  *   dYt [Bn][8][Ncp] fp64: y[q+1]-y[q], dimension-major, zero-padded; Ncp = Nc rounded up to a multiple of 16;
  *   B > 0: Gram (Bn = B, pair (a,b) at a*B+b); B == 0: paired (Bn = A).  out_final [P].
+ *   D = the path dimension (1..8): dimensions >= D of dXr / dYt must be zero; D <= 4 selects kernels that skip them.
  * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M-1 > 256/128/64 for dyadic 0/1/2):
  * use sk_static_increments_* + sk_solve_fwd_*. */
-int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                             int dyadic, int scheme, double *out_final, void *stream);
-int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                             int dyadic, int scheme, float *out_final, void *stream);
 
 /* Forward solve with the RBF static kernel fused in (csrc/sk_wave_fused.hip, KIND 1): the nodes
@@ -172,21 +173,21 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
  * |x - y|^2 is summed directly over the dimensions, not as |x|^2 + |y|^2 - 2<x,y>.
  *   Xr [A][Mrows][8] fp64: the path POINTS x_p, p < M = Mc + 1, zero padding rows / dims (path dim <= 8);
  *   Yt [Bn][8][Ncp] fp64: y_q, q < N = Nc + 1, dimension-major, zero-padded; Ncp = N rounded up to a multiple of 16;
- *   inv_sigma = 1 / sigma;  B > 0: Gram, B == 0: paired;  out_final [P].
+ *   inv_sigma = 1 / sigma;  B > 0: Gram, B == 0: paired;  out_final [P];  D as for sk_solve_fwd_linear_*.
  * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M > 256/128/64 for dyadic 0/1/2):
  * use sk_static_increments_* + sk_solve_fwd_*. */
-int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                          int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
-int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                          int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
 /* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
  * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */
-int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                                int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
  * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 0..2). */
-int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                                   int dyadic, int scheme, double *out_final, double *edges, void *stream);
 
 /* ---- adjoint solve ------------------------------------------------------------------------

@@ -47,12 +47,12 @@ SIGNATURES = {
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
-    "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "sk_solve_fwd_edges_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
@@ -217,14 +217,14 @@ class HipBackend:
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
-                    rc = lib.sk_solve_fwd_linear_edges_f64(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp,
+                    rc = lib.sk_solve_fwd_linear_edges_f64(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D,
                                                            int(dyadic), scheme, _ptr(out), _ptr(edges), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_linear_edges")
             fn = getattr(lib, "sk_solve_fwd_linear_" + _suffix(X))
-            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic), scheme, _ptr(out), _stream(X))
+            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, _ptr(out), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_linear")
@@ -256,14 +256,14 @@ class HipBackend:
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
-                    rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic),
+                    rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic),
                                                         scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_rbf_edges")
             fn = getattr(lib, "sk_solve_fwd_rbf_" + _suffix(X))
-            rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, int(dyadic), scheme, 1.0 / float(sigma),
+            rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, 1.0 / float(sigma),
                     _ptr(out), _stream(X))
         if rc == 2:
             return None

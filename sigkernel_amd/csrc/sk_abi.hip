@@ -220,59 +220,59 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
     return solve_fwd<float>(inc_c, ld, P, Mc, Nc, dyadic, scheme, flags, out_final, out_grid, out_edges, stream);
 }
 
-int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                             int dyadic, int scheme, double *out_final, void *stream) {
-    if (!dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (D < 1 || !dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, (hipStream_t)stream);
 }
-int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                             int dyadic, int scheme, float *out_final, void *stream) {
-    if (!dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (D < 1 || !dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, (hipStream_t)stream);
 }
 
-int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int dyadic,
+int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                          int scheme, double inv_sigma, double *out_final, void *stream) {
-    if (!Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
 }
-int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int dyadic,
+int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                          int scheme, double inv_sigma, float *out_final, void *stream) {
-    if (!Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
 }
 
-int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                                int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream) {
-    if (!Xr || !Yt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
+    if (D < 1 || !Xr || !Yt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out_final, edges, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, edges, (hipStream_t)stream);
 }
 
-int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                                   int dyadic, int scheme, double *out_final, double *edges, void *stream) {
-    if (!dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
+    if (D < 1 || !dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, g, out_final, edges, (hipStream_t)stream);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, edges, (hipStream_t)stream);
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {

@@ -89,11 +89,11 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
-int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                             TO *out, double *strip_edges, hipStream_t s);
 
 template <typename TO>
-int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, TO *out, double *strip_edges, hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------

@@ -32,6 +32,7 @@ struct FusedParams {
     int Mc, Nc, NUp, logL, PPG, n_steps;
     int u_f, lam_f, sel_f, naive;
     double inv_sigma;    // RBF: G = exp(-|x - y|^2 * inv_sigma)
+    int dims;            // path dimensions that can be non-zero (<= 8)
     int e_NUp, e_L;      // EDGES: units per row / lanes per pair of the strip layout the adjoint reads (strip_geom)
     WaveGroup wg;
 };
@@ -67,6 +68,30 @@ __device__ __forceinline__ void lds_read_dims_issue(d2_t (&t)[8], unsigned a_eve
                  "ds_read_b128 %7, %9 offset:768"
                  : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
                  : "v"(a_even), "v"(a_odd)
+                 : "memory");
+}
+// dims 0..3 only (ND = 4)
+__device__ __forceinline__ void lds_read_dims_issue(d2_t (&t)[4], unsigned a_even, unsigned a_odd) {
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %5\n\t"
+                 "ds_read_b128 %2, %4 offset:256\n\t"
+                 "ds_read_b128 %3, %5 offset:256"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                 : "v"(a_even), "v"(a_odd)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dims_wait(d2_t (&v)[4], d2_t (&t)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]) : "memory");
+}
+// the first 32 bytes of two consecutive 64-byte rows (ND = 4), one wait
+__device__ __forceinline__ void lds_read_half_rows(d2_t (&v)[4], unsigned a) {
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:64\n\t"
+                 "ds_read_b128 %3, %4 offset:80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a)
                  : "memory");
 }
 __device__ __forceinline__ void lds_dims_wait(d2_t (&v)[8], d2_t (&t)[8]) {
@@ -132,9 +157,9 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
     return __builtin_ldexp(p, (int)n);
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
-    constexpr bool RBF = KIND == 1;
+    constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
@@ -234,11 +259,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (x_lam0 == NUp) { x_lam0 = 0; x_q0 += 1; }
     };
 
-    double dxr[RC][FD];
+    double dxr[RC][ND];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
 #pragma unroll
-        for (int j = 0; j < FD; ++j) dxr[k][j] = 0.0;
+        for (int j = 0; j < ND; ++j) dxr[k][j] = 0.0;
     // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
     // of the first row of the lane below at the columns of units uk and uk + 1
     double own[RBF ? RC : 1][6], bel[4];
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
 
     // DMA: slab / window n+1 is issued when the steps of slab / window n begin, and waited for when they end.  The y
     // differences of a macro-step are read from LDS at the end of the previous one.
-    d2_t dyn[FD];
+    d2_t dyn[ND];
     auto read_y = [&]() {
         const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
         lds_read_dims_issue(dyn, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
@@ -309,8 +334,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 for (int i = 0; i < R; ++i) left[i] = 1.0;
             }
             const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
-            if constexpr (RC % 2 == 0) {   // two rows per LDS round trip (every wave takes this branch every step: some
-#pragma unroll                             // lane always starts a pair)
+            if constexpr (RC % 2 == 0 && ND == 8) {   // two rows per LDS round trip (every wave takes this branch every step:
+#pragma unroll                                        // some lane always starts a pair)
                 for (int k = 0; k < RC; k += 2) {
                     d2_t xv[8];
                     lds_read_line(xv, xa + k * 64u);
@@ -320,19 +345,30 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         dxr[k + 1][2 * j] = xv[4 + j][0]; dxr[k + 1][2 * j + 1] = xv[4 + j][1];
                     }
                 }
+            } else if constexpr (RC % 2 == 0) {
+#pragma unroll
+                for (int k = 0; k < RC; k += 2) {
+                    d2_t xv[4];
+                    lds_read_half_rows(xv, xa + k * 64u);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1];
+                        dxr[k + 1][2 * j] = xv[2 + j][0]; dxr[k + 1][2 * j + 1] = xv[2 + j][1];
+                    }
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < RC; ++k) {
                     d2_t xv[4];
                     lds_read_units<4>(xv, xa + k * 64u);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+                    for (int j = 0; j < ND / 2; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
                 }
             }
         }
 
         // -- y differences of the two coarse columns of this macro-step, all 8 dims
-        d2_t dyv[FD];
+        d2_t dyv[ND];
         lds_dims_wait(dyv, dyn);
 
         // -- top row of the block from the lane above
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 for (int q = 0; q < CW; ++q) {
                     double d2 = 0.0;
 #pragma unroll
-                    for (int j = 0; j < FD; ++j) {
+                    for (int j = 0; j < ND; ++j) {
                         const double df = dxr[k][j] - dyv[j][q];
                         d2 = fma(df, df, d2);
                     }
@@ -404,7 +440,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 for (int q = 0; q < CW; ++q) {
                     double g = 0.0;
 #pragma unroll
-                    for (int j = 0; j < FD; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                    for (int j = 0; j < ND; ++j) g = fma(dxr[k][j], dyv[j][q], g);
                     ginc[k][q] = g;
                 }
         }
@@ -499,7 +535,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         read_y();            // for macro-step t + 1
     }
     {   // the last read-ahead is never used, but its registers are not free before it has landed
-        d2_t drain[FD];
+        d2_t drain[ND];
         lds_dims_wait(drain, dyn);
     }
     if (EDGES) {
@@ -516,13 +552,22 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
-int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND>;
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
+int launch_fused_nd(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
+}
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
+int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+    // paths of dimension <= 4 skip the four zero dimensions (fp64, default scheme: the variants that are worth their build time)
+    if constexpr (!NAIVE && sizeof(TO) == 8) {
+        if (prm.dims <= 4) return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, blocks, lds_bytes, s);
+    }
+    return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, blocks, lds_bytes, s);
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
@@ -547,10 +592,10 @@ int launch_fused_dy(const FusedParams &prm, int blocks, size_t lds_bytes, hipStr
 // KIND 0: dXr [A][Mrows][8] / dYt [Bn][8][Ncp] are path differences; KIND 1: the same layouts hold the path points.
 // SK_ERR_UNSUPPORTED outside the kernel's scope.
 template <typename TO, int KIND>
-int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                      double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
     const int DY = g.dyadic;
-    if (DY > 2) return SK_ERR_UNSUPPORTED;
+    if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
     // linear: one unit = two increment columns.  RBF: one unit = two NODE columns, and the sweep of a pair's last unit
     // reads one node column of the following unit, which therefore has to exist as padding inside the pair's stream;
@@ -592,6 +637,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + (KIND == 1 ? 2 : 0);
     prm.inv_sigma = inv_sigma;
+    prm.dims = D;
     prm.e_NUp = NUp;
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
@@ -618,24 +664,24 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
 }  // namespace
 
 template <typename TO>
-int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                             TO *out, double *strip_edges, hipStream_t s) {
-    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, g, 0.0, out, strip_edges, s);
+    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, s);
 }
 // Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
 template <typename TO>
-int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
-    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, g, inv_sigma, out, strip_edges, s);
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, s);
 }
 
-template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double *,
+template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double *,
                                              double *, hipStream_t);
-template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, float *,
+template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, float *,
                                             double *, hipStream_t);
-template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, double *,
+template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, double *,
                                           double *, hipStream_t);
-template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, const Geom &, double, float *,
+template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, float *,
                                          double *, hipStream_t);
 
 }  // namespace sk

@@ -56,10 +56,11 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_deriv_f64(p, None, p, 0, 1, 4, 4, 0, 0, p, p, p, None) == 1
     assert lib.sk_deriv_increments_f64(p, p, p, 0.0, 1, 4, 4, p, p, p, 0, None) == 1              # eps must be positive
     assert lib.sk_linear_adjoint_f64(p, 2, p, 0, None, 1, 1, 4, 4, 2, p, None) == 1               # ldy < Nc
-    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 4, 4, 16, 1, 0, 0.0, p, None) == 1           # 1/sigma must be positive
-    assert lib.sk_solve_fwd_rbf_f64(p, None, 1, 1, 256, 4, 4, 16, 1, 0, 1.0, p, None) == 1
-    assert lib.sk_solve_fwd_rbf_f32(p, p, 1, 1, 256, 4, 4, 16, 3, 0, 1.0, p, None) == 2           # dyadic 3: not covered
-    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 1, 0, 1.0, p, None) == 2         # 129 node rows: two bands
+    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 4, 4, 16, 3, 1, 0, 0.0, p, None) == 1           # 1/sigma must be positive
+    assert lib.sk_solve_fwd_rbf_f64(p, None, 1, 1, 256, 4, 4, 16, 3, 1, 0, 1.0, p, None) == 1
+    assert lib.sk_solve_fwd_rbf_f32(p, p, 1, 1, 256, 4, 4, 16, 3, 3, 0, 1.0, p, None) == 2           # dyadic 3: not covered
+    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 3, 1, 0, 1.0, p, None) == 2      # 129 node rows: two bands
+    assert lib.sk_solve_fwd_linear_f64(p, p, 1, 1, 256, 4, 4, 16, 0, 1, 0, p, None) == 1                 # path dimension 0
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
