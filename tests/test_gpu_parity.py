@@ -249,6 +249,41 @@ def test_fuzz_random_shapes_against_oracle(be):
                 assert rel_err(K.cpu().numpy(), O.solve_coarse(O.increments(G), d, naive, nthreads=8)) <= 1e-11, (it, A, B, Mc, Nc, D, d)
 
 
+def test_fuzz_fused_forwards_against_the_streaming_route(be):
+    """150 random shapes: the fused linear / RBF forwards (values, and the edges they keep for the adjoint) against
+    sk_static_increments + sk_solve_fwd / sk_solve_adj on the same paths -- GPU against GPU, so large batches are cheap."""
+    rng = np.random.default_rng(77)
+    n_fused = n_edges = 0
+    for it in range(150):
+        d = int(rng.integers(0, 3))
+        cap = 64 * (4 >> d)
+        M = int(rng.integers(2, cap + 1)) if it % 5 else cap            # the largest single-band length every fifth time
+        N = int(rng.integers(2, 300))
+        A, B, D = int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 9))
+        naive = bool(rng.integers(0, 2))
+        kind = int(rng.integers(0, 2))
+        gen = torch.Generator().manual_seed(1000 + it)
+        X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+        param = 1.0 if kind == 0 else float(rng.uniform(0.3, 2.0))
+        inc = be.static_increments(kind, param, X, Y, gram=True)
+        want = be.solve_fwd(inc, d, naive)
+        if kind == 0:
+            res = be.solve_fwd_fused_linear(X, Y, 1.0, d, naive, gram=True, keep_edges=True)
+        else:
+            res = be.solve_fwd_fused_rbf(X, Y, param, d, naive, gram=True, keep_edges=True)
+        assert res is not None, (it, kind, A, B, M, N, D, d)
+        K, edges = res
+        n_fused += 1
+        assert rel_err(K.cpu().numpy(), want.cpu().numpy()) <= 1e-12, (it, kind, A, B, M, N, D, d, naive)
+        if edges is not None and A * B * (M << d) * (N << d) < 6e7:
+            n_edges += 1
+            _, W0, r0 = be.solve_adj(inc, d, naive, flags=_lib.FLAG_FAST_ONLY, return_residual=True)
+            _, W1, r1 = be.solve_adj(inc, d, naive, flags=_lib.FLAG_FAST_ONLY, return_residual=True, edges=edges)
+            tol = max(ADJ_TOL, 10 * float(r0.max()))
+            assert rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= tol, (it, kind, A, B, M, N, D, d, naive)
+    assert n_fused == 150 and n_edges >= 60
+
+
 def test_increments_and_transpose_bit_identical(be):
     rng = np.random.default_rng(0)
     for shape in [(3, 2, 2), (4, 10, 20), (2, 3, 128, 128), (5, 65, 7), (1, 300, 300)]:
