@@ -39,22 +39,9 @@ struct FusedParams {
 
 template <int N>
 __device__ __forceinline__ void lds_read_units(d2_t (&v)[N], unsigned addr);
-// even dimensions from a_even + {0, 256, 512, 768}, odd ones from a_odd + the same: the two addresses differ by +-128
-__device__ __forceinline__ void lds_read_dims(d2_t (&v)[8], unsigned a_even, unsigned a_odd) {
-    asm volatile("ds_read_b128 %0, %8\n\t"
-                 "ds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %8 offset:256\n\t"
-                 "ds_read_b128 %3, %9 offset:256\n\t"
-                 "ds_read_b128 %4, %8 offset:512\n\t"
-                 "ds_read_b128 %5, %9 offset:512\n\t"
-                 "ds_read_b128 %6, %8 offset:768\n\t"
-                 "ds_read_b128 %7, %9 offset:768\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                 : "v"(a_even), "v"(a_odd)
-                 : "memory");
-}
-// The same reads without the wait: they are issued at the end of a macro-step for the next one, so that their round trip
+// y units of a macro-step: even dimensions at a_even + {0, 256, 512, 768}, odd ones at a_odd + the same; the two addresses
+// differ by +-128 (parity swizzle of the slabs).
+// The reads carry no wait: they are issued at the end of a macro-step for the next one, so that their round trip
 // overlaps this wave's own block sweep.  `t` is written by the LDS and read by nothing until lds_dims_wait hands it
 // over (outputs tied to the temporaries' registers; tools/check_async_hazards.py lints the ISA for early uses).
 __device__ __forceinline__ void lds_read_dims_issue(d2_t (&t)[8], unsigned a_even, unsigned a_odd) {
