@@ -185,6 +185,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         ypar = (s0 + grp) & 1;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
+    const int lam7 = lam & 7;
     const int64_t pair0 = (wave_id * G + grp) * prm.PPG;
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
@@ -487,7 +488,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
 
         // -- K[MM][NN] of a pair
         if (uk == my_uf) {
-            if (psk >= 0 && psk < prm.PPG && pair0 + psk < prm.P) {
+            int pv = psk;
+            asm volatile("" : "+v"(pv));   // keeps the pair tests inside this (rarely taken) branch instead of in every step
+            if (pv >= 0 && pv < prm.PPG && pair0 + pv < prm.P) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                static_cast<TO *>(prm.out)[pair0 + psk] = (TO)v;
+                static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
             }
         }
 
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             if (uk == NUp) { uk = 0; psk += 1; }
         }
         u += 1;
-        if ((u & 7) == 0) {
+        if (((t + 1) & 7) == lam7) {   // (u & 7) == 0: u = t + 1 - lam modulo 8 (NUp is a multiple of 8)
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
             if (u == NUp) { u = 0; ps += 1; }
