@@ -132,6 +132,7 @@ struct ExpCoef {
     }
 };
 __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
+    x = fmax(x, -800.0);   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);

@@ -448,6 +448,22 @@ def test_fused_rbf_forward_keeps_usable_edges(be, A, B, M, N, D, d):
     assert float(r1.max()) <= 1e-9 and rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= ADJ_TOL
 
 
+def test_fused_rbf_forward_far_apart_points(be):
+    """Points so far apart that every node underflows (exp of -1e6 and of -1e300): all increments vanish, K = 1 exactly."""
+    X = torch.zeros(2, 12, 3, dtype=torch.float64, device=DEV)
+    for shift in (1e3, 1e150):
+        Y = X + shift
+        K = be.solve_fwd_fused_rbf(X, Y, 1.0, 1, False, gram=True)
+        assert torch.equal(K, torch.ones_like(K))
+    # a mix: one path of Y coincides with X, the other is far away
+    gen = torch.Generator().manual_seed(3)
+    Xw = walk(gen, 2, 12, 3).to(DEV)
+    Yw = torch.stack([Xw[0], Xw[1] + 1e8])
+    K = be.solve_fwd_fused_rbf(Xw, Yw, 0.5, 1, False, gram=True)
+    want = O.gram_forward(Xw.cpu(), Yw.cpu(), sigkernel_amd.RBFKernel(0.5), 1)
+    assert rel_err(K.cpu().numpy(), want) <= 1e-12
+
+
 def test_fused_rbf_forward_scope_and_route(be, monkeypatch):
     X = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
     assert be.solve_fwd_fused_rbf(X, X, 1.0, 1, False, True) is None            # 300 node rows > 128: two bands
