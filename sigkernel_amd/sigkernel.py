@@ -127,8 +127,8 @@ class _SigKernel(torch.autograd.Function):
         ctx.save_for_backward(X, Y)
         ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver = static_kernel, dyadic_order, _naive_solver
         ctx.workspace_bytes = workspace_bytes
-        if M < 2 or N < 2:  # a single point: the grid is its boundary, k = 1 (sigkernel.py:212-253 with MM = 0)
-            return torch.ones(A, dtype=X.dtype, device=X.device)
+        if M < 2 or N < 2 or A == 0:  # a single point: the grid is its boundary, k = 1 (sigkernel.py:212-253 with MM = 0);
+            return torch.ones(A, dtype=X.dtype, device=X.device)   # an empty batch: an empty result, like the CPU reference
         Xd, Yd = X.detach(), Y.detach()
         K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False)
         if K is not None:
@@ -147,7 +147,7 @@ class _SigKernel(torch.autograd.Function):
         be = _lib.get_backend()
         A, M, N = X.shape[0], X.shape[1], Y.shape[1]
         grad_X = torch.zeros_like(X)
-        if M >= 2 and N >= 2:
+        if M >= 2 and N >= 2 and A > 0:
             Yd = Y.detach()
             fused = _fused_static(sk, False) is not None
             per_row = (3 if fused else 8) * M * N * X.element_size()
@@ -264,7 +264,8 @@ class _SigKernelGram(torch.autograd.Function):
         ctx.save_for_backward(X, Y)
         ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver = static_kernel, dyadic_order, _naive_solver
         ctx.workspace_bytes = workspace_bytes
-        if M < 2 or N < 2:
+        ctx.sym_blocks = ctx.kept_edges = None
+        if M < 2 or N < 2 or A == 0 or B == 0:   # single points: k = 1; an empty batch: an empty matrix
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
         # `sym`: the reference's GPU path ignores it (sigkernel.py:366-382) and its CPU path silently assumes X is Y.
@@ -317,7 +318,7 @@ class _SigKernelGram(torch.autograd.Function):
                         grad_X[r1:] += be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
                     del W
             ctx.sym_blocks = None
-        elif M >= 2 and N >= 2:
+        elif M >= 2 and N >= 2 and A > 0 and B > 0:
             Yd = Y.detach()
             go = grad_output.to(X.dtype).contiguous()
             fused = _fused_static(sk, True) is not None

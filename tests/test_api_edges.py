@@ -101,3 +101,21 @@ def test_dyadic_orders_past_the_wavefront_kernels(d):
     gen = torch.Generator().manual_seed(7)
     X, Y = walk(gen, 3, 6, 2).cuda(), walk(gen, 2, 7, 2).cuda()
     _check_gram(S.RBFKernel(1.0), d, X, Y)
+
+
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_empty_batches_give_empty_results(kind):
+    """The reference's CPU solver returns empty arrays for an empty batch (cython_backend.pyx:72 allocates (A,B,..) and the
+    loops do not run); so does this, with a zero gradient of the right shape."""
+    S, _ = _api()
+    sk = S.SigKernel(S.LinearKernel() if kind == "linear" else S.RBFKernel(1.0), 1)
+    X0 = torch.zeros(0, 8, 3, dtype=torch.float64, device="cuda")
+    Y = torch.randn(4, 9, 3, dtype=torch.float64, device="cuda")
+    assert sk.compute_Gram(X0, Y).shape == (0, 4) and sk.compute_Gram(Y, X0).shape == (4, 0)
+    assert sk.compute_kernel(X0, X0).shape == (0,)
+    Xg = X0.clone().requires_grad_(True)
+    sk.compute_Gram(Xg, Y).sum().backward()
+    assert Xg.grad.shape == X0.shape
+    Yg = Y.clone().requires_grad_(True)
+    sk.compute_Gram(Yg, X0).sum().backward()
+    assert torch.equal(Yg.grad, torch.zeros_like(Y))
