@@ -1,4 +1,5 @@
-// sk_wave_fused.hip -- forward solver with the LINEAR static kernel fused in: the increments
+// sk_wave_fused.hip -- forward solver with the static kernel fused in (KIND 0: LINEAR, KIND 1: RBF, below).  The linear
+// increments
 //     inc[p][q] = s^2 <x[p+1]-x[p], y[q+1]-y[q]>
 // are formed inside the sweep from the path differences, so neither G_static nor the increment matrix exists in HBM
 // (SURVEY 8(f) #1 taken to its end).  The sweep is the one of sk_wave.hip (skewed row strips in registers, DPP neighbour
@@ -11,8 +12,19 @@
 //     halves of the 256-byte bank row without padding, odd slabs are stored with each pair of dimension rows swapped
 //     (the DMA lanes simply fetch the other row) and the reader addresses even and odd dimensions separately;
 //   * 32 extra FMAs per macro-step (RC*2 coarse cells x 8 dims) replace the increment read.
-// HBM traffic: the paths (MBs).  The kernel is bound by fp64 issue.  Scope: dim <= 8 (zero-padded), one band per
-// pair (M-1 <= 64*RC), dyadic <= 2; everything else takes sk_static_increments + sk_solve_fwd.
+// HBM traffic: the paths (MBs).  The kernel is bound by fp64 issue.  Scope: dim <= 8 (zero-padded; ND = 4 variants skip
+// the upper four dimensions), one band per pair (M-1 <= 64*RC), dyadic <= 2; everything else takes sk_static_increments
+// + sk_solve_fwd.
+//
+// KIND 1 (RBF): the two rings hold the path POINTS.  A lane evaluates the nodes G[p][q] = exp(-|x_p - y_q|^2 / sigma) of the
+// TOP node rows of its RC coarse rows at the two node columns of a unit (one exp per coarse cell) and takes the node row
+// under its last coarse row from the lane BELOW by DPP (wave_shl:1).  That lane is one macro-step behind, so the node
+// evaluation runs LAG = 2 units ahead of the block sweep: (u, ps) is the node cursor (it drives the rings and the reload
+// of the x rows), (uk, psk) the sweep cursor (it drives the K state, the outputs and the edges).  own[k][0..5] holds a
+// lane's node rows at the columns of units uk, uk+1, uk+2, bel[0..3] the row below at units uk, uk+1; the increments are
+// the reference's 4-corner differences ((G11 + G00) - G10) - G01.  The last lane's missing neighbour and the one column
+// a pair's last unit borrows from the next pair are padding: M <= 64*RC and N <= 2*NUp.
+// All waves are independent (no barrier, private LDS slice) and launched four per workgroup (sk_wave_common.h).
 #include "sk_wave_common.h"
 
 namespace sk {
