@@ -160,6 +160,8 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
+    constexpr bool AHEAD = !(RBF && EDGES);   // y units read one macro-step ahead: 2 * ND more VGPRs, which the RBF kernel
+                                              // that also keeps edges does not have below the 3-waves-per-SIMD line (168)
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
@@ -283,10 +285,22 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     for (int i = 0; i < S; ++i) { bot[i] = 1.0; ktop[i] = 1.0; }
 
     // EDGES: terminal row / column of every pair, register -> global, held one macro-step (see sk_wave.hip)
+    // Everything the per-step edge bookkeeping compares against is loop-invariant and PER LANE, and is kept in VGPRs (the
+    // asm pins): as wave-uniform values it filled the scalar file and came back through v_readlane in every macro-step.
     const int EP = EDGES ? (prm.e_NUp * S + prm.e_L * R) : 0;
+    int nvalid;   // pairs of this lane's group that exist: psk in [0, nvalid)
+    {
+        const int64_t left_pairs = prm.P - pair0;
+        nvalid = left_pairs <= 0 ? 0 : (left_pairs < prm.PPG ? (int)left_pairs : prm.PPG);
+    }
+    int erow_lim = EDGES && lam == prm.lam_f ? prm.e_NUp : 0;          // this lane holds the terminal row: units below this
+    int ecol_uf = EDGES && lam < prm.e_L ? prm.u_f : -1;               // the unit whose block holds the terminal column
+    int ecol_off = EDGES ? prm.e_NUp * S + lam * R : 0;
+    asm volatile("" : "+v"(nvalid), "+v"(erow_lim), "+v"(ecol_uf), "+v"(ecol_off));
+    double *ep_cur = EDGES ? prm.edges + (pair0 + psk) * EP : nullptr;   // edge block of the pair the sweep is in
+    double *e_ptr = ep_cur;                                              // ... of the values held for the next step's stores
     double erow[S];
     int erow_at = -1, ecol_at = -1;
-    int64_t e_pair = 0;
     const int k_f = (prm.Mc - 1) % RC;
     const bool row_in_bot = k_f == RC - 1;   // then the row values are the `bot` state (see sk_wave.hip)
 
@@ -302,10 +316,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_y();
     issue_x();
-    read_y();
+    if (AHEAD) read_y();
     for (int t = 0; t < prm.n_steps; ++t) {
         if (EDGES) {   // the edge values of the previous macro-step, straight from the state registers
-            double *const ep = prm.edges + e_pair * EP;
+            double *const ep = e_ptr;
             if (erow_at >= 0) {
 #pragma unroll
                 for (int cc = 0; cc < S; cc += 2) {
@@ -370,6 +384,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
 
         // -- y differences of the two coarse columns of this macro-step, all 8 dims
         d2_t dyv[ND];
+        if (!AHEAD) read_y();
         lds_dims_wait(dyv, dyn);
 
         // -- top row of the block from the lane above
@@ -485,10 +500,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         corner = top[S - 1];
 
         if (EDGES) {
-            const bool pair_ok = psk >= 0 && psk < prm.PPG && pair0 + psk < prm.P;
-            e_pair = pair0 + psk;
-            erow_at = (pair_ok && lam == prm.lam_f && uk < prm.e_NUp) ? uk * S : -1;
-            ecol_at = (pair_ok && uk == prm.u_f && lam < prm.e_L) ? prm.e_NUp * S + lam * R : -1;
+            const bool pair_ok = (unsigned)psk < (unsigned)nvalid;
+            e_ptr = ep_cur;
+            erow_at = (pair_ok && uk < erow_lim) ? uk * S : -1;
+            ecol_at = (pair_ok && uk == ecol_uf) ? ecol_off : -1;
             if (!row_in_bot) {
 #pragma unroll
                 for (int kk = 0; kk < RC - 1; ++kk)
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (uk == my_uf) {
             int pv = psk;
             asm volatile("" : "+v"(pv));   // keeps the pair tests inside this (rarely taken) branch instead of in every step
-            if (pv >= 0 && pv < prm.PPG && pair0 + pv < prm.P) {
+            if ((unsigned)pv < (unsigned)nvalid) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -520,29 +535,38 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         // -- advance
         if (RBF) {
             uk += 1;
-            if (uk == NUp) { uk = 0; psk += 1; }
+            if (uk == NUp) {
+                uk = 0;
+                psk += 1;
+                if (EDGES) ep_cur += EP;
+            }
         }
         u += 1;
         if (((t + 1) & 7) == lam7) {   // (u & 7) == 0: u = t + 1 - lam modulo 8 (NUp is a multiple of 8)
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
-            if (u == NUp) { u = 0; ps += 1; }
+            if (u == NUp) {
+                u = 0;
+                ps += 1;
+                if (EDGES && !RBF) ep_cur += EP;
+            }
         }
         if (!RBF) { uk = u; psk = ps; }
         if (((t + 1) & 7) == 0) {
-            // everything issued 8 macro-steps ago has had a whole slab period to land
+            // everything issued 8 macro-steps ago has had a whole slab period to land (leaving this step's edge stores in
+            // flight with a counted wait was measured: no gain, their cost is issue slots, not latency)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             issue_y();       // slab ((t + 1) >> 3) + 1
             issue_x();       // window t + 9 .. t + 16
         }
-        read_y();            // for macro-step t + 1
+        if (AHEAD) read_y();   // for macro-step t + 1
     }
-    {   // the last read-ahead is never used, but its registers are not free before it has landed
+    if (AHEAD) {   // the last read-ahead is never used, but its registers are not free before it has landed
         d2_t drain[ND];
         lds_dims_wait(drain, dyn);
     }
     if (EDGES) {
-        double *const ep = prm.edges + e_pair * EP;
+        double *const ep = e_ptr;
         if (erow_at >= 0) {
 #pragma unroll
             for (int cc = 0; cc < S; ++cc) ep[erow_at + cc] = row_in_bot ? bot[cc] : erow[cc];
@@ -555,41 +579,68 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// What the launcher has worked out before the kernel variant (and with it the register budget) is known
+struct FusedPlan {
+    int64_t P;
+    int G, NUp, L, lag;
+    size_t lds_bytes;   // per wave
+    int waves_per_cu;   // from LDS and the measured optimum; still to be capped by the variant's VGPR use
+};
+
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
-int launch_fused_nd(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND>;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
+    // persistent waves: all of them must be resident at once, so the variant's VGPR count caps the waves per SIMD
+    // (512 VGPRs per lane and SIMD; a variant over 168 holds two waves per SIMD, not three)
+    static int vgprs = 0;
+    if (vgprs == 0) {
+        hipFuncAttributes attr;
+        vgprs = hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 128;
+    }
+    int waves_per_cu = pl.waves_per_cu;
+    const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
+    if (waves_per_cu > by_regs) waves_per_cu = by_regs;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    const int64_t max_waves = 256LL * waves_per_cu;
+    int64_t waves = (pl.P + pl.G - 1) / pl.G;
+    if (waves > max_waves) waves = max_waves;
+    int64_t PPG = (pl.P + waves * pl.G - 1) / (waves * pl.G);
+    waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);
+    if (PPG > 0x3fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
+    prm.PPG = (int)PPG;
+    prm.n_steps = (int)(PPG * pl.NUp + (pl.L - 1)) + pl.lag;
+    prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
+    const size_t lds_block = wave_group_lds(prm.wg);
+    if (lds_block > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
+    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
     return check_launch();
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
-int launch_fused_e(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+int launch_fused_e(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     // paths of dimension <= 4 skip the four zero dimensions (fp64, default scheme: the variants that are worth their build time)
     if constexpr (!NAIVE && sizeof(TO) == 8) {
-        if (prm.dims <= 4) return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, blocks, lds_bytes, s);
+        if (prm.dims <= 4) return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, pl, s);
     }
-    return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, blocks, lds_bytes, s);
+    return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
-int launch_fused_one(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+int launch_fused_one(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     if constexpr (sizeof(TO) == 8) {   // the adjoint that consumes the edges exists for fp64, d = 0..2
-        if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true, KIND>(prm, blocks, lds_bytes, s);
+        if (prm.edges) return launch_fused_e<TO, DY, NAIVE, FULLWAVE, true, KIND>(prm, pl, s);
     }
     if (prm.edges) return SK_ERR_UNSUPPORTED;
-    return launch_fused_e<TO, DY, NAIVE, FULLWAVE, false, KIND>(prm, blocks, lds_bytes, s);
+    return launch_fused_e<TO, DY, NAIVE, FULLWAVE, false, KIND>(prm, pl, s);
 }
 
 template <typename TO, int DY, int KIND>
-int launch_fused_dy(const FusedParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
+int launch_fused_dy(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     const bool full = prm.logL == 6;
     if (prm.naive)
-        return full ? launch_fused_one<TO, DY, true, true, KIND>(prm, blocks, lds_bytes, s)
-                    : launch_fused_one<TO, DY, true, false, KIND>(prm, blocks, lds_bytes, s);
-    return full ? launch_fused_one<TO, DY, false, true, KIND>(prm, blocks, lds_bytes, s)
-                : launch_fused_one<TO, DY, false, false, KIND>(prm, blocks, lds_bytes, s);
+        return full ? launch_fused_one<TO, DY, true, true, KIND>(prm, pl, s) : launch_fused_one<TO, DY, true, false, KIND>(prm, pl, s);
+    return full ? launch_fused_one<TO, DY, false, true, KIND>(prm, pl, s) : launch_fused_one<TO, DY, false, false, KIND>(prm, pl, s);
 }
 
 // KIND 0: dXr [A][Mrows][8] / dYt [Bn][8][Ncp] are path differences; KIND 1: the same layouts hold the path points.
@@ -628,17 +679,11 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
-    int64_t waves = (g.P + G - 1) / G;
-    if (waves > max_waves) waves = max_waves;
-    int64_t PPG = (g.P + waves * G - 1) / (waves * G);
-    waves = (g.P + PPG * G - 1) / (PPG * G);
-    if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+    const FusedPlan pl{g.P, G, NUp, L, KIND == 1 ? 2 : 0, lds_bytes, waves_per_cu};
 
     FusedParams prm;
     prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.edges = strip_edges; prm.P = g.P; prm.B = B;
-    prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL; prm.PPG = (int)PPG;
-    prm.n_steps = (int)(PPG * NUp + (L - 1)) + (KIND == 1 ? 2 : 0);
+    prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.inv_sigma = inv_sigma;
     prm.dims = D;
     prm.e_NUp = NUp;
@@ -654,13 +699,10 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.sel_f = ((g.Mc - 1) % RC) * 2 + (g.Nc - 1) % 2;
     prm.naive = g.naive;
     (void)A;
-    prm.wg = wave_group(lds_bytes, waves, "SK_FUSED_WPB");
-    const int blocks = wave_group_blocks(prm.wg);
-    const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
-        case 0: return launch_fused_dy<TO, 0, KIND>(prm, blocks, lds_block, s);
-        case 1: return launch_fused_dy<TO, 1, KIND>(prm, blocks, lds_block, s);
-        default: return launch_fused_dy<TO, 2, KIND>(prm, blocks, lds_block, s);
+        case 0: return launch_fused_dy<TO, 0, KIND>(prm, pl, s);
+        case 1: return launch_fused_dy<TO, 1, KIND>(prm, pl, s);
+        default: return launch_fused_dy<TO, 2, KIND>(prm, pl, s);
     }
 }
 
