@@ -456,18 +456,23 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
 
 // linear: T2[b][q][k] = sum_a s_ab sum_p W[a,b,p,q] * dXr[a][p][k]   (dXr [A][Mrows][8]: scaled row differences, as the
 // fused forward takes them);  the caller forms dL/dy[b][n] = T2[b][n-1] - T2[b][n].
-template <typename T, int NT>
-__global__ __launch_bounds__(NT) void k_linear_adj2(const double *__restrict__ dXr, int Mrows, const T *__restrict__ W,
-                                                    int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0,
-                                                    int Mc, int Nc, int D, int col_tiles, T *__restrict__ Tout) {
+// A block is NT columns x NW waves: the waves split the sum over a (wave w takes a = w, w + NW, ...) and add their partial
+// sums through LDS in a fixed order, so the result does not depend on scheduling.  One wave per (b, column tile) left the
+// chip with a few waves per CU, each serially dependent on its own loads (measured on the rbf kernel: 1.1 TB/s).
+template <typename T, int NT, int NW>
+__global__ __launch_bounds__(NT *NW) void k_linear_adj2(const double *__restrict__ dXr, int Mrows, const T *__restrict__ W,
+                                                         int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0,
+                                                         int Mc, int Nc, int D, int col_tiles, T *__restrict__ Tout) {
     constexpr int DP = 8;
+    __shared__ double red[NW][DP][NT];
+    const int wv = threadIdx.x / NT, col = threadIdx.x % NT;
     const int64_t b = b0 + blockIdx.x / col_tiles;
-    const int q = (int)(blockIdx.x % col_tiles) * NT + threadIdx.x;
+    const int q = (int)(blockIdx.x % col_tiles) * NT + col;
     const int qc = min(q, Nc - 1);
     double acc[DP];
 #pragma unroll
     for (int k = 0; k < DP; ++k) acc[k] = 0.0;
-    for (int64_t a = 0; a < A; ++a) {
+    for (int64_t a = wv; a < A; a += NW) {
         const int64_t p = a * B + b;
         const double s = scale ? (double)scale[p] : 1.0;
         const T *w = W + p * Mc * ldw + qc;
@@ -490,22 +495,30 @@ __global__ __launch_bounds__(NT) void k_linear_adj2(const double *__restrict__ d
             for (int k = 0; k < DP; ++k) acc[k] = fma(c, dx[i * DP + k], acc[k]);
         }
     }
-    if (q < Nc) {
 #pragma unroll
-        for (int k = 0; k < DP; ++k)
-            if (k < D) Tout[((b - b0) * Nc + q) * (int64_t)D + k] = (T)acc[k];
+    for (int k = 0; k < DP; ++k) red[wv][k][col] = acc[k];
+    __syncthreads();
+    if (wv == 0 && q < Nc) {
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            double v = red[0][k][col];
+            for (int w = 1; w < NW; ++w) v += red[w][k][col];
+            if (k < D) Tout[((b - b0) * Nc + q) * (int64_t)D + k] = (T)v;
+        }
     }
 }
 
 // rbf: dL/dy[b][n][k] = (2/sigma) sum_a s_ab sum_m dG[m][n] G[m][n] (x[a][m][k] - y[b][n][k]),
 //      dG[m][n] = t_m - t_{m-1},  t_m = W[m][n] - W[m][n-1] (zero outside the matrix)
-template <typename T, int DMAX, int NT>
-__global__ __launch_bounds__(NT) void k_rbf_adj2(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W,
-                                                 int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0, int M,
-                                                 int N, int D, double inv_sigma, int col_tiles, T *__restrict__ gY) {
+template <typename T, int DMAX, int NT, int NW>
+__global__ __launch_bounds__(NT *NW) void k_rbf_adj2(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W,
+                                                      int64_t ldw, const T *__restrict__ scale, int64_t A, int64_t B, int b0, int M,
+                                                      int N, int D, double inv_sigma, int col_tiles, T *__restrict__ gY) {
+    __shared__ double red[NW][DMAX][NT];   // see k_linear_adj2: the waves of a block split the sum over a
+    const int wv = threadIdx.x / NT, col = threadIdx.x % NT;
     const int Mc = M - 1, Nc = N - 1;
     const int64_t b = b0 + blockIdx.x / col_tiles;
-    const int n = (int)(blockIdx.x % col_tiles) * NT + threadIdx.x;
+    const int n = (int)(blockIdx.x % col_tiles) * NT + col;
     const int nn = min(n, N - 1);
     const bool lf = nn >= 1, rt = nn < Nc;
     const int nl = max(nn - 1, 0), nr = min(nn, Nc - 1);
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(NT) void k_rbf_adj2(const T *__restrict__ X, const 
     }
     constexpr int MR = 4;   // node rows per iteration and path: their loads of W are issued before any is used
     constexpr int AU = 2;   // paths x_a in flight: independent exp chains (one wave per block leaves the SIMD little else)
-    for (int64_t a0 = 0; a0 < A; a0 += AU) {
+    for (int64_t a0 = (int64_t)wv * AU; a0 < A; a0 += NW * AU) {
         double s[AU], tprev[AU];
         const T *w[AU], *x[AU];
 #pragma unroll
@@ -563,10 +576,16 @@ __global__ __launch_bounds__(NT) void k_rbf_adj2(const T *__restrict__ X, const 
             }
         }
     }
-    if (n < N) {
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k)
-            if (k < D) gY[((b - b0) * N + n) * (int64_t)D + k] = (T)(2.0 * inv_sigma * acc[k]);
+    for (int k = 0; k < DMAX; ++k) red[wv][k][col] = acc[k];
+    __syncthreads();
+    if (wv == 0 && n < N) {
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            double v = red[0][k][col];
+            for (int w = 1; w < NW; ++w) v += red[w][k][col];
+            if (k < D) gY[((b - b0) * N + n) * (int64_t)D + k] = (T)(2.0 * inv_sigma * v);
+        }
     }
 }
 
@@ -720,19 +739,20 @@ int launch_static_adjoint2(int kind, double param, const T *X, const T *Y, const
         const int Nc = N - 1;
         const int col_tiles = (Nc + 63) / 64;
         if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_linear_adj2<T, 64>), dim3((unsigned)(nbk * col_tiles)), dim3(64), 0, s, dXr, Mrows, W, ldw, scale, A,
-                           B, b0, M - 1, Nc, D, col_tiles, out);
+        hipLaunchKernelGGL((k_linear_adj2<T, 64, 8>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * 8), 0, s, dXr, Mrows, W, ldw,
+                           scale, A, B, b0, M - 1, Nc, D, col_tiles, out);
         return check_launch();
     }
     const int col_tiles = (N + 63) / 64;
     if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-#define SK_RBF2(DM)                                                                                                     \
-    hipLaunchKernelGGL((k_rbf_adj2<T, DM, 64>), dim3((unsigned)(nbk * col_tiles)), dim3(64), 0, s, X, Y, W, ldw, scale, A, B, \
-                       b0, M, N, D, 1.0 / param, col_tiles, out)
-    if (D <= 4) SK_RBF2(4);
-    else if (D <= 8) SK_RBF2(8);
-    else if (D <= 16) SK_RBF2(16);
-    else if (D <= 32) SK_RBF2(32);
+    // 32 KB of LDS for the partial sums whatever the dimension: 8 waves up to dim 8, 4 at 16, 2 at 32
+#define SK_RBF2(DM, NW)                                                                                                  \
+    hipLaunchKernelGGL((k_rbf_adj2<T, DM, 64, NW>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * NW), 0, s, X, Y, W, ldw, scale, \
+                       A, B, b0, M, N, D, 1.0 / param, col_tiles, out)
+    if (D <= 4) SK_RBF2(4, 8);
+    else if (D <= 8) SK_RBF2(8, 8);
+    else if (D <= 16) SK_RBF2(16, 4);
+    else if (D <= 32) SK_RBF2(32, 2);
     else return SK_ERR_UNSUPPORTED;
 #undef SK_RBF2
     return check_launch();
