@@ -132,4 +132,58 @@ inline int check_launch() {
     return hipGetLastError() == hipSuccess ? SK_OK : SK_ERR_LAUNCH;
 }
 
+// ---- device math shared by the RBF kernels (sk_wave_fused.hip, sk_static.hip) ----------------------------------------
+// exp(x) for finite x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-term ln 2), Taylor polynomial of
+// degree 13 in |r| <= ln2 / 2 (truncation 4e-18), result scaled by 2^n; underflow goes through v_ldexp to 0.  Without the
+// range checks and special cases of the library exp this is 19 VALU instructions.
+// The 11 polynomial coefficients that are not inline constants live in VGPRs: as SGPR pairs they push the kernel's scalar
+// state into spills (v_readlane in the hot loop).
+struct ExpCoef {
+    double c[11];   // 1/13!, 1/12!, ..., 1/3!
+    __device__ __forceinline__ void init() {
+        const double k[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            c[i] = k[i];
+            asm volatile("" : "+v"(c[i]));
+        }
+    }
+};
+__device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
+    x = fmax(x, -800.0);   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = e.c[0];
+#pragma unroll
+    for (int i = 1; i < 11; ++i) p = fma(p, r, e.c[i]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+// the same with the coefficients left to the compiler (kernels whose scalar register file has room for them)
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -800.0);
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 }  // namespace sk

@@ -372,9 +372,10 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
     const int Mc = M - 1, Nc = N - 1;
     const int64_t a = blockIdx.x / row_groups;
     const int m0 = (int)(blockIdx.x % row_groups) * RM;
-    double xm[RM][DMAX], xs[RM], acc[RM][DMAX];
+    double xm[RM][DMAX], xs[RM], acc[RM][DMAX], cs[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
+        cs[r] = 0.0;
         const int m = min(m0 + r, M - 1);
         const T *x = X + (a * M + m) * (int64_t)D;
         xs[r] = 0.0;
@@ -402,11 +403,17 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
             wv[r] = (double)w[ro + nr];
         }
     };
+    // Per node the contribution is c (x_r - y): with d = y - x_ref (x_ref = the block's first row, so |d| is the size of the
+    // true difference and nothing cancels) it is accumulated as  cs[r] += c,  accd[r][k] += c d[k]  -- 9 operations instead
+    // of 16 -- and put together after the loops:  sum c (x_r - y) = (x_r - x_ref) cs[r] - accd[r][k].
     auto use = [&](int n, const double (&yn)[DMAX], const double (&wl)[RM + 1], const double (&wv)[RM + 1], double s) {
         const bool lf = n >= 1, rt = n < Nc;
-        double ys = 0.0, t[RM + 1];   // t[r] = W[r][n] - W[r][n-1] for W rows m0 - 1 + r (zero outside the matrix)
+        double ys = 0.0, t[RM + 1], dk[DMAX];   // t[r] = W[r][n] - W[r][n-1] for W rows m0 - 1 + r (zero outside the matrix)
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) ys = fma(yn[k], yn[k], ys);
+        for (int k = 0; k < DMAX; ++k) {
+            ys = fma(yn[k], yn[k], ys);
+            dk[k] = yn[k] - xm[0][k];
+        }
 #pragma unroll
         for (int r = 0; r <= RM; ++r) {
             const int wr = m0 - 1 + r;
@@ -418,10 +425,12 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
             double xy = 0.0;
 #pragma unroll
             for (int k = 0; k < DMAX; ++k) xy = fma(xm[r][k], yn[k], xy);
-            const double g = exp(-(fma(-2.0, xy, xs[r] + ys)) * inv_sigma);
+            // rbf: dist = -2 xy + (xs + ys) as the reference forms it (static_kernels.py:70-73); G = exp(-dist / sigma)
+            const double g = exp_nonpos(-(fma(-2.0, xy, xs[r] + ys)) * inv_sigma);   // (a rounding-size positive argument is fine)
             const double c = (m0 + r < M ? s : 0.0) * (t[r + 1] - t[r]) * g;
+            cs[r] += c;
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(c, xm[r][k] - yn[k], acc[r][k]);
+            for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(c, dk[k], acc[r][k]);
         }
     };
     for (int n = threadIdx.x; n < N; n += NT) {
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, 
     for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) {
-            const double v = block_sum<NT>(acc[r][k], red);
+            const double v = block_sum<NT>(fma(xm[r][k] - xm[0][k], cs[r], -acc[r][k]), red);
             if (threadIdx.x == 0 && k < D && m0 + r < M) gX[(a * M + m0 + r) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
         }
 }

@@ -126,37 +126,6 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
                  : "memory");
 }
 
-// exp(x) for finite x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-term ln 2), Taylor polynomial of
-// degree 13 in |r| <= ln2 / 2 (truncation 4e-18), result scaled by 2^n; underflow goes through v_ldexp to 0.  Without the
-// range checks and special cases of the library exp this is 19 VALU instructions.
-// The 11 polynomial coefficients that are not inline constants live in VGPRs: as SGPR pairs they push the kernel's scalar
-// state into spills (v_readlane in the hot loop).
-struct ExpCoef {
-    double c[11];   // 1/13!, 1/12!, ..., 1/3!
-    __device__ __forceinline__ void init() {
-        const double k[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
-                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
-#pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            c[i] = k[i];
-            asm volatile("" : "+v"(c[i]));
-        }
-    }
-};
-__device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
-    x = fmax(x, -800.0);   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points
-    const double n = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = e.c[0];
-#pragma unroll
-    for (int i = 1; i < 11; ++i) p = fma(p, r, e.c[i]);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)n);
-}
-
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
