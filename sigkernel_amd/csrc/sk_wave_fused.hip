@@ -239,8 +239,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
     // of the first row of the lane below at the columns of units uk and uk + 1
     double own[RBF ? RC : 1][6], bel[4];
+    // the variant that also keeps edges has no 22 VGPRs to spare for the coefficients below the 3-waves-per-SIMD line
+    constexpr bool PIN_EXP = RBF && !EDGES;
     ExpCoef expc;
-    if (RBF) expc.init();
+    if (PIN_EXP) expc.init();
 #pragma unroll
     for (int k = 0; k < (RBF ? RC : 1); ++k)
 #pragma unroll
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         const double df = dxr[k][j] - dyv[j][q];
                         d2 = fma(df, df, d2);
                     }
-                    own[k][4 + q] = exp_nonpos(-d2 * prm.inv_sigma, expc);
+                    own[k][4 + q] = PIN_EXP ? exp_nonpos(-d2 * prm.inv_sigma, expc) : exp_nonpos(-d2 * prm.inv_sigma);
                 }
             // the node row below this lane's last coarse row is the first row of the lane below, which is one macro-step
             // behind: what it has just evaluated are the columns of unit u - 1 = uk + 1
