@@ -105,6 +105,20 @@ int sk_linear_adjoint_f64(const double *dYt, int64_t ldy, const double *W, int64
 int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_t ldw, const float *scale, int64_t A, int64_t B,
                           int Mc, int Nc, int D, float *out, void *stream);
 
+/* Adjoint PDE AND LinearKernel contraction in one kernel (csrc/sk_wave_adj_fused.hip): the reverse sweep forms its increments
+ * from the path differences, recomputes K from the terminal edges a forward with edges kept (sk_solve_fwd_linear_edges_f64),
+ * and contracts W = d k / d inc with the y differences on the spot -- neither the increments nor W exist in HBM.  Replaces
+ * sigkernel.py:438-500 for LinearKernel, i.e. sk_static_increments + sk_solve_adj(EDGES_GIVEN) + sk_linear_adjoint.
+ *   dXr, dYt, Mrows, Ncp: the arrays sk_solve_fwd_linear_* takes;  edges: sk_strip_edges_bytes layout;  scale [A*B] nullable.
+ *   tpart [tpart_doubles] receives partial sums over b: viewed as [A][B / *ppg_out][*rows_out][8], sum over the chunk axis,
+ *   then T[a][p][:] = that[a][*rows_out - 1 - p][:] for p < Mc is what sk_linear_adjoint_* returns.  tpart == NULL: only
+ *   *ppg_out and *rows_out are set (size query: A * (B / ppg) * rows * 8 doubles).  err [A*B] zero-initialised: per-pair
+ *   self-check residual as for sk_solve_adj_*.  Gram only (B >= 1), fp64, dyadic 1 or 2, default scheme, one band per pair,
+ *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED. */
+int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                                int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
+                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream);
+
 /* Second-argument adjoint (Gram only): dL/dY from W for the pairs (a, b), b >= b0 -- the counterpart of sk_static_adjoint_*
  * that the reference never needs (it returns no gradient for its second argument, sigkernel.py:343, :412).  It exists for
  * compute_Gram(X, X, sym=True) with a gradient: only the blocks on and above the diagonal are solved, and a pair (a, b)

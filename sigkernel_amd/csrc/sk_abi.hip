@@ -275,6 +275,18 @@ int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t 
     return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, edges, (hipStream_t)stream);
 }
 
+int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
+                                int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
+                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream) {
+    if (!dXr || !dYt || !edges || A < 0 || B < 1 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (tpart && !err) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(A * B, Mc, Nc, dyadic, scheme);
+    return launch_adj_fused_linear(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, ppg_out, rows_out,
+                                   (hipStream_t)stream);
+}
+
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {
     if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16 || (elem_size != 4 && elem_size != 8)) return 0;
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);

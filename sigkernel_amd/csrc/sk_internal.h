@@ -96,6 +96,11 @@ template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, TO *out, double *strip_edges, hipStream_t s);
 
+// ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
+int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
+                            int *ppg_out, int *rows_out, hipStream_t s);
+
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);

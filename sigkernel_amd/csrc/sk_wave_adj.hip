@@ -49,73 +49,6 @@ struct AdjParams {
 // 14.8 ms, PF = 1 with 4 waves/CU 17.4 ms: occupancy buys more than prefetch depth.
 constexpr int ADJ_PF = 1;
 
-// Asynchronous 8-byte global loads into registers.  The compiler must never touch a destination register between the
-// load and the wait (it does not know the value is still in flight -- its own waitcnt insertion would drain every
-// LDS-DMA at the first use, which is why these are asm).  So the destinations are short-lived temporaries that nothing
-// reads: async_begin() defines them (no instruction), load_async() may or may not overwrite them (conditional code:
-// the merge is with an equally unread value, so no copy is needed), and async_wait() is the single instruction that
-// turns them into ordinary values -- its outputs are tied to the temporaries' registers.  tests/test_abi.py scans the
-// generated ISA for any instruction that touches a pending destination (tools/check_async_hazards.py).
-__device__ __forceinline__ void async_begin(double &t) { asm volatile("" : "=v"(t)); }
-__device__ __forceinline__ void load_async(double &dst, const double *p) {
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-template <int BYTE_OFF>   // immediate offset (13-bit signed): one address register pair serves a run of loads
-__device__ __forceinline__ void load_async_at(double &dst, const double *p) {
-    asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(BYTE_OFF) : "memory");
-}
-// dst[i] <- p[-i], i = 0 .. N-1
-template <int N, int M>
-__device__ __forceinline__ void load_run(double (&dst)[M], const double *p) {
-    static_assert(N <= M && N <= 8, "");
-    if constexpr (N > 0) load_async_at<0>(dst[0], p);
-    if constexpr (N > 1) load_async_at<-8>(dst[1], p);
-    if constexpr (N > 2) load_async_at<-16>(dst[2], p);
-    if constexpr (N > 3) load_async_at<-24>(dst[3], p);
-    if constexpr (N > 4) load_async_at<-32>(dst[4], p);
-    if constexpr (N > 5) load_async_at<-40>(dst[5], p);
-    if constexpr (N > 6) load_async_at<-48>(dst[6], p);
-    if constexpr (N > 7) load_async_at<-56>(dst[7], p);
-}
-
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[4], double (&t)[4]) {
-    asm volatile("s_waitcnt vmcnt(%8)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3])
-                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "n"(VM) : "memory");
-}
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[1], double (&t)[1]) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "=v"(o[0]) : "0"(t[0]), "n"(VM) : "memory");
-}
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[2], double (&t)[2]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "=v"(o[0]), "=v"(o[1]) : "0"(t[0]), "1"(t[1]), "n"(VM) : "memory");
-}
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[3], double (&t)[3]) {
-    asm volatile("s_waitcnt vmcnt(%6)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]) : "0"(t[0]), "1"(t[1]), "2"(t[2]), "n"(VM) : "memory");
-}
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[5], double (&t)[5]) {
-    asm volatile("s_waitcnt vmcnt(%10)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4])
-                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "n"(VM) : "memory");
-}
-template <int VM>
-__device__ __forceinline__ void async_wait(double (&o)[8], double (&t)[8]) {
-    asm volatile("s_waitcnt vmcnt(%16)"
-                 : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7])
-                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "5"(t[5]), "6"(t[6]), "7"(t[7]), "n"(VM) : "memory");
-}
-
-// 1/b for b = 1 - g^2/12 (close to 1): hardware estimate + two Newton steps, instead of the ~20-instruction IEEE
-// division sequence.  The result only has to be a consistent multiplier: a/b and 1/b are formed from the same value.
-__device__ __forceinline__ double fast_rcp(double b) {
-    double x = __builtin_amdgcn_rcp(b);
-    x = fma(x, fma(-b, x, 1.0), x);
-    x = fma(x, fma(-b, x, 1.0), x);
-    return x;
-}
-
 __device__ __forceinline__ void store_unit(double *dst, double a, double b) {
     d2_t v = {a, b};
     *reinterpret_cast<d2_t *>(dst) = v;

@@ -1,0 +1,448 @@
+// sk_wave_adj_fused.hip -- the adjoint solver with the LINEAR static kernel fused in, both ways:
+//   * the increments of the reverse sweep are formed from the path differences inside the kernel (the two LDS rings of
+//     sk_wave_fused.hip, filled back to front), so no increment matrix is read;
+//   * the weights W = d k / d inc are contracted on the spot with the y differences they belong to,
+//         T[a][p][:] = sum_b s_ab sum_q W[a,b,p,q] (y_b[q+1] - y_b[q])          (what sk_linear_adjoint_* forms from W),
+//     accumulated in registers over the pairs of one lane group, so no W matrix is written or read either.
+// What remains in HBM is the paths, the terminal edges the (fused) forward kept, and (chunks x A x M x 8) partial sums.
+// The two-state sweep itself (reverse PDE + backward recompute of K from the edges, self-check) is the one of
+// sk_wave_adj.hip; see there for the mathematics and for the edge prefetch.
+//
+// Decomposition: a lane group sweeps PPG consecutive pairs (a, b0 .. b0 + PPG - 1) of ONE path x_a -- the launcher picks
+// PPG as a divisor of B -- so its registers hold a partial sum over b for that a; it is stored (plain stores, no atomics:
+// the result does not depend on scheduling) to Tpart[group][flipped row][8], and the host adds the B / PPG chunks of an a.
+// Scope: Gram (B > 0), fp64, path dim <= 8, one band per pair, dyadic <= 2, default scheme.
+#include "sk_wave_common.h"
+
+namespace sk {
+namespace {
+
+constexpr int FD = 8;
+constexpr int Y_SLAB_PITCH = FD * 128;
+constexpr int X_SLOTS = 2;
+
+struct AdjFusedParams {
+    const double *dXr;     // [A][Mrows][8]  s^2 (x[p+1]-x[p]), zero rows / dims beyond Mc / D
+    const double *dYt;     // [B][8][Ncp]    y[q+1]-y[q], dimension-major, zero columns / dims beyond Nc / D
+    const double *edges;   // [P][NNp + MMp] strip layout (strip_geom)
+    const double *scale;   // [P] upstream gradient per pair, nullable
+    double *Tpart;         // [P / PPG][L*RC][8]  partial sums, flipped coarse rows
+    double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
+    int64_t P, B;
+    int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
+    WaveGroup wg;
+};
+
+__device__ __forceinline__ void lds_read_dims8(d2_t (&v)[8], unsigned a_even, unsigned a_odd) {
+    asm volatile("ds_read_b128 %0, %8\n\t"
+                 "ds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %8 offset:256\n\t"
+                 "ds_read_b128 %3, %9 offset:256\n\t"
+                 "ds_read_b128 %4, %8 offset:512\n\t"
+                 "ds_read_b128 %5, %9 offset:512\n\t"
+                 "ds_read_b128 %6, %8 offset:768\n\t"
+                 "ds_read_b128 %7, %9 offset:768\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a_even), "v"(a_odd)
+                 : "memory");
+}
+// RC consecutive 64-byte rows, one wait
+template <int NB128>
+__device__ __forceinline__ void lds_read_run(d2_t (&v)[NB128], unsigned a);
+template <>
+__device__ __forceinline__ void lds_read_run<4>(d2_t (&v)[4], unsigned a) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
+}
+
+template <int DY, bool FULLWAVE>
+__global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
+    constexpr int CW = 2;
+    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int XSLAB = RC * 512;
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
+    const unsigned lds0 = lds_offset(lds);
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int L = 1 << prm.logL, G = WAVE >> prm.logL;
+    const int lam = lane & (L - 1), grp = lane >> prm.logL;
+    const int NUp = prm.NUp;
+    const int Mcp = L * RC;
+    const int MM = prm.Mc << DY, MMp = Mcp << DY, NNp = (NUp * CW) << DY;
+    const int NSLAB = (L >> 3) + 2;
+    const unsigned y_bytes = (unsigned)(NSLAB * Y_SLAB_PITCH);
+    const unsigned x_base0 = (unsigned)G * y_bytes;
+    const double sc = 1.0 / (double)(1 << (2 * DY));
+    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+
+    // ---- consumer state (flipped coordinates; one band per pair) ---------------------------------------------------------
+    int u, ps;
+    {
+        ps = floor_div(-lam, NUp);
+        u = -lam - ps * NUp;
+    }
+    int yslab, ypar;
+    {
+        const int s0 = floor_div(-lam, 8);
+        yslab = ((s0 % NSLAB) + NSLAB) % NSLAB;
+        ypar = (s0 + grp) & 1;
+    }
+    const int lam7 = lam & 7;
+    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;   // all PPG pairs of the group share one a (PPG divides B)
+    const bool is_top = lam == 0;
+    const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
+    const int JMAX = (L + NUp - 1) / NUp;
+    const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * X_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
+                          (unsigned)((lam & 7) * RC * 64);
+
+    // ---- producers: the rings of sk_wave_fused.hip, filled in FLIPPED order ------------------------------------------------
+    // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
+    // columns stay in original order inside the 16-byte unit, as in the increment matrix the unfused kernel reads)
+    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
+    auto split_b = [&](int64_t p) -> int64_t { return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B; };
+    auto split_a = [&](int64_t p) -> int64_t { return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B; };
+    int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
+    auto issue_y = [&]() {
+        for (int g = 0; g < G; ++g) {
+            int64_t p = (wave_id * G + g) * prm.PPG + y_pi;
+            if (y_pi >= prm.PPG || p >= prm.P) p = 0;
+            const int64_t b = split_b(p);
+            const int krow = (lane >> 3) ^ ((y_par + g) & 1);
+            const int uo = NUp - 1 - (y_u0 + (lane & 7));
+            const double *src = prm.dYt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)uo * 2);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + y_slot * Y_SLAB_PITCH), 16, 0, 0);
+        }
+        y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
+        y_par ^= 1;
+        y_u0 += 8;
+        if (y_u0 == NUp) { y_u0 = 0; y_pi += 1; }
+    };
+    // x slabs: lanes lamj .. lamj+7 start pair pi during the window; LDS position i = (lam & 7) * RC + k holds the flipped
+    // coarse row lamj*RC + i, i.e. original row Mcp - 1 - (lamj*RC + i): each DMA lane fetches its 16-byte piece from there
+    int x_q0 = 0, x_lam0 = 0, x_slot = 0;
+    auto issue_x = [&]() {
+        for (int j = 0; j < JMAX; ++j) {
+            const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
+            if (lamj >= L) break;
+            for (int g = 0; g < G; ++g) {
+                int64_t p = (wave_id * G + g) * prm.PPG + pi;
+                if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
+                const int64_t a = split_a(p);
+                char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
+#pragma unroll
+                for (int c = 0; c < (XSLAB + 1023) / 1024; ++c)
+                    if (c * 1024 + lane * 16 < XSLAB) {
+                        const int i = c * 16 + (lane >> 2);                 // row position inside the slab
+                        const int row = Mcp - 1 - (lamj * RC + i);          // original coarse row (>= Mc: zero padding)
+                        const double *src = prm.dXr + (a * prm.Mrows + row) * FD + (lane & 3) * 2;
+                        __builtin_amdgcn_global_load_lds(src, (lds_void *)(dst + c * 1024), 16, 0, 0);
+                    }
+            }
+        }
+        x_slot = x_slot + 1 == X_SLOTS ? 0 : x_slot + 1;
+        x_lam0 += 8;
+        if (x_lam0 == NUp) { x_lam0 = 0; x_q0 += 1; }
+    };
+
+    // ---- terminal edges and the upstream gradient of the coming pair, one macro-step ahead (sk_wave_adj.hip) ---------------
+    const int E = NNp + MMp;
+    auto prefetch_edges = [&](int nu, int nps, double (&prow)[S], double (&pcol)[R + 1], double &pscale) {
+        int64_t pr = pair0 + nps;
+        pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
+        const double *e = prm.edges + pr * E;
+        if (is_top) {
+            const double *q = e + (NNp - nu * S - 2);
+            load_run<S - 1>(prow, q);
+            load_async(prow[S - 1], nu == NUp - 1 ? e : q - (S - 1));
+        }
+        if (nu == 0) {
+            const int i0 = lam * RC * r;
+            const double *q = e + (NNp - 1);
+#pragma unroll
+            for (int i = 0; i < R; ++i) load_async(pcol[i], q + min(MM, MMp - (i0 + i)));
+            load_async(pcol[R], q + max(min(MM, MMp - (i0 + R)), 1));
+            if (prm.scale) load_async(pscale, prm.scale + pr);
+        }
+    };
+    auto fix_edges = [&](int nu, double (&prow)[S], double (&pcol)[R + 1]) {
+        if (nu == NUp - 1) prow[S - 1] = 1.0;
+        if (nu == 0 && lam * RC * r + R == MMp) pcol[R] = 1.0;
+    };
+
+    double dxr[RC][FD], tacc[RC][FD];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int j = 0; j < FD; ++j) { dxr[k][j] = 0.0; tacc[k][j] = 0.0; }
+    double ktopR[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) ktopR[i] = 1.0;
+    double leftR[R], botR[S], cornerR = 1.0;
+    double leftF[R], botF[S], cornerF = 1.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = 1.0; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { botR[i] = 1.0; botF[i] = 1.0; }
+    double chk_val = 0.0;
+    int64_t chk_pair = -1;
+    double s_pair = 0.0;    // upstream gradient of the pair being swept (0 outside the group's pairs)
+    double nrow[S], ncol[R + 1], nscale = 0.0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) nrow[i] = 1.0;
+#pragma unroll
+    for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
+
+    issue_y();
+    issue_x();
+    {
+        double prow[S], pcol[R + 1], pscale[1], tsc[1];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+#pragma unroll
+        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
+        async_begin(pscale[0]);
+        prefetch_edges(u, ps, prow, pcol, pscale[0]);
+        async_wait<0>(nrow, prow);
+        async_wait<0>(ncol, pcol);
+        async_wait<0>(tsc, pscale);
+        fix_edges(u, nrow, ncol);
+        nscale = (u == 0 && ps >= 0 && ps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+    }
+    issue_y();
+    issue_x();
+
+    for (int t = 0; t < prm.n_steps; ++t) {
+        if (chk_pair >= 0) {
+            atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
+            chk_pair = -1;
+        }
+        int nu = u + 1, nps = ps;
+        if (nu == NUp) { nu = 0; nps += 1; }
+
+        // -- start of a (flipped) pair: boundaries, upstream gradient, this lane's x rows
+        if (u == 0) {
+            cornerR = 1.0;
+            cornerF = ncol[0];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = ncol[i + 1]; }
+            s_pair = nscale;
+            const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                d2_t xv[4];
+                lds_read_run<4>(xv, xa + k * 64u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+            }
+        }
+
+        // -- y differences of the unit (original column order inside the unit)
+        d2_t dyv[FD];
+        {
+            const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
+            lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        }
+
+        // -- top rows
+        double topR[S], topF[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            if (FULLWAVE) {
+                ktopR[i] = dpp_shr1(botR[i], ktopR[i]);
+                topR[i] = ktopR[i];
+                topF[i] = dpp_shr1(botF[i], nrow[i]);
+            } else {
+                const double shR = dpp_shr1(botR[i], 1.0);
+                const double shF = dpp_shr1(botF[i], 1.0);
+                topR[i] = is_top ? 1.0 : shR;
+                topF[i] = is_top ? nrow[i] : shF;
+            }
+        }
+
+        // -- next step's edge values (asynchronous)
+        double prow[S], pcol[R + 1], pscale[1];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+#pragma unroll
+        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
+        async_begin(pscale[0]);
+        prefetch_edges(nu, nps, prow, pcol, pscale[0]);
+
+        // -- increments (original column order q = 0, 1 of the unit) and coefficients
+        double ginc[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                double g = 0.0;
+#pragma unroll
+                for (int j = 0; j < FD; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                ginc[k][q] = g;
+            }
+        double ca[RC][CW], cb[RC][CW], ca2[RC][CW], cib[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const double g = ginc[k][CW - 1 - q];   // flipped column order inside the unit
+                const double g2 = g * g;
+                ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                cb[k][q] = fma(g2, -c_12, 1.0);
+                cib[k][q] = fast_rcp(cb[k][q]);
+                ca2[k][q] = ca[k][q] * cib[k][q];
+            }
+
+        // -- sweep the block, accumulate K * Krev per coarse cell
+        double acc[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) acc[k][q] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+            double aboveR = topR[cc], diagR = cc == 0 ? cornerR : topR[cc - 1];
+            double aboveF = topF[cc], diagF = cc == 0 ? cornerF : topF[cc - 1];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int k = rr >> DY, q = cc >> DY;
+                const double a = ca[k][q], b = cb[k][q], a2 = ca2[k][q], ib = cib[k][q];
+                const double lR = leftR[rr], lF = leftF[rr];
+                const double vR = fma(aboveR, a, fma(lR, a, -(diagR * b)));
+                const double vF = fma(aboveF, a2, fma(lF, a2, -(diagF * ib)));
+                acc[k][q] = fma(vF, diagR, acc[k][q]);
+                diagR = lR; aboveR = vR; leftR[rr] = vR;
+                diagF = lF; aboveF = vF; leftF[rr] = vF;
+            }
+            botR[cc] = aboveR;
+            botF[cc] = aboveF;
+        }
+        cornerR = topR[S - 1];
+        cornerF = topF[S - 1];
+
+        // -- W of the RC x 2 coarse cells, contracted with the y differences of their columns.  Only lanes inside their group's
+        //    pairs take part (a branch, not a multiplication by zero: the leftovers other lanes sweep may hold NaNs from LDS
+        //    slabs that were never written, and 0 * NaN would poison the lane's sum)
+        if (s_pair != 0.0) {
+            const double wsc = sc * s_pair;
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                const double w0 = acc[k][1] * wsc, w1 = acc[k][0] * wsc;   // original columns 0 and 1 of the unit
+#pragma unroll
+                for (int j = 0; j < FD; ++j) tacc[k][j] = fma(w0, dyv[j][0], fma(w1, dyv[j][1], tacc[k][j]));
+            }
+        }
+
+        // -- self-check on the last flipped unit (see sk_wave_adj.hip)
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+            double e = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
+            chk_val = e;
+            chk_pair = pair0 + ps;
+        }
+
+        // -- close the step: the edge values (and any ring piece issued in the previous step) have landed
+        {
+            double tsc[1];
+            async_wait<0>(nrow, prow);
+            async_wait<0>(ncol, pcol);
+            async_wait<0>(tsc, pscale);
+            fix_edges(nu, nrow, ncol);
+            if (nu == 0) nscale = (nps >= 0 && nps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+        }
+
+        // -- advance; the next slab / window is requested right after the wait, so it has a whole macro-step before the
+        //    next closing wait asks for it
+        u = nu;
+        ps = nps;
+        if (((t + 1) & 7) == lam7) {
+            yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
+            ypar ^= 1;
+        }
+        if (((t + 1) & 7) == 0) {
+            issue_y();
+            issue_x();
+        }
+    }
+    if (chk_pair >= 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
+
+    // ---- the group's partial sums: Tpart[group][flipped coarse row][8] ------------------------------------------------------
+    {
+        const int64_t gi = wave_id * G + grp;
+        if (gi * prm.PPG < prm.P) {
+            double *dst = prm.Tpart + (gi * Mcp + (int64_t)lam * RC) * FD;
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int j = 0; j < FD; j += 2) {
+                    d2_t v = {tacc[k][j], tacc[k][j + 1]};
+                    *reinterpret_cast<d2_t *>(dst + k * FD + j) = v;
+                }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int DY, bool FULLWAVE>
+int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
+    auto kern = k_adj_fused_linear<DY, FULLWAVE>;
+    if (lds_block > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
+    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
+    return check_launch();
+}
+
+}  // namespace
+
+// Rows of Tpart = (P / PPG) * L * RC; *ppg_out / *rows_out tell the caller how to fold it: Tpart viewed as
+// [A][B / PPG][L*RC][8], summed over the chunks, rows flipped (coarse row p = L*RC - 1 - r).  tpart == nullptr: query only.
+int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
+                            int *ppg_out, int *rows_out, hipStream_t s) {
+    const int DY = g.dyadic;
+    // dyadic 0 (four coarse rows per lane) would need 316 VGPRs for the two 4 x 8 register arrays: left to the unfused route
+    if (DY < 1 || DY > 2 || B <= 0 || g.naive || g.P != A * B) return SK_ERR_UNSUPPORTED;
+    const Strip st = strip_geom(g, 8);
+    if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
+    const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
+    if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
+    const int JMAX = (L + NUp - 1) / NUp;
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);
+    if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
+
+    // pairs per lane group: the smallest divisor of B that keeps the launch within the resident waves (8 per CU: the
+    // kernel holds ~230 VGPRs, two waves per SIMD)
+    const int wpc = env_int("SK_ADJF_WPC", 8);
+    const int64_t max_groups = 256LL * wpc * G;
+    int64_t PPG = 0;
+    for (int64_t d = 1; d <= B; ++d)
+        if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
+    if (PPG == 0 || PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+    const int64_t groups = g.P / PPG;
+    if (ppg_out) *ppg_out = (int)PPG;
+    if (rows_out) *rows_out = L * RC;
+    if (!tpart) return SK_OK;
+    if (tpart_doubles < (size_t)groups * L * RC * FD) return SK_ERR_WORKSPACE;
+    const int64_t waves = (groups + G - 1) / G;
+
+    AdjFusedParams prm;
+    prm.dXr = dXr; prm.dYt = dYt; prm.edges = edges; prm.scale = scale; prm.Tpart = tpart; prm.err = err;
+    prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
+    prm.PPG = (int)PPG;
+    prm.n_steps = (int)(PPG * NUp + (L - 1));
+    prm.wg = wave_group(lds_bytes, waves, "SK_ADJF_WPB");
+    const size_t lds_block = wave_group_lds(prm.wg);
+    const bool full = logL == 6;
+    switch (DY) {
+        case 1: return full ? launch_adjf<1, true>(prm, lds_block, s) : launch_adjf<1, false>(prm, lds_block, s);
+        default: return full ? launch_adjf<2, true>(prm, lds_block, s) : launch_adjf<2, false>(prm, lds_block, s);
+    }
+}
+
+}  // namespace sk

@@ -249,6 +249,57 @@ def test_fuzz_random_shapes_against_oracle(be):
                 assert rel_err(K.cpu().numpy(), O.solve_coarse(O.increments(G), d, naive, nthreads=8)) <= 1e-11, (it, A, B, Mc, Nc, D, d)
 
 
+def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
+    """sk_linear_adjoint_fused_f64 (adjoint PDE + LinearKernel contraction in one kernel, from the paths and the forward's
+    edges) against sk_static_increments -> sk_solve_adj -> sk_linear_adjoint on 80 random shapes; dL/dX agrees to 1e-11
+    (or to the kernel's own self-check residual where the kernel values are large)."""
+    monkeypatch.setattr(type(be), "ADJ_RESIDUAL_TOL", 1e-5)   # compare also where the product path would call the rescue
+    rng = np.random.default_rng(99)
+    n = 0
+    for it in range(80):
+        d = int(rng.integers(1, 3))
+        cap = 64 * (4 >> d)
+        M = int(rng.integers(2, cap + 1)) if it % 4 else cap
+        N = int(rng.integers(2, 200))
+        A, B, D = int(rng.integers(1, 30)), int(rng.integers(1, 48)), int(rng.integers(1, 9))
+        par = 1.0 if it % 3 else float(rng.uniform(0.5, 1.5))
+        gen = torch.Generator().manual_seed(2000 + it)
+        X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+        go = torch.randn(A * B, generator=gen, dtype=torch.float64).to(DEV) if it % 5 else None
+        K, edges = be.solve_fwd_fused_linear(X, Y, par, d, False, gram=True, keep_edges=True)
+        assert edges is not None
+        inc = be.static_increments(0, par, X, Y, gram=True)
+        _, W = be.solve_adj(inc, d, False, edges=edges, flags=_lib.FLAG_FAST_ONLY)
+        want = be.static_adjoint(0, par, X, Y, W, go, True)
+        got = be.linear_adjoint_fused(X, Y, par, d, edges, go, return_residual=True)
+        assert got is not None, (it, A, B, M, N, D, d)
+        n += 1
+        assert rel_err(got[0].cpu().numpy(), want.cpu().numpy()) <= max(1e-11, 10 * float(got[1])), (it, A, B, M, N, D, d, par)
+    assert n == 80
+    # outside its scope the kernel says so
+    X0 = torch.zeros(2, 20, 3, dtype=torch.float64, device=DEV)
+    assert be.linear_adjoint_fused(X0, X0, 1.0, 0, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 0
+    X1 = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
+    assert be.linear_adjoint_fused(X1, X1, 1.0, 1, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # two bands
+
+
+def test_fused_linear_adjoint_is_what_the_api_runs(be, monkeypatch):
+    """compute_mmd / compute_Gram gradients with LinearKernel go through the fused adjoint and agree with the unfused route."""
+    gen = torch.Generator().manual_seed(31)
+    X, Y = (walk(gen, 12, 40, 5)).to(DEV), (walk(gen, 9, 33, 5)).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1)
+    calls = []
+    orig = type(be).linear_adjoint_fused
+    monkeypatch.setattr(type(be), "linear_adjoint_fused", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    X1 = X.clone().requires_grad_(True)
+    sk.compute_mmd(X1, Y).backward()
+    assert calls, "LinearKernel backward did not use the fused adjoint"
+    monkeypatch.setenv("SK_NO_FUSED_ADJOINT", "1")
+    X2 = X.clone().requires_grad_(True)
+    sk.compute_mmd(X2, Y).backward()
+    assert rel_err(X1.grad.cpu().numpy(), X2.grad.cpu().numpy()) <= 1e-10
+
+
 def test_fuzz_fused_forwards_against_the_streaming_route(be):
     """150 random shapes: the fused linear / RBF forwards (values, and the edges they keep for the adjoint) against
     sk_static_increments + sk_solve_fwd / sk_solve_adj on the same paths -- GPU against GPU, so large batches are cheap."""
