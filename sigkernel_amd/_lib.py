@@ -272,35 +272,39 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, return_residual=False):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, return_residual=False, gram=True):
         """dL/dX (A,M,D) for the LINEAR static kernel straight from the paths and the forward's terminal edges: adjoint PDE and
-        contraction in one kernel (sk_linear_adjoint_fused_f64; Gram only, fp64, dim <= 8, one strip per pair, dyadic 1 or 2).
-        None outside that scope or when a pair fails the kernel's self-check (the caller takes the unfused route)."""
+        contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8, one strip per pair, dyadic 1 or 2; computed in fp64
+        whatever the dtype of X).  None outside that scope or when a pair fails the kernel's self-check (the caller takes the
+        unfused route).  gram=False: paired batch, Y [A,N,D], scale [A]."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if (X.dtype != torch.float64 or D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0
-                or Mc > 64 * (4 >> dyadic)):
+        if D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or Mc > 64 * (4 >> dyadic):
             return None
         dev = X.device
         Mrows, Ncp = 256, (Nc + 15) // 16 * 16
         dXr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
-        dXr[:, :Mc, :D] = (X[:, 1:] - X[:, :-1]) * (float(param) ** 2)
+        Xd, Yd = X.double(), Y.double()     # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
+        dXr[:, :Mc, :D] = (Xd[:, 1:] - Xd[:, :-1]) * (float(param) ** 2)
         dYt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
-        dYt[:, :D, :Nc] = (Y[:, 1:] - Y[:, :-1]).transpose(1, 2)
+        dYt[:, :D, :Nc] = (Yd[:, 1:] - Yd[:, :-1]).transpose(1, 2)
+        if scale is not None:
+            scale = scale.double().contiguous()
         lib = load()
+        P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
-        args = (_ptr(dXr), _ptr(dYt), A, B, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
+        args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
         with torch.cuda.device(dev):
             rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused (query)")
-            chunks = B // ppg.value
+            chunks = B // ppg.value if gram else 1
             tpart = torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
-            err = torch.zeros(A * B, dtype=torch.float64, device=dev)
+            err = torch.zeros(P, dtype=torch.float64, device=dev)
             rc = lib.sk_linear_adjoint_fused_f64(*args, _ptr(tpart), tpart.numel(), _ptr(err), ctypes.byref(ppg), ctypes.byref(rows),
                                                  _stream(X))
             if rc == 2:
@@ -310,11 +314,12 @@ class HipBackend:
         if not bool(res <= self.ADJ_RESIDUAL_TOL):      # exploding kernels: the stored-grid rescue lives on the unfused route
             return None
         T = tpart.sum(1).flip(1)[:, :Mc, :D]     # chunks of an a added in a fixed order; flipped rows back to p
-        g = torch.zeros(A, M, D, dtype=X.dtype, device=dev)
+        g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
         g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
         g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
         if float(param) != 1.0:
             g = g * (float(param) ** 2)
+        g = g.to(X.dtype)
         return (g, res) if return_residual else g
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):

@@ -278,11 +278,11 @@ int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t 
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
                                 size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream) {
-    if (!dXr || !dYt || !edges || A < 0 || B < 1 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (!dXr || !dYt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (tpart && !err) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
-    const Geom g = make_geom(A * B, Mc, Nc, dyadic, scheme);
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
     return launch_adj_fused_linear(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, ppg_out, rows_out,
                                    (hipStream_t)stream);
 }

@@ -11,7 +11,8 @@
 // Decomposition: a lane group sweeps PPG consecutive pairs (a, b0 .. b0 + PPG - 1) of ONE path x_a -- the launcher picks
 // PPG as a divisor of B -- so its registers hold a partial sum over b for that a; it is stored (plain stores, no atomics:
 // the result does not depend on scheduling) to Tpart[group][flipped row][8], and the host adds the B / PPG chunks of an a.
-// Scope: Gram (B > 0), fp64, path dim <= 8, one band per pair, dyadic <= 2, default scheme.
+// Paired batches (B = 0) run with PPG = 1: one lane group per pair.
+// Scope: fp64, path dim <= 8, one band per pair, dyadic 1 or 2, default scheme.
 #include "sk_wave_common.h"
 
 namespace sk {
@@ -28,7 +29,7 @@ struct AdjFusedParams {
     const double *scale;   // [P] upstream gradient per pair, nullable
     double *Tpart;         // [P / PPG][L*RC][8]  partial sums, flipped coarse rows
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
-    int64_t P, B;
+    int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p) and PPG = 1
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
     WaveGroup wg;
 };
@@ -104,8 +105,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
     // columns stay in original order inside the 16-byte unit, as in the increment matrix the unfused kernel reads)
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
-    auto split_b = [&](int64_t p) -> int64_t { return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B; };
-    auto split_a = [&](int64_t p) -> int64_t { return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B; };
+    auto split_b = [&](int64_t p) -> int64_t {   // B == 0: paired, pair p = (x_p, y_p)
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+    };
+    auto split_a = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+    };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
         for (int g = 0; g < G; ++g) {
@@ -407,7 +414,7 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
                             int *ppg_out, int *rows_out, hipStream_t s) {
     const int DY = g.dyadic;
     // dyadic 0 (four coarse rows per lane) would need 316 VGPRs for the two 4 x 8 register arrays: left to the unfused route
-    if (DY < 1 || DY > 2 || B <= 0 || g.naive || g.P != A * B) return SK_ERR_UNSUPPORTED;
+    if (DY < 1 || DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
     const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
@@ -420,7 +427,7 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     // kernel holds ~230 VGPRs, two waves per SIMD)
     const int wpc = env_int("SK_ADJF_WPC", 8);
     const int64_t max_groups = 256LL * wpc * G;
-    int64_t PPG = 0;
+    int64_t PPG = B > 0 ? 0 : 1;   // paired: every pair has its own x, one pair per lane group
     for (int64_t d = 1; d <= B; ++d)
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
     if (PPG == 0 || PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;

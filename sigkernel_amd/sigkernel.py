@@ -80,10 +80,11 @@ def _increments(be, static_kernel, Xd, Yd, gram):
 
 
 def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_linear_adjoint_fused_f64 covers the case: exactly LinearKernel, Gram, fp64, default scheme, dyadic 1 or 2,
-    path dim <= 8, one strip per pair (the kernel itself has the last word: it returns `unsupported` otherwise)."""
-    return (gram and type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused") and not naive
-            and X.dtype == torch.float64 and X.shape[2] <= 8 and dyadic in (1, 2)
+    """Whether sk_linear_adjoint_fused_f64 covers the case: exactly LinearKernel, default scheme, dyadic 1 or 2, path dim <= 8,
+    one strip per pair; Gram or paired; fp32 inputs are swept in fp64 (the kernel itself has the last word: it returns
+    `unsupported` otherwise)."""
+    return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused") and not naive
+            and X.shape[2] <= 8 and dyadic in (1, 2)
             and X.shape[1] - 1 <= 64 * (4 >> dyadic) and Y.shape[1] >= 2 and not os.environ.get("SK_NO_FUSED_ADJOINT"))
 
 
@@ -96,12 +97,13 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     this replaces the reference's h = 1e-9 finite difference (sigkernel.py:313-341, :472-500)."""
     fused = _fused_static(static_kernel, gram)
     if _fused_linear_adjoint_ok(be, static_kernel, Xt, Yt, dyadic, naive, gram):
-        # LinearKernel, Gram: adjoint PDE + contraction in one kernel, from the paths and the forward's terminal edges
-        if edges is None:
-            res = be.solve_fwd_fused_linear(Xt, Yt, 1.0, dyadic, naive, True, keep_edges=True)
+        # LinearKernel: adjoint PDE + contraction in one kernel, from the paths and the forward's terminal edges (fp64 sweep)
+        scale = fused[1]
+        if edges is None or Xt.dtype != torch.float64:
+            res = be.solve_fwd_fused_linear(Xt.double(), Yt.double(), scale, dyadic, naive, gram, keep_edges=True)
             edges = res[1] if res is not None else None
         if edges is not None:
-            g = be.linear_adjoint_fused(Xt, Yt, 1.0, dyadic, edges, None if go is None else go.reshape(-1).contiguous())
+            g = be.linear_adjoint_fused(Xt, Yt, scale, dyadic, edges, None if go is None else go.reshape(-1).contiguous(), gram=gram)
             if g is not None:
                 return g
     if fused is not None and hasattr(be, "static_adjoint"):

@@ -4,6 +4,8 @@ Everything goes through the C ABI (sigkernel_amd._lib.HipBackend -> libsigkernel
 Tolerances: north_star asks for <= 1e-6 relative error in fp64; the simple/exact kernels are
 bit-identical to the oracle, the fast kernels (FMA-contracted) are held to 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -281,6 +283,39 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
     assert be.linear_adjoint_fused(X0, X0, 1.0, 0, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 0
     X1 = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
     assert be.linear_adjoint_fused(X1, X1, 1.0, 1, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # two bands
+
+
+@pytest.mark.parametrize("A,M,N,D,d,par", [(7, 40, 33, 5, 1, 1.0), (70, 64, 64, 8, 2, 0.8), (3, 128, 17, 2, 1, 1.4), (1, 2, 2, 1, 2, 1.0)])
+def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par):
+    """Paired batches (compute_kernel gradients) and fp32 inputs (swept in fp64) through the fused adjoint."""
+    gen = torch.Generator().manual_seed(A + M + N)
+    X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, A, N, D) * 2).to(DEV)
+    go = torch.randn(A, generator=gen, dtype=torch.float64).to(DEV)
+    K, edges = be.solve_fwd_fused_linear(X, Y, par, d, False, gram=False, keep_edges=True)
+    assert edges is not None
+    inc = be.static_increments(0, par, X, Y, gram=False)
+    _, W = be.solve_adj(inc, d, False, edges=edges)
+    want = be.static_adjoint(0, par, X, Y, W, go, False)
+    got = be.linear_adjoint_fused(X, Y, par, d, edges, go, gram=False)
+    assert got is not None and rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-11
+    _, edges32 = be.solve_fwd_fused_linear(X.float().double(), Y.float().double(), par, d, False, gram=False, keep_edges=True)
+    got32 = be.linear_adjoint_fused(X.float(), Y.float(), par, d, edges32, go.float(), gram=False)
+    assert got32 is not None and got32.dtype == torch.float32
+    np.testing.assert_allclose(got32.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()))
+    # API level: compute_kernel gradients, fp64 and fp32, against the unfused route
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(scale=par), d)
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
+        res = []
+        for env in ("", "1"):
+            if env:
+                os.environ["SK_NO_FUSED_ADJOINT"] = env
+            else:
+                os.environ.pop("SK_NO_FUSED_ADJOINT", None)
+            Xg = X.to(dt).clone().requires_grad_(True)
+            (sk.compute_kernel(Xg, Y.to(dt)) * go.to(dt)).sum().backward()
+            res.append(Xg.grad.double().cpu().numpy())
+        os.environ.pop("SK_NO_FUSED_ADJOINT", None)
+        assert rel_err(res[0], res[1]) <= tol, (dt, rel_err(res[0], res[1]))
 
 
 def test_fused_linear_adjoint_is_what_the_api_runs(be, monkeypatch):
