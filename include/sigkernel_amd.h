@@ -113,7 +113,7 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
  *   tpart [tpart_doubles] receives partial sums over b: viewed as [A][B / *ppg_out][*rows_out][8], sum over the chunk axis,
  *   then T[a][p][:] = that[a][*rows_out - 1 - p][:] for p < Mc is what sk_linear_adjoint_* returns.  tpart == NULL: only
  *   *ppg_out and *rows_out are set (size query: A * (B / ppg) * rows * 8 doubles).  err [P] zero-initialised: per-pair
- *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic 1 or 2, default scheme, one band per pair,
+ *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic <= 2, default scheme, Mc <= 128 (64 at dyadic 2),
  *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED. */
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,

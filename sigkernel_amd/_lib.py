@@ -274,7 +274,7 @@ class HipBackend:
 
     def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, return_residual=False, gram=True):
         """dL/dX (A,M,D) for the LINEAR static kernel straight from the paths and the forward's terminal edges: adjoint PDE and
-        contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8, one strip per pair, dyadic 1 or 2; computed in fp64
+        contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8, dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64
         whatever the dtype of X).  None outside that scope or when a pair fails the kernel's self-check (the caller takes the
         unfused route).  gram=False: paired batch, Y [A,N,D], scale [A]."""
         _dev(X, "X")
@@ -282,7 +282,7 @@ class HipBackend:
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or Mc > 64 * (4 >> dyadic):
+        if D > 8 or dyadic not in (0, 1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or Mc > (64 if dyadic == 2 else 128):
             return None
         dev = X.device
         Mrows, Ncp = 256, (Nc + 15) // 16 * 16

@@ -12,7 +12,7 @@
 // PPG as a divisor of B -- so its registers hold a partial sum over b for that a; it is stored (plain stores, no atomics:
 // the result does not depend on scheduling) to Tpart[group][flipped row][8], and the host adds the B / PPG chunks of an a.
 // Paired batches (B = 0) run with PPG = 1: one lane group per pair.
-// Scope: fp64, path dim <= 8, one band per pair, dyadic 1 or 2, default scheme.
+// Scope: fp64, path dim <= 8, one band per pair (dyadic 0: up to 128 increment rows), dyadic <= 2, default scheme.
 #include "sk_wave_common.h"
 
 namespace sk {
@@ -31,6 +31,7 @@ struct AdjFusedParams {
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
     int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p) and PPG = 1
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
+    int E;                 // doubles per pair in `edges`
     WaveGroup wg;
 };
 
@@ -58,10 +59,11 @@ __device__ __forceinline__ void lds_read_run<4>(d2_t (&v)[4], unsigned a) {
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
 }
 
-template <int DY, bool FULLWAVE>
+// RC = coarse rows per lane: the forward kernels' choice at dyadic 1, 2; at dyadic 0 two instead of their four (register budget)
+template <int DY, int RC, bool FULLWAVE>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
     constexpr int CW = 2;
-    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
     constexpr int XSLAB = RC * 512;
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     };
 
     // ---- terminal edges and the upstream gradient of the coming pair, one macro-step ahead (sk_wave_adj.hip) ---------------
-    const int E = NNp + MMp;
+    // pair stride of the edges: the layout of the kernel that wrote them (at dyadic 0 its padded row count differs from ours)
+    const int E = DY == 0 ? prm.E : NNp + MMp;
     auto prefetch_edges = [&](int nu, int nps, double (&prow)[S], double (&pcol)[R + 1], double &pscale) {
         int64_t pr = pair0 + nps;
         pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
@@ -204,6 +207,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 #pragma unroll
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
 
+    {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite (see the contraction below)
+        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB);
+        const d2_t z = {0.0, 0.0};
+        for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     issue_y();
     issue_x();
     {
@@ -331,14 +340,15 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         cornerR = topR[S - 1];
         cornerF = topF[S - 1];
 
-        // -- W of the RC x 2 coarse cells, contracted with the y differences of their columns.  Only lanes inside their group's
-        //    pairs take part (a branch, not a multiplication by zero: the leftovers other lanes sweep may hold NaNs from LDS
-        //    slabs that were never written, and 0 * NaN would poison the lane's sum)
-        if (s_pair != 0.0) {
+        // -- W of the RC x 2 coarse cells, contracted with the y differences of their columns.  Lanes outside their group's
+        //    pairs sweep leftovers whose weights may be anything, NaN included: their w is SELECTED to zero, and the y values
+        //    they multiply are finite because the rings were zero-filled before the first DMA (0 * NaN would poison the sum)
+        {
+            const bool live = s_pair != 0.0;
             const double wsc = sc * s_pair;
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
-                const double w0 = acc[k][1] * wsc, w1 = acc[k][0] * wsc;   // original columns 0 and 1 of the unit
+                const double w0 = live ? acc[k][1] * wsc : 0.0, w1 = live ? acc[k][0] * wsc : 0.0;   // original columns 0, 1
 #pragma unroll
                 for (int j = 0; j < FD; ++j) tacc[k][j] = fma(w0, dyv[j][0], fma(w1, dyv[j][1], tacc[k][j]));
             }
@@ -396,9 +406,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, bool FULLWAVE>
+template <int DY, int RC, bool FULLWAVE>
 int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_linear<DY, FULLWAVE>;
+    auto kern = k_adj_fused_linear<DY, RC, FULLWAVE>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -413,11 +423,16 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
                             const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
                             int *ppg_out, int *rows_out, hipStream_t s) {
     const int DY = g.dyadic;
-    // dyadic 0 (four coarse rows per lane) would need 316 VGPRs for the two 4 x 8 register arrays: left to the unfused route
-    if (DY < 1 || DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
-    const Strip st = strip_geom(g, 8);
+    if (DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    const Strip st = strip_geom(g, 8);   // the layout of the edges
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
-    const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
+    // dyadic 0: the strip kernels give a lane four coarse rows; with the two 4 x 8 register arrays of this kernel that is
+    // 316 VGPRs, so it sweeps two rows per lane (pairs of up to 128 increments rows) and only shares the edge layout
+    const int RC = DY == 0 ? 2 : st.RC, NUp = st.NUp;
+    int logL = 3;
+    while (logL < 6 && (RC << logL) < g.Mc) ++logL;
+    const int L = 1 << logL, G = WAVE / L;
+    if (L * RC < g.Mc) return SK_ERR_UNSUPPORTED;
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);
@@ -442,13 +457,15 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     prm.dXr = dXr; prm.dYt = dYt; prm.edges = edges; prm.scale = scale; prm.Tpart = tpart; prm.err = err;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.PPG = (int)PPG;
+    prm.E = st.NNp + st.MMp;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.wg = wave_group(lds_bytes, waves, "SK_ADJF_WPB");
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     switch (DY) {
-        case 1: return full ? launch_adjf<1, true>(prm, lds_block, s) : launch_adjf<1, false>(prm, lds_block, s);
-        default: return full ? launch_adjf<2, true>(prm, lds_block, s) : launch_adjf<2, false>(prm, lds_block, s);
+        case 0: return full ? launch_adjf<0, 2, true>(prm, lds_block, s) : launch_adjf<0, 2, false>(prm, lds_block, s);
+        case 1: return full ? launch_adjf<1, 2, true>(prm, lds_block, s) : launch_adjf<1, 2, false>(prm, lds_block, s);
+        default: return full ? launch_adjf<2, 1, true>(prm, lds_block, s) : launch_adjf<2, 1, false>(prm, lds_block, s);
     }
 }
 

@@ -80,12 +80,12 @@ def _increments(be, static_kernel, Xd, Yd, gram):
 
 
 def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_linear_adjoint_fused_f64 covers the case: exactly LinearKernel, default scheme, dyadic 1 or 2, path dim <= 8,
-    one strip per pair; Gram or paired; fp32 inputs are swept in fp64 (the kernel itself has the last word: it returns
+    """Whether sk_linear_adjoint_fused_f64 covers the case: exactly LinearKernel, default scheme, dyadic <= 2, path dim <= 8,
+    at most 128 increments per path (64 at dyadic 2); Gram or paired; fp32 inputs are swept in fp64 (the kernel itself has the last word: it returns
     `unsupported` otherwise)."""
     return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused") and not naive
-            and X.shape[2] <= 8 and dyadic in (1, 2)
-            and X.shape[1] - 1 <= 64 * (4 >> dyadic) and Y.shape[1] >= 2 and not os.environ.get("SK_NO_FUSED_ADJOINT"))
+            and X.shape[2] <= 8 and dyadic in (0, 1, 2)
+            and X.shape[1] - 1 <= (64 if dyadic == 2 else 128) and Y.shape[1] >= 2 and not os.environ.get("SK_NO_FUSED_ADJOINT"))
 
 
 def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=None):

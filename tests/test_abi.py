@@ -62,7 +62,7 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 3, 1, 0, 1.0, p, None) == 2      # 129 node rows: two bands
     assert lib.sk_solve_fwd_linear_f64(p, p, 1, 1, 256, 4, 4, 16, 0, 1, 0, p, None) == 1                 # path dimension 0
     assert lib.sk_linear_adjoint_fused_f64(p, p, 1, -1, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, None, None, None) == 1  # B < 0
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 0, 0, p, None, None, 0, None, None, None, None) == 2   # dyadic 0
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 3, 0, p, None, None, 0, None, None, None, None) == 2   # dyadic 3
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():

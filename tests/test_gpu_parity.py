@@ -259,8 +259,8 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
     rng = np.random.default_rng(99)
     n = 0
     for it in range(80):
-        d = int(rng.integers(1, 3))
-        cap = 64 * (4 >> d)
+        d = int(rng.integers(0, 3))
+        cap = 65 if d == 2 else 129      # dyadic 0 sweeps two rows per lane here (four in the forward kernels)
         M = int(rng.integers(2, cap + 1)) if it % 4 else cap
         N = int(rng.integers(2, 200))
         A, B, D = int(rng.integers(1, 30)), int(rng.integers(1, 48)), int(rng.integers(1, 9))
@@ -280,12 +280,13 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
     assert n == 80
     # outside its scope the kernel says so
     X0 = torch.zeros(2, 20, 3, dtype=torch.float64, device=DEV)
-    assert be.linear_adjoint_fused(X0, X0, 1.0, 0, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 0
+    assert be.linear_adjoint_fused(X0, X0, 1.0, 3, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 3
     X1 = torch.zeros(2, 300, 3, dtype=torch.float64, device=DEV)
     assert be.linear_adjoint_fused(X1, X1, 1.0, 1, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # two bands
 
 
-@pytest.mark.parametrize("A,M,N,D,d,par", [(7, 40, 33, 5, 1, 1.0), (70, 64, 64, 8, 2, 0.8), (3, 128, 17, 2, 1, 1.4), (1, 2, 2, 1, 2, 1.0)])
+@pytest.mark.parametrize("A,M,N,D,d,par", [(7, 40, 33, 5, 1, 1.0), (70, 64, 64, 8, 2, 0.8), (3, 128, 17, 2, 1, 1.4), (1, 2, 2, 1, 2, 1.0),
+                                              (9, 129, 50, 8, 0, 1.0), (5, 30, 130, 3, 0, 0.9)])
 def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par):
     """Paired batches (compute_kernel gradients) and fp32 inputs (swept in fp64) through the fused adjoint."""
     gen = torch.Generator().manual_seed(A + M + N)
