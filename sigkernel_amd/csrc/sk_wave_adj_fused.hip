@@ -442,10 +442,10 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     // kernel holds ~230 VGPRs, two waves per SIMD)
     const int wpc = env_int("SK_ADJF_WPC", 8);
     const int64_t max_groups = 256LL * wpc * G;
-    int64_t PPG = B > 0 ? 0 : 1;   // paired: every pair has its own x, one pair per lane group
-    for (int64_t d = 1; d <= B; ++d)
+    int64_t PPG = B > 0 ? B : 1;   // paired: every pair has its own x, one pair per lane group.  Gram with more paths than
+    for (int64_t d = 1; d <= B; ++d)   // resident lane groups: one whole row of the Gram per group, launched in several rounds
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
-    if (PPG == 0 || PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+    if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
     const int64_t groups = g.P / PPG;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC;

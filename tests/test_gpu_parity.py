@@ -278,6 +278,14 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
         n += 1
         assert rel_err(got[0].cpu().numpy(), want.cpu().numpy()) <= max(1e-11, 10 * float(got[1])), (it, A, B, M, N, D, d, par)
     assert n == 80
+    # more paths than resident lane groups: one whole Gram row per group, several rounds of workgroups
+    gen = torch.Generator().manual_seed(77)
+    X, Y = walk(gen, 2600, 6, 2).to(DEV), walk(gen, 3, 7, 2).to(DEV)
+    K, edges = be.solve_fwd_fused_linear(X, Y, 1.0, 1, False, gram=True, keep_edges=True)
+    inc = be.static_increments(0, 1.0, X, Y, gram=True)
+    _, W = be.solve_adj(inc, 1, False, edges=edges)
+    got = be.linear_adjoint_fused(X, Y, 1.0, 1, edges, None)
+    assert got is not None and rel_err(got.cpu().numpy(), be.static_adjoint(0, 1.0, X, Y, W, None, True).cpu().numpy()) <= 1e-11
     # outside its scope the kernel says so
     X0 = torch.zeros(2, 20, 3, dtype=torch.float64, device=DEV)
     assert be.linear_adjoint_fused(X0, X0, 1.0, 3, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 3
