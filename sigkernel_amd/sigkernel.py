@@ -170,6 +170,8 @@ class _SigKernel(torch.autograd.Function):
             Yd = Y.detach()
             fused = _fused_static(sk, False) is not None
             per_row = (3 if fused else 8) * M * N * X.element_size()
+            if _fused_linear_adjoint_ok(be, sk, X, Yd, d, naive, False):
+                per_row = 4096 * M               # fused adjoint: edges and partial sums only
             go = grad_output.to(X.dtype).contiguous()
             for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
                 grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd[a0:a1].contiguous(),
@@ -348,6 +350,8 @@ class _SigKernelGram(torch.autograd.Function):
             go = grad_output.to(X.dtype).contiguous()
             fused = _fused_static(sk, True) is not None
             per_row = (3 if fused else 8) * B * M * N * X.element_size()
+            if _fused_linear_adjoint_ok(be, sk, X, Yd, d, naive, True):
+                per_row = 64 * B + 2048 * M      # fused adjoint: no matrix of size pairs x M x N, only the partial sums
             tiles = _edge_tiles(getattr(ctx, "kept_edges", None), A, per_row, _budget(X.device, ctx.workspace_bytes))
             ctx.kept_edges = None
             for a0, a1, edges in tiles:
