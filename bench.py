@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Gram entries/s of SigKernel.compute_Gram on MI355X.
+"""Headline benchmark: Gram entries/s of the signature-PDE-kernel hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4mini]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c4|c4mini|c5] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one compute_Gram call (static kernel -> increments -> PDE solve) over one batch of synthetic
-paths already resident in HBM.  At N = 1 the workload is BASELINE.json configs[2] (the headline:
-batch 512 x 512, len 128, dim 8, LinearKernel, dyadic 1, fp64, sym=False).  At N > 1 every rank owns 512
-rows of X (weak scaling: global Gram is (512 N) x 512), solves them with no data-path collective and one
-RCCL all-gather assembles the full matrix on every rank, exactly as sigkernel_amd.distributed does it.
+A "step" is one pass of the hot path over one batch of synthetic paths already resident in HBM:
+  * gram configs (c2, c3, c4mini, c5): one SigKernel.compute_Gram call (static kernel -> increments -> PDE solve);
+  * c4 (BASELINE configs[3]): one compute_mmd(X, Y).backward() -- three Gram matrices and two adjoint-PDE Grams.
+The default is BASELINE.json configs[2], the headline: batch 512 x 512, len 128, dim 8, LinearKernel, dyadic 1, fp64.
+
+N > 1 runs the PRODUCT's sharding, SigKernel(process_group=WORLD) (sigkernel_amd/distributed.py): the rows of X are
+split over the ranks, every rank solves its block with no data-path collective, and one RCCL all-gather assembles the
+full matrix on every rank.  --scaling weak (default for gram configs): X has N x rows_per_gpu rows; --scaling strong
+(default and only choice for c4, the config BASELINE names for 8 GPUs): the batch is fixed and divided.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the solver kernel against the HBM roofline (algorithmic bytes = coarse increment
-                 matrix read once + one value written per pair)
-  cpu_baseline : the CPU oracle (the C restatement of the reference's Cython solver) timed on this
-                 box's host cores on a bounded sample of the same workload
-  parity       : 64 random pairs of the timed input re-solved by the oracle
+  roofline     : the kernel that dominates the step against the ceiling that binds it (fp64 vector issue for the fused
+                 kernels, with the HBM-equivalent rate of the increments they never materialise as a second figure;
+                 HBM for the streaming solver), from HIP-event timings of its launches on the launch stream
+  adjoint      : forward-with-edges + adjoint at the same shape (HIP events), against 3 (M-1)(N-1) s bytes per entry
+  cpu_baseline : the CPU oracle (C restatement of the reference's Cython solver) on this box's host cores, on a bounded
+                 sample of the same workload: all threads (value) and one thread (the reference is single-threaded)
+  parity       : 64 random entries of the timed output and sampled gradient rows re-computed by the oracle
 """
 import argparse
 import json
@@ -33,16 +39,23 @@ sys.path.insert(0, ROOT)
 import sigkernel_amd  # noqa: E402
 from sigkernel_amd import _lib  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TF = 78.6   # MI355X fp64 vector peak (FMA = 2 flop), same guide
 
 CONFIGS = {
-    # name: (A per rank, B, M, N, D, kernel, dyadic, dtype, description)
-    "c3": (512, 512, 128, 128, 8, "linear", 1, torch.float64,
-           "BASELINE configs[2]: batch 512x512, len 128, dim 8, LinearKernel, dyadic 1, fp64, compute_Gram sym=False"),
-    "c2": (128, 128, 64, 64, 3, "rbf", 1, torch.float64,
-           "BASELINE configs[1]: batch 128x128, len 64, dim 3, RBFKernel(1.0), dyadic 1, fp64, compute_Gram"),
-    "c4mini": (512, 512, 64, 64, 4, "rbf", 2, torch.float64,
-               "BASELINE configs[3] reduced to 512x512 pairs: len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64"),
+    # name: rows of X (per GPU under weak scaling), B, M, N, D, static kernel, dyadic, dtype, mode, description
+    "c3": dict(A=512, B=512, M=128, N=128, D=8, kernel="linear", dyadic=1, dtype=torch.float64, mode="gram",
+               desc="BASELINE configs[2]: batch 512x512, len 128, dim 8, LinearKernel, dyadic 1, fp64, compute_Gram sym=False"),
+    "c2": dict(A=128, B=128, M=64, N=64, D=3, kernel="rbf", dyadic=1, dtype=torch.float64, mode="gram",
+               desc="BASELINE configs[1]: batch 128x128, len 64, dim 3, RBFKernel(1.0), dyadic 1, fp64, compute_Gram"),
+    "c4": dict(A=2048, B=2048, M=64, N=64, D=4, kernel="rbf", dyadic=2, dtype=torch.float64, mode="mmd",
+               desc="BASELINE configs[3]: batch_x 2048, batch_y 2048, len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64, "
+                    "compute_mmd(X, Y).backward() (3 Gram matrices + 2 adjoint-PDE Grams), Gram rows sharded over the GPUs"),
+    "c4mini": dict(A=512, B=512, M=64, N=64, D=4, kernel="rbf", dyadic=2, dtype=torch.float64, mode="gram",
+                   desc="BASELINE configs[3] reduced to 512x512 pairs: len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64, compute_Gram"),
+    "c5": dict(A=256, B=256, M=512, N=512, D=16, kernel="rbf", dyadic=2, dtype=torch.float32, mode="gram",
+               desc="BASELINE configs[4]: batch 256x256, len 512, dim 16, RBFKernel(1.0), dyadic 2, fp32, compute_Gram "
+                    "(grid 2044x2044 per pair)"),
 }
 
 
@@ -57,38 +70,93 @@ def static_kernel(name):
     return sigkernel_amd.LinearKernel() if name == "linear" else sigkernel_amd.RBFKernel(1.0)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
-    """Time the CPU oracle on a bounded sample of the SAME workload: the first `rows` rows of X against
-    all of Y, static kernel (torch, CPU) + increments + PDE solve with OpenMP over pairs on every host core."""
+    """Time the CPU oracle on a bounded sample of the SAME workload: the first `rows` rows of X against all of Y, static
+    kernel (torch, CPU) + increments + PDE solve -- with OpenMP over pairs on every host core (`value`, the generous
+    baseline) and on ONE thread (`single_thread_value`: the reference's Cython solver is single-threaded,
+    cython_backend.pyx:75,100)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     threads = min(cores, O.max_threads()) if O.max_threads() > 1 else cores
     B, M, N = Yc.shape[0], Xc.shape[1], Yc.shape[1]
     sk = static_kernel(kname)
-    # calibrate on a few pairs, then size the sample to ~budget_s seconds
-    G = sk.Gram_matrix(Xc[:1].double(), Yc[: min(B, 4 * threads)].double()).numpy()
-    inc = O.increments(G)
+    Xd, Yd = Xc.double(), Yc.double()
+
+    def run(rows, nthreads):
+        t0 = time.perf_counter()
+        G = sk.Gram_matrix(Xd[:rows], Yd).numpy()
+        inc = O.increments(G)
+        t1 = time.perf_counter()
+        vals = O.solve_coarse(inc, dyadic, nthreads=nthreads)
+        t2 = time.perf_counter()
+        return vals, t2 - t0, t2 - t1
+
+    # calibrate on a few pairs of one row, then size each sample to its share of the budget
+    nb = min(B, 4 * threads)
+    inc = O.increments(sk.Gram_matrix(Xd[:1], Yd[:nb]).numpy())
     t0 = time.perf_counter()
     O.solve_coarse(inc, dyadic, nthreads=threads)
-    per_pair = (time.perf_counter() - t0) / inc.shape[1]
-    rows = int(max(1, min(Xc.shape[0], budget_s / max(per_pair * B, 1e-9))))
+    per_pair_mt = (time.perf_counter() - t0) / nb
     t0 = time.perf_counter()
-    G = sk.Gram_matrix(Xc[:rows].double(), Yc.double()).numpy()
-    inc = O.increments(G)
-    t1 = time.perf_counter()
-    vals = O.solve_coarse(inc, dyadic, nthreads=threads)
-    t2 = time.perf_counter()
+    O.solve_coarse(inc[:, : max(1, nb // threads)], dyadic, nthreads=1)
+    per_pair_1t = (time.perf_counter() - t0) / max(1, nb // threads)
+    rows = int(max(1, min(Xc.shape[0], 0.6 * budget_s / max(per_pair_mt * B, 1e-9))))
+    vals, t_all, t_solve = run(rows, threads)
     pairs = rows * B
+    # one thread: a prefix of the first row's pairs (a whole row would take minutes at the long-sequence configs)
+    b1 = int(max(1, min(B, 0.4 * budget_s / max(per_pair_1t, 1e-9))))
+    t0 = time.perf_counter()
+    G1 = sk.Gram_matrix(Xd[:1], Yd[:b1]).numpy()
+    O.solve_coarse(O.increments(G1), dyadic, nthreads=1)
+    t_1 = time.perf_counter() - t0
     return {
-        "value": pairs / (t2 - t0),
+        "value": pairs / t_all,
         "unit": "entries/s",
         "cores": threads,
         "kind": "port",
+        "cpu_model": cpu_model(),
         "sample": "first %d of %d rows of X against all %d paths of Y (%d pairs, len %dx%d, dyadic %d); "
                   "static kernel + increments + solve, OpenMP over pairs" % (rows, Xc.shape[0], B, pairs, M, N, dyadic),
-        "solver_only_value": pairs / (t2 - t1),
-        "seconds": t2 - t0,
+        "solver_only_value": pairs / t_solve,
+        "seconds": t_all,
+        "single_thread_value": b1 / t_1,
+        "single_thread_sample": "row 0 of X against the first %d paths of Y, same pipeline on 1 thread, %.1f s" % (b1, t_1),
     }, vals, rows
+
+
+def time_launches(fn, reps):
+    """Per-call durations (ms) from HIP events recorded on the stream the calls are launched on (torch's current one)."""
+    for _ in range(2):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    return [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
+
+
+def traffic_entry(key, pairs):
+    """HBM bytes per launch from the PMC pass kept under profiles/ (tools/pmc_*.sh), if it matches this launch size."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tpath)).get(key)
+        if ent and ent.get("pairs_per_launch") == pairs:
+            return ent.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def main():
@@ -97,7 +165,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / adjoint / parity / cpu_baseline legs")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box")
@@ -123,21 +193,31 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
-    A, B, M, N, D, kname, dyadic, dtype, desc = CONFIGS[args.config]
-    Xc = make_paths(A, M, D, seed=1000 + rank, dtype=dtype)      # this rank's rows (weak scaling)
-    Yc = make_paths(B, N, D, seed=7, dtype=dtype)                 # replicated
+    cfg = CONFIGS[args.config]
+    A, B, M, N, D = cfg["A"], cfg["B"], cfg["M"], cfg["N"], cfg["D"]
+    kname, dyadic, dtype, mode = cfg["kernel"], cfg["dyadic"], cfg["dtype"], cfg["mode"]
+    scaling = args.scaling or ("strong" if mode == "mmd" else "weak")
+    if mode == "mmd" and scaling == "weak":
+        raise SystemExit("c4 is a fixed-size job (BASELINE configs[3]): use --scaling strong")
+    A_total = A * world if scaling == "weak" else A
+    # every rank holds the (small) inputs in full, exactly as SigKernel(process_group=...) expects; each solves its own rows
+    Xc = make_paths(A_total, M, D, seed=1000, dtype=dtype)
+    Yc = make_paths(B, N, D, seed=7, dtype=dtype)
     X, Y = Xc.to(dev), Yc.to(dev)
-    sk = sigkernel_amd.SigKernel(static_kernel(kname), dyadic)
+    sk = sigkernel_amd.SigKernel(static_kernel(kname), dyadic, process_group=dist.group.WORLD if use_dist else None)
+    sk1 = sigkernel_amd.SigKernel(static_kernel(kname), dyadic)       # single-GPU instance for the rank-0 extras
     be = _lib.get_backend()
     assert isinstance(be, _lib.HipBackend), "bench must run on the HIP back-end"
 
-    def step():
-        Kloc = sk.compute_Gram(X, Y)                     # this rank's (A x B) block
-        if use_dist:
-            out = torch.empty((world * A, B), dtype=Kloc.dtype, device=dev)
-            dist.all_gather_into_tensor(out, Kloc)       # the one collective of the path
-            return out
-        return Kloc
+    if mode == "gram":
+        def step():
+            return sk.compute_Gram(X, Y)                  # N > 1: rows sharded, one all-gather (sigkernel_amd.distributed)
+    else:
+        def step():
+            Xg = X.detach().requires_grad_(True)
+            loss = sk.compute_mmd(Xg, Y)
+            loss.backward()
+            return loss.detach(), Xg.grad
 
     def barrier():
         if use_dist:
@@ -145,11 +225,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        K = step()
+        out = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        K = step()
+        out = step()
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -157,12 +237,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    entries_per_step = world * A * B
+    entries_per_step = A_total * B if mode == "gram" else (A_total * A_total + B * B + A_total * B)
     cells_per_entry = ((M - 1) << dyadic) * ((N - 1) << dyadic)
     value = entries_per_step * args.steps / elapsed
+    dname = "f64" if dtype == torch.float64 else "f32"
 
     result = {
-        "metric": "Gram entries/sec (fp64)",
+        "metric": "Gram entries/sec (%s)" % ("fp64" if dtype == torch.float64 else "fp32 I/O, fp64 PDE state"),
         "value": value,
         "unit": "entries/s",
         "n_gpus": world,
@@ -170,121 +251,173 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "f64" if dtype == torch.float64 else "f32",
+        "dtype": dname,
         "data": "synthetic",
-        "config": {"workload": desc, "rows_per_gpu": A, "batch_y": B, "len_x": M, "len_y": N, "dim": D,
+        "config": {"workload": cfg["desc"], "name": args.config, "step": "compute_Gram" if mode == "gram" else
+                   "compute_mmd + backward (entries = the three Gram matrices of one step)",
+                   "batch_x": A_total, "rows_per_gpu": -(-A_total // world), "batch_y": B, "len_x": M, "len_y": N, "dim": D,
                    "static_kernel": kname, "dyadic_order": dyadic,
-                   "parallelism": "gram rows sharded over %d GPU(s), 1 all-gather" % world},
+                   "parallelism": "SigKernel(process_group): gram rows sharded over %d GPU(s), 1 all-gather per Gram" % world},
         "grid_cells_per_s": value * cells_per_entry,
     }
 
+    if rank == 0 and not args.no_extras:
+        extras(result, args, cfg, sk1, be, X, Y, Xc, Yc, out, A_total, world, value)
     if rank == 0:
-        s = X.element_size()
-        alg_per_pair = (M - 1) * (N - 1) * s + s                      # inc_c read once + 1 value out
-
-        def time_launches(fn, reps):
-            for _ in range(2):
-                fn()
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-            ev[0].record()
-            for i in range(reps):
-                fn()
-                ev[i + 1].record()
-            torch.cuda.synchronize()
-            return [ev[i].elapsed_time(ev[i + 1]) for i in range(reps)]
-
-        reps = max(3, args.steps)
-        # ---- (1) the kernel that dominates the timed step -------------------------------------------------------
-        # LinearKernel within the fused kernel's scope: one launch does static kernel + increments + PDE for the whole
-        # Gram and nothing of size pairs x M x N touches HBM.  Its "achieved" is the HBM-equivalent rate: the bytes the
-        # streaming solver would have had to read, over the launch time; the real limiter is fp64 issue.
-        from sigkernel_amd.sigkernel import _fused_forward, _increments
-        fused = _fused_forward(be, sk.static_kernel, X, Y, dyadic, False, gram=True) is not None
-        if fused:
-            ms = time_launches(lambda: _fused_forward(be, sk.static_kernel, X, Y, dyadic, False, gram=True), reps)
-            # host-side prep (path differences, two small allocations) is inside these launches' gaps; kernel time from
-            # rocprofv3 is within 3 % of this (profiles/)
-            pairs_f = A * B
-            avg = float(np.mean(ms))
-            fp64_ops = pairs_f * (cells_per_entry * 3 + (M - 1) * (N - 1) * (4 + 2 * D))   # FMA-class instructions x lanes
-            result["roofline"] = {
-                "bound": "hbm", "achieved": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "sk_solve_fwd_linear_f64 (k_fwd_fused: static kernel + increments + PDE in one launch)",
-                "pairs_per_launch": pairs_f, "algorithmic_bytes_per_launch": pairs_f * alg_per_pair, "avg_launch_ms": avg,
-                "min_launch_ms": float(np.min(ms)),
-                "note": "HBM-equivalent rate: the increment matrix is never materialised, actual HBM traffic is the paths "
-                        "(MBs); the kernel is bound by fp64 issue",
-                "fp64_tflops": 2 * fp64_ops / (avg * 1e-3) / 1e12, "fp64_vector_peak_tflops": 78.6,
-            }
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    ent = json.load(open(tpath)).get(args.config + "_fused")
-                    if ent and ent.get("pairs_per_launch") == pairs_f:
-                        result["roofline"]["traffic"] = ent.get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
-
-        # ---- (2) the HBM-streaming solver (every static kernel other than Linear, and what north_star describes):
-        #          increments resident in HBM, solver kernel alone, HIP events on the launch stream ----------------
-        rows = A
-        while rows > 1 and 2 * rows * B * M * N * s > 40e9:
-            rows //= 2
-        with torch.no_grad():
-            inc = _increments(be, sk.static_kernel, X[:rows], Y, gram=True)
-        launch_ms = time_launches(lambda: be.solve_fwd(inc, dyadic), reps)
-        avg_ms = float(np.mean(launch_ms))
-        pairs = rows * B
-        alg_bytes = pairs * alg_per_pair
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                ent = tj.get(args.config)
-                if ent and ent.get("pairs_per_launch") == pairs:
-                    traffic = ent.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        streaming = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "sk_solve_fwd_f64 (k_fwd_wave: increments streamed from HBM)", "pairs_per_launch": pairs,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "min_launch_ms": float(np.min(launch_ms)),
-            "solver_only_entries_per_s": pairs / (avg_ms * 1e-3),
-            "solver_only_cells_per_s": pairs * cells_per_entry / (avg_ms * 1e-3),
-        }
-        if fused:
-            result["roofline_streaming_solver"] = streaming
-        else:
-            result["roofline"] = streaming
-        del inc
-
-        # ---- parity of the timed output + CPU baseline ---------------------------------------------------
-        from oracle import oracle as O
-        Kc = K[:A].cpu().numpy()
-        rng = np.random.default_rng(0)
-        idx = rng.integers(0, A * B, size=64)
-        worst = 0.0
-        for p in idx:
-            a, b = divmod(int(p), B)
-            want = O.gram_forward(Xc[a:a + 1], Yc[b:b + 1], static_kernel(kname), dyadic)[0, 0]
-            worst = max(worst, abs(float(Kc[a, b]) - want) / abs(want))
-        result["parity"] = {"pairs_checked": 64, "max_rel_err_vs_oracle": worst, "tolerance": 1e-6, "ok": bool(worst <= 1e-6)}
-        if world == 1 and not args.no_cpu_baseline:
-            cb, vals, nrows = cpu_baseline(Xc, Yc, kname, dyadic, args.cpu_budget_s)
-            cb["max_rel_err_gpu_vs_cpu_sample"] = float(np.max(np.abs(Kc[:nrows] - vals) / np.abs(vals)))
-            result["cpu_baseline"] = cb
-            result["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(result))
         sys.stdout.flush()
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
+    """Rank 0, after the timed region: roofline of the dominant kernel, the adjoint leg, parity against the oracle and the
+    CPU baseline."""
+    from sigkernel_amd.sigkernel import _fused_forward, _increments
+    from oracle import oracle as O
+    A, B, M, N, D = cfg["A"], cfg["B"], cfg["M"], cfg["N"], cfg["D"]
+    kname, dyadic, dtype, mode = cfg["kernel"], cfg["dyadic"], cfg["dtype"], cfg["mode"]
+    s = X.element_size()
+    Mc, Nc = M - 1, N - 1
+    cells_per_entry = (Mc << dyadic) * (Nc << dyadic)
+    alg_per_pair = Mc * Nc * s + s                                   # SURVEY 8(d): inc_c read once + 1 value out
+    reps = max(3, min(args.steps, 10))
+    Xr = X[:A]                                                       # one GPU's rows
+
+    # ---- (1) the kernel that dominates the forward step ----------------------------------------------------------------
+    fused = _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True) is not None
+    if fused:
+        # Linear / RBF within the fused kernels' scope: one launch does static kernel + increments + PDE for the whole Gram;
+        # nothing of size pairs x M x N touches HBM, so the ceiling is fp64 vector issue.  FMA-class lane operations per pair:
+        # 3 per fine cell (stencil) + per coarse cell 4 (coefficients) + the static kernel (linear: D FMAs; rbf: 2 D for
+        # the distance, 19 for exp, 4 for the 4-corner difference).
+        ms = time_launches(lambda: _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True), reps)
+        avg = float(np.mean(ms))
+        pairs_f = A * B
+        per_coarse = 4 + (D if kname == "linear" else 2 * D + 23)
+        ops = pairs_f * (cells_per_entry * 3 + Mc * Nc * per_coarse)
+        tflops = 2 * ops / (avg * 1e-3) / 1e12
+        kern = "sk_solve_fwd_%s_%s (k_fwd_fused: static kernel + increments + PDE in one launch)" % (kname, "f64" if s == 8 else "f32")
+        result["roofline"] = {
+            "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TF,
+            "traffic": traffic_entry(args.config + "_fused", pairs_f),
+            "kernel": kern, "pairs_per_launch": pairs_f, "fp64_lane_ops_per_launch": ops, "avg_launch_ms": avg,
+            "min_launch_ms": float(np.min(ms)),
+            "cells_per_s": pairs_f * cells_per_entry / (avg * 1e-3),
+            "note": "algorithmic FMA-class operations (stencil 3/cell, coefficients 4/coarse cell, static kernel) x 2 flop over the "
+                    "launch time, against the fp64 vector peak; the increment matrix is never materialised, HBM traffic is the "
+                    "paths (MBs).  tools/ubench/fma_rate measures 63 TFLOP/s of independent v_fma_f64 on this part "
+                    "(profiles/r02_fma_rate.txt)",
+            "hbm_equivalent": {"achieved": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": pairs_f * alg_per_pair / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": pairs_f * alg_per_pair,
+                               "note": "bytes of the increment matrix the streaming solver would read, over this kernel's time"},
+        }
+
+    # ---- (2) the HBM-streaming solver (what north_star describes; every static kernel outside the fused scope):
+    #          increments resident in HBM, solver kernel alone ---------------------------------------------------------
+    rows = A
+    while rows > 1 and 2 * rows * B * M * N * s > 40e9:
+        rows //= 2
+    with torch.no_grad():
+        inc = _increments(be, sk.static_kernel, Xr[:rows], Y, gram=True)
+    launch_ms = time_launches(lambda: be.solve_fwd(inc, dyadic), reps)
+    avg_ms = float(np.mean(launch_ms))
+    pairs = rows * B
+    alg_bytes = pairs * alg_per_pair
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    streaming = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic_entry(args.config, pairs),
+        "kernel": "sk_solve_fwd_%s (k_fwd_wave: increments streamed from HBM)" % ("f64" if s == 8 else "f32"),
+        "pairs_per_launch": pairs, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+        "min_launch_ms": float(np.min(launch_ms)),
+        "solver_only_entries_per_s": pairs / (avg_ms * 1e-3),
+        "solver_only_cells_per_s": pairs * cells_per_entry / (avg_ms * 1e-3),
+    }
+    if fused:
+        result["roofline_streaming_solver"] = streaming
+    else:
+        result["roofline"] = streaming
+    del inc
+
+    # ---- (3) the adjoint leg: compute_Gram with a gradient pending + backward, HIP events -------------------------------
+    ra = A
+    while ra > 8 and 4 * ra * B * M * N * 8 > 40e9 and not fused:
+        ra //= 2
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(ra, B, generator=gen, dtype=torch.float64)
+    w[:, 32:] = 0.0                       # sparse upstream gradient: the oracle re-derives sampled rows from 32 pairs each
+    wd = w.to(dtype).to(X.device)
+    fwd_ms, bwd_ms = [], []
+    grad = None
+    for it in range(2 + min(reps, 5)):
+        Xg = Xr[:ra].detach().clone().requires_grad_(True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        K = sk.compute_Gram(Xg, Y)
+        e1.record()
+        (K * wd).sum().backward()
+        e2.record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            fwd_ms.append(e0.elapsed_time(e1))
+            bwd_ms.append(e1.elapsed_time(e2))
+        grad = Xg.grad
+    adj_bytes = ra * B * (3 * Mc * Nc * s + s)
+    tot = (float(np.mean(fwd_ms)) + float(np.mean(bwd_ms))) * 1e-3
+    result["adjoint"] = {
+        "what": "compute_Gram(X[:%d], Y) with X.requires_grad (forward keeps the terminal edges) + backward of a weighted sum" % ra,
+        "pairs": ra * B, "forward_ms": float(np.mean(fwd_ms)), "backward_ms": float(np.mean(bwd_ms)),
+        "algorithmic_bytes": adj_bytes, "hbm_equivalent_GBs": adj_bytes / tot / 1e9, "hbm_equivalent_frac": adj_bytes / tot / 1e9 / HBM_PEAK_GBS,
+        "entries_per_s_fwd_bwd": ra * B / tot,
+        "note": "3 (M-1)(N-1) s + s bytes per entry (SURVEY 8(d)); LinearKernel / RBFKernel backward passes that fuse the "
+                "static kernel move far fewer bytes -- this is the rate-equivalent the survey prescribes",
+    }
+
+    # ---- (4) parity of the timed output and of the gradient -----------------------------------------------------------
+    skern = static_kernel(kname)
+    rng = np.random.default_rng(0)
+    if mode == "gram":
+        Kc = out[:A].double().cpu().numpy()
+    else:
+        with torch.no_grad():
+            Kc = sk.compute_Gram(Xr, Y).double().cpu().numpy()
+    n_chk = 64 if cells_per_entry < 1e6 else 8
+    idx = rng.integers(0, A * B, size=n_chk)
+    worst = 0.0
+    for p in idx:
+        a, b = divmod(int(p), B)
+        want = O.gram_forward(Xc[a:a + 1], Yc[b:b + 1], skern, dyadic)[0, 0]
+        worst = max(worst, abs(float(Kc[a, b]) - want) / abs(want))
+    tol = 1e-6 if dtype == torch.float64 else 1e-4       # fp32 I/O: the reference's own fp32 bar (test_mps.py:32)
+    gworst, grows = 0.0, []
+    if cells_per_entry < 1e6:
+        for a in (0, ra - 1):
+            gp = O.gram_grad_points(Xc[a:a + 1], Yc[:32], skern, dyadic, nthreads=os.cpu_count() or 1)   # (1,32,M,D)
+            want = np.einsum("b,bmd->md", w[a, :32].numpy(), gp[0])
+            got = grad[a].double().cpu().numpy()
+            gworst = max(gworst, float(np.max(np.abs(got - want)) / np.max(np.abs(want))))
+            grows.append(a)
+    result["parity"] = {"pairs_checked": int(n_chk), "max_rel_err_vs_oracle": worst, "tolerance": tol, "ok": bool(worst <= tol),
+                        "grad_rows_checked": grows, "grad_max_rel_err_vs_oracle": gworst if grows else None,
+                        "grad_tolerance": 1e-6 if dtype == torch.float64 else 1e-4,
+                        "grad_ok": bool(gworst <= (1e-6 if dtype == torch.float64 else 1e-4)) if grows else None}
+    if mode == "mmd":
+        result["parity"]["mmd"] = float(out[0])
+
+    # ---- (5) CPU baseline -----------------------------------------------------------------------------------------------
+    if world == 1 and not args.no_cpu_baseline:
+        cb, vals, nrows = cpu_baseline(Xc[:A], Yc, kname, dyadic, args.cpu_budget_s)
+        cb["max_rel_err_gpu_vs_cpu_sample"] = float(np.max(np.abs(Kc[:nrows] - vals) / np.abs(vals)))
+        result["cpu_baseline"] = cb
+        if mode == "gram":
+            result["speedup_vs_cpu_baseline"] = value / cb["value"]
+            result["speedup_vs_cpu_single_thread"] = value / cb["single_thread_value"]
 
 
 if __name__ == "__main__":

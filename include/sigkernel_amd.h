@@ -145,6 +145,18 @@ int sk_increments_adjoint_f64(const double *W, int64_t ldw, const double *scale,
 int sk_increments_adjoint_f32(const float *W, int64_t ldw, const float *scale, int64_t P, int M, int N, float *dG,
                               void *stream);
 
+/* ---- path staging for the fused solvers -----------------------------------------------------
+ * Builds, in one launch, one of the two fp64 zero-padded arrays the fused kernels below read, from the caller's dense
+ * X [A,M,D] of either precision (replaces the tensor arithmetic the reference runs before its solver launch,
+ * static_kernels.py:26-33 / :58-73):
+ *   diff = 1: scale * (x[p+1] - x[p]), p < M-1 (differences of the up-cast points);  diff = 0: scale * x[p], p < M;
+ *   dim_major = 0: out [A][rows][fd] (the `dXr` / `Xr` layout);  dim_major = 1: out [A][fd][rows] (`dYt` / `Yt`, rows = Ncp);
+ *   rows >= M-1 (diff) or M; fd >= D; everything outside the valid range is written as zero. */
+int sk_prep_paths_f64(const double *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
+                      void *stream);
+int sk_prep_paths_f32(const float *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
+                      void *stream);
+
 /* ---- forward solve ------------------------------------------------------------------------
  * Solves the Goursat PDE for every pair and returns K[MM][NN].
  * Replaces sigkernel_cuda[A,T](...) (sigkernel.py:231; kernel cuda_backend.py:6-49),
@@ -224,6 +236,21 @@ int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t 
  *   workspace: sk_adj_workspace_bytes(...) bytes of device scratch.
  *   inc_c [P,Mc,ld]; out_final nullable [P]; W [P,Mc,ldw] (ldw = 0: dense); out_err nullable [P] doubles. */
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size);
+/*   flags = SK_FLAG_FAST_ONLY: what the fast implementation alone needs (P (edges + 1) doubles; 0 when it does not cover
+ *   the shape) -- the stored-grid figure grows with min(P, 1024) whole grids and is only needed for SK_FLAG_SIMPLE /
+ *   SK_FLAG_EXACT calls or shapes the fast kernels do not cover. */
+
+/* Device-side rescue of the fast adjoint: re-solves with stored grids exactly the pairs whose self-check residual
+ * err[p] (as written by sk_solve_adj_*) exceeds `tol` or is NaN, overwriting their W (and out_final when non-NULL).
+ * Enqueue it unconditionally right after sk_solve_adj_*: when no pair is flagged it reads P doubles and returns, so the
+ * caller never has to read the residuals back (the reference has no such step: it stores both grids for every pair,
+ * sigkernel.py:438-470).  workspace: k >= 1 slots of sk_adj_rescue_slot_bytes(Mc, Nc, dyadic) bytes; k slots re-solve k
+ * flagged pairs concurrently. */
+size_t sk_adj_rescue_slot_bytes(int Mc, int Nc, int dyadic);
+int sk_adj_rescue_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, const double *err,
+                      double tol, double *out_final, double *W, int64_t ldw, void *workspace, size_t workspace_bytes, void *stream);
+int sk_adj_rescue_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, const double *err,
+                      double tol, float *out_final, float *W, int64_t ldw, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Forward solve that also keeps what the fast adjoint needs -- the terminal row and column of K in the strip kernels'
  * padded layout -- so that a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN (workspace = `edges`) skips its forward sweep.

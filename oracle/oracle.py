@@ -15,7 +15,7 @@ _lib = None
 
 __all__ = ["build", "solve_fine", "gram_sym_fine", "solve_coarse", "adjoint_coarse",
            "increments", "increments_adjoint", "max_threads", "gram_forward", "gram_grad_points",
-           "solve_deriv_coarse", "kgrad"]
+           "gram_grad_weighted", "solve_deriv_coarse", "kgrad"]
 
 
 def build(force=False):
@@ -186,6 +186,21 @@ def gram_grad_points(X, Y, static_kernel, dyadic, naive=False, nthreads=1):
         (g,) = torch.autograd.grad(G, Xd, grad_outputs=mask, retain_graph=True)
         out[:, b] = g.numpy()
     return out
+
+
+def gram_grad_weighted(X, Y, w, static_kernel, dyadic, naive=False, nthreads=1):
+    """_SigKernelGram.backward for an upstream gradient w (A,B) (sigkernel.py:404-416 without the 2x rule):
+    numpy (A,M,D) = sum_b w[a,b] * gram_grad_points[a,b] -- one vector-Jacobian product instead of B of them, for the
+    batch sizes where the per-pair tensor (A,B,M,D) would not fit."""
+    import torch
+    Xd = X.detach().double().cpu().requires_grad_(True)
+    Yd = Y.detach().double().cpu()
+    with torch.enable_grad():
+        G = static_kernel.Gram_matrix(Xd, Yd)
+    _, W = adjoint_coarse(increments(G.detach().numpy()), dyadic, naive, nthreads=nthreads)
+    dG = torch.from_numpy(increments_adjoint(W)) * torch.as_tensor(np.asarray(w, dtype=np.float64))[:, :, None, None]
+    (g,) = torch.autograd.grad(G, Xd, grad_outputs=dG)
+    return g.numpy()
 
 
 def kgrad(X, Y, gamma, static_kernel, dyadic, eps=1e-4, nthreads=1):

@@ -56,6 +56,11 @@ SIGNATURES = {
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
                                            _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
+    "sk_adj_rescue_slot_bytes": (_sz, [_int, _int, _int]),
+    "sk_adj_rescue_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, ctypes.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "sk_adj_rescue_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, ctypes.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "sk_prep_paths_f64": (_int, [_vp, _i64, _int, _int, _int, _int, ctypes.c_double, _vp, _int, _int, _vp]),
+    "sk_prep_paths_f32": (_int, [_vp, _i64, _int, _int, _int, _int, ctypes.c_double, _vp, _int, _int, _vp]),
     "sk_strip_edges_bytes": (_sz, [_i64, _int, _int, _int, _int]),
     "sk_solve_fwd_edges_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_edges_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp]),
@@ -153,6 +158,18 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _prep_paths(X, diff, dim_major, scale, rows, fd=8):
+    """fp64, zero-padded staging of a path batch for the fused kernels in ONE launch (sk_prep_paths_*):
+    X (A,M,D) -> [A][rows][fd] (dim_major=False) or [A][fd][rows] (dim_major=True) of scale*(x[p+1]-x[p]) (diff) or
+    scale*x[p]."""
+    A, M, D = X.shape
+    out = torch.empty((A, fd, rows) if dim_major else (A, rows, fd), dtype=torch.float64, device=X.device)
+    fn = getattr(load(), "sk_prep_paths_" + _suffix(X))
+    _check(fn(_ptr(X), A, M, D, int(bool(diff)), int(bool(dim_major)), float(scale), _ptr(out), int(rows), int(fd), _stream(X)),
+           "sk_prep_paths")
+    return out
+
+
 class HipBackend:
     """The product back-end: every method enqueues HIP kernels on the current stream."""
 
@@ -206,14 +223,12 @@ class HipBackend:
             return None
         Mrows, Ncp = 256, (Nc + 15) // 16 * 16
         dev = X.device
-        dXr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
-        dXr[:, :Mc, :D] = (X[:, 1:] - X[:, :-1]).double() * (float(scale) ** 2)
-        dYt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
-        dYt[:, :D, :Nc] = (Y[:, 1:] - Y[:, :-1]).double().transpose(1, 2)
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with torch.cuda.device(dev):
+            dXr = _prep_paths(X, True, False, float(scale) ** 2, Mrows)     # s^2 (x[p+1] - x[p]), [A][256][8]
+            dYt = _prep_paths(Y, True, True, 1.0, Ncp)                      # y[q+1] - y[q], dimension-major [B][8][Ncp]
             if keep_edges and X.dtype == torch.float64 and 0 <= dyadic <= 2:
                 P = A * B if gram else A
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
@@ -245,14 +260,12 @@ class HipBackend:
             return None
         Mrows, Ncp = 256, (N + 15) // 16 * 16
         dev = X.device
-        Xr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
-        Xr[:, :M, :D] = X.double()
-        Yt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
-        Yt[:, :D, :N] = Y.double().transpose(1, 2)
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with torch.cuda.device(dev):
+            Xr = _prep_paths(X, False, False, 1.0, Mrows)     # the path points, [A][256][8]
+            Yt = _prep_paths(Y, False, True, 1.0, Ncp)        # dimension-major [B][8][Ncp]
             if keep_edges and X.dtype == torch.float64:
                 P = A * B if gram else A
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
@@ -272,11 +285,12 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, return_residual=False, gram=True):
-        """dL/dX (A,M,D) for the LINEAR static kernel straight from the paths and the forward's terminal edges: adjoint PDE and
-        contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8, dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64
-        whatever the dtype of X).  None outside that scope or when a pair fails the kernel's self-check (the caller takes the
-        unfused route).  gram=False: paired batch, Y [A,N,D], scale [A]."""
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True):
+        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel straight from the paths
+        and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
+        dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
+        gradient is only valid when the residual is <= ADJ_RESIDUAL_TOL (not NaN): the caller checks, without a
+        synchronisation per call, and takes the unfused route otherwise.  gram=False: paired batch, Y [A,N,D], scale [A]."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -286,18 +300,16 @@ class HipBackend:
             return None
         dev = X.device
         Mrows, Ncp = 256, (Nc + 15) // 16 * 16
-        dXr = torch.zeros(A, Mrows, 8, dtype=torch.float64, device=dev)
-        Xd, Yd = X.double(), Y.double()     # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
-        dXr[:, :Mc, :D] = (Xd[:, 1:] - Xd[:, :-1]) * (float(param) ** 2)
-        dYt = torch.zeros(B, 8, Ncp, dtype=torch.float64, device=dev)
-        dYt[:, :D, :Nc] = (Yd[:, 1:] - Yd[:, :-1]).transpose(1, 2)
         if scale is not None:
             scale = scale.double().contiguous()
         lib = load()
         P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
-        args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
         with torch.cuda.device(dev):
+            # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
+            dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
+            dYt = _prep_paths(Y, True, True, 1.0, Ncp)
+            args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
             rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), _stream(X))
             if rc == 2:
                 return None
@@ -310,9 +322,10 @@ class HipBackend:
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused")
+        # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device.  Exploding kernels
+        # (residual above ADJ_RESIDUAL_TOL) are the caller's to handle -- the stored-grid rescue lives on the unfused route --
+        # and it looks at the residuals of a whole backward pass ONCE (see sigkernel._FusedResiduals).
         res = err.max()
-        if not bool(res <= self.ADJ_RESIDUAL_TOL):      # exploding kernels: the stored-grid rescue lives on the unfused route
-            return None
         T = tpart.sum(1).flip(1)[:, :Mc, :D]     # chunks of an a added in a fixed order; flipped rows back to p
         g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
         g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
@@ -320,7 +333,7 @@ class HipBackend:
         if float(param) != 1.0:
             g = g * (float(param) ** 2)
         g = g.to(X.dtype)
-        return (g, res) if return_residual else g
+        return g, res
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels
@@ -340,8 +353,7 @@ class HipBackend:
                 T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
                 if D <= 8:      # pre-differenced, dimension-major y: every load of the contraction is coalesced
                     ldy = _padded_ld(N - 1, 8)
-                    dYt = torch.zeros(Y.shape[0], 8, ldy, dtype=torch.float64, device=X.device)
-                    dYt[:, :D, : N - 1] = (Y[:, 1:] - Y[:, :-1]).double().transpose(1, 2)
+                    dYt = _prep_paths(Y, True, True, 1.0, ldy)
                     fl = getattr(load(), "sk_linear_adjoint_" + _suffix(X))
                     _check(fl(_ptr(dYt), ldy, _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M - 1, N - 1, D, _ptr(T), _stream(X)),
                            "sk_linear_adjoint")
@@ -375,8 +387,7 @@ class HipBackend:
         with torch.cuda.device(dev):
             fn = getattr(load(), "sk_static_adjoint2_" + _suffix(X))
             if kind == 0:
-                dXr = torch.zeros(A, M - 1, 8, dtype=torch.float64, device=dev)
-                dXr[:, :, :D] = (X[:, 1:] - X[:, :-1]).double() * (float(param) ** 2)
+                dXr = _prep_paths(X, True, False, float(param) ** 2, M - 1)
                 T2 = torch.empty(B - b0, N - 1, D, dtype=X.dtype, device=dev)
                 _check(fn(0, float(param), None, None, _ptr(dXr), M - 1, _ptr(W), ldw, _ptr(scale), A, B, int(b0), M, N, D,
                           _ptr(T2), _stream(X)), "sk_static_adjoint2")
@@ -469,37 +480,63 @@ class HipBackend:
         err = torch.empty(batch, dtype=torch.float64, device=dev)
         lib = load()
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        es = inc_c.element_size()
         with torch.cuda.device(dev):
             fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
+            fast = False
             if edges is not None:
                 _dev(edges, "edges")
                 _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags) | FLAG_EDGES_GIVEN, None, _ptr(Wp), ldw,
                           _ptr(err), _ptr(edges), edges.numel() * 8, _stream(inc_c)), "sk_solve_adj (edges given)")
                 out = None
+                fast = True
             else:
-                nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), int(flags), inc_c.element_size()))
-                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-                _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags), _ptr(out), _ptr(Wp), ldw, _ptr(err),
-                          _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj")
-            W = Wp[..., :Nc]
-            if not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
-                bad = torch.nonzero((err.reshape(-1) > self.ADJ_RESIDUAL_TOL) | torch.isnan(err.reshape(-1))).reshape(-1)
-                if bad.numel():      # rare: re-solve those pairs with both grids stored
-                    sub = inc_c.reshape(P, Mc, Nc)[bad].contiguous()
-                    n = int(bad.numel())
-                    o2 = torch.empty(n, dtype=inc_c.dtype, device=dev)
-                    W2 = torch.empty(n, Mc, Nc, dtype=inc_c.dtype, device=dev)
-                    nb2 = int(lib.sk_adj_workspace_bytes(n, Mc, Nc, int(dyadic), FLAG_SIMPLE, inc_c.element_size()))
-                    ws2 = torch.empty(max(nb2, 1), dtype=torch.uint8, device=dev)
-                    _check(fn(_ptr(sub), Nc, n, Mc, Nc, int(dyadic), scheme, FLAG_SIMPLE, _ptr(o2), _ptr(W2), Nc, None,
-                              _ptr(ws2), nb2, _stream(inc_c)), "sk_solve_adj (stored-grid re-solve)")
-                    Wp.reshape(P, Mc, ldw)[bad, :, :Nc] = W2
-                    if out is not None:
-                        out.reshape(-1)[bad] = o2
-        # the caching allocator keeps `ws` alive for later work queued on this same stream
+                rc = 2
+                if not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+                    # first the fast kernels, with the workspace THEY need (P (edges + 1) doubles): the stored-grid figure is
+                    # min(P, 1024) whole pairs of grids -- tens of GB for long paths -- and is only taken when it is used
+                    nbytes = int(lib.sk_adj_workspace_bytes(P, Mc, Nc, int(dyadic), FLAG_FAST_ONLY, es))
+                    if nbytes:
+                        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                        rc = fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, int(flags) | FLAG_FAST_ONLY, _ptr(out), _ptr(Wp),
+                                ldw, _ptr(err), _ptr(ws), nbytes, _stream(inc_c))
+                        if rc != 2:
+                            _check(rc, "sk_solve_adj")
+                            fast = True
+                    if rc == 2 and (flags & FLAG_FAST_ONLY):
+                        _check(rc, "sk_solve_adj")
+                if rc == 2:      # stored-grid kernel: as many scratch slots as the budget allows (its blocks grid-stride)
+                    ws, nbytes = self._grid_scratch(P, Mc, Nc, dyadic, dev, 1024)
+                    _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, (int(flags) & ~FLAG_FAST_ONLY) | FLAG_SIMPLE,
+                              _ptr(out), _ptr(Wp), ldw, _ptr(err), _ptr(ws), nbytes, _stream(inc_c)), "sk_solve_adj (stored grids)")
+            if fast:
+                # pairs whose self-check residual is too large (exploding kernels) are re-solved with stored grids by a
+                # kernel that reads the residuals itself: nothing comes back to the host, the backward pass never synchronises
+                ws2, nb2 = self._grid_scratch(P, Mc, Nc, dyadic, dev, self.RESCUE_SLOTS)
+                if nb2:
+                    fr = getattr(lib, "sk_adj_rescue_" + _suffix(inc_c))
+                    _check(fr(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, _ptr(err), float(self.ADJ_RESIDUAL_TOL), _ptr(out),
+                              _ptr(Wp), ldw, _ptr(ws2), nb2, _stream(inc_c)), "sk_adj_rescue")
+        W = Wp[..., :Nc]
+        # the caching allocator keeps the scratch alive for the work queued on this same stream
         if return_residual:
             return out, W, err
         return out, W
+
+    RESCUE_SLOTS = 64                   # flagged pairs re-solved concurrently by sk_adj_rescue_*
+    GRID_SCRATCH_BYTES = 2 << 30        # cap on the stored-grid scratch (whole pairs of solution grids)
+
+    def _grid_scratch(self, P, Mc, Nc, dyadic, dev, max_slots):
+        """(uint8 tensor, bytes) holding up to max_slots pairs of solution grids, within GRID_SCRATCH_BYTES (at least one slot;
+        (None, 0) when a single slot exceeds half of the free memory)."""
+        slot = int(load().sk_adj_rescue_slot_bytes(Mc, Nc, int(dyadic)))
+        n = max(1, min(int(max_slots), int(P), self.GRID_SCRATCH_BYTES // max(slot, 1)))
+        free, _ = torch.cuda.mem_get_info(dev)
+        if n * slot > 0.5 * free:
+            n = int(0.5 * free // slot)
+        if n < 1:
+            return None, 0
+        return torch.empty(n * slot, dtype=torch.uint8, device=dev), n * slot
 
     def deriv_increments(self, G0, G1, G2, eps):
         """Static Gram matrices [..., M, N] of X, X + eps*gamma, X + 2*eps*gamma -> one tensor [3, ..., M-1, N-1]:

@@ -102,7 +102,7 @@ int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d
 
 extern "C" {
 
-int sk_version(void) { return 100; }
+int sk_version(void) { return 200; }
 
 const char *sk_status_string(int status) {
     switch (status) {
@@ -292,8 +292,47 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);
     const size_t simple = adj_simple_workspace_bytes(g);
     if (flags & (SK_FLAG_EXACT | SK_FLAG_SIMPLE)) return simple;
-    const size_t fast = adj_fast_workspace_bytes(g, elem_size);
+    const bool fast_shape = dyadic <= (elem_size == 8 ? 2 : 1);   // launch_adj_wave's scope
+    const size_t fast = fast_shape ? adj_fast_workspace_bytes(g, elem_size) : 0;
+    if (flags & SK_FLAG_FAST_ONLY) return fast;
     return fast > simple ? fast : simple;
+}
+
+size_t sk_adj_rescue_slot_bytes(int Mc, int Nc, int dyadic) {
+    if (Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
+    return (size_t)2 * (size_t)((Mc << dyadic) + 1) * (size_t)((Nc << dyadic) + 1) * sizeof(double);
+}
+
+int sk_adj_rescue_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, const double *err,
+                      double tol, double *out_final, double *W, int64_t ldw, void *workspace, size_t workspace_bytes, void *stream) {
+    if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, 0) || !err || !W || (ld != 0 && ld < Nc) || (ldw != 0 && ldw < Nc))
+        return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
+    return launch_adj_rescue<double>(inc_c, g, err, tol, out_final, W, ldw ? ldw : Nc, workspace, workspace_bytes,
+                                     (hipStream_t)stream);
+}
+int sk_adj_rescue_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, const double *err,
+                      double tol, float *out_final, float *W, int64_t ldw, void *workspace, size_t workspace_bytes, void *stream) {
+    if (bad_common(inc_c, P, Mc, Nc, dyadic, scheme, 0) || !err || !W || (ld != 0 && ld < Nc) || (ldw != 0 && ldw < Nc))
+        return SK_ERR_BAD_ARG;
+    if (P == 0) return SK_OK;
+    const Geom g = make_geom(P, Mc, Nc, dyadic, scheme, ld);
+    return launch_adj_rescue<float>(inc_c, g, err, tol, out_final, W, ldw ? ldw : Nc, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
+}
+
+int sk_prep_paths_f64(const double *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
+                      void *stream) {
+    if (!X || !out || A < 0 || M < 1 || D < 1 || fd < D || rows < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_prep_paths<double>(X, A, M, D, diff != 0, dim_major != 0, scale, out, rows, fd, (hipStream_t)stream);
+}
+int sk_prep_paths_f32(const float *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
+                      void *stream) {
+    if (!X || !out || A < 0 || M < 1 || D < 1 || fd < D || rows < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_prep_paths<float>(X, A, M, D, diff != 0, dim_major != 0, scale, out, rows, fd, (hipStream_t)stream);
 }
 
 size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size) {

@@ -33,6 +33,9 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t
 template <typename T>
 int launch_deriv_simple(const T *inc, const T *inc_d, const T *inc_dd, const Geom &g, T *out_k, T *out_kd, T *out_kdd,
                         hipStream_t s);
+template <typename T>
+int launch_adj_rescue(const T *inc_c, const Geom &g, const double *err, double tol, T *out_final, T *W, int64_t ldw, void *ws,
+                      size_t ws_bytes, hipStream_t s);
 size_t adj_simple_workspace_bytes(const Geom &g);
 size_t simple_lds_bytes(const Geom &g);
 
@@ -101,6 +104,11 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
                             const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
                             int *ppg_out, int *rows_out, hipStream_t s);
 
+// ---- sk_prep.hip: fp64, zero-padded, row-major / dimension-major staging of the paths for the fused kernels ----
+template <typename T>
+int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int FDp,
+                      hipStream_t s);
+
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);
@@ -156,7 +164,8 @@ struct ExpCoef {
     }
 };
 __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
-    x = fmax(x, -800.0);   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points
+    x = x < -800.0 ? -800.0 : x;   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points.
+                                   // A select, not fmax: a NaN exponent (NaN / inf coordinates) must stay NaN, as in the reference
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);
@@ -170,7 +179,7 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
 }
 // the same with the coefficients left to the compiler (kernels whose scalar register file has room for them)
 __device__ __forceinline__ double exp_nonpos(double x) {
-    x = fmax(x, -800.0);
+    x = x < -800.0 ? -800.0 : x;   // NaN-preserving clamp (see above)
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);

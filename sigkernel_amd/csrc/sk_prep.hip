@@ -1,0 +1,68 @@
+// sk_prep.hip -- path staging for the fused kernels (sk_wave_fused.hip, sk_wave_adj_fused.hip).
+//
+// The fused solvers read the two path batches in fp64, zero-padded, the first row-major and the second dimension-major:
+//     rows [A][Mrows][FD]   (differences s^2 (x[p+1]-x[p]) or points x[p])
+//     cols [B][FD][Ncp]     (differences y[q+1]-y[q] or points y[q])
+// One launch builds one of the two from the caller's dense (batch, length, dim) tensor of either precision, padding
+// included, so that the host layer issues no elementwise torch ops or zero-fills per call (they were 0.1-0.2 ms of a
+// 0.3 ms Gram at the C2 size).  The differences are formed from the UP-CAST points, as the edge-keeping forward and the
+// fused adjoint both expect.  Replaces the tensor arithmetic around static_kernels.py:26-33 / :58-73 that the reference
+// performs on the device before its solver launch.
+#include "sk_internal.h"
+
+namespace sk {
+namespace {
+
+template <typename T, bool DIFF, bool DIM_MAJOR>
+__global__ __launch_bounds__(256) void k_prep_paths(const T *__restrict__ X, int64_t A, int M, int D, double scale,
+                                                    double *__restrict__ out, int rows, int FDp) {
+    // one thread per output element; consecutive threads write consecutive addresses
+    const int64_t n = A * (int64_t)rows * FDp;
+    const int nvalid = DIFF ? M - 1 : M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t a;
+        int p, j;
+        if (DIM_MAJOR) {   // [a][j][p], p < rows
+            a = i / ((int64_t)rows * FDp);
+            const int rem = (int)(i - a * (int64_t)rows * FDp);
+            j = rem / rows;
+            p = rem - j * rows;
+        } else {           // [a][p][j]
+            a = i / ((int64_t)rows * FDp);
+            const int rem = (int)(i - a * (int64_t)rows * FDp);
+            p = rem / FDp;
+            j = rem - p * FDp;
+        }
+        double v = 0.0;
+        if (p < nvalid && j < D) {
+            const T *x = X + (a * M + p) * (int64_t)D + j;
+            v = DIFF ? ((double)x[D] - (double)x[0]) * scale : (double)x[0] * scale;
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int FDp,
+                      hipStream_t s) {
+    const int64_t n = A * (int64_t)rows * FDp;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(256);
+    if (diff) {
+        if (dim_major) hipLaunchKernelGGL((k_prep_paths<T, true, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        else hipLaunchKernelGGL((k_prep_paths<T, true, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+    } else {
+        if (dim_major) hipLaunchKernelGGL((k_prep_paths<T, false, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        else hipLaunchKernelGGL((k_prep_paths<T, false, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+    }
+    return check_launch();
+}
+
+template int launch_prep_paths<double>(const double *, int64_t, int, int, int, int, double, double *, int, int, hipStream_t);
+template int launch_prep_paths<float>(const float *, int64_t, int, int, int, int, double, double *, int, int, hipStream_t);
+
+}  // namespace sk

@@ -89,36 +89,68 @@ __global__ __launch_bounds__(WAVE) void k_fwd_simple(const T *__restrict__ inc_c
     }
 }
 
-// Robust adjoint: both solution grids are written to a per-block scratch slot, then every
+// Robust adjoint of one pair: both solution grids are written to the block's scratch slot, then every
 // coarse cell sums its r*r products in the oracle's order (i-major), so W is bit-identical
 // to oracle/sigkernel_oracle.c:sk_oracle_adjoint_coarse.
+template <typename T>
+__device__ void adj_pair(const T *__restrict__ inc, int64_t ld, int Mc, int Nc, int d, int naive, double *lds, double *Kf,
+                         double *Kr, T *__restrict__ out_final_p, T *__restrict__ Wp, int64_t ldw) {
+    const int MM = Mc << d, NN = Nc << d, r = 1 << d;
+    const double rs = 1.0 / (double)r;
+    const double v = sweep_pair<T, double, false>(inc, ld, Mc, Nc, d, naive, lds, Kf, nullptr);
+    sweep_pair<T, double, true>(inc, ld, Mc, Nc, d, naive, lds, Kr, nullptr);
+    __syncthreads();
+    if (threadIdx.x == 0 && out_final_p) *out_final_p = (T)v;
+    for (int c = threadIdx.x; c < Mc * Nc; c += WAVE) {
+        const int a = c / Nc, b = c - a * Nc;
+        double acc = 0.;
+        for (int ii = 0; ii < r; ++ii)
+            for (int jj = 0; jj < r; ++jj) {
+                const int i = a * r + ii, j = b * r + jj;
+                acc += Kf[(int64_t)i * (NN + 1) + j] * Kr[(int64_t)(MM - 1 - i) * (NN + 1) + (NN - 1 - j)];
+            }
+        Wp[(int64_t)a * ldw + b] = (T)((acc * rs) * rs);
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d,
                                                      int naive, T *__restrict__ out_final, T *__restrict__ W,
                                                      int64_t ldw, double *__restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int MM = Mc << d, NN = Nc << d, r = 1 << d;
-    const int64_t gs = (int64_t)(MM + 1) * (NN + 1);
-    const double rs = 1.0 / (double)r;
+    const int64_t gs = (int64_t)((Mc << d) + 1) * ((Nc << d) + 1);
     double *Kf = ws + (int64_t)blockIdx.x * 2 * gs;
     double *Kr = Kf + gs;
-    for (int64_t p = blockIdx.x; p < P; p += gridDim.x) {
-        const T *inc = inc_c + p * (int64_t)Mc * ld;
-        const double v = sweep_pair<T, double, false>(inc, ld, Mc, Nc, d, naive, lds, Kf, nullptr);
-        sweep_pair<T, double, true>(inc, ld, Mc, Nc, d, naive, lds, Kr, nullptr);
-        __syncthreads();
-        if (threadIdx.x == 0 && out_final) out_final[p] = (T)v;
-        for (int c = threadIdx.x; c < Mc * Nc; c += WAVE) {
-            const int a = c / Nc, b = c - a * Nc;
-            double acc = 0.;
-            for (int ii = 0; ii < r; ++ii)
-                for (int jj = 0; jj < r; ++jj) {
-                    const int i = a * r + ii, j = b * r + jj;
-                    acc += Kf[(int64_t)i * (NN + 1) + j] * Kr[(int64_t)(MM - 1 - i) * (NN + 1) + (NN - 1 - j)];
-                }
-            W[p * (int64_t)Mc * ldw + (int64_t)a * ldw + b] = (T)((acc * rs) * rs);
+    for (int64_t p = blockIdx.x; p < P; p += gridDim.x)
+        adj_pair<T>(inc_c + p * (int64_t)Mc * ld, ld, Mc, Nc, d, naive, lds, Kf, Kr, out_final ? out_final + p : nullptr,
+                    W + p * (int64_t)Mc * ldw, ldw);
+}
+
+// Device-side rescue of the fast adjoint: every block scans 64 self-check residuals at a time and re-solves, with both
+// grids stored, exactly the pairs whose residual exceeds `tol` (or is NaN).  Launched unconditionally after the fast
+// kernel: when nothing is flagged (the normal case) it reads P doubles and exits, so the host never has to look at the
+// residuals -- no device-to-host synchronisation in a backward pass.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void k_adj_rescue(const T *__restrict__ inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d,
+                                                     int naive, const double *__restrict__ err, double tol,
+                                                     T *__restrict__ out_final, T *__restrict__ W, int64_t ldw,
+                                                     double *__restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t gs = (int64_t)((Mc << d) + 1) * ((Nc << d) + 1);
+    double *Kf = ws + (int64_t)blockIdx.x * 2 * gs;
+    double *Kr = Kf + gs;
+    for (int64_t p0 = (int64_t)blockIdx.x * WAVE; p0 < P; p0 += (int64_t)gridDim.x * WAVE) {
+        const int64_t p = p0 + threadIdx.x;
+        const bool bad = p < P && !(err[p] <= tol);
+        unsigned long long m = __ballot(bad);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t q = p0 + b;
+            adj_pair<T>(inc_c + q * (int64_t)Mc * ld, ld, Mc, Nc, d, naive, lds, Kf, Kr, out_final ? out_final + q : nullptr,
+                        W + q * (int64_t)Mc * ldw, ldw);
         }
-        __syncthreads();
     }
 }
 
@@ -223,6 +255,31 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t
                        g.naive, out_final, W, ldw, (double *)ws);
     return check_launch();
 }
+
+// Re-solve, with stored grids, the pairs whose fast-adjoint residual err[p] exceeds tol.  ws: any number (>= 1) of
+// per-block scratch slots of 2 (MM+1)(NN+1) doubles; the blocks grid-stride over the residuals.
+template <typename T>
+int launch_adj_rescue(const T *inc_c, const Geom &g, const double *err, double tol, T *out_final, T *W, int64_t ldw, void *ws,
+                      size_t ws_bytes, hipStream_t s) {
+    const size_t lds = simple_lds_bytes(g);
+    if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
+    const int64_t gs = (int64_t)(g.MM + 1) * (g.NN + 1);
+    const size_t per_block = (size_t)2 * gs * sizeof(double);
+    if (!ws || ws_bytes < per_block) return SK_ERR_WORKSPACE;
+    int64_t blocks = (int64_t)(ws_bytes / per_block);
+    const int64_t need = (g.P + WAVE - 1) / WAVE;
+    if (blocks > need) blocks = need;
+    if (blocks > 1024) blocks = 1024;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)k_adj_rescue<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_adj_rescue<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic, g.naive,
+                       err, tol, out_final, W, ldw, (double *)ws);
+    return check_launch();
+}
+template int launch_adj_rescue<double>(const double *, const Geom &, const double *, double, double *, double *, int64_t, void *,
+                                       size_t, hipStream_t);
+template int launch_adj_rescue<float>(const float *, const Geom &, const double *, double, float *, float *, int64_t, void *, size_t,
+                                      hipStream_t);
 
 template int launch_fwd_simple<double>(const double *, const Geom &, double *, double *, double *, hipStream_t);
 template int launch_fwd_simple<float>(const float *, const Geom &, float *, float *, double *, hipStream_t);

@@ -389,7 +389,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         const double df = dxr[k][j] - dyv[j][q];
                         d2 = fma(df, df, d2);
                     }
-                    own[k][4 + q] = PIN_EXP ? exp_nonpos(-d2 * prm.inv_sigma, expc) : exp_nonpos(-d2 * prm.inv_sigma);
+                    // d2 * 0 is 0 for finite distances and NaN for an infinite (or NaN) one: the reference's
+                    // |x|^2 + |y|^2 - 2<x,y> is inf - inf = NaN for an infinite coordinate, and so is this exponent
+                    const double ex = fma(-d2, prm.inv_sigma, d2 * 0.0);
+                    own[k][4 + q] = PIN_EXP ? exp_nonpos(ex, expc) : exp_nonpos(ex);
                 }
             // the node row below this lane's last coarse row is the first row of the lane below, which is one macro-step
             // behind: what it has just evaluated are the columns of unit u - 1 = uk + 1

@@ -43,30 +43,34 @@ class ShardedGram(torch.autograd.Function):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         A = X.shape[0]
         lo, hi, chunk = row_range(A, rank, world)
-        ctx.save_for_backward(X, Y)
-        ctx.args = (static_kernel, dyadic_order, sym, _naive_solver, workspace_bytes, group)
-        with torch.no_grad():
-            if hi > lo:
-                Kloc = _SigKernelGram.apply(X.detach()[lo:hi].contiguous(), Y.detach(), static_kernel, dyadic_order,
-                                            False, _naive_solver, workspace_bytes)
-            else:
-                Kloc = torch.empty((0, Y.shape[0]), dtype=X.dtype, device=X.device)
+        ctx.args = (group, A)
+        ctx.local = None
+        ctx.meta = (tuple(X.shape[1:]), X.dtype, X.device)
+        if hi > lo:
+            # the local block goes through the single-GPU Function with its graph kept: when a gradient is pending its forward
+            # keeps the terminal edges of every pair, so that backward runs the adjoint sweep only (no second forward solve)
+            Xl = X.detach()[lo:hi].contiguous().requires_grad_(X.requires_grad)
+            with torch.enable_grad():
+                Kl = _SigKernelGram.apply(Xl, Y.detach(), static_kernel, dyadic_order, False, _naive_solver, workspace_bytes)
+            if X.requires_grad:
+                ctx.local = (Xl, Kl)
+            Kloc = Kl.detach()
+        else:
+            Kloc = torch.empty((0, Y.shape[0]), dtype=X.dtype, device=X.device)
         return _all_gather_rows(Kloc, A, chunk, group)
 
     @staticmethod
     def backward(ctx, grad_output):
-        X, Y = ctx.saved_tensors
-        static_kernel, dyadic_order, sym, naive, workspace_bytes, group = ctx.args
+        group, A = ctx.args
+        tail, dtype, device = ctx.meta
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        A = X.shape[0]
         lo, hi, chunk = row_range(A, rank, world)
-        if hi > lo:
-            Xl = X.detach()[lo:hi].contiguous().requires_grad_(True)
-            with torch.enable_grad():
-                Kl = _SigKernelGram.apply(Xl, Y.detach(), static_kernel, dyadic_order, False, naive, workspace_bytes)
-            (gl,) = torch.autograd.grad(Kl, Xl, grad_output[lo:hi].to(X.dtype))
+        if hi > lo and ctx.local is not None:
+            Xl, Kl = ctx.local
+            ctx.local = None
+            (gl,) = torch.autograd.grad(Kl, Xl, grad_output[lo:hi].to(dtype))
         else:
-            gl = torch.empty((0,) + tuple(X.shape[1:]), dtype=X.dtype, device=X.device)
+            gl = torch.zeros((hi - lo,) + tail, dtype=dtype, device=device)
         grad_X = _all_gather_rows(gl, A, chunk, group)
         if ctx.needs_input_grad[1]:      # the reference's 2x rule (sigkernel.py:410-412)
             grad_X = 2 * grad_X

@@ -89,23 +89,13 @@ def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
 
 
 def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=None):
-    """dL/dX for one tile: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
+    """dL/dX for one tile on the unfused routes: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
 
-    Fused route (LinearKernel / RBFKernel): sk_static_increments -> sk_solve_adj -> sk_static_adjoint.
-    Generic route (any duck-typed static kernel): G with autograd -> sk_increments -> sk_solve_adj ->
+    Linear / RBF: sk_static_increments -> sk_solve_adj -> sk_static_adjoint.
+    Generic (any duck-typed static kernel): G with autograd -> sk_increments -> sk_solve_adj ->
     sk_increments_adjoint (scaled by the upstream gradient) -> one vector-Jacobian product through the static kernel;
     this replaces the reference's h = 1e-9 finite difference (sigkernel.py:313-341, :472-500)."""
     fused = _fused_static(static_kernel, gram)
-    if _fused_linear_adjoint_ok(be, static_kernel, Xt, Yt, dyadic, naive, gram):
-        # LinearKernel: adjoint PDE + contraction in one kernel, from the paths and the forward's terminal edges (fp64 sweep)
-        scale = fused[1]
-        if edges is None or Xt.dtype != torch.float64:
-            res = be.solve_fwd_fused_linear(Xt.double(), Yt.double(), scale, dyadic, naive, gram, keep_edges=True)
-            edges = res[1] if res is not None else None
-        if edges is not None:
-            g = be.linear_adjoint_fused(Xt, Yt, scale, dyadic, edges, None if go is None else go.reshape(-1).contiguous(), gram=gram)
-            if g is not None:
-                return g
     if fused is not None and hasattr(be, "static_adjoint"):
         inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
         if inc is not None:
@@ -122,6 +112,57 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     del W
     (g,) = torch.autograd.grad(G, Xg, dG)
     return g
+
+
+def _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget):
+    """dL/dX for all rows through sk_linear_adjoint_fused_f64 (adjoint PDE + LinearKernel contraction in one kernel, from the
+    paths and the forward's terminal edges; no matrix of size pairs x M x N): one launch per row tile.  None when the kernel
+    does not cover the case or some pair failed its self-check (exploding kernels: the residuals of all tiles are looked at
+    ONCE, here -- the only host synchronisation of a backward pass); the caller then takes the unfused route, tiled by ITS
+    transient memory."""
+    A, M = Xd.shape[0], Xd.shape[1]
+    scale = _fused_static(static_kernel, gram)[1]
+    per_row = (64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M      # edges and partial sums only
+    grad = torch.empty_like(Xd)
+    residuals = []
+    for a0, a1, edges in _edge_tiles(kept, A, per_row, budget):
+        Xt = Xd[a0:a1].contiguous()
+        Yt = Yd if gram else Yd[a0:a1].contiguous()
+        if edges is None or Xd.dtype != torch.float64:     # fp32 paths are swept in fp64: edges of the up-cast paths
+            res = be.solve_fwd_fused_linear(Xt.double(), Yt.double(), scale, dyadic, naive, gram, keep_edges=True)
+            edges = res[1] if res is not None else None
+        if edges is None:
+            return None
+        res = be.linear_adjoint_fused(Xt, Yt, scale, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(),
+                                      gram=gram)
+        if res is None:
+            return None
+        grad[a0:a1] = res[0]
+        residuals.append(res[1])
+    if residuals:
+        worst = torch.stack([r.reshape(()) for r in residuals]).max()
+        if not bool(worst <= be.ADJ_RESIDUAL_TOL):      # also False for NaN
+            return None
+    return grad
+
+
+def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, workspace_bytes):
+    """dL/dX (A,M,D) of a Gram block (gram=True: go (A,B)) or a paired batch (go (A,)): the fused linear adjoint when it
+    applies, else the unfused routes tiled over rows by their transient memory (3 (Linear/RBF) or 8 (generic) arrays of the
+    size of the tile's increments).  kept: what forward left for the tiles ([(a0, a1, edges)] or None)."""
+    A, M, N = Xd.shape[0], Xd.shape[1], Yd.shape[1]
+    budget = _budget(Xd.device, workspace_bytes)
+    if _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram):
+        g = _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget)
+        if g is not None:
+            return g
+    fused = _fused_static(static_kernel, gram) is not None
+    per_row = (3 if fused else 8) * (Yd.shape[0] if gram else 1) * M * N * Xd.element_size()
+    grad = torch.empty_like(Xd)
+    for a0, a1, edges in _edge_tiles(kept, A, per_row, budget, strict=True):
+        grad[a0:a1] = _tile_gradient(be, static_kernel, Xd[a0:a1].contiguous(), Yd if gram else Yd[a0:a1].contiguous(),
+                                     go[a0:a1].contiguous(), dyadic, naive, gram, edges=edges)
+    return grad
 
 
 def _check_inputs(X, Y, paired):
@@ -167,15 +208,9 @@ class _SigKernel(torch.autograd.Function):
         A, M, N = X.shape[0], X.shape[1], Y.shape[1]
         grad_X = torch.zeros_like(X)
         if M >= 2 and N >= 2 and A > 0:
-            Yd = Y.detach()
-            fused = _fused_static(sk, False) is not None
-            per_row = (3 if fused else 8) * M * N * X.element_size()
-            if _fused_linear_adjoint_ok(be, sk, X, Yd, d, naive, False):
-                per_row = 4096 * M               # fused adjoint: edges and partial sums only
             go = grad_output.to(X.dtype).contiguous()
-            for a0, a1 in _tiles(A, per_row, _budget(X.device, ctx.workspace_bytes)):
-                grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd[a0:a1].contiguous(),
-                                               go[a0:a1].contiguous(), d, naive, gram=False)
+            grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, False, None,
+                                    ctx.workspace_bytes)
         return grad_X, None, None, None, None, None
 
 
@@ -258,15 +293,19 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     return K
 
 
-def _edge_tiles(kept, n_rows, per_row, budget):
-    """Row tiles of a backward pass with the terminal edges forward kept for them: [(a0, a1, edges or None)]."""
+def _edge_tiles(kept, n_rows, per_row, budget, strict=False):
+    """Row tiles of a backward pass with the terminal edges forward kept for them: [(a0, a1, edges or None)].
+    strict: never hand back a tile with more rows than `budget` allows (the kept tiling may have been sized for a route with
+    less transient memory); kept edges that do not match the tiling are then dropped and the adjoint sweeps forward itself."""
     tiles = [(a0, a1, None) for a0, a1 in _tiles(n_rows, per_row, budget)]
-    if kept and len(kept) == 1 and kept[0][:2] == (0, n_rows) and kept[0][2] is not None and len(tiles) > 1:
+    if kept and len(kept) == 1 and kept[0][:2] == (0, n_rows) and kept[0][2] is not None:
+        if len(tiles) == 1:
+            return kept
         full = kept[0][2]              # the fused forward kept one block for all rows: slice it per tile
         per = full.numel() // n_rows
         return [(a0, a1, full[a0 * per:a1 * per]) for a0, a1, _ in tiles]
-    if kept:                           # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
-        return kept
+    if kept and (not strict or max(a1 - a0 for a0, a1, _ in kept) <= tiles[0][1] - tiles[0][0]):
+        return kept                    # the tiling of forward, with the edges it kept (None where the strip kernels did not apply)
     return tiles
 
 
@@ -346,17 +385,10 @@ class _SigKernelGram(torch.autograd.Function):
                     del W
             ctx.sym_blocks = None
         elif M >= 2 and N >= 2 and A > 0 and B > 0:
-            Yd = Y.detach()
             go = grad_output.to(X.dtype).contiguous()
-            fused = _fused_static(sk, True) is not None
-            per_row = (3 if fused else 8) * B * M * N * X.element_size()
-            if _fused_linear_adjoint_ok(be, sk, X, Yd, d, naive, True):
-                per_row = 64 * B + 2048 * M      # fused adjoint: no matrix of size pairs x M x N, only the partial sums
-            tiles = _edge_tiles(getattr(ctx, "kept_edges", None), A, per_row, _budget(X.device, ctx.workspace_bytes))
-            ctx.kept_edges = None
-            for a0, a1, edges in tiles:
-                grad_X[a0:a1] = _tile_gradient(be, sk, X.detach()[a0:a1].contiguous(), Yd.contiguous(),
-                                               go[a0:a1].contiguous(), d, naive, gram=True, edges=edges)
+            kept, ctx.kept_edges = getattr(ctx, "kept_edges", None), None
+            grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, True, kept,
+                                    ctx.workspace_bytes)
         # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
         # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
         if ctx.needs_input_grad[1]:

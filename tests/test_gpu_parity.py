@@ -12,13 +12,12 @@ import torch
 
 import sigkernel_amd
 from sigkernel_amd import _lib
-from conftest import golden, golden_gram_cases, make_kernel, rel_err, walk
+from conftest import golden, golden_gram_cases, grad_tol, make_kernel, rel_err, walk
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
 FAST_TOL = 1e-12
-GRAD_TOL = 2e-5      # vs reference fixtures (reference FD noise floor, tests/test_oracle.py)
 ADJ_TOL = 1e-10      # vs the CPU oracle's closed form
 F32_RTOL, F32_ATOL = 1e-4, 1e-5   # the reference's own fp32 acceptance (sigkernel/test_mps.py:32)
 
@@ -273,7 +272,7 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
         inc = be.static_increments(0, par, X, Y, gram=True)
         _, W = be.solve_adj(inc, d, False, edges=edges, flags=_lib.FLAG_FAST_ONLY)
         want = be.static_adjoint(0, par, X, Y, W, go, True)
-        got = be.linear_adjoint_fused(X, Y, par, d, edges, go, return_residual=True)
+        got = be.linear_adjoint_fused(X, Y, par, d, edges, go)
         assert got is not None, (it, A, B, M, N, D, d)
         n += 1
         assert rel_err(got[0].cpu().numpy(), want.cpu().numpy()) <= max(1e-11, 10 * float(got[1])), (it, A, B, M, N, D, d, par)
@@ -285,7 +284,7 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
     inc = be.static_increments(0, 1.0, X, Y, gram=True)
     _, W = be.solve_adj(inc, 1, False, edges=edges)
     got = be.linear_adjoint_fused(X, Y, 1.0, 1, edges, None)
-    assert got is not None and rel_err(got.cpu().numpy(), be.static_adjoint(0, 1.0, X, Y, W, None, True).cpu().numpy()) <= 1e-11
+    assert got is not None and float(got[1]) <= 1e-10 and rel_err(got[0].cpu().numpy(), be.static_adjoint(0, 1.0, X, Y, W, None, True).cpu().numpy()) <= 1e-11
     # outside its scope the kernel says so
     X0 = torch.zeros(2, 20, 3, dtype=torch.float64, device=DEV)
     assert be.linear_adjoint_fused(X0, X0, 1.0, 3, torch.zeros(8, dtype=torch.float64, device=DEV), None) is None      # dyadic 3
@@ -306,10 +305,11 @@ def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par):
     _, W = be.solve_adj(inc, d, False, edges=edges)
     want = be.static_adjoint(0, par, X, Y, W, go, False)
     got = be.linear_adjoint_fused(X, Y, par, d, edges, go, gram=False)
-    assert got is not None and rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-11
+    assert got is not None and rel_err(got[0].cpu().numpy(), want.cpu().numpy()) <= 1e-11
     _, edges32 = be.solve_fwd_fused_linear(X.float().double(), Y.float().double(), par, d, False, gram=False, keep_edges=True)
     got32 = be.linear_adjoint_fused(X.float(), Y.float(), par, d, edges32, go.float(), gram=False)
-    assert got32 is not None and got32.dtype == torch.float32
+    assert got32 is not None and got32[0].dtype == torch.float32
+    got32 = got32[0]
     np.testing.assert_allclose(got32.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()))
     # API level: compute_kernel gradients, fp64 and fp32, against the unfused route
     sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(scale=par), d)
@@ -617,24 +617,24 @@ def test_api_gram_and_gradients_vs_reference(be, name):
     assert rel_err(K.cpu().numpy(), c["gram"]) <= 1e-11
     Xg = X.clone().requires_grad_(True)
     (sk.compute_Gram(Xg, Y) * w).sum().backward()
-    assert rel_err(Xg.grad.cpu().numpy(), c["grad_w"]) <= GRAD_TOL
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_w"]) <= grad_tol(name, "grad_w")
     n = c["paired"].shape[0]
     Xg = X[:n].clone().requires_grad_(True)
     Kp = sk.compute_kernel(Xg, Y[:n])
     assert rel_err(Kp.detach().cpu().numpy(), c["paired"]) <= 1e-11
     (Kp * torch.from_numpy(c["wp"]).to(DEV)).sum().backward()
-    assert rel_err(Xg.grad.cpu().numpy(), c["grad_paired"]) <= GRAD_TOL
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_paired"]) <= grad_tol(name, "grad_paired")
     if "mmd" in c:
         Xg = X.clone().requires_grad_(True)
         mmd = sk.compute_mmd(Xg, Y)
         mmd.backward()
         assert abs(float(mmd.detach()) - float(c["mmd"])) <= 1e-11
-        assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= GRAD_TOL
+        assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= grad_tol(name, "grad_mmd")
         Xg = X.clone().requires_grad_(True)
         G = sk.compute_Gram(Xg, Xg, sym=True)
         G.sum().backward()
         assert rel_err(G.detach().cpu().numpy(), c["gram_xx_sym"]) <= 1e-11
-        assert rel_err(Xg.grad.cpu().numpy(), c["grad_xx_sum"]) <= GRAD_TOL
+        assert rel_err(Xg.grad.cpu().numpy(), c["grad_xx_sum"]) <= grad_tol(name, "grad_xx_sum")
 
 
 def test_api_readme_example(be):
@@ -647,7 +647,7 @@ def test_api_readme_example(be):
     mmd = sk.compute_mmd(Xg, Y)
     mmd.backward()
     assert abs(float(mmd.detach()) - float(c["mmd"])) <= 1e-11
-    assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= GRAD_TOL
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= grad_tol("readme_c1", "grad_mmd")
     assert abs(float(sk.compute_scoring_rule(X, Z[:1])) - float(c["scoring_rule"])) <= 1e-11
     assert abs(float(sk.compute_expected_scoring_rule(X, Z)) - float(c["expected_scoring_rule"])) <= 1e-11
     assert abs(float(sk.compute_distance(X, Y)) - float(c["distance"])) <= 1e-11

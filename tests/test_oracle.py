@@ -5,7 +5,7 @@ import pytest
 import scipy.special
 import torch
 
-from conftest import golden, golden_gram_cases, make_kernel, rel_err
+from conftest import golden, golden_gram_cases, make_kernel, rel_err, grad_tol
 from oracle import oracle as O
 
 FWD_TOL = 1e-13   # the oracle is the same arithmetic as the reference: expect exactly 0
@@ -13,7 +13,6 @@ FWD_TOL = 1e-13   # the oracle is the same arithmetic as the reference: expect e
 # (sigkernel.py:472-487): its own gradients carry rounding noise of 1e-7..7e-6 (max-norm relative;
 # largest on the rough RBF cases).  test_adjoint_vs_noise_free_reference_formula shows the noise is the
 # reference's, not ours: against the same formula evaluated in extended precision we agree to 1e-8.
-GRAD_TOL = 2e-5
 
 
 def test_solver_grids_bit_identical():
@@ -55,10 +54,10 @@ def test_adjoint_matches_reference_gradients(name):
     X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
     gp = O.gram_grad_points(X, Y, make_kernel(c), int(c["dyadic"]), bool(c["naive"]))   # (A,B,M,D)
     grad = np.einsum("ab,abmd->amd", c["w"], gp)
-    assert rel_err(grad, c["grad_w"]) <= GRAD_TOL
+    assert rel_err(grad, c["grad_w"]) <= grad_tol(name, "grad_w")
     if "grad_xx_sum" in c:
         gp_xx = O.gram_grad_points(X, X, make_kernel(c), int(c["dyadic"]), bool(c["naive"]))
-        assert rel_err(2 * gp_xx.sum(axis=1), c["grad_xx_sum"]) <= GRAD_TOL   # the 2x rule, sigkernel.py:410-412
+        assert rel_err(2 * gp_xx.sum(axis=1), c["grad_xx_sum"]) <= grad_tol(name, "grad_xx_sum")   # the 2x rule, sigkernel.py:410-412
 
 
 def test_adjoint_weights_are_the_exact_derivative_of_the_surrogate():
@@ -138,4 +137,6 @@ def test_adjoint_vs_noise_free_reference_formula(name):
             fd[:, :, m, k] = (W * dinc).sum(axis=(2, 3))
     gp = O.gram_grad_points(torch.from_numpy(X), torch.from_numpy(Y), make_kernel(c), d, bool(c["naive"]))
     assert rel_err(gp, fd) <= 1e-7
-    assert rel_err(np.einsum("ab,abmd->amd", c["w"], fd), c["grad_w"]) <= GRAD_TOL
+    # the same formula in double with the same h is what the reference ran: its distance from the long-double evaluation IS
+    # the round-off noise the fixture carries -- the bound the per-fixture tolerances (conftest.grad_tol) rest on
+    assert rel_err(np.einsum("ab,abmd->amd", c["w"], fd), c["grad_w"]) <= grad_tol(name, "grad_w")
