@@ -206,6 +206,26 @@ int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t 
                          int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                          int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
+/* Forward solve with the static kernel fused in for LONG or WIDE paths (csrc/sk_wave_fused_mb.hip): any number of bands per
+ * pair (M - 1 beyond 256/128/64 at dyadic 0/1/2) and path dimensions up to 16 -- BASELINE configs[4] (len 512, dim 16,
+ * RBF, dyadic 2) runs in this one kernel with nothing of size P*M*N in HBM.  Replaces, like the two families above,
+ * static_kernels.py:26-33 / :58-73 + sigkernel.py:362-382 (Gram) / :216-234 (paired).
+ *   kind 0 (linear, param unused): Xr [A][Mrows][fd] = s^2 (x[p+1]-x[p]), Yt [Bn][fd][Ncp] = y[q+1]-y[q];
+ *   kind 1 (rbf, param = sigma):   Xr = the points x[p], Yt = the points y[q];  both fp64, zero-padded, as sk_prep_paths_* builds
+ *   them;  fd = 8 for D <= 8, 16 for D <= 16;  Mrows >= sk_solve_fwd_static_rows(kind, Mc, dyadic);
+ *   Ncp >= 2 NUp with NUp = ceil8((Nc + 1 + kind) / 2), NUp >= 72;  B > 0: Gram, B == 0: paired;  out_final [P];
+ *   workspace: sk_solve_fwd_static_workspace_bytes(...) bytes (one band-boundary row per resident wave; 0 = unsupported).
+ * SK_ERR_UNSUPPORTED: dyadic > 2, D > 16, or a second path too short for the band pipeline (N < ~130: use the kernels above,
+ * sk_static_increments_* + sk_solve_fwd_*, or swap the arguments -- the kernel is symmetric). */
+size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
+int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
+int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
+                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
+                            void *stream);
+int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
+                            int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace, size_t workspace_bytes,
+                            void *stream);
+
 /* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
  * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,

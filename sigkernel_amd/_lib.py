@@ -51,6 +51,12 @@ SIGNATURES = {
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
     "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_static_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
+    "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
+    "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
+                                       _vp, _sz, _vp]),
+    "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
+                                       _vp, _sz, _vp]),
     "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
@@ -284,6 +290,45 @@ class HipBackend:
             return None
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
+
+    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram):
+        """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for
+        pairs that need several bands of a wavefront and for path dims up to 16 (sk_solve_fwd_static_*, csrc/sk_wave_fused_mb.hip):
+        nothing of size pairs x M x N in HBM.  None outside the kernel's scope (dyadic > 2, dim > 16, naive scheme, second path
+        shorter than ~130 points)."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if naive or D > 16 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or (kind == 1 and not float(param) > 0):
+            return None
+        lib = load()
+        P = A * B if gram else A
+        nbytes = int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), D))
+        if not nbytes:
+            return None
+        fd = 8 if D <= 8 else 16
+        Mrows = int(lib.sk_solve_fwd_static_rows(int(kind), Mc, int(dyadic)))
+        NUp = ((Nc + 1 + int(kind)) // 2 + 7) // 8 * 8
+        Ncp = 2 * NUp
+        dev = X.device
+        out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
+        with torch.cuda.device(dev):
+            if kind == 0:
+                Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
+                Yt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
+            else:
+                Xr = _prep_paths(X, False, False, 1.0, Mrows, fd)
+                Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            fn = getattr(lib, "sk_solve_fwd_static_" + _suffix(X))
+            rc = fn(int(kind), float(param), _ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, fd, int(dyadic),
+                    SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
+        if rc == 2:
+            return None
+        _check(rc, "sk_solve_fwd_static")
+        return out
 
     def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel straight from the paths

@@ -98,6 +98,18 @@ int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d
     return launch_fwd_wave<T>(inc_c, g.ld, g, out_final, edges, (hipStream_t)stream);
 }
 
+template <typename TO>
+int solve_fwd_static(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
+                     int Ncp, int D, int fd, int dyadic, int scheme, TO *out_final, void *ws, size_t ws_bytes, void *stream) {
+    if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
+    if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_fwd_fused_mb<TO>(kind, Xr, Yt, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, out_final, ws, ws_bytes,
+                                   (hipStream_t)stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -254,6 +266,27 @@ int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t 
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
     return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+}
+
+size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
+    if (P <= 0 || Mc < 1 || Nc < 1) return 0;
+    return fused_mb_workspace_bytes(kind, P, Mc, Nc, dyadic, D);
+}
+int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
+    if (Mc < 1 || dyadic < 0 || dyadic > 2) return 0;
+    return fused_mb_rows(kind, Mc, dyadic);
+}
+int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
+                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    return solve_fwd_static<double>(kind, param, Xr, Yt, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+                                    workspace_bytes, stream);
+}
+int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
+                            int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    return solve_fwd_static<float>(kind, param, Xr, Yt, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+                                   workspace_bytes, stream);
 }
 
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,

@@ -99,6 +99,13 @@ template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, TO *out, double *strip_edges, hipStream_t s);
 
+// ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
+template <typename TO>
+int launch_fwd_fused_mb(int kind, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd,
+                        const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s);
+size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
+int fused_mb_rows(int kind, int Mc, int dyadic);
+
 // ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
                             const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,

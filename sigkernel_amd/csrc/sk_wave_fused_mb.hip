@@ -1,0 +1,662 @@
+// sk_wave_fused_mb.hip -- forward solver with the static kernel fused in, for pairs that need SEVERAL BANDS of a wavefront
+// (long paths: M - 1 > 64 RC) and for path dimensions up to 16.  KIND 0: LinearKernel, KIND 1: RBFKernel.
+//
+// One 64-lane wavefront sweeps one pair at a time (L = 64, persistent over its share of the pairs).  Lane `lam` owns RC
+// coarse rows of a band of 64 RC rows and runs `lam` macro-steps behind lane 0 (skewed row strips, DPP neighbour exchange:
+// sk_wave.hip); the bands of a pair and then the next pair follow each other in one virtual column stream, so the skew
+// fills once per wave.  As in sk_wave_fused.hip nothing of size pairs x M x N exists: the increments of a macro-step's
+// RC x 2 coarse cells are formed from the paths, which the wave streams through two small LDS rings (y: slabs of 8 units
+// x FD dims over the virtual column stream, parity-swizzled; x: the rows of the 8 lanes that start a band during the next
+// 8 macro-steps).  What is new here:
+//
+//   * Bands.  The bottom lane's last fine row is the top boundary of the next band, needed NUp - 63 macro-steps later by
+//     lane 0.  It travels through a per-wave row in GLOBAL memory (caller's workspace, L2-resident) instead of LDS, where
+//     a whole row of the pair (16 KB at 2044 fine columns) would cost the kernel its occupancy -- but never with a memory
+//     operation per macro-step: lane 63 stages its entries in LDS, every 8 macro-steps the wave writes the finished chunk
+//     of 8 units through to L2 with one coalesced store, and lane 0's chunk of the coming window arrives by LDS-DMA together
+//     with the path slabs (one window ahead, past the L1).  All global traffic is issued at window boundaries and waited
+//     for 8 macro-steps later; the first version loaded lane 0's entry from global memory every step and ran at the
+//     latency of that load (1.2 us per macro-step).
+//   * RBF nodes "from above".  A lane evaluates the nodes G[p][q] = exp(-|x_p - y_q|^2 / sigma) of the BOTTOM node rows of
+//     its RC coarse rows (rows r0+1 .. r0+RC) one unit ahead of the block sweep, and takes the node row r0 above its first
+//     coarse row from the lane above -- which is one macro-step ahead, so the values exist already and no lag between lanes
+//     is needed (the single-band kernel takes the row BELOW from the lane below and runs its sweep two units behind).  Lane
+//     0 gets that row from the previous band's bottom lane through the same global row mechanism, and in band 0 -- node
+//     row 0 of the pair -- evaluates it itself: a divergent branch that the wave pays for 1 / nb of the time.
+//   * FD = 16 dimensions (zero-padded), two LDS-DMA instructions per y slab.
+//
+// Scope: dyadic <= 2, path dim <= 16, N <= 2 NUp with NUp >= 80 units (a chunk must be flushed and acknowledged before the
+// window that consumes it is fetched: NUp - 63 >= 17 macro-steps), any M.  Shorter second paths with long first paths: the caller swaps the arguments (the kernel is symmetric).
+// Replaces, for LinearKernel / RBFKernel on long or wide paths, static_kernels.py:26-33 / :58-73 + sigkernel.py:362-382.
+#include "sk_wave_common.h"
+
+namespace sk {
+namespace {
+
+constexpr int MB_L = WAVE;   // lanes per pair
+constexpr int MB_X_SLOTS = 2;
+
+struct FusedMbParams {
+    const double *Xr;   // [A][Mrows][FD]: KIND 0: s^2 (x[p+1]-x[p]);  KIND 1: x[p]; zero rows / dims beyond the path
+    const double *Yt;   // [Bn][FD][Ncp]: KIND 0: y[q+1]-y[q];  KIND 1: y[q]; dimension-major, zero-padded
+    void *out;          // [P]
+    double *ws;         // per wave: [NUp + 8][E] band-boundary row + a chunk of ones, E = S doubles of K (+ 2 node values, KIND 1) per unit
+    int64_t P, B;       // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired
+    int Mrows, Ncp, Mc, Nc, NUp, nb, PPW, n_steps;
+    int u_f, lam_f, band_f, sel_f;
+    double inv_sigma;
+    int64_t ws_stride;  // doubles per wave
+    WaveGroup wg;
+};
+
+// 16-byte asynchronous global load past the L1 (sc0 sc1: the line was written by another lane of this wave a few
+// macro-steps ago and must come from L2).  Destination handling as in sk_wave_common.h (load_async / async_wait).
+__device__ __forceinline__ void async_begin2(d2_t &t) { asm volatile("" : "=v"(t)); }
+__device__ __forceinline__ void load_async_x4(d2_t &dst, const double *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int BYTE_OFF>
+__device__ __forceinline__ void load_async_x4_at(d2_t &dst, const double *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(dst) : "v"(p), "n"(BYTE_OFF) : "memory");
+}
+// 16-byte store written through to L2 (device scope): another lane of this wave loads it from there a few macro-steps
+// later; a wave-scope store may be acknowledged by the L1 first
+__device__ __forceinline__ void store_through(double *p, d2_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait2(d2_t (&o)[1], d2_t (&t)[1]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "=v"(o[0]) : "0"(t[0]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait2(d2_t (&o)[4], d2_t (&t)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait2(d2_t (&o)[2], d2_t (&t)[2]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "=v"(o[0]), "=v"(o[1]) : "0"(t[0]), "1"(t[1]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait2(d2_t (&o)[3], d2_t (&t)[3]) {
+    asm volatile("s_waitcnt vmcnt(%6)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]) : "0"(t[0]), "1"(t[1]), "2"(t[2]), "n"(VM) : "memory");
+}
+template <int VM>
+__device__ __forceinline__ void async_wait2(d2_t (&o)[5], d2_t (&t)[5]) {
+    asm volatile("s_waitcnt vmcnt(%10)" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "n"(VM) : "memory");
+}
+
+// N consecutive 16-byte LDS reads at a stride of 256 bytes from two interleaved bases (even / odd dimension rows of a
+// parity-swizzled y slab, see sk_wave_fused.hip), one wait
+template <int ND>
+__device__ __forceinline__ void lds_read_dims(d2_t (&v)[ND], unsigned a_even, unsigned a_odd);
+template <>
+__device__ __forceinline__ void lds_read_dims<8>(d2_t (&v)[8], unsigned a_even, unsigned a_odd) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %8 offset:256\n\tds_read_b128 %3, %9 offset:256\n\t"
+                 "ds_read_b128 %4, %8 offset:512\n\tds_read_b128 %5, %9 offset:512\n\t"
+                 "ds_read_b128 %6, %8 offset:768\n\tds_read_b128 %7, %9 offset:768\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a_even), "v"(a_odd) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_dims<16>(d2_t (&v)[16], unsigned a_even, unsigned a_odd) {
+    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\t"
+                 "ds_read_b128 %2, %16 offset:256\n\tds_read_b128 %3, %17 offset:256\n\t"
+                 "ds_read_b128 %4, %16 offset:512\n\tds_read_b128 %5, %17 offset:512\n\t"
+                 "ds_read_b128 %6, %16 offset:768\n\tds_read_b128 %7, %17 offset:768\n\t"
+                 "ds_read_b128 %8, %16 offset:1024\n\tds_read_b128 %9, %17 offset:1024\n\t"
+                 "ds_read_b128 %10, %16 offset:1280\n\tds_read_b128 %11, %17 offset:1280\n\t"
+                 "ds_read_b128 %12, %16 offset:1536\n\tds_read_b128 %13, %17 offset:1536\n\t"
+                 "ds_read_b128 %14, %16 offset:1792\n\tds_read_b128 %15, %17 offset:1792\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]),
+                   "=&v"(v[8]), "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+                 : "v"(a_even), "v"(a_odd) : "memory");
+}
+// FD consecutive doubles (one x row), one wait
+template <int ND>
+__device__ __forceinline__ void lds_read_xrow(double (&x)[ND], unsigned a) {
+    static_assert(ND == 8 || ND == 16, "");
+    double lo[8];
+    lds_read_row1<8>(lo, a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = lo[i];
+    if constexpr (ND == 16) {
+        double hi[8];
+        lds_read_row1<8>(hi, a + 64u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[8 + i] = hi[i];
+    }
+}
+
+// E consecutive doubles of a top lane's boundary entry (E = 2, 4, 6, 8 or 10), issued WITHOUT a wait: the reads complete
+// at the macro-step's first lgkmcnt(0) (the y read right behind them); lds_pend_take hands the values over afterwards.
+template <int NP>
+__device__ __forceinline__ void lds_read_pend(d2_t (&t)[NP], unsigned a);
+template <> __device__ __forceinline__ void lds_read_pend<1>(d2_t (&t)[1], unsigned a) {
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(t[0]) : "v"(a) : "memory");
+}
+template <> __device__ __forceinline__ void lds_read_pend<2>(d2_t (&t)[2], unsigned a) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(t[0]), "=&v"(t[1]) : "v"(a) : "memory");
+}
+template <> __device__ __forceinline__ void lds_read_pend<3>(d2_t (&t)[3], unsigned a) {
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]) : "v"(a) : "memory");
+}
+template <> __device__ __forceinline__ void lds_read_pend<4>(d2_t (&t)[4], unsigned a) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(a) : "memory");
+}
+template <> __device__ __forceinline__ void lds_read_pend<5>(d2_t (&t)[5], unsigned a) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48\n\t"
+                 "ds_read_b128 %4, %5 offset:64"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]) : "v"(a) : "memory");
+}
+template <int NP>
+__device__ __forceinline__ void lds_pend_take(d2_t (&o)[NP], d2_t (&t)[NP]) { async_wait2<63>(o, t); }   // vmcnt(63): no wait at all
+
+template <typename TO, int DY, bool NAIVE, int KIND, int FD>
+__global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams prm) {
+    constexpr bool RBF = KIND == 1;
+    constexpr int LAG = RBF ? 1 : 0;   // macro-steps by which the block sweep trails the node evaluation
+    constexpr int CW = 2;
+    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int L = MB_L;
+    constexpr int XROW = FD * 8;              // bytes of one x row
+    constexpr int XSLAB = 8 * RC * XROW;      // the rows of 8 lanes
+    constexpr int YSLAB = FD * 128;           // FD dimension rows of 8 units
+    constexpr int NSLAB = L / 8 + 2;
+    constexpr int NDMA_Y = YSLAB / 1024, NDMA_X = (XSLAB + 1023) / 1024;
+    // band boundary: per unit of the stream S doubles of K (bottom fine row of the band being left) and, RBF, the 2 node
+    // values under it -- E doubles; 8 units make a chunk
+    constexpr int E = S + (RBF ? 2 : 0), NP = E / 2, CHUNK = 8 * E * 8;
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
+    const unsigned lds0 = lds_offset(lds);
+    // LDS map of a wave: [y ring: NSLAB slabs][x ring: 2 slabs][boundary chunks in: 2 slots][boundary chunk out]
+    //                    [RBF: x row 0 of the pair, 2 slots of XROW bytes]
+    constexpr unsigned X_BASE = NSLAB * YSLAB, BI_BASE = X_BASE + MB_X_SLOTS * XSLAB, BO_BASE = BI_BASE + 2 * CHUNK,
+                       T_BASE = BO_BASE + CHUNK;
+
+    const int lam = threadIdx.x & (WAVE - 1);
+    const int NUp = prm.NUp, nb = prm.nb;
+    const double sc = 1.0 / (double)(1 << (2 * DY));
+    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const bool is_top = lam == 0, is_bot = lam == L - 1;
+
+    // ---- cursors: (u, band, ps) = where this lane's node evaluation / path reads are; (uk, bandk, psk) = its block sweep,
+    //      LAG macro-steps behind.  Virtual unit v = t - lam over the stream [pair][band][unit].
+    int u, band, ps, uk, bandk, psk;
+    {
+        int sig = floor_div(-lam, NUp);
+        u = -lam - sig * NUp;
+        ps = floor_div(sig, nb);
+        band = sig - ps * nb;
+        sig = floor_div(-lam - LAG, NUp);
+        uk = -lam - LAG - sig * NUp;
+        psk = floor_div(sig, nb);
+        bandk = sig - psk * nb;
+    }
+    int yslab, ypar;
+    {
+        const int s0 = floor_div(-lam, 8);
+        yslab = ((s0 % NSLAB) + NSLAB) % NSLAB;
+        ypar = s0 & 1;
+    }
+    const int lam7 = lam & 7;
+    const int64_t pair0 = wave_id * prm.PPW;
+    int nvalid;   // pairs of this wave that exist
+    {
+        const int64_t left_pairs = prm.P - pair0;
+        nvalid = left_pairs <= 0 ? 0 : (left_pairs < prm.PPW ? (int)left_pairs : prm.PPW);
+    }
+    const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
+    const unsigned my_x = lds0 + X_BASE + (unsigned)((lam & 7) * RC * XROW);
+
+    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
+    auto split_b = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+    };
+    auto split_a = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+    };
+
+    // the wave's boundary row in global memory: [NUp][E] doubles, position = the producing / consuming lane's unit u
+    double *const wsrow = prm.ws + wave_id * prm.ws_stride;
+
+    // ---- producers (wave-uniform control), once per window of 8 macro-steps ------------------------------------------
+    // y slab s = virtual units [8s, 8s+8): unit offset y_u0 in the row, of pair-in-wave y_pi (every band re-reads its pair's y)
+    int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
+    auto issue_y = [&]() {
+        int64_t p = pair0 + y_pi;
+        if (y_pi >= prm.PPW || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
+        const int64_t b = split_b(p);
+#pragma unroll
+        for (int c = 0; c < NDMA_Y; ++c) {
+            const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);     // odd slabs: dimension rows swapped in pairs
+            const double *src = prm.Yt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lam & 7)) * 2);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+        }
+        y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
+        y_par ^= 1;
+        y_u0 += 8;
+        if (y_u0 == NUp) {
+            y_u0 = 0;
+            y_band += 1;
+            if (y_band == nb) { y_band = 0; y_pi += 1; }
+        }
+    };
+    // x slab for the lanes x_lam0 .. x_lam0+7 that start row unit (x_pi, x_band) during the window (NUp > L: at most one row
+    // unit starts per window); KIND 1 owns the node rows r0+1 .. r0+RC, KIND 0 the rows r0 ..;  and the boundary chunk lane 0
+    // consumes during the window: positions x_lam0 .. x_lam0+7 of the wave's global row (lane 0's unit IS the window's offset)
+    int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
+    auto issue_x = [&]() {
+        int64_t p = pair0 + x_pi;
+        if (x_pi >= prm.PPW || p >= prm.P) p = 0;
+        const int64_t a = split_a(p);
+        const int lamj = x_lam0 < L ? x_lam0 : 0;     // nobody starts: fetch something valid
+        const char *src = reinterpret_cast<const char *>(prm.Xr + (a * prm.Mrows + (int64_t)(x_band * L + lamj) * RC + (RBF ? 1 : 0)) * FD);
+        char *dst = lds + X_BASE + x_slot * XSLAB;
+#pragma unroll
+        for (int c = 0; c < NDMA_X; ++c) {
+            const int off = c * 1024 + lam * 16;
+            if (XSLAB % 1024 == 0 || off < XSLAB)   // partial last piece: the lanes past its end are masked out of the DMA
+                __builtin_amdgcn_global_load_lds(src + off, (lds_void *)(dst + c * 1024), 16, 0, 0);
+        }
+        if (RBF) {   // node row 0 of the pair the window's row unit belongs to (lane 0 evaluates it itself in band 0)
+            const char *s0 = reinterpret_cast<const char *>(prm.Xr + a * prm.Mrows * FD) + lam * 16;
+            if (lam < XROW / 16)   // XROW bytes only: the other lanes are masked out of the DMA
+                __builtin_amdgcn_global_load_lds(s0, (lds_void *)(lds + T_BASE + (x_pi & 1) * XROW), 16, 0, 0);
+        }
+        if (lam < CHUNK / 16) {   // past the L1 (aux = sc0 | sc1): the chunk was written through to L2 by this wave's flush
+            // K[0][.] = 1 is the top boundary of band 0: entries whose K part belongs to a sweep in band 0 come from the ones
+            // chunk behind the row, so that the consumer needs no select.  The sweep trails the window's row unit by LAG
+            // units: with LAG = 1 entry 0 of a row unit's first window still belongs to the PREVIOUS band's sweep.
+            const bool ones_rest = x_band == 0;
+            const bool ones_first = LAG == 0 || x_lam0 > 0 ? ones_rest : x_band == (nb > 1 ? 1 : 0);
+            const int piece = lam * 2;                           // doubles from the chunk's start
+            const bool first_k = piece < S;                      // K part of entry 0
+            const bool ones = first_k ? ones_first : ones_rest;  // (node parts of band-0 windows are never used)
+            const double *sb = (ones ? wsrow + (int64_t)NUp * E : wsrow + (int64_t)x_lam0 * E) + piece;
+            __builtin_amdgcn_global_load_lds(sb, (lds_void *)(lds + BI_BASE + x_slot * CHUNK), 16, 0, 17);
+        }
+        x_slot ^= 1;
+        x_lam0 += 8;
+        if (x_lam0 == NUp) {
+            x_lam0 = 0;
+            x_band += 1;
+            if (x_band == nb) { x_band = 0; x_pi += 1; }
+        }
+    };
+    // the bottom lane's staged chunk (its units f_pos .. f_pos+7) -> the wave's global row, written through to L2
+    int f_pos = -(L - 1) - 7 + 7;   // unit at which the next chunk of the bottom lane starts; < 0: lane 63 has not started
+    {
+        // lane 63's stream unit at macro-step t is t - 63; its first whole chunk [0, 8) is complete at t = 70
+        f_pos = 0;
+    }
+    auto flush_chunk = [&]() {
+        if (lam < CHUNK / 16) {
+            d2_t v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + BO_BASE + (unsigned)(lam * 16)) : "memory");
+            store_through(wsrow + (int64_t)f_pos * E + lam * 2, v);
+        }
+        f_pos += 8;
+        if (f_pos == NUp) f_pos = 0;
+    };
+
+    double xr[RC][FD];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int j = 0; j < FD; ++j) xr[k][j] = 0.0;
+    // RBF: node values of this lane's rows at the columns of units uk (0..1) and uk+1 (2..3); the row above at the same columns
+    double own[RBF ? RC : 1][4], abv[4];
+#pragma unroll
+    for (int k = 0; k < (RBF ? RC : 1); ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) own[k][c] = 1.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) abv[c] = 1.0;
+    double left[R], bot[S], corner = 1.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) left[i] = 1.0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) bot[i] = 1.0;
+    ExpCoef expc;   // the polynomial's coefficients in VGPRs: as SGPR pairs they spill the scalar state (v_readlane in the loop)
+    if (RBF) expc.init();
+
+    // ones for the windows whose sweep is in band 0 (see issue_x); visible to the LDS-DMA after the vmcnt(0) below
+    if (lam < CHUNK / 16) store_through(wsrow + (int64_t)NUp * E + lam * 2, d2_t{1.0, 1.0});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    issue_y();
+    issue_x();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_y();
+    issue_x();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    for (int t = 0; t < prm.n_steps; ++t) {
+        // -- lane 0: the boundary entry of its unit u (K row for the sweep of uk, node pair at the columns of unit u), from
+        //    the chunk the window's LDS-DMA brought in; no wait here (see lds_read_pend)
+        d2_t pend[NP], bnd[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) async_begin2(pend[i]);
+        // (lane 0's unit is t modulo NUp: a uniform address, read by every lane as a broadcast -- no divergent region around an
+        // asynchronous read)
+        lds_read_pend<NP>(pend, lds0 + BI_BASE + (unsigned)(((t >> 3) & 1) * CHUNK + (t & 7) * (E * 8)));
+
+        // -- start of a row unit for the sweep: left boundary K[i][0] = 1
+        if (uk == 0) {
+            corner = 1.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) left[i] = 1.0;
+        }
+        // -- start of a row unit for the path reads: this lane's x rows (differences / points)
+        if (u == 0) {
+            const unsigned xa = my_x + (unsigned)(((t >> 3) & 1) * XSLAB);
+#pragma unroll
+            for (int k = 0; k < RC; ++k) lds_read_xrow<FD>(xr[k], xa + k * XROW);
+        }
+
+        // -- y differences / points of the two columns of unit u, all FD dims (its lgkmcnt(0) also covers lane 0's entry)
+        d2_t yv[FD];
+        {
+            const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
+            lds_read_dims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        }
+        lds_pend_take<NP>(bnd, pend);
+
+        // -- top row of the block: from the lane above, or (lane 0) the band boundary / the pair's boundary K[0][.] = 1
+        //    (wave_shr leaves lane 0's destination = the `old` operand untouched: the boundary entry, ones in band 0)
+        double top[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) top[i] = dpp_shr1(bot[i], bnd[i >> 1][i & 1]);
+
+        // -- increments per coarse cell
+        double ginc[RC][CW];
+        if constexpr (RBF) {
+            // the row above at the columns of unit u = uk + 1: the lane above evaluated them one macro-step ago
+            abv[2] = dpp_shr1(own[RC - 1][0], bnd[NP - 1][0]);   // lane 0 keeps the boundary entry's node pair
+            abv[3] = dpp_shr1(own[RC - 1][1], bnd[NP - 1][1]);
+            if (is_top && band == 0) {   // node row 0 of the pair: nobody above has it
+                double x0[FD];
+                lds_read_xrow<FD>(x0, lds0 + T_BASE + (unsigned)((ps & 1) * XROW));
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) {
+                        const double df = x0[j] - yv[j][q];
+                        d2 = fma(df, df, d2);
+                    }
+                    abv[2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
+                }
+            }
+            // this lane's node rows at the two columns of unit u = uk + 1
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    double d2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) {
+                        const double df = xr[k][j] - yv[j][q];
+                        d2 = fma(df, df, d2);
+                    }
+                    // d2 * 0 is NaN for an infinite / NaN distance, as the reference's |x|^2 + |y|^2 - 2<x,y> is (sk_wave_fused.hip)
+                    own[k][2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
+                }
+            // 4-corner differences in the reference's order (sigkernel.py:362-363): ((G11 + G00) - G10) - G01
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    const double t0 = k == 0 ? abv[q] : own[(k + RC - 1) % RC][q];
+                    const double t1 = k == 0 ? abv[q + 1] : own[(k + RC - 1) % RC][q + 1];
+                    ginc[k][q] = ((own[k][q + 1] + t0) - own[k][q]) - t1;
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    double g = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) g = fma(xr[k][j], yv[j][q], g);
+                    ginc[k][q] = g;
+                }
+        }
+        double ca[RC][CW], cbm[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const double g = ginc[k][q];
+                if (NAIVE) {
+                    ca[k][q] = fma(g, c_half, 1.0);
+                    cbm[k][q] = 1.0;
+                } else {
+                    const double g2 = g * g;
+                    ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                    cbm[k][q] = fma(g2, -c_12, 1.0);
+                }
+            }
+
+        // -- sweep the R x S block
+        double cand[RC][CW];
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+            double above = top[cc];
+            double diag = cc == 0 ? corner : top[cc - 1];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const double a = ca[rr >> DY][cc >> DY], b = cbm[rr >> DY][cc >> DY];
+                const double k10 = left[rr];
+                double v;
+                if (NAIVE) v = fma(above, a, fma(k10, a, -diag));
+                else v = fma(above, a, fma(k10, a, -(diag * b)));
+                diag = k10;
+                above = v;
+                left[rr] = v;
+                if ((rr & (r - 1)) == r - 1 && (cc & (r - 1)) == r - 1) cand[rr >> DY][cc >> DY] = v;
+            }
+            bot[cc] = above;
+        }
+        corner = top[S - 1];
+
+        // -- lane 63: this step's boundary entry (position = its unit u) into the outgoing chunk
+        if (is_bot) {
+            const unsigned ea = lds0 + BO_BASE + (unsigned)((u & 7) * (E * 8));
+#pragma unroll
+            for (int cc = 0; cc < S; cc += 2) lds_write_b128(ea + cc * 8u, d2_t{bot[cc], bot[cc + 1]});
+            if (RBF) lds_write_b128(ea + S * 8u, d2_t{own[RC - 1][2], own[RC - 1][3]});
+        }
+
+        // -- K[MM][NN] of a pair
+        if (uk == my_uf) {
+            int pv = psk, bv = bandk;
+            asm volatile("" : "+v"(pv), "+v"(bv));
+            if (bv == prm.band_f && (unsigned)pv < (unsigned)nvalid) {
+                double v = cand[0][0];
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        double cv = cand[k][q];
+                        asm volatile("" : "+v"(cv));
+                        if (k * CW + q == prm.sel_f) v = cv;
+                    }
+                static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
+            }
+        }
+
+        // -- shift the node history
+        if constexpr (RBF) {
+#pragma unroll
+            for (int k = 0; k < RC; ++k) { own[k][0] = own[k][2]; own[k][1] = own[k][3]; }
+            abv[0] = abv[2];
+            abv[1] = abv[3];
+        }
+
+        // -- advance the cursors
+        if (RBF) {
+            uk += 1;
+            if (uk == NUp) {
+                uk = 0;
+                bandk += 1;
+                if (bandk == nb) { bandk = 0; psk += 1; }
+            }
+        }
+        u += 1;
+        if (((t + 1) & 7) == lam7) {   // (u & 7) == 0
+            yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
+            ypar ^= 1;
+            if (u == NUp) {
+                u = 0;
+                band += 1;
+                if (band == nb) { band = 0; ps += 1; }
+            }
+        }
+        if (!RBF) { uk = u; bandk = band; psk = ps; }
+
+        // -- window bookkeeping.  Lane 63's unit is t - 63: its chunk is complete when (t + 1) & 7 == 7 and goes out then;
+        //    one macro-step later everything in flight is waited for and the next window's LDS-DMA is issued
+        if (((t + 1) & 7) == 7 && t >= L - 1 + 7) flush_chunk();
+        if (((t + 1) & 7) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue_y();
+            issue_x();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename TO, int DY, bool NAIVE, int KIND, int FD>
+int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
+    auto kern = k_fwd_fused_mb<TO, DY, NAIVE, KIND, FD>;
+    static int vgprs = 0;
+    if (vgprs == 0) {
+        hipFuncAttributes attr;
+        vgprs = hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
+    }
+    const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
+    if (waves_per_cu > by_regs) waves_per_cu = by_regs;
+    if (waves_per_cu < 1) waves_per_cu = 1;
+    const int64_t max_waves = 256LL * waves_per_cu;
+    int64_t waves = P < max_waves ? P : max_waves;
+    int64_t PPW = (P + waves - 1) / waves;
+    waves = (P + PPW - 1) / PPW;
+    if (PPW > 0x3fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double)) return SK_ERR_WORKSPACE;
+    prm.PPW = (int)PPW;
+    prm.n_steps = (int)(PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0));
+    prm.ws = ws;
+    prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
+    const size_t lds_block = wave_group_lds(prm.wg);
+    if (lds_block > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
+    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
+    return check_launch();
+}
+
+struct MbPlan {
+    int RC, S, NUp, nb, fd, waves_per_cu;
+    size_t lds_bytes;
+    int64_t ws_stride;   // doubles per wave
+    bool ok;
+};
+
+MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D) {
+    MbPlan pl{};
+    pl.ok = false;
+    if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16 || (kind != 0 && kind != 1)) return pl;
+    pl.RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
+    pl.S = 2 << dyadic;
+    pl.fd = D <= 8 ? 8 : 16;
+    const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
+    pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
+    if (pl.NUp < MB_L + 16) return pl;                      // band boundary slack (see the header)
+    pl.nb = (Mc + MB_L * pl.RC - 1) / (MB_L * pl.RC);
+    const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
+    const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
+    pl.lds_bytes = (size_t)(MB_L / 8 + 2) * pl.fd * 128 + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
+    pl.ws_stride = (int64_t)(pl.NUp + 8) * (pl.S + (kind == 1 ? 2 : 0));   // the row + a chunk of ones
+    int wpc = (int)((160 * 1024) / pl.lds_bytes);
+    const int wpc_env = env_int("SK_FUSEDMB_WPC", 0);
+    if (wpc > 12) wpc = 12;
+    if (wpc_env > 0) wpc = wpc < wpc_env ? wpc : wpc_env;
+    else if (wpc > 4) wpc &= ~3;
+    if (wpc < 1) wpc = 1;
+    pl.waves_per_cu = wpc;
+    pl.ok = true;
+    return pl;
+}
+
+template <typename TO, int DY, int KIND>
+int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, int64_t P, double *ws, size_t ws_bytes, hipStream_t s) {
+    if (naive) return SK_ERR_UNSUPPORTED;   // the _naive_solver scheme is not built for this kernel (streaming route instead)
+    if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+    return launch_mb_one<TO, DY, false, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+}
+
+}  // namespace
+
+// Workspace (bytes) of sk_solve_fwd_static_*: one boundary row per resident wave; 0 outside the kernel's scope.
+size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
+    const MbPlan pl = mb_plan(kind, Mc, Nc, dyadic, D);
+    if (!pl.ok || P <= 0) return 0;
+    const int64_t max_waves = 256LL * 16;   // an upper bound on the resident waves whatever the variant's register count
+    const int64_t waves = P < max_waves ? P : max_waves;
+    return (size_t)waves * (size_t)pl.ws_stride * sizeof(double);
+}
+// rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
+int fused_mb_rows(int kind, int Mc, int dyadic) {
+    const int RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
+    const int nb = (Mc + MB_L * RC - 1) / (MB_L * RC);
+    return nb * MB_L * RC + 8;
+}
+
+template <typename TO>
+int launch_fwd_fused_mb(int kind, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd,
+                        const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D);
+    if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
+    if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < fused_mb_rows(kind, g.Mc, g.dyadic)) return SK_ERR_UNSUPPORTED;
+    FusedMbParams prm{};
+    prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
+    prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb; prm.inv_sigma = inv_sigma; prm.ws_stride = pl.ws_stride;
+    const int row_unit = (g.Mc - 1) / pl.RC;      // lane-row that holds the last coarse row
+    prm.u_f = (g.Nc - 1) / 2;
+    prm.lam_f = row_unit % MB_L;
+    prm.band_f = row_unit / MB_L;
+    prm.sel_f = ((g.Mc - 1) % pl.RC) * 2 + (g.Nc - 1) % 2;
+    (void)A;
+    double *w = static_cast<double *>(ws);
+    if (kind == 0) {
+        switch (g.dyadic) {
+            case 0: return launch_mb_dy<TO, 0, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+            case 1: return launch_mb_dy<TO, 1, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+            default: return launch_mb_dy<TO, 2, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+        }
+    }
+    switch (g.dyadic) {
+        case 0: return launch_mb_dy<TO, 0, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+        case 1: return launch_mb_dy<TO, 1, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+        default: return launch_mb_dy<TO, 2, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+    }
+}
+
+template int launch_fwd_fused_mb<double>(int, const double *, const double *, int64_t, int64_t, int, int, int, int, const Geom &, double,
+                                         double *, void *, size_t, hipStream_t);
+template int launch_fwd_fused_mb<float>(int, const double *, const double *, int64_t, int64_t, int, int, int, int, const Geom &, double,
+                                        float *, void *, size_t, hipStream_t);
+
+}  // namespace sk

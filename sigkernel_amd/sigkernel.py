@@ -50,21 +50,23 @@ def _fused_static(static_kernel, gram):
 
 
 def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=False):
-    """Whole forward in one kernel when the static kernel is exactly LinearKernel (sk_solve_fwd_linear_*) or exactly
-    RBFKernel (sk_solve_fwd_rbf_*) and the shape fits: the increments are formed inside the solver.  None otherwise.
+    """Whole forward in one kernel when the static kernel is exactly LinearKernel or exactly RBFKernel and the shape fits:
+    the increments are formed inside the solver.  Single-band pairs of path dim <= 8: sk_solve_fwd_linear_* /
+    sk_solve_fwd_rbf_*; several bands per pair or dims up to 16 (no edges): sk_solve_fwd_static_*.  None otherwise.
     keep_edges: (K, edges)."""
+    Xd, Yd = Xd.contiguous(), Yd.contiguous()
+    res, kind = None, None
     if type(static_kernel) is LinearKernel and hasattr(be, "solve_fwd_fused_linear"):
-        scale = 1.0 if gram else float(static_kernel.scale)
-        if keep_edges:
-            return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram, keep_edges=True)
-        return be.solve_fwd_fused_linear(Xd.contiguous(), Yd.contiguous(), scale, dyadic, naive, gram)
-    if (type(static_kernel) is RBFKernel and hasattr(be, "solve_fwd_fused_rbf") and float(static_kernel.sigma) > 0
+        kind, param = 0, (1.0 if gram else float(static_kernel.scale))
+        res = be.solve_fwd_fused_linear(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
+    elif (type(static_kernel) is RBFKernel and hasattr(be, "solve_fwd_fused_rbf") and float(static_kernel.sigma) > 0
             and not os.environ.get("SK_NO_FUSED_RBF")):
-        if keep_edges:
-            return be.solve_fwd_fused_rbf(Xd.contiguous(), Yd.contiguous(), float(static_kernel.sigma), dyadic, naive, gram,
-                                          keep_edges=True)
-        return be.solve_fwd_fused_rbf(Xd.contiguous(), Yd.contiguous(), float(static_kernel.sigma), dyadic, naive, gram)
-    return None
+        kind, param = 1, float(static_kernel.sigma)
+        res = be.solve_fwd_fused_rbf(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
+    if res is None and kind is not None and not keep_edges and hasattr(be, "solve_fwd_fused_static") \
+            and not os.environ.get("SK_NO_FUSED_MB"):
+        res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram)
+    return res
 
 
 def _increments(be, static_kernel, Xd, Yd, gram):

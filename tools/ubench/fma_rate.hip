@@ -17,6 +17,9 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
                 else if (OP == 3) v[i] = __builtin_rint(v[i]);
                 else if (OP == 4) v[i] = __builtin_ldexp(v[i], (int)threadIdx.x & 1);
                 else if (OP == 5) v[i] = (double)((int)v[i]);          // cvt_i32_f64 + cvt_f64_i32
+                else if (OP == 7) v[i] = (double)((float)v[i] * 1.0000001f);   // cvt_f32_f64 + mul_f32 + cvt_f64_f32
+                else if (OP == 8) { float f = __builtin_bit_cast(float, (int)(__builtin_bit_cast(long long, v[i]) >> 32)); v[i] = (double)f + b; }   // cvt_f64_f32 + add
+                else if (OP == 9) { int lo = __builtin_amdgcn_update_dpp(0, (int)__builtin_bit_cast(long long, v[i]), 0x138, 0xf, 0xf, false); v[i] = __builtin_bit_cast(double, ((long long)lo << 32) | (unsigned)lo); }   // 1 dpp mov (+ pack)
                 else v[i] = v[i] - b;
             }
     }
@@ -42,9 +45,10 @@ void run(const char *name, int wpc, double *d) {
 }
 int main() {
     double *d; hipMalloc(&d, 8);
-    for (int wpc : {8, 12}) {
+    for (int wpc : {4, 8, 12}) {
         run<0>("fma_f64", wpc, d); run<1>("mul_f64", wpc, d); run<2>("add_f64", wpc, d); run<3>("rndne_f64", wpc, d);
-        run<4>("ldexp_f64", wpc, d); run<5>("cvt_pair", wpc, d);
+        run<4>("ldexp_f64", wpc, d); run<5>("cvt_pair", wpc, d); run<7>("f64->f32->f64", wpc, d); run<8>("cvt_f64_f32+add", wpc, d);
+        run<9>("dpp_mov", wpc, d);
     }
     return 0;
 }
