@@ -151,6 +151,9 @@ int sk_increments_adjoint_f32(const float *W, int64_t ldw, const float *scale, i
  * static_kernels.py:26-33 / :58-73):
  *   diff = 1: scale * (x[p+1] - x[p]), p < M-1 (differences of the up-cast points);  diff = 0: scale * x[p], p < M;
  *   dim_major = 0: out [A][rows][fd] (the `dXr` / `Xr` layout);  dim_major = 1: out [A][fd][rows] (`dYt` / `Yt`, rows = Ncp);
+ *   dim_major = 2 (f32 entry point, diff = 0, fd and rows even): per path fd/2 rows of FLOAT [rows/2][4], the 4 floats of a unit =
+ *   {dim 2j col 2u, dim 2j col 2u+1, dim 2j+1 col 2u, dim 2j+1 col 2u+1}, then one row of DOUBLE |x_p|^2 [rows]: (fd/2 + 1) * rows * 8
+ *   bytes per path (the fp32 ring of sk_solve_fwd_static_f32);
  *   rows >= M-1 (diff) or M; fd >= D; everything outside the valid range is written as zero. */
 int sk_prep_paths_f64(const double *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
                       void *stream);
@@ -222,9 +225,11 @@ int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
 int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
                             int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
                             void *stream);
-int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
-                            int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace, size_t workspace_bytes,
-                            void *stream);
+/* f32: yt_f32 = 1 (kind 1, fd = 16 only): Yt holds the fp32 points packed as sk_prep_paths_f32 layout 2 writes them -- half
+ * the LDS ring, twice the resident waves at 16 dimensions; arithmetic stays fp64.  yt_f32 = 0: Yt is the fp64 array above. */
+int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows,
+                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
  * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */

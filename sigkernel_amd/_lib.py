@@ -55,8 +55,8 @@ SIGNATURES = {
     "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
     "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
                                        _vp, _sz, _vp]),
-    "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
-                                       _vp, _sz, _vp]),
+    "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
+                                       _vp, _vp, _sz, _vp]),
     "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
@@ -315,16 +315,24 @@ class HipBackend:
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         with torch.cuda.device(dev):
+            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
             if kind == 0:
                 Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
                 Yt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
             else:
                 Xr = _prep_paths(X, False, False, 1.0, Mrows, fd)
-                Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
+                if y32:      # fp32 points, two dimensions per 16-byte unit: half the LDS ring (sk_prep_paths_f32 layout 2)
+                    Yt = torch.empty(B, fd // 2 + 1, Ncp, 2, dtype=torch.float32, device=dev)   # packed points + a row of fp64 norms
+                    _check(lib.sk_prep_paths_f32(_ptr(Y), B, N, D, 0, 2, 1.0, _ptr(Yt), Ncp, fd, _stream(X)), "sk_prep_paths (packed fp32)")
+                else:
+                    Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            fn = getattr(lib, "sk_solve_fwd_static_" + _suffix(X))
-            rc = fn(int(kind), float(param), _ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, fd, int(dyadic),
-                    SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
+            if X.dtype == torch.float32:
+                rc = lib.sk_solve_fwd_static_f32(int(kind), float(param), _ptr(Xr), _ptr(Yt), int(y32), A, B if gram else 0, Mrows, Mc,
+                                                 Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
+            else:
+                rc = lib.sk_solve_fwd_static_f64(int(kind), float(param), _ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp,
+                                                 D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_static")

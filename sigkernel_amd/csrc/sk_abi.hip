@@ -99,14 +99,14 @@ int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d
 }
 
 template <typename TO>
-int solve_fwd_static(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
-                     int Ncp, int D, int fd, int dyadic, int scheme, TO *out_final, void *ws, size_t ws_bytes, void *stream) {
+int solve_fwd_static(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Mc,
+                     int Nc, int Ncp, int D, int fd, int dyadic, int scheme, TO *out_final, void *ws, size_t ws_bytes, void *stream) {
     if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
     if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_mb<TO>(kind, Xr, Yt, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, out_final, ws, ws_bytes,
+    return launch_fwd_fused_mb<TO>(kind, Xr, Yt, yt_f32, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, out_final, ws, ws_bytes,
                                    (hipStream_t)stream);
 }
 
@@ -279,13 +279,13 @@ int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
 int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
                             int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
                             void *stream) {
-    return solve_fwd_static<double>(kind, param, Xr, Yt, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+    return solve_fwd_static<double>(kind, param, Xr, Yt, 0, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
                                     workspace_bytes, stream);
 }
-int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
-                            int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace, size_t workspace_bytes,
-                            void *stream) {
-    return solve_fwd_static<float>(kind, param, Xr, Yt, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows,
+                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    return solve_fwd_static<float>(kind, param, Xr, Yt, yt_f32, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
                                    workspace_bytes, stream);
 }
 
@@ -359,13 +359,15 @@ int sk_prep_paths_f64(const double *X, int64_t A, int M, int D, int diff, int di
                       void *stream) {
     if (!X || !out || A < 0 || M < 1 || D < 1 || fd < D || rows < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
+    if (dim_major == 2) return SK_ERR_UNSUPPORTED;   // the packed fp32 layout is for fp32 paths (exact)
     return launch_prep_paths<double>(X, A, M, D, diff != 0, dim_major != 0, scale, out, rows, fd, (hipStream_t)stream);
 }
 int sk_prep_paths_f32(const float *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
                       void *stream) {
     if (!X || !out || A < 0 || M < 1 || D < 1 || fd < D || rows < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
-    return launch_prep_paths<float>(X, A, M, D, diff != 0, dim_major != 0, scale, out, rows, fd, (hipStream_t)stream);
+    if (dim_major == 2 && ((fd & 1) || (rows & 1))) return SK_ERR_BAD_ARG;
+    return launch_prep_paths<float>(X, A, M, D, diff != 0, dim_major, scale, out, rows, fd, (hipStream_t)stream);
 }
 
 size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size) {

@@ -101,8 +101,8 @@ int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
 
 // ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
 template <typename TO>
-int launch_fwd_fused_mb(int kind, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd,
-                        const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s);
+int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D,
+                        int fd, const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s);
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int fused_mb_rows(int kind, int Mc, int dyadic);
 
@@ -179,6 +179,22 @@ __device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
     double p = e.c[0];
 #pragma unroll
     for (int i = 1; i < 11; ++i) p = fma(p, r, e.c[i]);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+// the same polynomial started at coefficient I0 (degree 13 - I0): I0 = 3 is degree 10, truncation 0.3466^11 / 11! = 2e-13 --
+// below what fp32 results can resolve (the fp32-ring kernel of sk_wave_fused_mb.hip), three FMAs shorter
+template <int I0>
+__device__ __forceinline__ double exp_nonpos_from(double x, const ExpCoef &e) {
+    x = x < -800.0 ? -800.0 : x;
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = e.c[I0];
+#pragma unroll
+    for (int i = I0 + 1; i < 11; ++i) p = fma(p, r, e.c[i]);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

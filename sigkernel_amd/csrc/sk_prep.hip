@@ -42,6 +42,42 @@ __global__ __launch_bounds__(256) void k_prep_paths(const T *__restrict__ X, int
     }
 }
 
+// Layout 2 (the fp32 y ring of sk_wave_fused_mb.hip): per path fd / 2 rows of packed fp32 points followed by ONE row of
+// fp64 squared norms -- as bytes, a dimension-major fp64 array [A][fd / 2 + 1][rows]:
+//   rows 0 .. fd/2 - 1: float [rows / 2][4], the 4 floats of a unit = {dim 2j col 2u, dim 2j col 2u+1, dim 2j+1 col 2u,
+//                       dim 2j+1 col 2u+1};    row fd / 2: double |x_p|^2 (of the scaled, up-cast points), zero past the path.
+// Points only (an fp32 point is stored exactly; a difference would be rounded).
+template <typename T>
+__global__ __launch_bounds__(256) void k_prep_paths_packed32(const T *__restrict__ X, int64_t A, int M, int D, double scale,
+                                                             float *__restrict__ out, int rows, int FDp) {
+    const int64_t per = (int64_t)rows * (FDp + 2);     // floats per path
+    const int64_t n = A * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = i / per;
+        int rem = (int)(i - a * per);
+        if (rem < rows * FDp) {
+            const int jp = rem / (2 * rows);
+            rem -= jp * 2 * rows;
+            const int uu = rem >> 2, w = rem & 3;
+            const int j = 2 * jp + (w >> 1), p = 2 * uu + (w & 1);
+            float v = 0.f;
+            if (p < M && j < D) v = (float)((double)X[(a * M + p) * (int64_t)D + j] * scale);
+            out[i] = v;
+        } else {
+            rem -= rows * FDp;
+            if (rem & 1) continue;       // one thread per double
+            const int p = rem >> 1;
+            double q2 = 0.0;
+            if (p < M)
+                for (int j = 0; j < D; ++j) {
+                    const double v = (double)(float)((double)X[(a * M + p) * (int64_t)D + j] * scale);   // the value the ring holds
+                    q2 = fma(v, v, q2);
+                }
+            *reinterpret_cast<double *>(out + i) = q2;
+        }
+    }
+}
+
 }  // namespace
 
 template <typename T>
@@ -52,6 +88,13 @@ int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_maj
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
     const dim3 g((unsigned)blocks), b(256);
+    if (dim_major == 2) {
+        if (diff) return SK_ERR_UNSUPPORTED;
+        blocks = (A * (int64_t)rows * (FDp + 2) + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL((k_prep_paths_packed32<T>), dim3((unsigned)blocks), b, 0, s, X, A, M, D, scale, reinterpret_cast<float *>(out), rows, FDp);
+        return check_launch();
+    }
     if (diff) {
         if (dim_major) hipLaunchKernelGGL((k_prep_paths<T, true, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
         else hipLaunchKernelGGL((k_prep_paths<T, true, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);

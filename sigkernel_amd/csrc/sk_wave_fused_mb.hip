@@ -158,8 +158,18 @@ template <> __device__ __forceinline__ void lds_read_pend<5>(d2_t (&t)[5], unsig
 template <int NP>
 __device__ __forceinline__ void lds_pend_take(d2_t (&o)[NP], d2_t (&t)[NP]) { async_wait2<63>(o, t); }   // vmcnt(63): no wait at all
 
-template <typename TO, int DY, bool NAIVE, int KIND, int FD>
+// Y32: the y ring holds fp32 points (fp32 inputs: exactly the caller's values), two dimensions per 16-byte unit --
+// {dim 2j col 0, dim 2j col 1, dim 2j+1 col 0, dim 2j+1 col 1} -- so a slab has FD / 2 rows and the ring half the bytes: at
+// FD = 16 that is what lets two waves share a SIMD.  Everything is still computed in fp64 (one v_cvt per value).  The slab
+// carries one more row, |y_q|^2 in fp64, and the squared distance is formed like the reference does
+// (static_kernels.py:70-73), |x|^2 + |y|^2 - 2<x,y>: FD FMAs per node instead of 2 FD operations.  With fp32 inputs the
+// products are exact in fp64 and the cancellation costs nothing the inputs could resolve; the fp64-ring variants keep the
+// direct sum over (x - y)^2.  The slab pitch (9 x 128 bytes) is an odd multiple of 128, so lanes 8 apart (same unit of
+// neighbouring slabs) hit different halves of the bank row without the parity swizzle of the fp64 ring.
+template <typename TO, int DY, bool Y32, int KIND, int FD>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams prm) {
+    constexpr bool NAIVE = false;   // the _naive_solver scheme is not built for this kernel
+    constexpr int FDY = Y32 ? FD / 2 : FD;   // rows of a y slab
     constexpr bool RBF = KIND == 1;
     constexpr int LAG = RBF ? 1 : 0;   // macro-steps by which the block sweep trails the node evaluation
     constexpr int CW = 2;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     constexpr int L = MB_L;
     constexpr int XROW = FD * 8;              // bytes of one x row
     constexpr int XSLAB = 8 * RC * XROW;      // the rows of 8 lanes
-    constexpr int YSLAB = FD * 128;           // FD dimension rows of 8 units
+    constexpr int YSLAB = FDY * 128 + (Y32 ? 128 : 0);   // FDY rows of 8 units (+ Y32: one row of |y|^2, fp64)
     constexpr int NSLAB = L / 8 + 2;
     constexpr int NDMA_Y = YSLAB / 1024, NDMA_X = (XSLAB + 1023) / 1024;
     // band boundary: per unit of the stream S doubles of K (bottom fine row of the band being left) and, RBF, the 2 node
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     const int NUp = prm.NUp, nb = prm.nb;
     const double sc = 1.0 / (double)(1 << (2 * DY));
     const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double two_inv_sigma = 2.0 * prm.inv_sigma;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
 
     // ---- cursors: (u, band, ps) = where this lane's node evaluation / path reads are; (uk, bandk, psk) = its block sweep,
@@ -238,11 +249,20 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         int64_t p = pair0 + y_pi;
         if (y_pi >= prm.PPW || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
         const int64_t b = split_b(p);
+        if constexpr (Y32) {
+            const double *row0 = prm.Yt + b * (FDY + 1) * (int64_t)prm.Ncp;
+            __builtin_amdgcn_global_load_lds(row0 + ((lam >> 3) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lam & 7)) * 2),
+                                             (lds_void *)(lds + y_slot * YSLAB), 16, 0, 0);
+            if (lam < 8)   // the |y|^2 row: 128 bytes
+                __builtin_amdgcn_global_load_lds(row0 + (FDY * (int64_t)prm.Ncp + (int64_t)(y_u0 + lam) * 2),
+                                                 (lds_void *)(lds + y_slot * YSLAB + FDY * 128), 16, 0, 0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NDMA_Y; ++c) {
-            const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);     // odd slabs: dimension rows swapped in pairs
-            const double *src = prm.Yt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lam & 7)) * 2);
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+            for (int c = 0; c < NDMA_Y; ++c) {
+                const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);     // odd slabs: dimension rows swapped in pairs
+                const double *src = prm.Yt + ((b * FDY + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lam & 7)) * 2);
+                __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+            }
         }
         y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
         y_par ^= 1;
@@ -311,7 +331,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (f_pos == NUp) f_pos = 0;
     };
 
-    double xr[RC][FD];
+    double xr[RC][FD], xsn[RC];   // Y32: xsn = -|x_row|^2 / sigma
+#pragma unroll
+    for (int k = 0; k < RC; ++k) xsn[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < RC; ++k)
 #pragma unroll
@@ -364,15 +386,42 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             const unsigned xa = my_x + (unsigned)(((t >> 3) & 1) * XSLAB);
 #pragma unroll
             for (int k = 0; k < RC; ++k) lds_read_xrow<FD>(xr[k], xa + k * XROW);
+            if constexpr (Y32) {
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    double q2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) q2 = fma(xr[k][j], xr[k][j], q2);
+                    xsn[k] = -q2 * prm.inv_sigma;
+                }
+            }
         }
 
         // -- y differences / points of the two columns of unit u, all FD dims (its lgkmcnt(0) also covers lane 0's entry)
         d2_t yv[FD];
+        d2_t ysq_p[1], ysq_t[1];
+        async_begin2(ysq_p[0]);
         {
             const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
-            lds_read_dims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            if constexpr (Y32) {
+                d2_t raw[FDY];
+                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=&v"(ysq_p[0]) : "v"(ya) : "memory");   // |y|^2 of the two columns
+                lds_read_dims<FDY>(raw, ya, ya + 128u);    // no swizzle (see the header)
+#pragma unroll
+                for (int jp = 0; jp < FDY; ++jp) {
+                    const f4_t f = __builtin_bit_cast(f4_t, raw[jp]);
+                    yv[2 * jp] = d2_t{(double)f[0], (double)f[1]};
+                    yv[2 * jp + 1] = d2_t{(double)f[2], (double)f[3]};
+                }
+            } else {
+                lds_read_dims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            }
         }
         lds_pend_take<NP>(bnd, pend);
+        lds_pend_take<1>(ysq_t, ysq_p);
+        double ysn[CW];   // Y32: -|y_q|^2 / sigma
+#pragma unroll
+        for (int q = 0; q < CW; ++q) ysn[q] = Y32 ? -ysq_t[0][q] * prm.inv_sigma : 0.0;
 
         // -- top row of the block: from the lane above, or (lane 0) the band boundary / the pair's boundary K[0][.] = 1
         //    (wave_shr leaves lane 0's destination = the `old` operand untouched: the boundary entry, ones in band 0)
@@ -389,15 +438,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             if (is_top && band == 0) {   // node row 0 of the pair: nobody above has it
                 double x0[FD];
                 lds_read_xrow<FD>(x0, lds0 + T_BASE + (unsigned)((ps & 1) * XROW));
+                if constexpr (Y32) {
+                    double q2 = 0.0;
 #pragma unroll
-                for (int q = 0; q < CW; ++q) {
-                    double d2 = 0.0;
+                    for (int j = 0; j < FD; ++j) q2 = fma(x0[j], x0[j], q2);
+                    const double x0n = -q2 * prm.inv_sigma;
 #pragma unroll
-                    for (int j = 0; j < FD; ++j) {
-                        const double df = x0[j] - yv[j][q];
-                        d2 = fma(df, df, d2);
+                    for (int q = 0; q < CW; ++q) {
+                        double xy = 0.0;
+#pragma unroll
+                        for (int j = 0; j < FD; ++j) xy = fma(x0[j], yv[j][q], xy);
+                        abv[2 + q] = exp_nonpos_from<3>(fma(xy, two_inv_sigma, x0n + ysn[q]), expc);
                     }
-                    abv[2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < CW; ++q) {
+                        double d2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < FD; ++j) {
+                            const double df = x0[j] - yv[j][q];
+                            d2 = fma(df, df, d2);
+                        }
+                        abv[2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
+                    }
                 }
             }
             // this lane's node rows at the two columns of unit u = uk + 1
@@ -405,14 +468,22 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             for (int k = 0; k < RC; ++k)
 #pragma unroll
                 for (int q = 0; q < CW; ++q) {
-                    double d2 = 0.0;
+                    if constexpr (Y32) {
+                        // -(|x|^2 + |y|^2 - 2<x,y>) / sigma, the reference's form (an infinite coordinate gives inf - inf = NaN as there)
+                        double xy = 0.0;
 #pragma unroll
-                    for (int j = 0; j < FD; ++j) {
-                        const double df = xr[k][j] - yv[j][q];
-                        d2 = fma(df, df, d2);
+                        for (int j = 0; j < FD; ++j) xy = fma(xr[k][j], yv[j][q], xy);
+                        own[k][2 + q] = exp_nonpos_from<3>(fma(xy, two_inv_sigma, xsn[k] + ysn[q]), expc);
+                    } else {
+                        double d2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < FD; ++j) {
+                            const double df = xr[k][j] - yv[j][q];
+                            d2 = fma(df, df, d2);
+                        }
+                        // d2 * 0 is NaN for an infinite / NaN distance, as the reference's |x|^2 + |y|^2 - 2<x,y> is (sk_wave_fused.hip)
+                        own[k][2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
                     }
-                    // d2 * 0 is NaN for an infinite / NaN distance, as the reference's |x|^2 + |y|^2 - 2<x,y> is (sk_wave_fused.hip)
-                    own[k][2 + q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
                 }
             // 4-corner differences in the reference's order (sigkernel.py:362-363): ((G11 + G00) - G10) - G01
 #pragma unroll
@@ -539,9 +610,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, int KIND, int FD>
+template <typename TO, int DY, bool Y32, int KIND, int FD>
 int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_mb<TO, DY, NAIVE, KIND, FD>;
+    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD>;
     static int vgprs = 0;
     if (vgprs == 0) {
         hipFuncAttributes attr;
@@ -574,7 +645,7 @@ struct MbPlan {
     bool ok;
 };
 
-MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D) {
+MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false) {
     MbPlan pl{};
     pl.ok = false;
     if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16 || (kind != 0 && kind != 1)) return pl;
@@ -587,7 +658,7 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D) {
     pl.nb = (Mc + MB_L * pl.RC - 1) / (MB_L * pl.RC);
     const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
     const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
-    pl.lds_bytes = (size_t)(MB_L / 8 + 2) * pl.fd * 128 + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
+    pl.lds_bytes = (size_t)(MB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
     pl.ws_stride = (int64_t)(pl.NUp + 8) * (pl.S + (kind == 1 ? 2 : 0));   // the row + a chunk of ones
     int wpc = (int)((160 * 1024) / pl.lds_bytes);
     const int wpc_env = env_int("SK_FUSEDMB_WPC", 0);
@@ -601,8 +672,15 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D) {
 }
 
 template <typename TO, int DY, int KIND>
-int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, int64_t P, double *ws, size_t ws_bytes, hipStream_t s) {
+int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y32, int64_t P, double *ws, size_t ws_bytes,
+                 hipStream_t s) {
     if (naive) return SK_ERR_UNSUPPORTED;   // the _naive_solver scheme is not built for this kernel (streaming route instead)
+    if (y32) {   // fp32 y ring: built where it pays (RBF points of fp32 inputs, 16 dims)
+        if constexpr (KIND == 1 && sizeof(TO) == 4) {
+            if (pl.fd == 16) return launch_mb_one<TO, DY, true, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+        }
+        return SK_ERR_UNSUPPORTED;
+    }
     if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
     return launch_mb_one<TO, DY, false, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
 }
@@ -625,9 +703,13 @@ int fused_mb_rows(int kind, int Mc, int dyadic) {
 }
 
 template <typename TO>
-int launch_fwd_fused_mb(int kind, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd,
-                        const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s) {
-    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D);
+int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D,
+                        int fd, const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s) {
+    // yt_f32: Yt holds fp32 values packed two dimensions per 16-byte unit (sk_prep_paths_* layout 2): byte for byte a
+    // dimension-major fp64 array of fd / 2 rows, which is how the kernel addresses it
+    const double *Yt = static_cast<const double *>(Yt_any);
+    const bool y32 = yt_f32 != 0;
+    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32);
     if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
     if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < fused_mb_rows(kind, g.Mc, g.dyadic)) return SK_ERR_UNSUPPORTED;
     FusedMbParams prm{};
@@ -642,21 +724,21 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const double *Yt, int64_t A,
     double *w = static_cast<double *>(ws);
     if (kind == 0) {
         switch (g.dyadic) {
-            case 0: return launch_mb_dy<TO, 0, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
-            case 1: return launch_mb_dy<TO, 1, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
-            default: return launch_mb_dy<TO, 2, 0>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+            case 0: return launch_mb_dy<TO, 0, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+            case 1: return launch_mb_dy<TO, 1, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+            default: return launch_mb_dy<TO, 2, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
         }
     }
     switch (g.dyadic) {
-        case 0: return launch_mb_dy<TO, 0, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
-        case 1: return launch_mb_dy<TO, 1, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
-        default: return launch_mb_dy<TO, 2, 1>(prm, pl, g.naive, g.P, w, ws_bytes, s);
+        case 0: return launch_mb_dy<TO, 0, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+        case 1: return launch_mb_dy<TO, 1, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+        default: return launch_mb_dy<TO, 2, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
     }
 }
 
-template int launch_fwd_fused_mb<double>(int, const double *, const double *, int64_t, int64_t, int, int, int, int, const Geom &, double,
+template int launch_fwd_fused_mb<double>(int, const double *, const void *, int, int64_t, int64_t, int, int, int, int, const Geom &, double,
                                          double *, void *, size_t, hipStream_t);
-template int launch_fwd_fused_mb<float>(int, const double *, const double *, int64_t, int64_t, int, int, int, int, const Geom &, double,
+template int launch_fwd_fused_mb<float>(int, const double *, const void *, int, int64_t, int64_t, int, int, int, int, const Geom &, double,
                                         float *, void *, size_t, hipStream_t);
 
 }  // namespace sk

@@ -320,3 +320,77 @@ def test_nan_coordinates_give_nan_on_every_route(kernel, monkeypatch):
         # an infinite coordinate: the reference's |x|^2 + |y|^2 - 2<x,y> is inf - inf = NaN (static_kernels.py:70-73), linear
         # increments are inf - inf as well: the row is poisoned on every route
         assert not torch.isfinite(K[2]).any(), (kernel, env, K)
+
+
+# ---------------------------------------------------------------------------------------------
+# the multi-band fused forward (sk_solve_fwd_static_*, csrc/sk_wave_fused_mb.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_fused_multiband_forward_against_the_oracle_and_the_streaming_route():
+    """LinearKernel / RBFKernel formed inside the solver for pairs that need several bands of a wavefront and path dims up to
+    16: 90 random shapes (both kinds, dyadic 0..2, dims 1..16, 1..10 bands, ragged second paths, paired and Gram, many pairs
+    per wave, fp32 and fp64 tensors -- fp32 RBF at dim > 8 takes the packed-fp32 ring) against sk_static_increments +
+    sk_solve_fwd (1e-11 / fp32: 2e-6), every fifth one also against the CPU oracle."""
+    from sigkernel_amd.sigkernel import _increments
+    be = _lib.get_backend()
+    rng = np.random.default_rng(0)
+    n = 0
+    for it in range(90):
+        kind = int(rng.integers(0, 2))
+        d = int(rng.integers(0, 3))
+        D = int(rng.integers(1, 17))
+        M = int(rng.integers(2, 700 >> d)) if it % 3 else int(rng.integers(60, 140))
+        N = int(rng.integers(160, 420))
+        A, B = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+        gram = bool(it % 4)
+        if it % 7 == 6:
+            A, B, M, N = 40, 90, int(rng.integers(20, 200 >> d) + 2), 160 + int(rng.integers(0, 30))    # many pairs per wave
+        if not gram:
+            B = A
+        dt = torch.float32 if it % 5 == 4 else torch.float64
+        gen = torch.Generator().manual_seed(100 + it)
+        Xc, Yc = walk(gen, A, M, D, dt) * 1.5, walk(gen, B, N, D, dt) * 1.5
+        X, Y = Xc.to(DEV), Yc.to(DEV)
+        sk = sigkernel_amd.LinearKernel(0.9) if kind == 0 else sigkernel_amd.RBFKernel(0.8)
+        par = (1.0 if gram else 0.9) if kind == 0 else 0.8
+        K = be.solve_fwd_fused_static(kind, par, X, Y, d, False, gram)
+        assert K is not None and K.dtype == dt, (it, kind, d, D, M, N)
+        want = be.solve_fwd(_increments(be, sk, X.double(), Y.double(), gram), d)
+        tol = 1e-11 if dt == torch.float64 else 2e-6
+        assert rel_err(K.double().cpu().numpy(), want.cpu().numpy()) <= tol, (it, kind, d, D, A, B, M, N, gram, dt)
+        if it % 5 == 0 and gram and A * B * (M << d) * (N << d) < 3e8:
+            ref = O.gram_forward(Xc.double(), Yc.double(), sk, d, nthreads=NT)
+            assert rel_err(K.double().cpu().numpy(), ref) <= tol
+        n += 1
+    assert n == 90
+
+
+@pytest.mark.gpu
+def test_fused_multiband_scope_and_c5_route(monkeypatch):
+    """Outside its scope the kernel says so (the caller falls back to increments in HBM); inside it -- the C5 shape -- it is
+    what compute_Gram runs: nothing of size pairs x M x N is materialised (sk_static_increments is never called)."""
+    be = _lib.get_backend()
+    Z = lambda A, M, D, dt=torch.float64: torch.zeros(A, M, D, dtype=dt, device=DEV)
+    assert be.solve_fwd_fused_static(1, 1.0, Z(2, 300, 3), Z(2, 100, 3), 1, False, True) is None      # second path too short
+    assert be.solve_fwd_fused_static(1, 1.0, Z(2, 300, 17), Z(2, 300, 17), 1, False, True) is None     # dim 17
+    assert be.solve_fwd_fused_static(1, 1.0, Z(2, 300, 3), Z(2, 300, 3), 3, False, True) is None       # dyadic 3
+    assert be.solve_fwd_fused_static(0, 1.0, Z(2, 300, 3), Z(2, 300, 3), 1, True, True) is None        # naive scheme
+    gen = torch.Generator().manual_seed(8)
+    X, Y = walk(gen, 3, 512, 16, torch.float32).to(DEV), walk(gen, 5, 512, 16, torch.float32).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
+    monkeypatch.setenv("SK_NO_FUSED_MB", "1")
+    K_stream = sk.compute_Gram(X, Y)
+    monkeypatch.delenv("SK_NO_FUSED_MB")
+    monkeypatch.setattr(type(be), "static_increments", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("increments materialised")))
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    K = sk.compute_Gram(X, Y)
+    assert torch.cuda.max_memory_allocated() - base < 600 << 20      # workspace rows only (the increments would be 16 MB per pair)
+    assert rel_err(K.cpu().numpy(), K_stream.cpu().numpy()) <= 2e-6
+    # fp64 tensors of the same shape: the fp64 ring
+    K64 = sk.compute_Gram(X.double(), Y.double())
+    assert rel_err(K64.cpu().numpy(), O.gram_forward(X.double().cpu(), Y.double().cpu(), sigkernel_amd.RBFKernel(1.0), 2, nthreads=NT)) <= 1e-11
+    # LinearKernel on long paths (two bands at dyadic 1) goes the same way
+    Xl, Yl = walk(gen, 4, 300, 8).to(DEV), walk(gen, 3, 280, 8).to(DEV)
+    Kl = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1).compute_Gram(Xl, Yl)
+    assert rel_err(Kl.cpu().numpy(), O.gram_forward(Xl.cpu(), Yl.cpu(), sigkernel_amd.LinearKernel(), 1, nthreads=NT)) <= 1e-11
