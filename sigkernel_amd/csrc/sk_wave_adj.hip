@@ -47,7 +47,14 @@ struct AdjParams {
 // (being written out as W) + PF (in flight) slots.  Measured at d = 1 (131072 pairs of 127x127, forward + adjoint):
 // PF = 1 with 8 waves/CU (20 KB of LDS per wave) 13.3 ms, PF = 2 with 7 waves/CU (22 KB) 14.4 ms, PF = 2 with 4 waves/CU
 // 14.8 ms, PF = 1 with 4 waves/CU 17.4 ms: occupancy buys more than prefetch depth.
-constexpr int ADJ_PF = 1;
+#ifndef SK_ADJ_PF
+#define SK_ADJ_PF 2
+#endif
+#ifndef SK_ADJ_XSLOT
+#define SK_ADJ_XSLOT 0
+#endif
+constexpr int ADJ_PF = SK_ADJ_PF;
+constexpr int ADJ_XSLOT = SK_ADJ_XSLOT;   // extra ring slots beyond 8 + PF (experiments)
 
 __device__ __forceinline__ void store_unit(double *dst, double a, double b) {
     d2_t v = {a, b};
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     // ring slots: a slot is fetched PF steps ahead, consumed for 8 steps while its units are overwritten in place by
     // the W units of the same positions, and written out as whole lines on the 9th step
-    constexpr int NSLOT = LINE_UNITS + 1 + PF;
+    constexpr int NSLOT = LINE_UNITS + ADJ_XSLOT + PF;
     constexpr int SLOT_BYTES = RC * 1024;
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
@@ -492,7 +499,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     const int G = WAVE / L;
     const bool multiband = nb > 1;
 
-    size_t lds_bytes = (size_t)(LINE_UNITS + 1 + ADJ_PF) * RC * 1024;
+    size_t lds_bytes = (size_t)(LINE_UNITS + ADJ_XSLOT + ADJ_PF) * RC * 1024;
     if (multiband) lds_bytes += (size_t)G * 2 * NUp * S * sizeof(double);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
