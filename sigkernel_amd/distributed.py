@@ -6,7 +6,8 @@ rows [r*ceil(A/R), (r+1)*ceil(A/R)) of X, Y is replicated (it is tiny), and ONE 
 (rows x B) value blocks gives every rank the full matrix -- a few MB per rank, latency-bound on the
 point-to-point xGMI links, so no bucketing or ring tuning is warranted.  In backward the gradient rows are
 rank-local too (row a of grad_X needs only row a of grad_output, also under the reference's 2x rule), and
-a second all-gather returns the full grad_X.
+a second all-gather returns the full grad_X.  A symmetric Gram without a gradient (compute_mmd's K_YY) is solved on the
+triangle, folded over the ranks so that the load stays even (`_folded_symmetric_gram`).
 
 Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 """
@@ -33,6 +34,35 @@ def _all_gather_rows(block, n_rows, chunk, group):
     out = torch.empty((world * chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
     return out[:n_rows]
+
+
+def _folded_symmetric_gram(X, static_kernel, dyadic_order, naive, workspace_bytes, group):
+    """compute_Gram(X, X, sym=True) without a gradient, sharded: only the pairs on and above the diagonal are solved, like the
+    reference's CPU solver does (cython_backend.pyx:74-97).  The rows are cut into 2R blocks and rank r takes blocks r and
+    2R-1-r, each against the columns from its own first row on: every rank solves (2R+1)/(2R)^2 of the square, half of its
+    row-shard, and the load is even.  One all-gather of the two zero-padded strips per rank, then the mirror."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    A = X.shape[0]
+    bs = -(-A // (2 * world))
+    strips = torch.zeros(2, bs, A, dtype=X.dtype, device=X.device)
+    Xd = X.detach()
+    with torch.no_grad():
+        for slot, blk in enumerate((rank, 2 * world - 1 - rank)):
+            lo, hi = min(blk * bs, A), min((blk + 1) * bs, A)
+            if hi > lo:
+                strips[slot, : hi - lo, lo:] = _SigKernelGram.apply(Xd[lo:hi].contiguous(), Xd[lo:].contiguous(), static_kernel,
+                                                                    dyadic_order, False, naive, workspace_bytes)
+    full = torch.empty(world * 2, bs, A, dtype=X.dtype, device=X.device)     # rank-major concatenation along dim 0
+    dist.all_gather_into_tensor(full, strips, group=group)
+    full = full.reshape(world, 2, bs, A)
+    K = torch.empty(2 * world * bs, A, dtype=X.dtype, device=X.device)
+    for r in range(world):
+        K[r * bs:(r + 1) * bs] = full[r, 0]
+        K[(2 * world - 1 - r) * bs:(2 * world - r) * bs] = full[r, 1]
+    K = K[:A]
+    iu = torch.triu_indices(A, A, offset=1, device=X.device)
+    K[iu[1], iu[0]] = K[iu[0], iu[1]]
+    return K
 
 
 class ShardedGram(torch.autograd.Function):
@@ -81,6 +111,10 @@ def sharded_gram(sigkernel, X, Y, sym=False, group=None):
     """Full (A, B) Gram matrix on every rank; each rank solves only its rows."""
     if not dist.is_initialized():
         raise RuntimeError("sharded_gram needs torch.distributed to be initialised (one process per GPU)")
+    same = X.shape == Y.shape and X.data_ptr() == Y.data_ptr() and X.stride() == Y.stride()
+    if (sym and same and not X.requires_grad and dist.get_world_size(group) > 1 and X.shape[0] >= 2 and X.shape[1] >= 2):
+        return _folded_symmetric_gram(X, sigkernel.static_kernel, sigkernel.dyadic_order, sigkernel._naive_solver,
+                                      sigkernel.workspace_bytes, group)
     return ShardedGram.apply(X, Y, sigkernel.static_kernel, sigkernel.dyadic_order, sym, sigkernel._naive_solver,
                              sigkernel.workspace_bytes, group)
 

@@ -110,3 +110,44 @@ def test_sharded_gram_over_rccl_single_rank(tmp_path):
     assert rel_err(got["gram"], c["gram"]) <= 1e-12
     assert rel_err(got["grad_w"], c["grad_w"]) <= 2e-5
     assert float(got["kd_err"]) == 0.0
+
+
+def _sym_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sigkernel_amd
+        from sigkernel_amd import _lib, distributed
+        from fake_backend import OracleBackend
+        _lib.set_backend(OracleBackend())
+        calls = []
+        orig = distributed._SigKernelGram.apply
+        distributed._SigKernelGram.apply = staticmethod(lambda X, Y, *a: (calls.append(X.shape[0] * Y.shape[0]), orig(X, Y, *a))[1])
+        gen = torch.Generator().manual_seed(3)
+        X = torch.cumsum(torch.randn(11, 7, 2, generator=gen, dtype=torch.float64), dim=1) * 0.3
+        sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.7), 1, process_group=dist.group.WORLD)
+        K = sk.compute_Gram(X, X, sym=True)
+        np.savez(os.path.join(out_dir, "sym%d.npz" % rank), gram=K.numpy(), pairs=np.array(sum(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_symmetric_gram_is_folded_over_the_ranks(tmp_path, world):
+    """compute_Gram(X, X, sym=True) without a gradient under a process group: every rank solves about half of its row shard (the
+    pairs on and above the diagonal, folded so that the load is even) and all ranks end with the full, exactly symmetric matrix."""
+    mp.spawn(_sym_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import sigkernel_amd
+    from oracle import oracle as O
+    gen = torch.Generator().manual_seed(3)
+    X = torch.cumsum(torch.randn(11, 7, 2, generator=gen, dtype=torch.float64), dim=1) * 0.3
+    want = O.gram_forward(X, X, sigkernel_amd.RBFKernel(0.7), 1)
+    solved = []
+    for r in range(world):
+        got = dict(np.load(tmp_path / ("sym%d.npz" % r)))
+        assert rel_err(got["gram"], want) <= 1e-13 and np.array_equal(got["gram"], got["gram"].T)
+        solved.append(int(got["pairs"]))
+    assert max(solved) <= 0.75 * (11 * 11 / world) + 11 and sum(solved) < 0.75 * 11 * 11, solved
