@@ -47,14 +47,13 @@ struct AdjParams {
 // (being written out as W) + PF (in flight) slots.  Measured at d = 1 (131072 pairs of 127x127, forward + adjoint):
 // PF = 1 with 8 waves/CU (20 KB of LDS per wave) 13.3 ms, PF = 2 with 7 waves/CU (22 KB) 14.4 ms, PF = 2 with 4 waves/CU
 // 14.8 ms, PF = 1 with 4 waves/CU 17.4 ms: occupancy buys more than prefetch depth.
-#ifndef SK_ADJ_PF
-#define SK_ADJ_PF 2
-#endif
-#ifndef SK_ADJ_XSLOT
-#define SK_ADJ_XSLOT 0
-#endif
-constexpr int ADJ_PF = SK_ADJ_PF;
-constexpr int ADJ_XSLOT = SK_ADJ_XSLOT;   // extra ring slots beyond 8 + PF (experiments)
+// Ring = 8 slots being consumed + PF in flight: the finished W line of a slot is read at the top of the very step that re-fetches
+// the slot (the read is waited for before the fetch is issued), so no spare slot is needed.  PF = 1 where the ring is what
+// bounds the resident waves (dyadic 0, 1: 36 / 18 KB + the edge chunks = 4 / 8 waves per CU), 2 at dyadic 2 (10 KB).
+constexpr int adj_pf(int dy) { return dy >= 2 ? 2 : 1; }
+// the pair's terminal row K[MM][.] reaches the top lanes through LDS: per window of 8 macro-steps one chunk of 8 S + 2 doubles
+// per lane group (the 8 S values the window consumes, widened to 16-byte alignment), two slots
+constexpr int adj_chunk_bytes(int S) { return (4 * S + 1) * 16; }
 
 __device__ __forceinline__ void store_unit(double *dst, double a, double b) {
     d2_t v = {a, b};
@@ -67,13 +66,13 @@ __device__ __forceinline__ void store_unit(float *dst, double a, double b, doubl
 
 template <typename T, int DY, bool NAIVE, bool MULTIBAND, bool FULLWAVE>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
-    constexpr int PF = ADJ_PF;
+    constexpr int PF = adj_pf(DY);
     constexpr int CW = Unit<T>::CW;
     typedef typename Unit<T>::vec vec_t;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     // ring slots: a slot is fetched PF steps ahead, consumed for 8 steps while its units are overwritten in place by
     // the W units of the same positions, and written out as whole lines on the 9th step
-    constexpr int NSLOT = LINE_UNITS + ADJ_XSLOT + PF;
+    constexpr int NSLOT = LINE_UNITS + PF;
     constexpr int SLOT_BYTES = RC * 1024;
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
@@ -102,8 +101,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
-    // LDS map: [increment ring][MULTIBAND: Kr and Kf band boundary rows]
-    const unsigned bnd_r = lds0 + NSLOT * SLOT_BYTES + (unsigned)(grp * 2 * NUp * S) * 8u;
+    // LDS map: [increment ring][edge-row chunks: 2 slots x G groups][MULTIBAND: Kr and Kf band boundary rows]
+    constexpr int ECG = adj_chunk_bytes(S);                 // one group's chunk
+    const unsigned ec_base = lds0 + NSLOT * SLOT_BYTES;
+    const unsigned ec_slot = (unsigned)(G * ECG);           // one slot (all groups)
+    const unsigned bnd_r = ec_base + 2 * ec_slot + (unsigned)(grp * 2 * NUp * S) * 8u;
     const unsigned bnd_f = bnd_r + (unsigned)(NUp * S) * 8u;
 
     // ---- producer: increments, whole lines, back to front (see sk_wave.hip for the forward-order twin) ----
@@ -208,18 +210,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     // so no LDS is spent on them.  (The first version staged whole pairs of edges in an LDS ring: 12 KB per wave, which
     // held the kernel at one wave per SIMD.)
     const int E = NNp + MMp;
-    auto prefetch_edges = [&](int nu, int nband, int nps, double (&prow)[S], double (&pcol)[R + 1]) {
-        int64_t pr = pair0 + nps;
-        pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);     // not-yet-started / finished lanes: any valid pair, value unused
-        const double *e = prm.edges + pr * E;
-        if (is_top && (!MULTIBAND || nband == 0)) {
-            // Kf[0][j'] = K[MM][NNp - j'], j' = nu*S + i + 1, stored at [NNp - j' - 1]; only the very last element of a row
-            // (nu = NUp-1, i = S-1) asks for K[MM][0] = 1, which is not stored: clamped here, fixed up after the wait
-            const double *q = e + (NNp - nu * S - 2);
-            load_run<S - 1>(prow, q);
-            load_async(prow[S - 1], nu == NUp - 1 ? e : q - (S - 1));
-        }
+    auto prefetch_edges = [&](int nu, int nband, int nps, double (&pcol)[R + 1]) {
         if (nu == 0) {
+            int64_t pr = pair0 + nps;
+            pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);     // not-yet-started / finished lanes: any valid pair, value unused
+            const double *e = prm.edges + pr * E;
             // Kf[i'][0] = K[min(MM, MMp - i')][NN], i' = i0 .. i0 + R (corner first), stored at [NNp + row - 1]; rows past
             // MM of the padded strip hold garbage, hence the min; only i' = MMp asks for K[0][NN] = 1 (fixed up after the wait)
             const int i0 = (nband * L + lam) * RC * r;
@@ -229,10 +224,36 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
             load_async(pcol[R], q + max(min(MM, MMp - (i0 + R)), 1));
         }
     };
-    // after the wait: the two positions whose value is the (unstored) boundary 1
-    auto fix_edges = [&](int nu, int nband, double (&prow)[S], double (&pcol)[R + 1]) {
-        if (nu == NUp - 1) prow[S - 1] = 1.0;
+    // after the wait: the position whose value is the (unstored) boundary 1
+    auto fix_edges = [&](int nu, int nband, double (&pcol)[R + 1]) {
         if (nu == 0 && (nband * L + lam) * RC * r + R == MMp) pcol[R] = 1.0;
+    };
+    // The terminal ROW K[MM][.] of the pair feeds the group's top lane, S values per macro-step: Kf[0][j'] = K[MM][NNp - j'],
+    // j' = u S + i + 1, stored at index k = NNp - u S - i - 2 of the pair's edge block.  The 8 S values of a window of 8
+    // macro-steps are contiguous (descending k); once per window one LDS-DMA brings the aligned span
+    // [NNp - (u0 + 8) S - 2, NNp - u0 S - 1] (u0 = the window's first unit; 4 S + 1 sixteen-byte pieces) of every lane
+    // group, one window ahead, into the slot the previous window has finished with -- no global load and no address arithmetic per
+    // macro-step (the first version loaded the S values every step, one macro-step ahead: 16 % of the kernel).  The one
+    // value outside the block (k = -1 = K[MM][0] = 1, last unit of a row) falls in a masked piece and is fixed up.
+    constexpr int NPC = 4 * S + 1;   // pieces per group
+    int ec_u0 = 0, ec_band = 0, ec_ps = 0, ec_fill = 0;   // window to fetch next: first unit, band, pair-in-group, slot
+    auto issue_edge_chunk = [&]() {
+        for (int c = 0; c * WAVE < G * NPC; ++c) {
+            const int idx = c * WAVE + lane, g = idx / NPC, i = idx - g * NPC;
+            int64_t pr = (wave_id * G + g) * prm.PPG + ec_ps;
+            pr = (pr < 0 || pr >= prm.P) ? 0 : pr;
+            const int k = NNp - (ec_u0 + LINE_UNITS) * S - 2 + 2 * i;
+            if (g < G && k >= 0)
+                __builtin_amdgcn_global_load_lds(prm.edges + pr * E + k, (lds_void *)(lds + NSLOT * SLOT_BYTES + ec_fill * (G * ECG) + c * 1024),
+                                                 16, 0, 0);
+        }
+        ec_fill ^= 1;
+        ec_u0 += LINE_UNITS;
+        if (ec_u0 == NUp) {
+            ec_u0 = 0;
+            ec_band += 1;
+            if (ec_band == nb) { ec_band = 0; ec_ps += 1; }
+        }
     };
 
     double ktopR[S];
@@ -247,36 +268,40 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
 
     double chk_val = 0.0;      // pending self-check result (see the end of the macro-step)
     int64_t chk_pair = -1;
-    // edge values of the coming macro-step: requested at the top of a step (after this step's values have been consumed),
-    // complete at its end
-    double nrow[S], ncol[R + 1];
-#pragma unroll
-    for (int i = 0; i < S; ++i) nrow[i] = 1.0;
+    // column-edge values of the coming macro-step: requested at the top of a step (after this step's values have been
+    // consumed), complete at its end
+    double ncol[R + 1];
 #pragma unroll
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
     {
-        double prow[S], pcol[R + 1];
-#pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+        double pcol[R + 1];
 #pragma unroll
         for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
-        prefetch_edges(u, band, ps, prow, pcol);
+        issue_edge_chunk();     // window 0 (older than the line fetches below: complete after the counted wait)
+        prefetch_edges(u, band, ps, pcol);
 #pragma unroll
         for (int f = 0; f < PF; ++f) issue_fetch();
-        async_wait<(PF - 1) * RC>(nrow, prow);   // the line of macro-step 0 and the edge values
-        async_wait<(PF - 1) * RC>(ncol, pcol);
-        fix_edges(u, band, nrow, ncol);
+        async_wait<(PF - 1) * RC>(ncol, pcol);   // the line of macro-step 0 and the edge values
+        fix_edges(u, band, ncol);
     }
 
     for (int t = 0; t < prm.n_steps; ++t) {
         vec_t gv[RC];
         const unsigned my_unit = rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4));
+        // the top lane's S terminal-row values of this macro-step, from the window's chunk (lane 0's unit is t modulo NUp; every
+        // lane of the group reads the same address): issued without a wait, complete at the increments' lgkmcnt(0) below
+        double trow_p[S], trow[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+        lds_read_f64_run<S>(trow_p, ec_base + (unsigned)(((t >> 3) & 1) * ec_slot + grp * ECG + ((7 - (t & 7)) * S + 1) * 8));
         {   // the increments (their line arrived before the previous step's closing wait) and the W line whose last
             // unit was written in the previous macro-step: one LDS round trip for both
             vec_t wv[RC];
             lds_read_rows_pair(gv, my_unit, wv, lds0 + (unsigned)(wslot * SLOT_BYTES + lane * 16));
             if (t >= LINE_UNITS) store_lines(wv);
         }
+        lds_take<S>(trow, trow_p);
+        if ((t & 7) == 0) issue_edge_chunk();   // the NEXT window's chunk, into the slot the previous window has finished with
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
             chk_pair = -1;
@@ -305,7 +330,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
             // what a top lane sees: Kr[0][j'] = 1 and Kf[0][j'] = the prefetched K[MM][.] values, or the band boundary
             double tbR[S], tbF[S];
 #pragma unroll
-            for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = nrow[i]; }
+            for (int i = 0; i < S; ++i) { tbR[i] = 1.0; tbF[i] = trow[S - 1 - i]; }
+            if (u == NUp - 1) tbF[S - 1] = 1.0;     // K[MM][0] = 1 is not stored (only a top lane's value is used)
             if (MULTIBAND) {
                 if (is_top && band > 0) {
                     // both boundary rows in one LDS round trip (a top lane exists in every wave, every macro-step)
@@ -333,12 +359,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
 
         // -- request the next step's edge values (asynchronously, into temporaries: see async_wait), then the increment
         //    lines of macro-step t + PF, the newest operations in flight
-        double prow[S], pcol[R + 1];
-#pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+        double pcol[R + 1];
 #pragma unroll
         for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
-        prefetch_edges(nu, nband, nps, prow, pcol);
+        prefetch_edges(nu, nband, nps, pcol);
         issue_fetch();
 
         // -- coefficients per coarse cell: a, b for Kr;  a/b, 1/b for the backward recompute of K
@@ -432,9 +456,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         // -- close the step: everything requested from global memory in it (next line, W lines, edge values) has landed
         // -- close the step.  Lanes that requested nothing get garbage here and never read it: nrow matters to a top lane
         //    (which requests every step), ncol to a lane in the step right after its request
-        async_wait<(PF - 1) * RC>(nrow, prow);
         async_wait<(PF - 1) * RC>(ncol, pcol);
-        fix_edges(nu, nband, nrow, ncol);
+        fix_edges(nu, nband, ncol);
 
         // -- advance
         if ((nu & 7) == 0) {
@@ -499,7 +522,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     const int G = WAVE / L;
     const bool multiband = nb > 1;
 
-    size_t lds_bytes = (size_t)(LINE_UNITS + ADJ_XSLOT + ADJ_PF) * RC * 1024;
+    size_t lds_bytes = (size_t)(LINE_UNITS + adj_pf(DY)) * RC * 1024 + (size_t)2 * G * adj_chunk_bytes(S);
     if (multiband) lds_bytes += (size_t)G * 2 * NUp * S * sizeof(double);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 

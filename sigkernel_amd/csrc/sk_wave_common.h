@@ -195,6 +195,42 @@ __device__ __forceinline__ void lds_read_2rows<8>(double (&a)[8], double (&b)[8]
     for (int i = 0; i < 4; ++i) { a[2 * i] = t[i][0]; a[2 * i + 1] = t[i][1]; b[2 * i] = t[4 + i][0]; b[2 * i + 1] = t[4 + i][1]; }
 }
 
+// N consecutive doubles starting at `addr` (8-byte aligned), issued WITHOUT a wait: the destinations are temporaries nobody
+// reads until lds_take hands them over after a later s_waitcnt lgkmcnt(0) (same discipline as load_async / async_wait)
+template <int N>
+__device__ __forceinline__ void lds_read_f64_run(double (&t)[N], unsigned a);
+template <>
+__device__ __forceinline__ void lds_read_f64_run<2>(double (&t)[2], unsigned a) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(t[0]), "=&v"(t[1]) : "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_f64_run<4>(double (&t)[4], unsigned a) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_f64_run<8>(double (&t)[8], unsigned a) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                 : "v"(a) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_take(double (&o)[N], double (&t)[N]);
+template <>
+__device__ __forceinline__ void lds_take<2>(double (&o)[2], double (&t)[2]) {
+    asm volatile("" : "=v"(o[0]), "=v"(o[1]) : "0"(t[0]), "1"(t[1]));
+}
+template <>
+__device__ __forceinline__ void lds_take<4>(double (&o)[4], double (&t)[4]) {
+    asm volatile("" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]) : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]));
+}
+template <>
+__device__ __forceinline__ void lds_take<8>(double (&o)[8], double (&t)[8]) {
+    asm volatile("" : "=v"(o[0]), "=v"(o[1]), "=v"(o[2]), "=v"(o[3]), "=v"(o[4]), "=v"(o[5]), "=v"(o[6]), "=v"(o[7])
+                 : "0"(t[0]), "1"(t[1]), "2"(t[2]), "3"(t[3]), "4"(t[4]), "5"(t[5]), "6"(t[6]), "7"(t[7]));
+}
+
 __device__ __forceinline__ void lds_write_f64(unsigned addr, double v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
