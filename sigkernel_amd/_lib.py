@@ -291,7 +291,7 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
 
-    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram):
+    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False):
         """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for
         pairs that need several bands of a wavefront and for path dims up to 16 (sk_solve_fwd_static_*, csrc/sk_wave_fused_mb.hip):
         nothing of size pairs x M x N in HBM.  None outside the kernel's scope (dyadic > 2, dim > 16, naive scheme, second path
@@ -307,7 +307,12 @@ class HipBackend:
         P = A * B if gram else A
         nbytes = int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), D))
         if not nbytes:
-            return None
+            # the band pipeline needs a second path of ~160 points or more; the kernel is symmetric in its arguments (both static
+            # kernels and the stencil are), so a long first path against a short second one is solved as K(y, x)
+            if _swapped or not int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Nc, Mc, int(dyadic), D)):
+                return None
+            Kt = self.solve_fwd_fused_static(kind, param, Y, X, dyadic, naive, gram, _swapped=True)
+            return None if Kt is None else (Kt.t().contiguous() if gram else Kt)
         fd = 8 if D <= 8 else 16
         Mrows = int(lib.sk_solve_fwd_static_rows(int(kind), Mc, int(dyadic)))
         NUp = ((Nc + 1 + int(kind)) // 2 + 7) // 8 * 8
