@@ -101,24 +101,26 @@ def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
         t2 = time.perf_counter()
         return vals, t2 - t0, t2 - t1
 
-    # calibrate on a few pairs of one row, then size each sample to its share of the budget
-    nb = min(B, 4 * threads)
-    inc = O.increments(sk.Gram_matrix(Xd[:1], Yd[:nb]).numpy())
+    # calibrate the WHOLE pipeline (static kernel + increments + solve) on one row, then size each sample to its share of the
+    # budget: 60 % for the all-threads run, 40 % for the single-thread one
     t0 = time.perf_counter()
-    O.solve_coarse(inc, dyadic, nthreads=threads)
-    per_pair_mt = (time.perf_counter() - t0) / nb
+    run(1, threads)
+    per_row_mt = time.perf_counter() - t0
+    nb1 = max(1, min(B, 64))
     t0 = time.perf_counter()
-    O.solve_coarse(inc[:, : max(1, nb // threads)], dyadic, nthreads=1)
-    per_pair_1t = (time.perf_counter() - t0) / max(1, nb // threads)
-    rows = int(max(1, min(Xc.shape[0], 0.6 * budget_s / max(per_pair_mt * B, 1e-9))))
+    O.solve_coarse(O.increments(sk.Gram_matrix(Xd[:1], Yd[:nb1]).numpy()), dyadic, nthreads=1)
+    per_pair_1t = (time.perf_counter() - t0) / nb1
+    rows = int(max(1, min(Xc.shape[0], 0.6 * budget_s / max(per_row_mt, 1e-9))))
     vals, t_all, t_solve = run(rows, threads)
     pairs = rows * B
-    # one thread: a prefix of the first row's pairs (a whole row would take minutes at the long-sequence configs)
-    b1 = int(max(1, min(B, 0.4 * budget_s / max(per_pair_1t, 1e-9))))
+    # one thread: whole rows when a row fits the budget, else a prefix of row 0's pairs (long-sequence configs)
+    n1 = int(max(1, min(Xc.shape[0] * B, 0.4 * budget_s / max(per_pair_1t, 1e-9))))
+    rows1, b1 = (n1 // B, B) if n1 >= B else (1, n1)
     t0 = time.perf_counter()
-    G1 = sk.Gram_matrix(Xd[:1], Yd[:b1]).numpy()
+    G1 = sk.Gram_matrix(Xd[:rows1], Yd[:b1]).numpy()
     O.solve_coarse(O.increments(G1), dyadic, nthreads=1)
     t_1 = time.perf_counter() - t0
+    b1 = rows1 * b1
     return {
         "value": pairs / t_all,
         "unit": "entries/s",
@@ -130,7 +132,7 @@ def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
         "solver_only_value": pairs / t_solve,
         "seconds": t_all,
         "single_thread_value": b1 / t_1,
-        "single_thread_sample": "row 0 of X against the first %d paths of Y, same pipeline on 1 thread, %.1f s" % (b1, t_1),
+        "single_thread_sample": "%d pairs (%d row(s) of X), same pipeline on 1 thread, %.1f s" % (b1, rows1, t_1),
     }, vals, rows
 
 
