@@ -119,6 +119,21 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
                                 size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream);
 
+/* Adjoint PDE AND RBFKernel chain rule in one kernel (csrc/sk_wave_adj_fused_rbf.hip): the reverse sweep evaluates the nodes
+ * G = exp(-|x - y|^2 / sigma) itself, forms its increments as their 4-corner differences, recomputes K from the terminal edges a
+ * forward with edges kept (sk_solve_fwd_rbf_edges_f64), and pushes W = d k / d inc through the difference and the exponential on
+ * the spot -- neither the increments nor W nor G_static exist in HBM.  Replaces sigkernel.py:419-502 + :404-416 for RBFKernel,
+ * i.e. sk_static_increments + sk_solve_adj(EDGES_GIVEN) + sk_static_adjoint.
+ *   Xr [A][Mrows][8], Yt [Bn][8][Ncp]: the POINT arrays sk_solve_fwd_rbf_* takes;  edges: sk_strip_edges_bytes layout;
+ *   scale [P] nullable (upstream gradient per pair).  gpart [gpart_doubles] receives partial sums over b, viewed as
+ *   [A][B / *ppg_out][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
+ *   dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == NULL: size query only.  err [P] zero-initialised: self-check residual
+ *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2, default scheme, path dim <= 8, one band per pair with
+ *   M <= lanes x rows per lane and N - 1 <= 2 NUp - 1; otherwise SK_ERR_UNSUPPORTED. */
+int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
+                             int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
+                             size_t gpart_doubles, double *err, int *ppg_out, int *rows_out, int *outw_out, void *stream);
+
 /* Second-argument adjoint (Gram only): dL/dY from W for the pairs (a, b), b >= b0 -- the counterpart of sk_static_adjoint_*
  * that the reference never needs (it returns no gradient for its second argument, sigkernel.py:343, :412).  It exists for
  * compute_Gram(X, X, sym=True) with a gradient: only the blocks on and above the diagonal are solved, and a pair (a, b)

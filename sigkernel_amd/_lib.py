@@ -61,6 +61,8 @@ SIGNATURES = {
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
                                            _vp]),
+    "sk_rbf_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp,
+                                        _sz, _vp, _vp, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_adj_rescue_slot_bytes": (_sz, [_int, _int, _int]),
     "sk_adj_rescue_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, ctypes.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
@@ -392,6 +394,47 @@ class HipBackend:
             g = g * (float(param) ** 2)
         g = g.to(X.dtype)
         return g, res
+
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True):
+        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel straight from the paths and
+        the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
+        sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
+        linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
+            return None
+        dev = X.device
+        Mrows, Ncp = 256, (N + 15) // 16 * 16
+        if scale is not None:
+            scale = scale.double().contiguous()
+        lib = load()
+        P, Bk = (A * B, B) if gram else (A, 0)
+        ppg, rows, outw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            Xr = _prep_paths(X, False, False, 1.0, Mrows)
+            Yt = _prep_paths(Y, False, True, 1.0, Ncp)
+            args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_DEFAULT, float(sigma), _ptr(edges), _ptr(scale))
+            tail = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), _stream(X))
+            rc = lib.sk_rbf_adjoint_fused_f64(*args, None, 0, None, *tail)
+            if rc == 2:
+                return None
+            _check(rc, "sk_rbf_adjoint_fused (query)")
+            chunks = B // ppg.value if gram else 1
+            gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
+            err = torch.zeros(P, dtype=torch.float64, device=dev)
+            rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), *tail)
+            if rc == 2:
+                return None
+            _check(rc, "sk_rbf_adjoint_fused")
+        res = err.max()
+        T = gpart.sum(1)[:, :M]                                   # chunks of an a added in a fixed order
+        cs, accd = T[..., 0:1], T[..., 2:2 + D]
+        g = (-2.0 / float(sigma)) * (X.double() * cs - accd)     # sum_c V G (-2/sigma) (x_r - y_c)
+        return g.to(X.dtype), res
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

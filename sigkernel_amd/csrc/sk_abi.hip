@@ -320,6 +320,18 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
                                    (hipStream_t)stream);
 }
 
+int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
+                             int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
+                             size_t gpart_doubles, double *err, int *ppg_out, int *rows_out, int *outw_out, void *stream) {
+    if (!Xr || !Yt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ppg_out, rows_out,
+                                outw_out, (hipStream_t)stream);
+}
+
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {
     if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16 || (elem_size != 4 && elem_size != 8)) return 0;
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);

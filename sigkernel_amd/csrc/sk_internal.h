@@ -116,6 +116,11 @@ template <typename T>
 int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int FDp,
                       hipStream_t s);
 
+// ---- sk_wave_adj_fused_rbf.hip: adjoint with the RBF static kernel fused in (nodes, increments, contraction in the sweep) ----
+int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
+                         double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
+                         int *ppg_out, int *rows_out, int *outw_out, hipStream_t s);
+
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>
 int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld, hipStream_t s);

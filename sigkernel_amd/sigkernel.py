@@ -90,6 +90,15 @@ def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
             and X.shape[1] - 1 <= (64 if dyadic == 2 else 128) and Y.shape[1] >= 2 and not os.environ.get("SK_NO_FUSED_ADJOINT"))
 
 
+def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
+    """Whether sk_rbf_adjoint_fused_f64 is worth trying: exactly RBFKernel, default scheme, dyadic 1..2, path dim <= 4 (the 8-dim
+    variants spill registers and lose to the unfused route), one band per pair (the kernel has the last word: `unsupported`
+    for the shapes whose node rows / columns do not fit its lanes and units)."""
+    return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused") and not naive and float(static_kernel.sigma) > 0
+            and X.shape[2] <= 4 and dyadic in (1, 2) and X.shape[1] <= 64 * (4 >> dyadic) and Y.shape[1] >= 2
+            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF"))
+
+
 def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=None):
     """dL/dX for one tile on the unfused routes: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
 
@@ -116,14 +125,15 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     return g
 
 
-def _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget):
-    """dL/dX for all rows through sk_linear_adjoint_fused_f64 (adjoint PDE + LinearKernel contraction in one kernel, from the
-    paths and the forward's terminal edges; no matrix of size pairs x M x N): one launch per row tile.  None when the kernel
-    does not cover the case or some pair failed its self-check (exploding kernels: the residuals of all tiles are looked at
-    ONCE, here -- the only host synchronisation of a backward pass); the caller then takes the unfused route, tiled by ITS
-    transient memory."""
+def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget):
+    """dL/dX for all rows through the fused adjoints -- sk_linear_adjoint_fused_f64 / sk_rbf_adjoint_fused_f64: adjoint PDE and
+    the static kernel's chain rule in one kernel, from the paths and the forward's terminal edges; no matrix of size pairs x M x N
+    -- one launch per row tile.  None when the kernel does not cover the case or some pair failed its self-check (exploding
+    kernels: the residuals of all tiles are looked at ONCE, here -- the only host synchronisation of a backward pass); the
+    caller then takes the unfused route, tiled by ITS transient memory."""
     A, M = Xd.shape[0], Xd.shape[1]
-    scale = _fused_static(static_kernel, gram)[1]
+    linear = type(static_kernel) is LinearKernel
+    param = _fused_static(static_kernel, gram)[1]
     per_row = (64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M      # edges and partial sums only
     grad = torch.empty_like(Xd)
     residuals = []
@@ -131,12 +141,13 @@ def _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, k
         Xt = Xd[a0:a1].contiguous()
         Yt = Yd if gram else Yd[a0:a1].contiguous()
         if edges is None or Xd.dtype != torch.float64:     # fp32 paths are swept in fp64: edges of the up-cast paths
-            res = be.solve_fwd_fused_linear(Xt.double(), Yt.double(), scale, dyadic, naive, gram, keep_edges=True)
+            fwd = be.solve_fwd_fused_linear if linear else be.solve_fwd_fused_rbf
+            res = fwd(Xt.double(), Yt.double(), param, dyadic, naive, gram, keep_edges=True)
             edges = res[1] if res is not None else None
         if edges is None:
             return None
-        res = be.linear_adjoint_fused(Xt, Yt, scale, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(),
-                                      gram=gram)
+        adj = be.linear_adjoint_fused if linear else be.rbf_adjoint_fused
+        res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram)
         if res is None:
             return None
         grad[a0:a1] = res[0]
@@ -149,13 +160,14 @@ def _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, k
 
 
 def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, workspace_bytes):
-    """dL/dX (A,M,D) of a Gram block (gram=True: go (A,B)) or a paired batch (go (A,)): the fused linear adjoint when it
+    """dL/dX (A,M,D) of a Gram block (gram=True: go (A,B)) or a paired batch (go (A,)): the fused linear / RBF adjoint when it
     applies, else the unfused routes tiled over rows by their transient memory (3 (Linear/RBF) or 8 (generic) arrays of the
     size of the tile's increments).  kept: what forward left for the tiles ([(a0, a1, edges)] or None)."""
     A, M, N = Xd.shape[0], Xd.shape[1], Yd.shape[1]
     budget = _budget(Xd.device, workspace_bytes)
-    if _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram):
-        g = _fused_linear_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget)
+    if (_fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
+            or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
+        g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget)
         if g is not None:
             return g
     fused = _fused_static(static_kernel, gram) is not None

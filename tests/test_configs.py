@@ -254,9 +254,11 @@ def test_backward_passes_synchronise_at_most_once():
     synchronise at all; a LinearKernel one looks at the fused adjoint's self-check residuals exactly once per backward."""
     import warnings
     gen = torch.Generator().manual_seed(3)
-    X, Y = walk(gen, 12, 40, 4).to(DEV), walk(gen, 9, 33, 4).to(DEV)
     w = torch.randn(12, 9, generator=gen, dtype=torch.float64).to(DEV)
-    for kern, allowed in ((sigkernel_amd.RBFKernel(1.0), 0), (sigkernel_amd.LinearKernel(), 1)):
+    # (static kernel, path dim, synchronisations allowed): the fused adjoints (LinearKernel; RBFKernel on paths of dim <= 4) look at
+    # their self-check residuals once per backward pass; the unfused RBF route (dim 6) never synchronises
+    for kern, D, allowed in ((sigkernel_amd.RBFKernel(1.0), 6, 0), (sigkernel_amd.RBFKernel(1.0), 4, 1), (sigkernel_amd.LinearKernel(), 4, 1)):
+        X, Y = walk(gen, 12, 40, D).to(DEV), walk(gen, 9, 33, D).to(DEV)
         sk = sigkernel_amd.SigKernel(kern, 1)
         Xg = X.clone().requires_grad_(True)
         (sk.compute_Gram(Xg, Y) * w).sum().backward()        # warm-up: library load, allocator
@@ -404,3 +406,83 @@ def test_fused_multiband_scope_and_c5_route(monkeypatch):
     Xl, Yl = walk(gen, 4, 300, 8).to(DEV), walk(gen, 3, 280, 8).to(DEV)
     Kl = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1).compute_Gram(Xl, Yl)
     assert rel_err(Kl.cpu().numpy(), O.gram_forward(Xl.cpu(), Yl.cpu(), sigkernel_amd.LinearKernel(), 1, nthreads=NT)) <= 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused RBF adjoint (sk_rbf_adjoint_fused_f64, csrc/sk_wave_adj_fused_rbf.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_fused_rbf_adjoint_against_the_unfused_route(monkeypatch):
+    """Adjoint PDE + node evaluation + chain rule through the 4-corner difference and the exponential in one kernel, from the
+    paths and the forward's terminal edges, against sk_static_increments -> sk_solve_adj -> sk_static_adjoint on 100 random
+    shapes (dyadic 1..2, dims 1..8, Gram and paired, with and without an upstream gradient); dL/dX agrees to 1e-10."""
+    be = _lib.get_backend()
+    monkeypatch.setenv("SK_ADJR_ALL", "1")        # also the register-spilling 8-dim variants the host layer does not use
+    rng = np.random.default_rng(1)
+    n = 0
+    for it in range(100):
+        d = int(rng.integers(1, 3))
+        cap = 64 * (4 >> d)
+        M = int(rng.integers(2, cap + 1)) if it % 4 else cap
+        N = int(rng.integers(2, 150))
+        A, B, D = int(rng.integers(1, 20)), int(rng.integers(1, 30)), int(rng.integers(1, 9))
+        gram = bool(it % 3)
+        if not gram:
+            B = A
+        sig = float(rng.uniform(0.5, 1.5))
+        gen = torch.Generator().manual_seed(300 + it)
+        X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+        go = torch.randn(A * B if gram else A, generator=gen, dtype=torch.float64).to(DEV) if it % 5 else None
+        res = be.solve_fwd_fused_rbf(X, Y, sig, d, False, gram, keep_edges=True)
+        assert res is not None and res[1] is not None
+        got = be.rbf_adjoint_fused(X, Y, sig, d, res[1], go, gram=gram)
+        if got is None:       # node rows / columns that do not fit the edge layout's lanes and units: the unfused route's business
+            continue
+        inc = be.static_increments(1, sig, X, Y, gram)
+        _, W = be.solve_adj(inc, d, False, edges=res[1])
+        want = be.static_adjoint(1, sig, X, Y, W, go, gram)
+        assert rel_err(got[0].cpu().numpy(), want.cpu().numpy()) <= max(1e-10, 10 * float(got[1])), (it, d, A, B, M, N, D, gram)
+        n += 1
+    assert n >= 60
+
+
+@pytest.mark.gpu
+def test_fused_rbf_adjoint_is_what_the_api_runs(monkeypatch):
+    """compute_Gram / compute_kernel gradients with RBFKernel on paths of dim <= 4 go through the fused adjoint and agree with the
+    unfused route and with the oracle's closed form; compute_mmd (triangular K_XX + fused K_XY) agrees with the reference fixture."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(31)
+    Xc, Yc = walk(gen, 12, 40, 4), walk(gen, 9, 33, 4)
+    X, Y = Xc.to(DEV), Yc.to(DEV)
+    w = torch.randn(12, 9, generator=gen, dtype=torch.float64)
+    k = sigkernel_amd.RBFKernel(0.8)
+    sk = sigkernel_amd.SigKernel(k, 2)
+    calls = []
+    orig = type(be).rbf_adjoint_fused
+    monkeypatch.setattr(type(be), "rbf_adjoint_fused", lambda self, *a, **kw: (calls.append(1), orig(self, *a, **kw))[1])
+    X1 = X.clone().requires_grad_(True)
+    (sk.compute_Gram(X1, Y) * w.to(DEV)).sum().backward()
+    assert calls, "RBFKernel backward did not use the fused adjoint"
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, 2, nthreads=8)
+    assert rel_err(X1.grad.cpu().numpy(), want) <= 1e-10
+    Xp = X[:9].clone().requires_grad_(True)
+    sk.compute_kernel(Xp, Y).sum().backward()
+    monkeypatch.setenv("SK_NO_FUSED_ADJOINT", "1")
+    X2 = X.clone().requires_grad_(True)
+    (sk.compute_Gram(X2, Y) * w.to(DEV)).sum().backward()
+    Xq = X[:9].clone().requires_grad_(True)
+    sk.compute_kernel(Xq, Y).sum().backward()
+    assert rel_err(X1.grad.cpu().numpy(), X2.grad.cpu().numpy()) <= 1e-10
+    assert rel_err(Xp.grad.cpu().numpy(), Xq.grad.cpu().numpy()) <= 1e-10
+    monkeypatch.delenv("SK_NO_FUSED_ADJOINT")
+    c = golden("gram_c4mini_rbf_d2")
+    Xf, Yf = torch.from_numpy(c["X"]).to(DEV), torch.from_numpy(c["Y"]).to(DEV)
+    n0 = len(calls)
+    Xg = Xf.clone().requires_grad_(True)
+    sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"])).compute_mmd(Xg, Yf).backward()
+    assert len(calls) > n0
+    assert rel_err(Xg.grad.cpu().numpy(), c["grad_mmd"]) <= grad_tol("gram_c4mini_rbf_d2", "grad_mmd")
+    # fp32 tensors: swept in fp64 on the up-cast paths
+    X3 = X.float().clone().requires_grad_(True)
+    (sk.compute_Gram(X3, Y.float()) * w.float().to(DEV)).sum().backward()
+    assert X3.grad.dtype == torch.float32 and rel_err(X3.grad.cpu().numpy(), want) <= 2e-4
