@@ -65,6 +65,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
     constexpr int XSLAB = RC * 512;
+    constexpr int NPC = 4 * S + 1, ECG = NPC * 16;   // terminal-row chunk of one lane group (sk_wave_adj.hip)
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
     const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     const int JMAX = (L + NUp - 1) / NUp;
     const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * X_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
                           (unsigned)((lam & 7) * RC * 64);
+    const unsigned ec_off = x_base0 + (unsigned)(G * X_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
+    const unsigned ec_slot = (unsigned)(G * ECG);
 
     // ---- producers: the rings of sk_wave_fused.hip, filled in FLIPPED order ------------------------------------------------
     // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
@@ -161,16 +164,27 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     // ---- terminal edges and the upstream gradient of the coming pair, one macro-step ahead (sk_wave_adj.hip) ---------------
     // pair stride of the edges: the layout of the kernel that wrote them (at dyadic 0 its padded row count differs from ours)
     const int E = DY == 0 ? prm.E : NNp + MMp;
-    auto prefetch_edges = [&](int nu, int nps, double (&prow)[S], double (&pcol)[R + 1], double &pscale) {
-        int64_t pr = pair0 + nps;
-        pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
-        const double *e = prm.edges + pr * E;
-        if (is_top) {
-            const double *q = e + (NNp - nu * S - 2);
-            load_run<S - 1>(prow, q);
-            load_async(prow[S - 1], nu == NUp - 1 ? e : q - (S - 1));
+    // the terminal ROW reaches the top lanes through LDS chunks fetched once per window of 8 macro-steps (sk_wave_adj.hip:
+    // issue_edge_chunk); the terminal COLUMN and the upstream gradient are loaded into registers one macro-step ahead
+    int ec_u0 = 0, ec_ps = 0, ec_fill = 0;
+    auto issue_edge_chunk = [&]() {
+        for (int c = 0; c * WAVE < G * NPC; ++c) {
+            const int idx = c * WAVE + lane, g = idx / NPC, i = idx - g * NPC;
+            int64_t pr = (wave_id * G + g) * prm.PPG + ec_ps;
+            pr = (ec_ps >= prm.PPG || pr >= prm.P) ? 0 : pr;
+            const int k = NNp - (ec_u0 + LINE_UNITS) * S - 2 + 2 * i;
+            if (g < G && k >= 0)
+                __builtin_amdgcn_global_load_lds(prm.edges + pr * E + k, (lds_void *)(lds + ec_off + ec_fill * (G * ECG) + c * 1024), 16, 0, 0);
         }
+        ec_fill ^= 1;
+        ec_u0 += LINE_UNITS;
+        if (ec_u0 == NUp) { ec_u0 = 0; ec_ps += 1; }
+    };
+    auto prefetch_edges = [&](int nu, int nps, double (&pcol)[R + 1], double &pscale) {
         if (nu == 0) {
+            int64_t pr = pair0 + nps;
+            pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
+            const double *e = prm.edges + pr * E;
             const int i0 = lam * RC * r;
             const double *q = e + (NNp - 1);
 #pragma unroll
@@ -179,8 +193,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             if (prm.scale) load_async(pscale, prm.scale + pr);
         }
     };
-    auto fix_edges = [&](int nu, double (&prow)[S], double (&pcol)[R + 1]) {
-        if (nu == NUp - 1) prow[S - 1] = 1.0;
+    auto fix_edges = [&](int nu, double (&pcol)[R + 1]) {
         if (nu == 0 && lam * RC * r + R == MMp) pcol[R] = 1.0;
     };
 
@@ -201,38 +214,39 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     double chk_val = 0.0;
     int64_t chk_pair = -1;
     double s_pair = 0.0;    // upstream gradient of the pair being swept (0 outside the group's pairs)
-    double nrow[S], ncol[R + 1], nscale = 0.0;
-#pragma unroll
-    for (int i = 0; i < S; ++i) nrow[i] = 1.0;
+    double ncol[R + 1], nscale = 0.0;
 #pragma unroll
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite (see the contraction below)
-        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB);
+        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB + 2 * G * ECG);
         const d2_t z = {0.0, 0.0};
         for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     issue_y();
     issue_x();
+    issue_edge_chunk();
     {
-        double prow[S], pcol[R + 1], pscale[1], tsc[1];
-#pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+        double pcol[R + 1], pscale[1], tsc[1];
 #pragma unroll
         for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
         async_begin(pscale[0]);
-        prefetch_edges(u, ps, prow, pcol, pscale[0]);
-        async_wait<0>(nrow, prow);
+        prefetch_edges(u, ps, pcol, pscale[0]);
         async_wait<0>(ncol, pcol);
         async_wait<0>(tsc, pscale);
-        fix_edges(u, nrow, ncol);
+        fix_edges(u, ncol);
         nscale = (u == 0 && ps >= 0 && ps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
     }
     issue_y();
     issue_x();
 
     for (int t = 0; t < prm.n_steps; ++t) {
+        // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
+        double trow_p[S], trow[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+        lds_read_f64_run<S>(trow_p, lds0 + ec_off + (unsigned)(((t >> 3) & 1) * ec_slot + grp * ECG + ((7 - (t & 7)) * S + 1) * 8));
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
             chk_pair = -1;
@@ -263,31 +277,33 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
             lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
+        lds_take<S>(trow, trow_p);
+        if ((t & 7) == 0) issue_edge_chunk();
 
         // -- top rows
         double topR[S], topF[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
+            double tf = trow[S - 1 - i];
+            if (i == S - 1 && u == NUp - 1) tf = 1.0;     // K[MM][0] = 1 is not stored
             if (FULLWAVE) {
                 ktopR[i] = dpp_shr1(botR[i], ktopR[i]);
                 topR[i] = ktopR[i];
-                topF[i] = dpp_shr1(botF[i], nrow[i]);
+                topF[i] = dpp_shr1(botF[i], tf);
             } else {
                 const double shR = dpp_shr1(botR[i], 1.0);
                 const double shF = dpp_shr1(botF[i], 1.0);
                 topR[i] = is_top ? 1.0 : shR;
-                topF[i] = is_top ? nrow[i] : shF;
+                topF[i] = is_top ? tf : shF;
             }
         }
 
         // -- next step's edge values (asynchronous)
-        double prow[S], pcol[R + 1], pscale[1];
-#pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(prow[i]);
+        double pcol[R + 1], pscale[1];
 #pragma unroll
         for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
         async_begin(pscale[0]);
-        prefetch_edges(nu, nps, prow, pcol, pscale[0]);
+        prefetch_edges(nu, nps, pcol, pscale[0]);
 
         // -- increments (original column order q = 0, 1 of the unit) and coefficients
         double ginc[RC][CW];
@@ -366,10 +382,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         // -- close the step: the edge values (and any ring piece issued in the previous step) have landed
         {
             double tsc[1];
-            async_wait<0>(nrow, prow);
             async_wait<0>(ncol, pcol);
             async_wait<0>(tsc, pscale);
-            fix_edges(nu, nrow, ncol);
+            fix_edges(nu, ncol);
             if (nu == 0) nscale = (nps >= 0 && nps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
         }
 
@@ -435,7 +450,8 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     if (L * RC < g.Mc) return SK_ERR_UNSUPPORTED;
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);
+    const int S = 2 << DY;
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16;
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     // pairs per lane group: the smallest divisor of B that keeps the launch within the resident waves (8 per CU: the
