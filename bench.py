@@ -46,8 +46,9 @@ CONFIGS = {
     # name: rows of X (per GPU under weak scaling), B, M, N, D, static kernel, dyadic, dtype, mode, description
     "c3": dict(A=512, B=512, M=128, N=128, D=8, kernel="linear", dyadic=1, dtype=torch.float64, mode="gram",
                desc="BASELINE configs[2]: batch 512x512, len 128, dim 8, LinearKernel, dyadic 1, fp64, compute_Gram sym=False"),
-    "c2": dict(A=128, B=128, M=64, N=64, D=3, kernel="rbf", dyadic=1, dtype=torch.float64, mode="gram",
-               desc="BASELINE configs[1]: batch 128x128, len 64, dim 3, RBFKernel(1.0), dyadic 1, fp64, compute_Gram"),
+    "c2": dict(A=128, B=128, M=64, N=64, D=3, kernel="rbf", dyadic=1, dtype=torch.float64, mode="gram", sym=True,
+               desc="BASELINE configs[1]: batch 128, len 64, dim 3, RBFKernel(1.0), dyadic 1, fp64, compute_Gram(X, X, sym=True) "
+                    "(entries = the 128 x 128 matrix returned; the 8256 pairs on and above the diagonal are solved)"),
     "c4": dict(A=2048, B=2048, M=64, N=64, D=4, kernel="rbf", dyadic=2, dtype=torch.float64, mode="mmd",
                desc="BASELINE configs[3]: batch_x 2048, batch_y 2048, len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64, "
                     "compute_mmd(X, Y).backward() (3 Gram matrices + 2 adjoint-PDE Grams), Gram rows sharded over the GPUs"),
@@ -203,9 +204,13 @@ def main():
         raise SystemExit("c4 is a fixed-size job (BASELINE configs[3]): use --scaling strong")
     A_total = A * world if scaling == "weak" else A
     # every rank holds the (small) inputs in full, exactly as SigKernel(process_group=...) expects; each solves its own rows
+    sym = bool(cfg.get("sym"))
     Xc = make_paths(A_total, M, D, seed=1000, dtype=dtype)
-    Yc = make_paths(B, N, D, seed=7, dtype=dtype)
-    X, Y = Xc.to(dev), Yc.to(dev)
+    Yc = Xc if sym else make_paths(B, N, D, seed=7, dtype=dtype)
+    if sym:
+        B = A_total
+    X = Xc.to(dev)
+    Y = X if sym else Yc.to(dev)
     sk = sigkernel_amd.SigKernel(static_kernel(kname), dyadic, process_group=dist.group.WORLD if use_dist else None)
     sk1 = sigkernel_amd.SigKernel(static_kernel(kname), dyadic)       # single-GPU instance for the rank-0 extras
     be = _lib.get_backend()
@@ -213,7 +218,7 @@ def main():
 
     if mode == "gram":
         def step():
-            return sk.compute_Gram(X, Y)                  # N > 1: rows sharded, one all-gather (sigkernel_amd.distributed)
+            return sk.compute_Gram(X, Y, sym=sym)         # N > 1: rows sharded, one all-gather (sigkernel_amd.distributed)
     else:
         def step():
             Xg = X.detach().requires_grad_(True)
@@ -283,6 +288,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
     from oracle import oracle as O
     A, B, M, N, D = cfg["A"], cfg["B"], cfg["M"], cfg["N"], cfg["D"]
     kname, dyadic, dtype, mode = cfg["kernel"], cfg["dyadic"], cfg["dtype"], cfg["mode"]
+    sym = bool(cfg.get("sym"))
     s = X.element_size()
     Mc, Nc = M - 1, N - 1
     cells_per_entry = (Mc << dyadic) * (Nc << dyadic)
@@ -293,13 +299,15 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
     # ---- (1) the kernel that dominates the forward step ----------------------------------------------------------------
     fused = _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True) is not None
     if fused:
+        run_fused = (lambda: sk.compute_Gram(Xr, Xr, sym=True)) if sym else \
+            (lambda: _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True))
         # Linear / RBF within the fused kernels' scope: one launch does static kernel + increments + PDE for the whole Gram;
         # nothing of size pairs x M x N touches HBM, so the ceiling is fp64 vector issue.  FMA-class lane operations per pair:
         # 3 per fine cell (stencil) + per coarse cell 4 (coefficients) + the static kernel (linear: D FMAs; rbf: 2 D for
         # the distance, 19 for exp, 4 for the 4-corner difference).
-        ms = time_launches(lambda: _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True), reps)
+        ms = time_launches(run_fused, reps)
         avg = float(np.mean(ms))
-        pairs_f = A * B
+        pairs_f = A * (A + 1) // 2 if sym else A * B        # sym: the pairs on and above the diagonal, one launch
         per_coarse = 4 + (D if kname == "linear" else 2 * D + 23)
         ops = pairs_f * (cells_per_entry * 3 + Mc * Nc * per_coarse)
         tflops = 2 * ops / (avg * 1e-3) / 1e12

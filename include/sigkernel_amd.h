@@ -224,6 +224,19 @@ int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t 
                          int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                          int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
+/* Symmetric Gram matrix of ONE path batch with the fused kernels above: only the A (A + 1) / 2 pairs on and above the diagonal are
+ * solved (what the reference's CPU solver does for sym=True, cython_backend.pyx:74-97; its GPU path ignores `sym`), in ONE launch,
+ * and each value is written to out[a][b] and out[b][a]: out [A][A] is exactly symmetric.  dXr / dXt (Xr / Xt): the row-major and
+ * the dimension-major staging of the SAME paths, as sk_solve_fwd_linear_* (sk_solve_fwd_rbf_*) take them; Mc = Nc = M - 1. */
+int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, double *out, void *stream);
+int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, float *out, void *stream);
+int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                             int scheme, double inv_sigma, double *out, void *stream);
+int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                             int scheme, double inv_sigma, float *out, void *stream);
+
 /* Forward solve with the static kernel fused in for LONG or WIDE paths (csrc/sk_wave_fused_mb.hip): any number of bands per
  * pair (M - 1 beyond 256/128/64 at dyadic 0/1/2) and path dimensions up to 16 -- BASELINE configs[4] (len 512, dim 16,
  * RBF, dyadic 2) runs in this one kernel with nothing of size P*M*N in HBM.  Replaces, like the two families above,

@@ -57,6 +57,10 @@ SIGNATURES = {
                                        _vp, _sz, _vp]),
     "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _vp, _vp, _sz, _vp]),
+    "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
     "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
@@ -292,6 +296,34 @@ class HipBackend:
             return None
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
+
+    def solve_fwd_fused_sym(self, kind, param, X, dyadic, naive):
+        """Symmetric Gram matrix K[a][b] = k(x_a, x_b) of ONE batch with the static kernel formed inside the solver: only the pairs
+        on and above the diagonal are solved, in one launch, each written twice (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*).
+        None outside the single-band fused kernels' scope (dim > 8, dyadic > 2, more than one band)."""
+        _dev(X, "X")
+        A, M, D = X.shape
+        Mc = M - 1
+        rows = Mc if kind == 0 else M
+        if D > 8 or dyadic > 2 or Mc < 1 or rows > 64 * (4 >> min(dyadic, 2)) or (kind == 1 and not float(param) > 0):
+            return None
+        Mrows, Ncp = 256, ((Mc if kind == 0 else M) + 15) // 16 * 16
+        out = torch.empty(A, A, dtype=X.dtype, device=X.device)
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        lib = load()
+        with torch.cuda.device(X.device):
+            if kind == 0:
+                Xr, Xt = _prep_paths(X, True, False, float(param) ** 2, Mrows), _prep_paths(X, True, True, 1.0, Ncp)
+                rc = getattr(lib, "sk_solve_fwd_linear_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic),
+                                                                           scheme, _ptr(out), _stream(X))
+            else:
+                Xr, Xt = _prep_paths(X, False, False, 1.0, Mrows), _prep_paths(X, False, True, 1.0, Ncp)
+                rc = getattr(lib, "sk_solve_fwd_rbf_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme,
+                                                                        1.0 / float(param), _ptr(out), _stream(X))
+        if rc == 2:
+            return None
+        _check(rc, "sk_solve_fwd_*_sym")
+        return out
 
     def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False):
         """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for

@@ -110,6 +110,19 @@ int solve_fwd_static(int kind, double param, const double *Xr, const void *Yt, i
                                    (hipStream_t)stream);
 }
 
+// symmetric Gram of ONE path batch: only the A (A + 1) / 2 pairs on and above the diagonal are solved, each written twice
+template <typename TO>
+int solve_fwd_sym(int kind, const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                  int scheme, double inv_sigma, TO *out, void *stream) {
+    if (D < 1 || !Xr || !Xt || !out || A < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (kind == 1 && (!(inv_sigma > 0.0) || !(inv_sigma < 1e300))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(A * (A + 1) / 2, Mc, Nc, dyadic, scheme);
+    if (kind == 0) return launch_fwd_fused_linear<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, out, nullptr, (hipStream_t)stream, 1);
+    return launch_fwd_fused_rbf<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, inv_sigma, out, nullptr, (hipStream_t)stream, 1);
+}
+
 }  // namespace
 
 extern "C" {
@@ -287,6 +300,23 @@ int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void
                             size_t workspace_bytes, void *stream) {
     return solve_fwd_static<float>(kind, param, Xr, Yt, yt_f32, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
                                    workspace_bytes, stream);
+}
+
+int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, double *out, void *stream) {
+    return solve_fwd_sym<double>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, stream);
+}
+int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, float *out, void *stream) {
+    return solve_fwd_sym<float>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, stream);
+}
+int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                             int scheme, double inv_sigma, double *out, void *stream) {
+    return solve_fwd_sym<double>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, stream);
+}
+int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                             int scheme, double inv_sigma, float *out, void *stream) {
+    return solve_fwd_sym<float>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, stream);
 }
 
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,

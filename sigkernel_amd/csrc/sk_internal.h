@@ -93,11 +93,11 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, hipStream_t s);
+                            TO *out, double *strip_edges, hipStream_t s, int tri = 0);
 
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s);
+                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri = 0);
 
 // ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
 template <typename TO>

@@ -46,6 +46,8 @@ struct FusedParams {
     double inv_sigma;    // RBF: G = exp(-|x - y|^2 * inv_sigma)
     int dims;            // path dimensions that can be non-zero (<= 8)
     int e_NUp, e_L;      // EDGES: units per row / lanes per pair of the strip layout the adjoint reads (strip_geom)
+    int tri;             // 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
+                         // path batch (A = B); out is [A][A] and receives both (a, b) and (b, a)
     WaveGroup wg;
 };
 
@@ -126,6 +128,17 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
                  : "memory");
 }
 
+// pair p of the row-major upper triangle (diagonal included) of an A x A matrix -> (a, b), a <= b
+__device__ __forceinline__ void tri_split(int64_t p, int64_t A, int64_t &a, int64_t &b) {
+    const double t = (double)(2 * A + 1);
+    int64_t r = (int64_t)((t - sqrt(t * t - 8.0 * (double)p)) * 0.5);
+    r = r < 0 ? 0 : (r >= A ? A - 1 : r);
+    while (r > 0 && r * A - r * (r - 1) / 2 > p) --r;                       // first pair of row r: r A - r (r - 1) / 2
+    while (r + 1 < A && (r + 1) * A - (r + 1) * r / 2 <= p) ++r;
+    a = r;
+    b = r + (p - (r * A - r * (r - 1) / 2));
+}
+
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
@@ -186,10 +199,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
+        if (prm.tri) { int64_t a, b; tri_split(p, prm.B, a, b); return b; }
         return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
+        if (prm.tri) { int64_t a, b; tri_split(p, prm.B, a, b); return a; }
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
     };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
@@ -502,7 +517,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
+                if (prm.tri) {      // the pair and its mirror image
+                    int64_t a, b;
+                    tri_split(pair0 + pv, prm.B, a, b);
+                    static_cast<TO *>(prm.out)[a * prm.B + b] = (TO)v;
+                    static_cast<TO *>(prm.out)[b * prm.B + a] = (TO)v;
+                } else {
+                    static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
+                }
             }
         }
 
@@ -621,7 +643,8 @@ int launch_fused_dy(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) 
 // SK_ERR_UNSUPPORTED outside the kernel's scope.
 template <typename TO, int KIND>
 int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                     double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
+                     double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri = 0) {
+    if (tri && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
     const int DY = g.dyadic;
     if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
@@ -660,6 +683,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.inv_sigma = inv_sigma;
     prm.dims = D;
+    prm.tri = tri;
     prm.e_NUp = NUp;
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
@@ -684,23 +708,23 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
 
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, hipStream_t s) {
-    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, s);
+                            TO *out, double *strip_edges, hipStream_t s, int tri) {
+    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, s, tri);
 }
 // Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s) {
-    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, s);
+                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri) {
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, s, tri);
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double *,
-                                             double *, hipStream_t);
+                                             double *, hipStream_t, int);
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, float *,
-                                            double *, hipStream_t);
+                                            double *, hipStream_t, int);
 template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, double *,
-                                          double *, hipStream_t);
+                                          double *, hipStream_t, int);
 template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, float *,
-                                         double *, hipStream_t);
+                                         double *, hipStream_t, int);
 
 }  // namespace sk

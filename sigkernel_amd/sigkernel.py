@@ -281,6 +281,16 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     The result is exactly symmetric.  keep_blocks (a list, when a gradient is pending) receives (r0, r1, kept edges) per
     row block for _SigKernelGram.backward's triangular adjoint."""
     A = Xd.shape[0]
+    if keep_blocks is None and hasattr(be, "solve_fwd_fused_sym"):
+        # exactly LinearKernel / RBFKernel within the single-band fused kernels' scope: the triangle in ONE launch, every value
+        # written to both halves (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*)
+        kind = 0 if type(static_kernel) is LinearKernel else 1 if (type(static_kernel) is RBFKernel
+                                                                    and not os.environ.get("SK_NO_FUSED_RBF")) else None
+        if kind is not None:
+            param = 1.0 if kind == 0 else float(static_kernel.sigma)
+            K = be.solve_fwd_fused_sym(kind, param, Xd, dyadic_order, naive) if (kind == 0 or param > 0) else None
+            if K is not None:
+                return K
     K = torch.empty(A, A, dtype=Xd.dtype, device=Xd.device)
     cells = float(A) * A * ((Xd.shape[1] - 1) << dyadic_order) ** 2
     # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of

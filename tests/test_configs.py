@@ -486,3 +486,29 @@ def test_fused_rbf_adjoint_is_what_the_api_runs(monkeypatch):
     X3 = X.float().clone().requires_grad_(True)
     (sk.compute_Gram(X3, Y.float()) * w.float().to(DEV)).sum().backward()
     assert X3.grad.dtype == torch.float32 and rel_err(X3.grad.cpu().numpy(), want) <= 2e-4
+
+
+@pytest.mark.gpu
+def test_symmetric_gram_in_one_triangular_launch(monkeypatch):
+    """compute_Gram(X, X, sym=True) without a gradient, LinearKernel / RBFKernel within the fused kernels' scope: the pairs on and
+    above the diagonal in ONE launch (sk_solve_fwd_*_sym_*), every value written to both halves -- against the oracle, exactly
+    symmetric, for batch sizes around the lane-group and wave boundaries; BASELINE configs[1] (batch 128, len 64, dim 3) included."""
+    be = _lib.get_backend()
+    calls = []
+    orig = type(be).solve_fwd_fused_sym
+    monkeypatch.setattr(type(be), "solve_fwd_fused_sym", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    gen = torch.Generator().manual_seed(12)
+    for A, M, D, d, kern, dt in ((1, 9, 2, 1, sigkernel_amd.RBFKernel(0.7), torch.float64), (2, 30, 3, 0, sigkernel_amd.LinearKernel(), torch.float64),
+                                 (7, 64, 8, 2, sigkernel_amd.RBFKernel(1.0), torch.float64), (130, 20, 4, 1, sigkernel_amd.LinearKernel(), torch.float64),
+                                 (128, 64, 3, 1, sigkernel_amd.RBFKernel(1.0), torch.float64), (33, 40, 5, 1, sigkernel_amd.RBFKernel(1.3), torch.float32)):
+        Xc = walk(gen, A, M, D, dt) * 1.5
+        X = Xc.to(DEV)
+        n0 = len(calls)
+        K = sigkernel_amd.SigKernel(kern, d).compute_Gram(X, X, sym=True)
+        assert len(calls) == n0 + 1 and K.shape == (A, A) and K.dtype == dt and torch.equal(K, K.t())
+        want = O.gram_forward(Xc.double(), Xc.double(), kern, d, nthreads=NT)
+        assert rel_err(K.double().cpu().numpy(), want) <= (1e-11 if dt == torch.float64 else 2e-6), (A, M, D, d)
+    # outside the single-band scope the tiled route still answers (two bands at dyadic 1)
+    Xl = walk(gen, 5, 300, 3).to(DEV)
+    Kl = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1).compute_Gram(Xl, Xl, sym=True)
+    assert torch.equal(Kl, Kl.t()) and rel_err(Kl.cpu().numpy(), O.gram_forward(Xl.cpu(), Xl.cpu(), sigkernel_amd.RBFKernel(1.0), 1, nthreads=NT)) <= 1e-11
