@@ -79,14 +79,20 @@ __device__ __forceinline__ float readlane_f64(float v, int l) {
 }
 
 // static kernel at one node: x (wave-uniform), its squared norm xs, y node (per lane) and its squared norm ys
-template <int DMAX, int KIND>
+// FAST: the stripped exp of sk_internal.h (19 instructions, finite arguments <= a rounding above 0) -- the plain increments;
+// the derivative increments keep the library exp: their 1/eps^2 amplification makes the last bit of a node part of the result
+// the fixtures pin (section 4.6 of DESIGN.md)
+template <int DMAX, int KIND, bool FAST = false>
 __device__ __forceinline__ double static_node(const double (&xv)[DMAX], double xs, const double (&yv)[DMAX], double ys,
                                                double inv_sigma) {
     double xy = 0.0;
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) xy = fma(xv[k], yv[k], xy);
     // rbf: dist = -2 xy + (xs + ys);  G = exp(-dist / sigma)          (static_kernels.py:53-56, :70-73)
-    return KIND == 0 ? xy : exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+    if constexpr (KIND == 0) return xy;
+    const double e = -(fma(-2.0, xy, xs + ys)) * inv_sigma;
+    if constexpr (FAST) return exp_nonpos(e);
+    return exp(e);
 }
 template <int DMAX>
 __device__ __forceinline__ double sqnorm(const double (&v)[DMAX]) {
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
                     for (int k = 0; k < DMAX; ++k) xr[v][k] = xv[k];
                 }
                 xsq[v] = sqnorm<DMAX>(xv);
-                E[v] = (TA)static_node<DMAX, KIND>(xv, xsq[v], ye, yse, inv_sigma);
+                E[v] = (TA)static_node<DMAX, KIND, NV == 1>(xv, xsq[v], ye, yse, inv_sigma);
             }
         }
         const int rows = min(SK_TPB, M - i0);
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
                 }
                 const double xs_row = readlane_f64(xsq[v], r);
 #pragma unroll
-                for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND>(xv, xs_row, yn[c], ys[c], inv_sigma);
+                for (int c = 0; c < CPT; ++c) g[c][v] = (TA)static_node<DMAX, KIND, NV == 1>(xv, xs_row, yn[c], ys[c], inv_sigma);
             }
 #pragma unroll
             for (int c = 0; c < CPT; ++c) {
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(NT *NW) void k_rbf_adj2(const T *__restrict__ X, co
                         xs = fma(xv[k], xv[k], xs);
                         xy = fma(xv[k], yn[k], xy);
                     }
-                    const double g = exp(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+                    const double g = exp_nonpos(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
                     const double c = (m < M ? s[u] : 0.0) * (tcur - tprev[u]) * g;
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, xv[k] - yn[k], acc[k]);
