@@ -225,7 +225,8 @@ class HipBackend:
         """K[MM][NN] for the LINEAR static kernel with the increments formed inside the solver (nothing of size
         pairs x M x N in HBM).  Returns None outside the kernel's scope (dim > 8, dyadic > 2, more than one band).
         keep_edges: returns (K, edges) with the terminal row/column of every pair for solve_adj(..., edges=...)
-        (edges None where that is not available: fp32, dyadic 0)."""
+        or the fused adjoint (edges None where that is not available: fp32 tensors -- the adjoint sweeps up-cast paths and forms
+        its own edges)."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
