@@ -139,6 +139,32 @@ __device__ __forceinline__ void tri_split(int64_t p, int64_t A, int64_t &a, int6
     b = r + (p - (r * A - r * (r - 1) / 2));
 }
 
+// x-row reloads straight into the row registers (read-write operands: under a divergent branch the inactive lanes keep theirs)
+__device__ __forceinline__ void lds_load_line(d2_t (&r0)[4], d2_t (&r1)[4], unsigned a) {     // 128 contiguous bytes: two rows of 8 dims
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
+                 "ds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3])
+                 : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_load_half_rows(d2_t (&r0)[2], d2_t (&r1)[2], unsigned a) {   // the first 32 bytes of two 64-byte rows
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(r0[0]), "+v"(r0[1]), "+v"(r1[0]), "+v"(r1[1]) : "v"(a) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_load_row(d2_t (&r)[N], unsigned a);
+template <>
+__device__ __forceinline__ void lds_load_row<4>(d2_t (&r)[4], unsigned a) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_load_row<2>(d2_t (&r)[2], unsigned a) {
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : "v"(a) : "memory");
+}
+
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
@@ -246,11 +272,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (x_lam0 == NUp) { x_lam0 = 0; x_q0 += 1; }
     };
 
-    double dxr[RC][ND];
+    // this lane's x rows as 16-byte register pairs: the reload's ds_read_b128 lands in them directly (tied "+v" operands:
+    // the lanes that do not start a pair keep their values under the exec mask) -- no temporaries, no v_mov per macro-step
+    d2_t dxq[RC][ND / 2];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
 #pragma unroll
-        for (int j = 0; j < ND; ++j) dxr[k][j] = 0.0;
+        for (int j = 0; j < ND / 2; ++j) dxq[k][j] = d2_t{0.0, 0.0};
     // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
     // of the first row of the lane below at the columns of units uk and uk + 1
     double own[RBF ? RC : 1][6], bel[4];
@@ -337,34 +365,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
             if constexpr (RC % 2 == 0 && ND == 8) {   // two rows per LDS round trip (every wave takes this branch every step:
 #pragma unroll                                        // some lane always starts a pair)
-                for (int k = 0; k < RC; k += 2) {
-                    d2_t xv[8];
-                    lds_read_line(xv, xa + k * 64u);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1];
-                        dxr[k + 1][2 * j] = xv[4 + j][0]; dxr[k + 1][2 * j + 1] = xv[4 + j][1];
-                    }
-                }
+                for (int k = 0; k < RC; k += 2) lds_load_line(dxq[k], dxq[k + 1], xa + k * 64u);
             } else if constexpr (RC % 2 == 0) {
 #pragma unroll
-                for (int k = 0; k < RC; k += 2) {
-                    d2_t xv[4];
-                    lds_read_half_rows(xv, xa + k * 64u);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1];
-                        dxr[k + 1][2 * j] = xv[2 + j][0]; dxr[k + 1][2 * j + 1] = xv[2 + j][1];
-                    }
-                }
+                for (int k = 0; k < RC; k += 2) lds_load_half_rows(dxq[k], dxq[k + 1], xa + k * 64u);
             } else {
 #pragma unroll
-                for (int k = 0; k < RC; ++k) {
-                    d2_t xv[4];
-                    lds_read_units<4>(xv, xa + k * 64u);
-#pragma unroll
-                    for (int j = 0; j < ND / 2; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
-                }
+                for (int k = 0; k < RC; ++k) lds_load_row<ND / 2>(dxq[k], xa + k * 64u);
             }
         }
 
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                     double d2 = 0.0;
 #pragma unroll
                     for (int j = 0; j < ND; ++j) {
-                        const double df = dxr[k][j] - dyv[j][q];
+                        const double df = dxq[k][j >> 1][j & 1] - dyv[j][q];
                         d2 = fma(df, df, d2);
                     }
                     // d2 * 0 is 0 for finite distances and NaN for an infinite (or NaN) one: the reference's
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 for (int q = 0; q < CW; ++q) {
                     double g = 0.0;
 #pragma unroll
-                    for (int j = 0; j < ND; ++j) g = fma(dxr[k][j], dyv[j][q], g);
+                    for (int j = 0; j < ND; ++j) g = fma(dxq[k][j >> 1][j & 1], dyv[j][q], g);
                     ginc[k][q] = g;
                 }
         }
