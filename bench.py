@@ -104,9 +104,11 @@ def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
 
     # calibrate the WHOLE pipeline (static kernel + increments + solve) on one row, then size each sample to its share of the
     # budget: 60 % for the all-threads run, 40 % for the single-thread one
+    run(1, threads)                       # warm-up: thread pool, torch CPU kernels, page faults
+    crow = max(1, min(Xc.shape[0], 2))
     t0 = time.perf_counter()
-    run(1, threads)
-    per_row_mt = time.perf_counter() - t0
+    run(crow, threads)
+    per_row_mt = (time.perf_counter() - t0) / crow
     nb1 = max(1, min(B, 64))
     t0 = time.perf_counter()
     O.solve_coarse(O.increments(sk.Gram_matrix(Xd[:1], Yd[:nb1]).numpy()), dyadic, nthreads=1)
