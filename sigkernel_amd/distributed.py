@@ -26,13 +26,24 @@ def row_range(n_rows, rank, world):
     return lo, min(lo + chunk, n_rows), chunk
 
 
+def _gather(out, inp, group):
+    """all_gather_into_tensor; a gloo group is given host copies of device tensors (gloo moves no HIP memory: this is the
+    test configuration -- several ranks sharing one GPU -- not a production path, which is RCCL)."""
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def _all_gather_rows(block, n_rows, chunk, group):
     """block: this rank's rows, shape (rows_r, ...) with rows_r <= chunk -> (n_rows, ...) on every rank."""
     world = dist.get_world_size(group)
     pad = torch.zeros((chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
     pad[: block.shape[0]] = block
     out = torch.empty((world * chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+    _gather(out, pad.contiguous(), group)
     return out[:n_rows]
 
 
@@ -53,7 +64,7 @@ def _folded_symmetric_gram(X, static_kernel, dyadic_order, naive, workspace_byte
                 strips[slot, : hi - lo, lo:] = _SigKernelGram.apply(Xd[lo:hi].contiguous(), Xd[lo:].contiguous(), static_kernel,
                                                                     dyadic_order, False, naive, workspace_bytes)
     full = torch.empty(world * 2, bs, A, dtype=X.dtype, device=X.device)     # rank-major concatenation along dim 0
-    dist.all_gather_into_tensor(full, strips, group=group)
+    _gather(full, strips, group)
     full = full.reshape(world, 2, bs, A)
     K = torch.empty(2 * world * bs, A, dtype=X.dtype, device=X.device)
     for r in range(world):

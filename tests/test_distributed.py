@@ -151,3 +151,46 @@ def test_sharded_symmetric_gram_is_folded_over_the_ranks(tmp_path, world):
         assert rel_err(got["gram"], want) <= 1e-13 and np.array_equal(got["gram"], got["gram"].T)
         solved.append(int(got["pairs"]))
     assert max(solved) <= 0.75 * (11 * 11 / world) + 11 and sum(solved) < 0.75 * 11 * 11, solved
+
+
+def _hip_gloo_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sigkernel_amd
+        res = {}
+        for name in ("gram_c4mini_rbf_d2", "gram_c3mini_lin_d1"):
+            c = golden(name)
+            X, Y, w = (torch.from_numpy(c[k]).cuda() for k in ("X", "Y", "w"))
+            sk = sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"]), process_group=dist.group.WORLD)
+            Xg = X.clone().requires_grad_(True)
+            K = sk.compute_Gram(Xg, Y)
+            (K * w).sum().backward()
+            res[name + ".gram"], res[name + ".grad_w"] = K.detach().cpu().numpy(), Xg.grad.cpu().numpy()
+            Xg = X.clone().requires_grad_(True)
+            mmd = sk.compute_mmd(Xg, Y)
+            mmd.backward()
+            res[name + ".mmd"], res[name + ".grad_mmd"] = mmd.detach().cpu().numpy(), Xg.grad.cpu().numpy()
+        np.savez(os.path.join(out_dir, "hipgloo%d.npz" % rank), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_gram_two_ranks_sharing_one_gpu(tmp_path):
+    """World size 2 with the HIP kernels: two processes share the one GPU of the box, each solves its row shard on it, the
+    collectives go through gloo (host copies).  RCCL cannot be used for this (it refuses two ranks on one device); the RCCL
+    path itself is covered by the single-rank test above and bench.py --force-dist."""
+    from conftest import grad_tol
+    mp.spawn(_hip_gloo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = dict(np.load(tmp_path / ("hipgloo%d.npz" % r)))
+        for name in ("gram_c4mini_rbf_d2", "gram_c3mini_lin_d1"):
+            c = golden(name)
+            assert rel_err(got[name + ".gram"], c["gram"]) <= 1e-11
+            assert rel_err(got[name + ".grad_w"], c["grad_w"]) <= grad_tol(name, "grad_w")
+            assert abs(float(got[name + ".mmd"]) - float(c["mmd"])) <= 1e-11
+            assert rel_err(got[name + ".grad_mmd"], c["grad_mmd"]) <= grad_tol(name, "grad_mmd")

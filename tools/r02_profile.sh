@@ -19,7 +19,7 @@ pmc() {  # tag regex bench-args...
 }
 mkdir -p $OUT/pmc_c5 $OUT/pmc_c4 $OUT/pmc_c3
 pmc c5 "k_fwd_fused_mb" --config c5 --steps 2 --warmup 1 --no-extras
-pmc c4 "k_adj_wave|k_fwd_fused|k_static|k_rbf" --config c4 --steps 1 --warmup 1 --no-extras
+pmc c4 "k_adj_wave|k_adj_fused|k_fwd_fused|k_static|k_rbf" --config c4 --steps 1 --warmup 1 --no-extras
 pmc c3 "k_fwd_fused" --config c3 --steps 3 --warmup 1 --no-extras
 cd $REPO
 python - $OUT <<'PY' > $OUT/summary.txt 2>&1
