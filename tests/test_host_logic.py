@@ -123,3 +123,53 @@ def test_input_validation(oracle_backend):
         sk.compute_kernel(torch.rand(2, 3, 2), torch.rand(3, 3, 2))
     with pytest.raises(ValueError):
         sk.compute_Gram(torch.rand(2, 3), torch.rand(2, 3, 3))
+
+
+class _FusedFake:
+    """The oracle-backed fake with a fused linear adjoint whose self-check residual the test controls: exercises the
+    once-per-backward residual check and the re-tiled fallback of sigkernel._rows_gradient on CPU."""
+
+    def __init__(self, base, residual):
+        self._base, self._residual, self.fused_calls, self.tile_rows = base, residual, 0, []
+        self.ADJ_RESIDUAL_TOL = 1e-8
+
+    def __getattr__(self, name):
+        return getattr(self._base, name)
+
+    def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram, keep_edges=False):
+        return None          # forward takes the tiled route; the fused adjoint asks for edges itself
+
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True):
+        self.fused_calls += 1
+        return torch.full_like(X, float("nan")), torch.tensor(self._residual, dtype=torch.float64)
+
+    def static_increments(self, kind, param, X, Y, gram):
+        self.tile_rows.append(X.shape[0])
+        return self._base.static_increments(kind, param, X, Y, gram)
+
+
+def test_failed_fused_adjoint_falls_back_tiled_by_the_unfused_budget():
+    """when the fused linear adjoint's self-check fails (or the kernel does not cover the case) the backward pass
+    must take the unfused route in tiles sized for THAT route's transient memory, and look at the residuals only once."""
+    from sigkernel_amd import _lib, sigkernel as skmod
+    from fake_backend import OracleBackend
+    c = golden("gram_c3mini_lin_d1")
+    X, Y, w = (torch.from_numpy(c[k]) for k in ("X", "Y", "w"))
+    A, M, B, N = X.shape[0], X.shape[1], Y.shape[0], Y.shape[1]
+    budget = 3 * B * M * N * 8 * 2          # room for two rows of the unfused route
+    fake = _FusedFake(OracleBackend(), residual=1.0)
+    # the fused route needs a forward that keeps edges: hand the fake one that returns a token
+    fake.solve_fwd_fused_linear = lambda X, Y, scale, dyadic, naive, gram, keep_edges=False: (
+        (torch.zeros(X.shape[0], Y.shape[0], dtype=X.dtype), torch.zeros(1)) if keep_edges else None)
+    prev = _lib.set_backend(fake)
+    try:
+        sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), int(c["dyadic"]), workspace_bytes=budget)
+        Xg = X.clone().requires_grad_(True)
+        K = sk.compute_Gram(Xg, Y)
+        fake.tile_rows.clear()
+        (K * w).sum().backward()
+    finally:
+        _lib.set_backend(prev)
+    assert fake.fused_calls >= 1                                   # tried (in its own, larger tiles), residual 1.0 > 1e-8 -> fallback
+    assert fake.tile_rows and max(fake.tile_rows) <= 2 and sum(fake.tile_rows) == A, fake.tile_rows
+    assert rel_err(Xg.grad.numpy(), c["grad_w"]) <= grad_tol("gram_c3mini_lin_d1", "grad_w")
