@@ -353,5 +353,68 @@ __device__ __forceinline__ int64_t wave_slot(const WaveGroup &wg, char *lds_bloc
     return id < wg.n_waves ? id : -1;
 }
 
+// ---- unequal shares for the waves that share a SIMD ---------------------------------------------------------------------
+// The SIMD arbiter favours the OLDEST resident wave: measured on the fused forward (3 four-wave workgroups per CU, equal
+// shares, profiles/r02_wave_placement.txt) the three waves of every SIMD finished after 2.8, 4.0 and 5.0 ms -- the SIMD ran
+// with two waves for a fifth of the launch and with one for another fifth.  The dispatcher fills the CUs in workgroup order
+// (workgroup i, i + #CU, i + 2 #CU share a CU; verified from HW_ID on all 1024 SIMDs), so a wave's age rank is
+// blockIdx / #CU, and the launchers give rank r the fraction w[r] of the pairs, chosen so that all ranks finish together.
+// A wrong guess about placement costs speed, never correctness: the split is a partition of the pairs whatever the ranks.
+struct RankSplit {
+    int nranks;              // 1: every wave gets cnt[0] pairs per lane group (the plain equal split)
+    int waves_per_rank;      // #CU * waves per workgroup
+    int cnt[4];              // pairs per lane group of a wave of rank r
+    int64_t base[5];         // first pair of rank r; base[nranks] >= P
+};
+
+// host: split P pairs over `waves` waves of G lane groups each.  `resident` is the number of waves the launch keeps on the
+// chip at once (#CU * waves per CU); ranks are only used when the launch fills it (waves == resident) with whole workgroups.
+inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, const char *env_name) {
+    RankSplit rs{};
+    const int64_t per = (P + waves * G - 1) / (waves * G);
+    rs.nranks = 1; rs.waves_per_rank = 0x7fffffff; rs.cnt[0] = (int)per; rs.base[0] = 0; rs.base[1] = per * waves * G;
+    const int64_t wpr = (int64_t)n_cu * wpb;
+    const int nr = wpr > 0 ? (int)(waves / wpr) : 0;
+    if (waves != resident || nr < 2 || nr > 4 || (int64_t)nr * wpr != waves) return rs;
+    // measured finishing times with equal shares, per number of ranks (see above); SK_RANK_W="50,30,20" overrides (per cent)
+    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.68, 0.32, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+    double w[4];
+    for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
+    const char *e = getenv(env_name);
+    if (!e || !*e) e = getenv("SK_RANK_W");
+    if (e && *e) {
+        double v[4] = {0, 0, 0, 0}, tot = 0;
+        int n = 0;
+        for (const char *q = e; *q && n < 4; ++n) { v[n] = atof(q); tot += v[n]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        if (n == nr && tot > 0) for (int r = 0; r < nr; ++r) w[r] = v[r] / tot;
+    }
+    const int64_t T = (P + wpr * G - 1) / (wpr * G);   // pairs per lane group summed over the ranks of one SIMD slot
+    if (T < 4 * nr) return rs;                          // too few pairs for the split to matter
+    int64_t used = 0;
+    rs.nranks = nr; rs.waves_per_rank = (int)wpr;
+    for (int r = 0; r < nr; ++r) {
+        int64_t c = r + 1 < nr ? (int64_t)(w[r] * (double)T + 0.5) : T - used;
+        if (c < 1) c = 1;
+        if (r + 1 == nr && c < 1) c = 1;
+        rs.cnt[r] = (int)c;
+        rs.base[r] = used * wpr * G;
+        used += c;
+    }
+    rs.base[nr] = used * wpr * G;
+    return rs;
+}
+
+// device: this wave's share -- pairs per lane group, first pair of its lane group 0, and the end of its rank's range
+__device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t wave_id, int G, int64_t P, int &ppg, int64_t &first, int64_t &end) {
+    int r = (int)(wave_id / rs.waves_per_rank);
+    if (r >= rs.nranks) r = rs.nranks - 1;
+    ppg = rs.cnt[0]; first = rs.base[0]; end = rs.base[1];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (r == i) { ppg = rs.cnt[i]; first = rs.base[i]; end = rs.base[i + 1]; }
+    first += (wave_id - (int64_t)r * rs.waves_per_rank) * G * ppg;
+    if (end > P) end = P;
+}
+
 }  // namespace
 }  // namespace sk

@@ -49,6 +49,7 @@ struct FusedParams {
     int tri;             // 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
                          // path batch (A = B); out is [A][A] and receives both (a, b) and (b, a)
     WaveGroup wg;
+    RankSplit rs;        // pairs per wave by age rank (sk_wave_common.h); PPG and n_steps are the largest share's
 };
 
 template <int N>
@@ -139,30 +140,35 @@ __device__ __forceinline__ void tri_split(int64_t p, int64_t A, int64_t &a, int6
     b = r + (p - (r * A - r * (r - 1) / 2));
 }
 
-// x-row reloads straight into the row registers (read-write operands: under a divergent branch the inactive lanes keep theirs)
+// x-row reloads straight into the row registers (read-write operands: under a divergent branch the inactive lanes keep theirs).
+// No wait inside: lds_rows_wait (or any later s_waitcnt lgkmcnt(0) that precedes the first use) hands the rows over.
+__device__ __forceinline__ void lds_rows_wait(d2_t (&r)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
+}
+__device__ __forceinline__ void lds_rows_wait(d2_t (&r)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : : "memory");
+}
 __device__ __forceinline__ void lds_load_line(d2_t (&r0)[4], d2_t (&r1)[4], unsigned a) {     // 128 contiguous bytes: two rows of 8 dims
     asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
                  "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
-                 "ds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 "ds_read_b128 %7, %8 offset:112"
                  : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3])
                  : "v"(a) : "memory");
 }
 __device__ __forceinline__ void lds_load_half_rows(d2_t (&r0)[2], d2_t (&r1)[2], unsigned a) {   // the first 32 bytes of two 64-byte rows
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80\n\t"
-                 "s_waitcnt lgkmcnt(0)"
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80"
                  : "+v"(r0[0]), "+v"(r0[1]), "+v"(r1[0]), "+v"(r1[1]) : "v"(a) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void lds_load_row(d2_t (&r)[N], unsigned a);
 template <>
 __device__ __forceinline__ void lds_load_row<4>(d2_t (&r)[4], unsigned a) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
-                 "s_waitcnt lgkmcnt(0)"
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
                  : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "v"(a) : "memory");
 }
 template <>
 __device__ __forceinline__ void lds_load_row<2>(d2_t (&r)[2], unsigned a) {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : "v"(a) : "memory");
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "+v"(r[0]), "+v"(r[1]) : "v"(a) : "memory");
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
@@ -209,9 +215,35 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
     const int lam7 = lam & 7;
-    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;
+    // Without edges nothing needs the per-lane cursors in every macro-step: the step counter is kept modulo NUp in scalar
+    // registers (tm, tq) and a lane compares it with constants of its own -- u == 0 when tm == c_u0, uk == 0 when
+    // tm == c_uk0, the pair's K[MM][NN] is ready when tm == c_out -- and the y ring is walked by two running addresses
+    // (a_e, a_o: even / odd dimension rows, see lds_read_dims_issue).  Saves ~10 VALU instructions per macro-step.
+    constexpr bool CUR = EDGES;   // per-lane (u, ps, uk, psk, yslab, ypar) cursors
+    constexpr bool MID = false;   // fetch_next in the middle of a step instead of at its end (see there)
+    // x rows may stay in flight across the loop edge -- not in the variant that is short of registers, where the allocator
+    // moves the destinations of pending loads (tools/check_async_hazards.py)
+    constexpr bool INFLIGHT_X = !(KIND == 1 && DY == 0 && ND == 8);   // next step's LDS reads are issued mid-step (see fetch_next)
+    int tm = 0, tq = 0;
+    int c_u0 = lam % NUp, c_uk0 = (lam + LAG) % NUp;
+    int c_out = lam == prm.lam_f ? (lam + LAG + prm.u_f) % NUp : -1;
+    int c_kq = floor_div(-lam - LAG, NUp), c_kr = (-lam - LAG) - c_kq * NUp;   // t - lam - LAG = (tq + c_kq) NUp + tm + c_kr
+    int c_u0m1 = (c_u0 + NUp - 1) % NUp;                                        // tm of the step BEFORE the lane starts a pair
+    asm volatile("" : "+v"(c_u0), "+v"(c_uk0), "+v"(c_out), "+v"(c_kq), "+v"(c_kr), "+v"(c_u0m1));
+    unsigned a_e;   // the odd rows are at a_e ^ 128: wave slices and slabs are 256-byte aligned, a slab row is 128 bytes
+    int PPG;               // this wave's pairs per lane group, the first pair of its group 0, the end of its rank's range
+    int64_t wave_first, P_end;
+    rank_share(prm.rs, wave_id, G, prm.P, PPG, wave_first, P_end);
+    const int n_steps = PPG * NUp + (L - 1) + LAG;
+    const int64_t pair0 = wave_first + (int64_t)grp * PPG;
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
+    const unsigned y_lim = my_y + y_bytes;
+    const unsigned ring_bytes = FULLWAVE ? (unsigned)(((WAVE >> 3) + 2) * Y_SLAB_PITCH) : y_bytes;   // = y_bytes, as a literal when L = 64
+    {
+        const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((-lam & 7) << 4));
+        a_e = ya + (unsigned)(ypar << 7);
+    }
     // lanes NUp apart start (different) pairs at the same macro-step: one x slab per such "lap" j = lam / NUp
     const int JMAX = (L + NUp - 1) / NUp;
     const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * X_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
@@ -236,8 +268,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
     auto issue_y = [&]() {                            // ring slot, parity of the virtual slab number
         for (int g = 0; g < G; ++g) {
-            int64_t p = (wave_id * G + g) * prm.PPG + y_pi;
-            if (y_pi >= prm.PPG || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
+            int64_t p = wave_first + (int64_t)g * PPG + y_pi;
+            if (y_pi >= PPG || p >= P_end) p = 0;    // past the end: fetch something valid, never consumed
             const int64_t b = split_b(p);
             const int krow = (lane >> 3) ^ ((y_par + g) & 1);   // odd slabs (per group): dimension rows swapped in pairs
             const double *src = prm.dYt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
@@ -256,8 +288,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = (wave_id * G + g) * prm.PPG + pi;
-                if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
+                int64_t p = wave_first + (int64_t)g * PPG + pi;
+                if (pi < 0 || pi >= PPG || p >= P_end) p = 0;
                 const int64_t a = split_a(p);
                 const char *src = reinterpret_cast<const char *>(prm.dXr + (a * prm.Mrows + (int64_t)lamj * RC) * FD);
                 char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
@@ -279,6 +311,18 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int j = 0; j < ND / 2; ++j) dxq[k][j] = d2_t{0.0, 0.0};
+    auto load_x_rows = [&](unsigned xa) {
+        if constexpr (RC % 2 == 0 && ND == 8) {   // two rows per instruction group
+#pragma unroll
+            for (int k = 0; k < RC; k += 2) lds_load_line(dxq[k], dxq[k + 1], xa + k * 64u);
+        } else if constexpr (RC % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < RC; k += 2) lds_load_half_rows(dxq[k], dxq[k + 1], xa + k * 64u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RC; ++k) lds_load_row<ND / 2>(dxq[k], xa + k * 64u);
+        }
+    };
     // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
     // of the first row of the lane below at the columns of units uk and uk + 1
     double own[RBF ? RC : 1][6], bel[4];
@@ -304,8 +348,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     const int EP = EDGES ? (prm.e_NUp * S + prm.e_L * R) : 0;
     int nvalid;   // pairs of this lane's group that exist: psk in [0, nvalid)
     {
-        const int64_t left_pairs = prm.P - pair0;
-        nvalid = left_pairs <= 0 ? 0 : (left_pairs < prm.PPG ? (int)left_pairs : prm.PPG);
+        const int64_t left_pairs = P_end - pair0;
+        nvalid = left_pairs <= 0 ? 0 : (left_pairs < PPG ? (int)left_pairs : PPG);
     }
     int erow_lim = EDGES && lam == prm.lam_f ? prm.e_NUp : 0;          // this lane holds the terminal row: units below this
     int ecol_uf = EDGES && lam < prm.e_L ? prm.u_f : -1;               // the unit whose block holds the terminal column
@@ -322,16 +366,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // differences of a macro-step are read from LDS at the end of the previous one.
     d2_t dyn[ND];
     auto read_y = [&]() {
-        const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
-        lds_read_dims_issue(dyn, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        if constexpr (CUR) {
+            const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
+            lds_read_dims_issue(dyn, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        } else {
+            lds_read_dims_issue(dyn, a_e, a_e ^ 128u);
+        }
     };
+    unsigned x_rd_off = 0;   // ring slot the x rows of this 8-step window are read from: ((t >> 3) % X_SLOTS) * JMAX * XSLAB
+    static_assert(X_SLOTS == 2, "x_rd_off toggles between two slots");
     issue_y();
     issue_x();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_y();
     issue_x();
+    if constexpr (!CUR) {
+        if (c_u0 == 0) {   // lanes that start a pair in macro-step 0 (their K state is 1.0 already)
+            load_x_rows(my_x);
+#pragma unroll
+            for (int k = 0; k < RC; ++k) lds_rows_wait(dxq[k]);
+        }
+    }
     if (AHEAD) read_y();
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         if (EDGES) {   // the edge values of the previous macro-step, straight from the state registers
             double *const ep = e_ptr;
             if (erow_at >= 0) {
@@ -350,39 +407,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             }
         }
 
-        // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows
-        if (RBF && uk == 0) {
-            corner = 1.0;
-#pragma unroll
-            for (int i = 0; i < R; ++i) left[i] = 1.0;
-        }
-        if (u == 0) {
-            if (!RBF) {
-                corner = 1.0;
-#pragma unroll
-                for (int i = 0; i < R; ++i) left[i] = 1.0;
-            }
-            const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
-            if constexpr (RC % 2 == 0 && ND == 8) {   // two rows per LDS round trip (every wave takes this branch every step:
-#pragma unroll                                        // some lane always starts a pair)
-                for (int k = 0; k < RC; k += 2) lds_load_line(dxq[k], dxq[k + 1], xa + k * 64u);
-            } else if constexpr (RC % 2 == 0) {
-#pragma unroll
-                for (int k = 0; k < RC; k += 2) lds_load_half_rows(dxq[k], dxq[k + 1], xa + k * 64u);
-            } else {
-#pragma unroll
-                for (int k = 0; k < RC; ++k) lds_load_row<ND / 2>(dxq[k], xa + k * 64u);
-            }
-        }
-
-        // -- y differences of the two coarse columns of this macro-step, all 8 dims
-        d2_t dyv[ND];
-        if (!AHEAD) read_y();
-        lds_dims_wait(dyv, dyn);
-
         // -- top row of the block from the lane above
         double top[S];
         if (FULLWAVE) {   // lane 0 keeps the 1.0 of the persistent `old` register ktop[i] (see sk_wave.hip)
+            // corner = the previous step's last top value, taken before the DPP overwrites it.  (An opaque move: left to the
+            // compiler, the copy is made three times over.)
+            asm volatile("v_mov_b64 %0, %1" : "=v"(corner) : "v"(ktop[S - 1]));
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 ktop[i] = dpp_shr1(bot[i], ktop[i]);
@@ -395,6 +425,37 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 top[i] = is_top ? 1.0 : sh;
             }
         }
+
+        // -- start of a pair: left boundary K[i][0] = 1, and this lane's x rows.  Without edges the rows were fetched during the
+        // previous macro-step (below); the wait for the y units hands them over.
+        if constexpr (!CUR) {
+            if (tm == (RBF ? c_uk0 : c_u0)) {
+                corner = 1.0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) left[i] = 1.0;
+            }
+        } else {
+            if (RBF && uk == 0) {
+                corner = 1.0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) left[i] = 1.0;
+            }
+            if (u == 0) {
+                if (!RBF) {
+                    corner = 1.0;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) left[i] = 1.0;
+                }
+                load_x_rows(my_x + x_rd_off);
+#pragma unroll
+                for (int k = 0; k < RC; ++k) lds_rows_wait(dxq[k]);
+            }
+        }
+
+        // -- y differences of the two coarse columns of this macro-step, all 8 dims
+        d2_t dyv[ND];
+        if (!AHEAD) read_y();
+        lds_dims_wait(dyv, dyn);
 
         // -- increments and coefficients per coarse cell
         double ca[RC][CW], cbm[RC][CW];
@@ -456,6 +517,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                     ginc[k][q] = g;
                 }
         }
+        // The y units of the NEXT macro-step and the x rows of a lane that starts a pair in it, fetched at the end of this
+        // step and handed over by the single LDS wait at the top of the next (one LDS round trip per step instead of two).  On
+        // a window boundary the rows are in the window whose DMA is waited for here.  Issuing the reads in the middle of the
+        // step, under the sweep, was tried (MID): no faster, and the compiler copies the destination registers around.
+        auto fetch_next = [&]() {
+            const bool turn = ((t + 1) & 7) == 0;   // the next step opens a y slab (for lane 0) and an x window: their DMA
+            if (turn) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // was issued 8 steps ago
+            a_e += 16;
+            if (((t + 1) & 7) == lam7) {   // next slab: the other parity, 1024 - 128 bytes on, wrapping at the end of the ring
+                asm volatile("");          // (a real branch: if-converted, the update costs two more VALU instructions per step)
+                const unsigned e = (a_e + (unsigned)(Y_SLAB_PITCH - 128)) ^ 128u;
+                a_e = e - (e >= y_lim ? ring_bytes : 0u);
+            }
+            read_y();
+            if (tm == c_u0m1) {
+                load_x_rows(my_x + (turn ? x_rd_off ^ (unsigned)(JMAX * XSLAB) : x_rd_off));
+                if constexpr (!INFLIGHT_X) {
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) lds_rows_wait(dxq[k]);
+                }
+            }
+        };
+        if constexpr (!CUR && MID) fetch_next();
 #pragma unroll
         for (int k = 0; k < RC; ++k)
 #pragma unroll
@@ -493,7 +577,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             }
             bot[cc] = above;
         }
-        corner = top[S - 1];
+        if (!FULLWAVE) corner = top[S - 1];
 
         if (EDGES) {
             const bool pair_ok = (unsigned)psk < (unsigned)nvalid;
@@ -511,8 +595,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         }
 
         // -- K[MM][NN] of a pair
-        if (uk == my_uf) {
-            int pv = psk;
+        if (CUR ? uk == my_uf : tm == c_out) {
+            int pv = CUR ? psk : tq + c_kq + (tm + c_kr >= NUp ? 1 : 0);
             asm volatile("" : "+v"(pv));   // keeps the pair tests inside this (rarely taken) branch instead of in every step
             if ((unsigned)pv < (unsigned)nvalid) {
                 double v = cand[0][0];
@@ -536,7 +620,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         }
 
         // -- advance
-        if (RBF) {
+        if constexpr (!CUR) {
+            if constexpr (!MID) fetch_next();
+            tm += 1;
+            if (tm == NUp) { tm = 0; tq += 1; }
+        }
+        if (CUR && RBF) {
             uk += 1;
             if (uk == NUp) {
                 uk = 0;
@@ -544,8 +633,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 if (EDGES) ep_cur += EP;
             }
         }
-        u += 1;
-        if (((t + 1) & 7) == lam7) {   // (u & 7) == 0: u = t + 1 - lam modulo 8 (NUp is a multiple of 8)
+        if constexpr (CUR) u += 1;
+        if (CUR && ((t + 1) & 7) == lam7) {   // (u & 7) == 0: u = t + 1 - lam modulo 8 (NUp is a multiple of 8)
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
             if (u == NUp) {
@@ -554,17 +643,20 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 if (EDGES && !RBF) ep_cur += EP;
             }
         }
-        if (!RBF) { uk = u; psk = ps; }
+        if (CUR && !RBF) { uk = u; psk = ps; }
         if (((t + 1) & 7) == 0) {
             // everything issued 8 macro-steps ago has had a whole slab period to land (leaving this step's edge stores in
             // flight with a counted wait was measured: no gain, their cost is issue slots, not latency)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             issue_y();       // slab ((t + 1) >> 3) + 1
             issue_x();       // window t + 9 .. t + 16
+            x_rd_off ^= (unsigned)(JMAX * XSLAB);
         }
-        if (AHEAD) read_y();   // for macro-step t + 1
+        if (AHEAD && CUR) read_y();   // for macro-step t + 1
     }
-    if (AHEAD) {   // the last read-ahead is never used, but its registers are not free before it has landed
+    if constexpr (!CUR) {   // the last read-ahead is never used, but its registers are not free before it has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (no VGPR is written between here and the end of the kernel)
+    } else if (AHEAD) {
         d2_t drain[ND];
         lds_dims_wait(drain, dyn);
     }
@@ -607,12 +699,16 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (pl.P + pl.G - 1) / pl.G;
     if (waves > max_waves) waves = max_waves;
-    int64_t PPG = (pl.P + waves * pl.G - 1) / (waves * pl.G);
-    waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);
+    prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
+    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, 256, "SK_FUSED_RANK_W");
+    int64_t PPG = prm.rs.cnt[0];   // the largest share
+    if (prm.rs.nranks == 1) {      // equal shares: no more waves than the pairs need
+        waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);
+        prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
+    }
     if (PPG > 0x3fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
     prm.PPG = (int)PPG;
     prm.n_steps = (int)(PPG * pl.NUp + (pl.L - 1)) + pl.lag;
-    prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
@@ -669,7 +765,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int G = WAVE / L;
     const int JMAX = (L + NUp - 1) / NUp;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);   // (a multiple of 256: the y reads rely on 256-byte aligned slices)
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
