@@ -377,7 +377,7 @@ inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, i
     const int nr = wpr > 0 ? (int)(waves / wpr) : 0;
     if (waves != resident || nr < 2 || nr > 4 || (int64_t)nr * wpr != waves) return rs;
     // measured finishing times with equal shares, per number of ranks (see above); SK_RANK_W="50,30,20" overrides (per cent)
-    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.68, 0.32, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
     double w[4];
     for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
     const char *e = getenv(env_name);

@@ -47,6 +47,7 @@ struct FusedMbParams {
     double inv_sigma;
     int64_t ws_stride;  // doubles per wave
     WaveGroup wg;
+    RankSplit rs;        // pairs per wave by age rank; PPW / n_steps are the largest share's
 };
 
 // 16-byte asynchronous global load past the L1 (sc0 sc1: the line was written by another lane of this wave a few
@@ -220,11 +221,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         ypar = s0 & 1;
     }
     const int lam7 = lam & 7;
-    const int64_t pair0 = wave_id * prm.PPW;
+    int PPW;               // this wave's pairs (by age rank, sk_wave_common.h), its first pair, the end of its rank's range
+    int64_t pair0, P_end;
+    rank_share(prm.rs, wave_id, 1, prm.P, PPW, pair0, P_end);
+    const int n_steps = PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0);
     int nvalid;   // pairs of this wave that exist
     {
-        const int64_t left_pairs = prm.P - pair0;
-        nvalid = left_pairs <= 0 ? 0 : (left_pairs < prm.PPW ? (int)left_pairs : prm.PPW);
+        const int64_t left_pairs = P_end - pair0;
+        nvalid = left_pairs <= 0 ? 0 : (left_pairs < PPW ? (int)left_pairs : PPW);
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
     const unsigned my_x = lds0 + X_BASE + (unsigned)((lam & 7) * RC * XROW);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
         int64_t p = pair0 + y_pi;
-        if (y_pi >= prm.PPW || p >= prm.P) p = 0;    // past the end: fetch something valid, never consumed
+        if (y_pi >= PPW || p >= P_end) p = 0;    // past the end: fetch something valid, never consumed
         const int64_t b = split_b(p);
         if constexpr (Y32) {
             const double *row0 = prm.Yt + b * (FDY + 1) * (int64_t)prm.Ncp;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
     auto issue_x = [&]() {
         int64_t p = pair0 + x_pi;
-        if (x_pi >= prm.PPW || p >= prm.P) p = 0;
+        if (x_pi >= PPW || p >= P_end) p = 0;
         const int64_t a = split_a(p);
         const int lamj = x_lam0 < L ? x_lam0 : 0;     // nobody starts: fetch something valid
         const char *src = reinterpret_cast<const char *>(prm.Xr + (a * prm.Mrows + (int64_t)(x_band * L + lamj) * RC + (RBF ? 1 : 0)) * FD);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     issue_x();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         // -- lane 0: the boundary entry of its unit u (K row for the sweep of uk, node pair at the columns of unit u), from
         //    the chunk the window's LDS-DMA brought in; no wait here (see lds_read_pend)
         d2_t pend[NP], bnd[NP];
@@ -623,14 +627,16 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = P < max_waves ? P : max_waves;
-    int64_t PPW = (P + waves - 1) / waves;
-    waves = (P + PPW - 1) / PPW;
+    prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
+    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, 256, "SK_FUSEDMB_RANK_W");
+    int64_t PPW = prm.rs.cnt[0];   // the largest share
+    if (prm.rs.nranks == 1) waves = (P + PPW - 1) / PPW;
     if (PPW > 0x3fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double)) return SK_ERR_WORKSPACE;
     prm.PPW = (int)PPW;
     prm.n_steps = (int)(PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0));
     prm.ws = ws;
-    prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
+    if (prm.rs.nranks == 1) prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
