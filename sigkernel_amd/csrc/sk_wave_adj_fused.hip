@@ -31,6 +31,7 @@ struct AdjFusedParams {
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
     int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p) and PPG = 1
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
+    ChunkSplit cs;         // chunk sizes by wave age rank; PPG / n_steps are the equal split's
     int E;                 // doubles per pair in `edges`
     WaveGroup wg;
 };
@@ -97,7 +98,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         ypar = (s0 + grp) & 1;
     }
     const int lam7 = lam & 7;
-    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;   // all PPG pairs of the group share one a (PPG divides B)
+    // all pairs of the group share one a; how many they are depends on the wave's age rank (ChunkSplit, sk_wave_common.h)
+    int64_t pair0, gslot;
+    int PPG;
+    chunk_share(prm.cs, wave_id * G + grp, prm.B > 0 ? prm.P / prm.B : prm.P, prm.B, prm.P, pair0, gslot, PPG);
+    PPG = __builtin_amdgcn_readfirstlane(PPG);   // (one rank per wave)
+    const int n_steps = PPG * NUp + (L - 1);
+    auto group_first = [&](int g) -> int64_t { return readlane64(pair0, g << prm.logL); };
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
     const int JMAX = (L + NUp - 1) / NUp;
@@ -121,8 +128,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
         for (int g = 0; g < G; ++g) {
-            int64_t p = (wave_id * G + g) * prm.PPG + y_pi;
-            if (y_pi >= prm.PPG || p >= prm.P) p = 0;
+            int64_t p = group_first(g) + y_pi;
+            if (y_pi >= PPG || p >= prm.P) p = 0;
             const int64_t b = split_b(p);
             const int krow = (lane >> 3) ^ ((y_par + g) & 1);
             const int uo = NUp - 1 - (y_u0 + (lane & 7));
@@ -142,8 +149,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = (wave_id * G + g) * prm.PPG + pi;
-                if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
+                int64_t p = group_first(g) + pi;
+                if (pi < 0 || pi >= PPG || p >= prm.P) p = 0;
                 const int64_t a = split_a(p);
                 char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
 #pragma unroll
@@ -170,8 +177,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     auto issue_edge_chunk = [&]() {
         for (int c = 0; c * WAVE < G * NPC; ++c) {
             const int idx = c * WAVE + lane, g = idx / NPC, i = idx - g * NPC;
-            int64_t pr = (wave_id * G + g) * prm.PPG + ec_ps;
-            pr = (ec_ps >= prm.PPG || pr >= prm.P) ? 0 : pr;
+            int64_t pr = gather64(pair0, (g < G ? g : 0) << prm.logL) + ec_ps;   // (g differs per lane here)
+            pr = (ec_ps >= PPG || pr >= prm.P) ? 0 : pr;
             const int k = NNp - (ec_u0 + LINE_UNITS) * S - 2 + 2 * i;
             if (g < G && k >= 0)
                 __builtin_amdgcn_global_load_lds(prm.edges + pr * E + k, (lds_void *)(lds + ec_off + ec_fill * (G * ECG) + c * 1024), 16, 0, 0);
@@ -236,12 +243,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         async_wait<0>(ncol, pcol);
         async_wait<0>(tsc, pscale);
         fix_edges(u, ncol);
-        nscale = (u == 0 && ps >= 0 && ps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+        nscale = (u == 0 && ps >= 0 && ps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
     }
     issue_y();
     issue_x();
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
         double trow_p[S], trow[S];
 #pragma unroll
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         }
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             async_wait<0>(ncol, pcol);
             async_wait<0>(tsc, pscale);
             fix_edges(nu, ncol);
-            if (nu == 0) nscale = (nps >= 0 && nps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+            if (nu == 0) nscale = (nps >= 0 && nps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
         }
 
         // -- advance; the next slab / window is requested right after the wait, so it has a whole macro-step before the
@@ -406,9 +413,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 
     // ---- the group's partial sums: Tpart[group][flipped coarse row][8] ------------------------------------------------------
     {
-        const int64_t gi = wave_id * G + grp;
-        if (gi * prm.PPG < prm.P) {
-            double *dst = prm.Tpart + (gi * Mcp + (int64_t)lam * RC) * FD;
+        if (pair0 < prm.P) {
+            double *dst = prm.Tpart + (gslot * Mcp + (int64_t)lam * RC) * FD;
 #pragma unroll
             for (int k = 0; k < RC; ++k)
 #pragma unroll
@@ -434,9 +440,10 @@ int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
 
 // Rows of Tpart = (P / PPG) * L * RC; *ppg_out / *rows_out tell the caller how to fold it: Tpart viewed as
 // [A][B / PPG][L*RC][8], summed over the chunks, rows flipped (coarse row p = L*RC - 1 - r).  tpart == nullptr: query only.
-int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                            int *ppg_out, int *rows_out, hipStream_t s) {
+namespace {
+int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                                 const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
+                                 int *ppg_out, int *rows_out, int64_t *rows_per_launch, int64_t *epair, int64_t force_nch, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges
@@ -461,6 +468,21 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     int64_t PPG = B > 0 ? B : 1;   // paired: every pair has its own x, one pair per lane group.  Gram with more paths than
     for (int64_t d = 1; d <= B; ++d)   // resident lane groups: one whole row of the Gram per group, launched in several rounds
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
+    if (epair) *epair = st.NNp + st.MMp;
+    if (force_nch > 0) PPG = B / force_nch;
+    else if (rows_per_launch) {   // see launch_adj_fused_rbf_rows (sk_wave_adj_fused_rbf.hip)
+        *rows_per_launch = 0;
+        const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJF_WPB").wpb;
+        const int64_t gpr = 256LL * wpb * G;
+        const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
+        const int64_t nch = B > 0 ? B / PPG : 1;
+        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
+            for (int64_t m = nr; m <= B && m <= max_groups; m += nr)
+                if (m >= nch && B % m == 0 && max_groups % m == 0 && B / m >= 4 * nr) {
+                    if (A >= max_groups / m) { *rows_per_launch = max_groups / m; PPG = B / m; }
+                    break;
+                }
+    }
     if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
     const int64_t groups = g.P / PPG;
     if (ppg_out) *ppg_out = (int)PPG;
@@ -476,6 +498,7 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     prm.E = st.NNp + st.MMp;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.wg = wave_group(lds_bytes, waves, "SK_ADJF_WPB");
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, 256, "SK_ADJF_RANK_W");
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     switch (DY) {
@@ -483,6 +506,35 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
         case 1: return full ? launch_adjf<1, 2, true>(prm, lds_block, s) : launch_adjf<1, 2, false>(prm, lds_block, s);
         default: return full ? launch_adjf<2, 1, true>(prm, lds_block, s) : launch_adjf<2, 1, false>(prm, lds_block, s);
     }
+}
+}  // namespace
+
+int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
+                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
+                            int *ppg_out, int *rows_out, hipStream_t s) {
+    int ppg = 0, rows = 0;
+    int64_t per_launch = 0, epair = 0;
+    int rc = launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, nullptr, 0, err, &ppg, &rows, &per_launch, &epair, 0, s);
+    if (rc != SK_OK) return rc;
+    if (ppg_out) *ppg_out = ppg;
+    if (rows_out) *rows_out = rows;
+    if (!tpart) return SK_OK;
+    if (per_launch <= 0 || B <= 0)
+        return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, nullptr, nullptr, nullptr, nullptr,
+                                            B > 0 ? B / ppg : 0, s);
+    // several launches of per_launch rows each, all with the same chunks per a (so that tpart keeps one layout)
+    const int64_t nch = B / ppg, slot = (int64_t)rows * FD;
+    if (tpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
+    for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
+        const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;
+        Geom gs = g;
+        gs.P = An * B;
+        rc = launch_adj_fused_linear_rows(dXr + a0 * Mrows * FD, dYt, An, B, Mrows, Ncp, gs, edges + a0 * B * epair, scale ? scale + a0 * B : nullptr,
+                                          tpart + a0 * nch * slot, (size_t)(An * nch * slot), err ? err + a0 * B : nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, nch, s);
+        if (rc != SK_OK) return rc;
+    }
+    return SK_OK;
 }
 
 }  // namespace sk

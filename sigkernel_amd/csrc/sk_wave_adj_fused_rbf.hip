@@ -41,6 +41,7 @@ struct AdjRbfParams {
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
     int64_t P, B;
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
+    ChunkSplit cs;         // chunk sizes by wave age rank; PPG / n_steps are the equal split's
     double inv_sigma;
     WaveGroup wg;
 };
@@ -110,7 +111,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         ypar = (s0 + grp) & 1;
     }
     const int lam7 = lam & 7;
-    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;   // all PPG pairs of the group share one a (PPG divides B)
+    // all pairs of the group share one a; how many they are depends on the wave's age rank (ChunkSplit, sk_wave_common.h)
+    int64_t pair0, gslot;
+    int PPG;
+    chunk_share(prm.cs, wave_id * G + grp, prm.B > 0 ? prm.P / prm.B : prm.P, prm.B, prm.P, pair0, gslot, PPG);
+    PPG = __builtin_amdgcn_readfirstlane(PPG);   // (one rank per wave)
+    const int n_steps = PPG * NUp + (L - 1) + 1;   // + 1: node column 0 of the last pair completes one step later
+    auto group_first = [&](int g) -> int64_t { return readlane64(pair0, g << prm.logL); };
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
     const int JMAX = (L + NUp - 1) / NUp;
@@ -135,8 +142,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
         for (int g = 0; g < G; ++g) {
-            int64_t p = (wave_id * G + g) * prm.PPG + y_pi;
-            if (y_pi >= prm.PPG || p >= prm.P) p = 0;
+            int64_t p = group_first(g) + y_pi;
+            if (y_pi >= PPG || p >= prm.P) p = 0;
             const int64_t b = split_b(p);
             const int krow = (lane >> 3) ^ ((y_par + g) & 1);
             const int uo = NUp - 1 - (y_u0 + (lane & 7));      // flipped unit -> original unit (node columns 2uo, 2uo+1)
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = (wave_id * G + g) * prm.PPG + pi;
-                if (pi < 0 || pi >= prm.PPG || p >= prm.P) p = 0;
+                int64_t p = group_first(g) + pi;
+                if (pi < 0 || pi >= PPG || p >= prm.P) p = 0;
                 const int64_t a = split_a(p);
                 char *dst = lds + x_base0 + ((g * RX_SLOTS + x_slot) * JMAX + j) * XSLAB;
 #pragma unroll
@@ -179,8 +186,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     auto issue_edge_chunk = [&]() {
         for (int c = 0; c * WAVE < G * NPC; ++c) {
             const int idx = c * WAVE + lane, g = idx / NPC, i = idx - g * NPC;
-            int64_t pr = (wave_id * G + g) * prm.PPG + ec_ps;
-            pr = (ec_ps >= prm.PPG || pr >= prm.P) ? 0 : pr;
+            int64_t pr = gather64(pair0, (g < G ? g : 0) << prm.logL) + ec_ps;   // (g differs per lane here)
+            pr = (ec_ps >= PPG || pr >= prm.P) ? 0 : pr;
             const int k = NNp - (ec_u0 + LINE_UNITS) * S - 2 + 2 * i;
             if (g < G && k >= 0)
                 __builtin_amdgcn_global_load_lds(prm.edges + pr * E + k,
@@ -263,12 +270,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         async_wait<0>(ncol, pcol);
         async_wait<0>(tsc, pscale);
         fix_edges(u, ncol);
-        nscale = (u == 0 && ps >= 0 && ps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+        nscale = (u == 0 && ps >= 0 && ps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
     }
     issue_y();
     issue_x();
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
         double trow_p[S], trow[S];
 #pragma unroll
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         lastW[0] = wk[RC - 1][0]; lastW[1] = wk[RC - 1][1];
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             async_wait<0>(ncol, pcol);
             async_wait<0>(tsc, pscale);
             fix_edges(nu, ncol);
-            if (nu == 0) nscale = (nps >= 0 && nps < prm.PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+            if (nu == 0) nscale = (nps >= 0 && nps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
         }
         u = nu;
         ps = nps;
@@ -488,9 +495,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
 
     // ---- the group's partial sums: Gpart[group][node row][OUTW], node row r_k = Mcp - lam RC - k; node row 0 from the bottom lane
     {
-        const int64_t gi = wave_id * G + grp;
-        if (gi * prm.PPG < prm.P) {
-            double *base = prm.Gpart + gi * (int64_t)(Mcp + 1) * OUTW;
+        if (pair0 < prm.P) {
+            double *base = prm.Gpart + gslot * (int64_t)(Mcp + 1) * OUTW;
 #pragma unroll
             for (int k = 0; k <= RC; ++k) {
                 if (k == RC && lam != L - 1) break;
@@ -518,9 +524,10 @@ int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
 
 // gpart viewed as [A][B / PPG][*rows_out][*outw_out] and summed over the chunk axis gives, per node row r < M of x_a,
 // cs = that[a][r][0] and accd = that[a][r][2 .. 2 + D): dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == nullptr: query.
-int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                         int *ppg_out, int *rows_out, int *outw_out, hipStream_t s) {
+namespace {
+int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
+                              double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
+                              int *ppg_out, int *rows_out, int *outw_out, int64_t *rows_per_launch, int64_t force_nch, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY < 1 || DY > 2 || B < 0 || g.naive || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges; the sweep uses the same lanes and units
@@ -541,6 +548,22 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     int64_t PPG = B > 0 ? B : 1;
     for (int64_t d = 1; d <= B; ++d)
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
+    if (force_nch > 0) PPG = B / force_nch;
+    else if (rows_per_launch) {
+        // Shares by wave age rank (ChunkSplit) need a launch that fills the chip exactly, with the chunks of an a a multiple of
+        // the ranks: when the equal split does not give that, the caller sweeps the rows in several such launches.
+        *rows_per_launch = 0;
+        const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJR_WPB").wpb;
+        const int64_t gpr = 256LL * wpb * G;
+        const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
+        const int64_t nch = B > 0 ? B / PPG : 1;
+        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
+            for (int64_t m = nr; m <= B && m <= max_groups; m += nr)
+                if (m >= nch && B % m == 0 && max_groups % m == 0 && B / m >= 4 * nr) {
+                    if (A >= max_groups / m) { *rows_per_launch = max_groups / m; PPG = B / m; }
+                    break;
+                }
+    }
     if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
     const int64_t groups = g.P / PPG;
     const int OUTW = ND + 2;
@@ -558,6 +581,7 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     prm.inv_sigma = inv_sigma;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + 1;    // + 1: node column 0 of the last pair completes one step later
     prm.wg = wave_group(lds_bytes, waves, "SK_ADJR_WPB");
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, 256, "SK_ADJR_RANK_W");
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     if (DY == 1) {
@@ -566,6 +590,39 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     }
     if (ND == 4) return full ? launch_adjr<2, 1, true, 4>(prm, lds_block, s) : launch_adjr<2, 1, false, 4>(prm, lds_block, s);
     return full ? launch_adjr<2, 1, true, 8>(prm, lds_block, s) : launch_adjr<2, 1, false, 8>(prm, lds_block, s);
+}
+}  // namespace
+
+int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
+                         double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
+                         int *ppg_out, int *rows_out, int *outw_out, hipStream_t s) {
+    int ppg = 0, rows = 0, outw = 0;
+    int64_t per_launch = 0;
+    int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, &ppg, &rows, &outw, &per_launch, 0, s);
+    if (rc != SK_OK) return rc;
+    if (ppg_out) *ppg_out = ppg;
+    if (rows_out) *rows_out = rows;
+    if (outw_out) *outw_out = outw;
+    if (!gpart) return SK_OK;
+    if (per_launch <= 0 || B <= 0)
+        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, gpart, gpart_doubles, err, nullptr, nullptr, nullptr,
+                                         nullptr, B > 0 ? B / ppg : 0, s);
+    // several launches of per_launch rows each, all with the same chunks per a (so that gpart keeps one layout)
+    const int64_t nch = B / ppg;
+    const int64_t slot = (int64_t)rows * outw;
+    if (gpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
+    const Strip st = strip_geom(g, 8);
+    const int64_t Epair = (int64_t)st.NUp * (2 << g.dyadic) + (int64_t)(1 << st.logL) * st.RC * (1 << g.dyadic);   // edge doubles per pair
+    for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
+        const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;
+        Geom gs = g;
+        gs.P = An * B;
+        rc = launch_adj_fused_rbf_rows(Xr + a0 * Mrows * RFD, Yt, An, B, Mrows, Ncp, D, gs, inv_sigma, edges + a0 * B * Epair,
+                                       scale ? scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
+                                       err ? err + a0 * B : nullptr, nullptr, nullptr, nullptr, nullptr, nch, s);
+        if (rc != SK_OK) return rc;
+    }
+    return SK_OK;
 }
 
 }  // namespace sk

@@ -416,5 +416,74 @@ __device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t wave_id,
     if (end > P) end = P;
 }
 
+// The fused adjoints split a Gram differently: a lane group sweeps one CHUNK of the B pairs of one path x_a and leaves a
+// partial sum in slot a * nch + c, which the host adds over c.  Chunks need not be equal for that, so the chunks swept by the
+// oldest waves are made longer: chunk c of every a belongs to rank c / cpr, and rank r's chunks hold size[r] pairs.
+struct ChunkSplit {
+    int nr;              // 1: nch equal chunks of size[0] pairs, group gi = a * nch + c
+    int cpr, nch;        // chunks of one a per rank; chunks of one a
+    int64_t gpr;         // lane groups per rank (= waves per rank * G)
+    int size[4];         // pairs in a chunk of rank r
+    int off[4];          // first pair (within the B of an a) of rank r's chunks
+};
+
+inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, const char *env_name) {
+    ChunkSplit cs{};
+    const int64_t nch = B > 0 ? B / PPG : 1;
+    cs.nr = 1; cs.cpr = (int)nch; cs.nch = (int)nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = (int)PPG; cs.off[0] = 0;
+    const int64_t gpr = (int64_t)n_cu * wpb * G;
+    if (B <= 0 || gpr <= 0 || A * nch != max_groups || max_groups % gpr) return cs;
+    const int nr = (int)(max_groups / gpr);
+    if (nr < 2 || nr > 4 || nch % nr || PPG < 4 * nr) return cs;
+    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+    double w[4];
+    for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
+    const char *e = getenv(env_name);
+    if (!e || !*e) e = getenv("SK_RANK_W");
+    if (e && *e) {
+        double v[4] = {0, 0, 0, 0}, tot = 0;
+        int n = 0;
+        for (const char *q = e; *q && n < 4; ++n) { v[n] = atof(q); tot += v[n]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        if (n == nr && tot > 0) for (int r = 0; r < nr; ++r) w[r] = v[r] / tot;
+    }
+    const int cpr = (int)(nch / nr);
+    const int64_t T = B / cpr;            // pairs of one a per "column" of ranks: sum of the sizes
+    int64_t used = 0;
+    for (int r = 0; r < nr; ++r) {
+        int64_t c = r + 1 < nr ? (int64_t)(w[r] * (double)T + 0.5) : T - used;
+        if (c < 1 || used + c > T - (nr - 1 - r)) return cs;   // (degenerate weights: keep the equal chunks)
+        cs.size[r] = (int)c;
+        cs.off[r] = (int)(used * cpr);
+        used += c;
+    }
+    cs.nr = nr; cs.cpr = cpr; cs.gpr = gpr;
+    return cs;
+}
+
+// device (per lane): lane group gi -> its first pair, its slot in the partial-sum array, and the pairs it sweeps
+__device__ __forceinline__ void chunk_share(const ChunkSplit &cs, int64_t gi, int64_t A, int64_t B, int64_t P, int64_t &first, int64_t &slot, int &ppg) {
+    if (B <= 0) { first = gi < P ? gi : P; slot = gi; ppg = 1; return; }   // paired batch: one pair per lane group
+    int r = (int)(gi / cs.gpr);
+    if (r >= cs.nr) r = cs.nr - 1;
+    int sz = cs.size[0], of = cs.off[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (r == i) { sz = cs.size[i]; of = cs.off[i]; }
+    const int64_t j = gi - (int64_t)r * cs.gpr;
+    const int64_t a = j / cs.cpr;
+    const int cl = (int)(j - a * cs.cpr);
+    ppg = sz;
+    slot = a * cs.nch + (int64_t)r * cs.cpr + cl;
+    first = a < A ? a * B + of + (int64_t)cl * sz : P;
+}
+__device__ __forceinline__ int64_t gather64(int64_t v, int src_lane) {   // per-lane source (ds_bpermute: no LDS memory involved)
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)v), hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(v >> 32));
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ int64_t readlane64(int64_t v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
 }  // namespace
 }  // namespace sk
