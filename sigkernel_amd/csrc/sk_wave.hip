@@ -42,7 +42,8 @@ struct WaveParams {
     int naive;
     double *edges;     // nullable [P, NNp + MMp]: K[MM][1..NNp] then K[1..MMp][NN] (EDGES variant; padded strip sizes)
     int k_f;           // coarse row inside the lane's block that holds the pair's last row
-    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
+    WaveGroup wg;
+    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's      // workgroups of independent waves (sk_wave_common.h)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
         band = sig - ps * nb;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;   // the unit at which this lane holds K[MM][NN] (if ever)
-    const int64_t pair0 = (wave_id * G + (lane >> prm.logL)) * prm.PPG;
+    int PPG;               // this wave's pairs per lane group (by age rank, sk_wave_common.h), its first pair, the end of its rank
+    int64_t first_pair, P_end;
+    rank_share(prm.rs, wave_id, G, prm.P, PPG, first_pair, P_end);
+    const int n_steps = PPG * nb * NUp + (L - 1);
+    const int64_t pair0 = first_pair + (int64_t)(lane >> prm.logL) * PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     // ring slot of the line this lane is reading: the line it started at macro-step ts sits in slot ts % NSLOT
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
@@ -104,9 +109,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
     // the end of a pair, pairs past P and the not-yet-started lanes of the pipeline fall outside num_records
     // (or into a neighbouring pair) and the bounds-checked buffer load returns without touching memory.
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = wave_id * G * prm.PPG;
-    int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
-    const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
+    int64_t span = (P_end - first_pair) * pair_bytes;
+    const int64_t wave_span = (int64_t)G * PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
     if (span < 0) span = 0;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
         st_m = (v0 - sg * NUp) / LINE_UNITS;
         const int ps0 = floor_div(sg, nb);
         st_band = sg - ps0 * nb;
-        st_off = (unsigned)((gc * prm.PPG + ps0) * (int)pair_bytes + (st_band * L + ip * LINE_UNITS) * RC * ldb +
+        st_off = (unsigned)((gc * PPG + ps0) * (int)pair_bytes + (st_band * L + ip * LINE_UNITS) * RC * ldb +
                             st_m * 128 + (lane & 7) * 16);
     }
     int fj = 0, fslot = 0;   // class and ring slot of the next fetch step (uniform)
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
 #pragma unroll
     for (int f = 0; f < PF; ++f) issue_fetch();
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         issue_fetch();   // the line needed at macro-step t + PF
         // -- increments of this macro-step: RC rows x CW coarse columns (waits for the fetch of step t)
         vec_t gv[RC];
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
         // -- terminal row and column of the pair: note where they go, the next macro-step stores them (see above).  The
         //    column relies on the padding columns of the last unit being zero (K is constant along zero increments).
         if (EDGES) {
-            const bool pair_ok = ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P;
+            const bool pair_ok = ps >= 0 && ps < PPG && pair0 + ps < P_end;
             e_pair = pair0 + ps;                       // only read where one of the offsets below is set
             erow_at = (pair_ok && lam == prm.lam_f && band == nb - 1) ? u * S : -1;
             ecol_at = (pair_ok && u == prm.u_f) ? NUp * S + (band * L + lam) * R : -1;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
 
         // -- K[MM][NN] of a pair: one lane, once per pair (the asm keeps the select chain inside the branch)
         if (u == my_uf) {
-            if (band == nb - 1 && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+            if (band == nb - 1 && ps >= 0 && ps < PPG && pair0 + ps < P_end) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -438,6 +442,9 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     // the HBM-bound streaming sweep gains nothing from even SIMD loads and is a few per cent faster with single-wave
     // workgroups (per 131072 pairs of 127 x 127: d = 0 2.70 vs 2.80 ms, with strip edges at d = 1 3.77 vs 3.98 ms)
     prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 1);
+    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, 256, "SK_WAVE_RANK_W");   // equal shares (single-wave workgroups: no fixed age order)
+    prm.rs.cnt[0] = (int)PPG;
+    prm.rs.base[1] = PPG * waves * G;
     const int blocks = wave_group_blocks(prm.wg);
     const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {

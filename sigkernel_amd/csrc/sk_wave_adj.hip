@@ -37,7 +37,8 @@ struct AdjParams {
     int64_t ldb, ldwb;     // row strides in bytes
     int Mc, Nc;
     int NUp, nb, logL, PPG, n_steps, naive;
-    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
+    WaveGroup wg;
+    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's      // workgroups of independent waves (sk_wave_common.h)
 };
 
 // Prefetch distance of the increment lines, in macro-steps.  Memory operations of a macro-step are issued at its top in
@@ -97,7 +98,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         ps = floor_div(sig, nb);
         band = sig - ps * nb;
     }
-    const int64_t pair0 = (wave_id * G + grp) * prm.PPG;
+    int PPG;               // this wave's pairs per lane group (by age rank, sk_wave_common.h), its first pair, the end of its rank
+    int64_t first_pair, P_end;
+    rank_share(prm.rs, wave_id, G, prm.P, PPG, first_pair, P_end);
+    const int n_steps = PPG * nb * NUp + (L - 1);
+    const int64_t pair0 = first_pair + (int64_t)grp * PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot = (((-(u & 7)) % NSLOT) + NSLOT) % NSLOT;
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
@@ -110,9 +115,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
 
     // ---- producer: increments, whole lines, back to front (see sk_wave.hip for the forward-order twin) ----
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = wave_id * G * prm.PPG;
-    int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
-    const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
+    int64_t span = (P_end - first_pair) * pair_bytes;
+    const int64_t wave_span = (int64_t)G * PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
     if (span < 0) span = 0;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         st_m = (v0 - sg * NUp) / LINE_UNITS;
         const int ps0 = floor_div(sg, nb);
         st_band = sg - ps0 * nb;
-        st_off = (unsigned)((gc * prm.PPG + ps0) * (int)pair_bytes +
+        st_off = (unsigned)((gc * PPG + ps0) * (int)pair_bytes +
                             (Mcp - 1 - (st_band * L + ip * LINE_UNITS) * RC) * ldb + (NLp - 1 - st_m) * 128 +
                             (7 - (lane & 7)) * 16);
     }
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         wt_ps = floor_div(sg, nb);
         wt_band = sg - wt_ps * nb;
         wt_row = (wt_band * L + ip * LINE_UNITS) * RC;
-        wt_off = (unsigned)((wt_gc * prm.PPG + wt_ps) * (int)pairw_bytes + (Mcp - 1 - wt_row) * ldwb +
+        wt_off = (unsigned)((wt_gc * PPG + wt_ps) * (int)pairw_bytes + (Mcp - 1 - wt_row) * ldwb +
                             (NLp - 1 - wt_m) * 128 + (7 - (lane & 7)) * 16);
     }
     char *const w_wave = static_cast<char *>(prm.W) + first_pair * pairw_bytes;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     // write the finished line of class wj (8 lanes x RC rows per instruction, 128 contiguous bytes per row)
     // wv: the finished line, read from lds0 + wslot * SLOT_BYTES + lane * 16 by the caller
     auto store_lines = [&](const vec_t (&wv)[RC]) {
-        const bool pair_ok = wt_ps >= 0 && wt_ps < prm.PPG && first_pair + (int64_t)wt_gc * prm.PPG + wt_ps < prm.P;
+        const bool pair_ok = wt_ps >= 0 && wt_ps < PPG && first_pair + (int64_t)wt_gc * PPG + wt_ps < P_end;
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
             const int orow = Mcp - 1 - (wt_row + wj * RC + k);
@@ -240,8 +244,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
     auto issue_edge_chunk = [&]() {
         for (int c = 0; c * WAVE < G * NPC; ++c) {
             const int idx = c * WAVE + lane, g = idx / NPC, i = idx - g * NPC;
-            int64_t pr = (wave_id * G + g) * prm.PPG + ec_ps;
-            pr = (pr < 0 || pr >= prm.P) ? 0 : pr;
+            int64_t pr = first_pair + (int64_t)(g < G ? g : 0) * PPG + ec_ps;
+            pr = (pr < 0 || pr >= P_end) ? 0 : pr;
             const int k = NNp - (ec_u0 + LINE_UNITS) * S - 2 + 2 * i;
             if (g < G && k >= 0)
                 __builtin_amdgcn_global_load_lds(prm.edges + pr * E + k, (lds_void *)(lds + NSLOT * SLOT_BYTES + ec_fill * (G * ECG) + c * 1024),
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         fix_edges(u, band, ncol);
     }
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         vec_t gv[RC];
         const unsigned my_unit = rd_lane + (unsigned)(slot * SLOT_BYTES + ((u & 7) << 4));
         // the top lane's S terminal-row values of this macro-step, from the window's chunk (lane 0's unit is t modulo NUp; every
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_wave(const AdjParams prm) {
         // -- self-check on the last flipped unit: the recomputed K on the j = 0 boundary must be 1.  The worst deviation is
         //    held in a register and sent at the top of the next macro-step together with the other memory operations: an
         //    atomic issued here would sit, with its whole latency, in front of the closing vmcnt(0).
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < P_end) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -538,16 +542,29 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
     if (waves > max_waves) waves = max_waves;
-    int64_t PPG = (g.P + waves * G - 1) / (waves * G);
-    waves = (g.P + PPG * G - 1) / (PPG * G);
-    if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
     const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
     if (pair_bytes > (1LL << 29)) return SK_ERR_UNSUPPORTED;
-    if ((PPG * G + 1) * pair_bytes >= (1LL << 31)) {
-        PPG = ((1LL << 31) - 1) / (G * pair_bytes) - 1;
-        if (PPG < 1) return SK_ERR_UNSUPPORTED;
+    // shares by wave age rank when the launch fills the chip with four-wave workgroups and the largest share's span fits
+    // the 32-bit buffer offsets; otherwise equal shares
+    // (this kernel waits on HBM as much as on the vector unit: measured optimum 58 / 42 at d = 1, against 66 / 34 for the fused kernels)
+    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};   // (three and four ranks: not measured, equal)
+    WaveGroup wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, 256, "SK_ADJ_RANK_W", shares);
+    if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_ADJ_RANK_W");
+    int64_t PPG = rs.cnt[0];
+    if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
+        if ((PPG * G + 1) * pair_bytes >= (1LL << 31)) {
+            PPG = ((1LL << 31) - 1) / (G * pair_bytes) - 1;
+            if (PPG < 1) return SK_ERR_UNSUPPORTED;
+            waves = (g.P + PPG * G - 1) / (PPG * G);
+        }
+        wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_ADJ_RANK_W");
+        rs.cnt[0] = (int)PPG;
+        rs.base[1] = PPG * waves * G;
     }
+    if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
 
     AdjParams prm;
     prm.inc = inc_c; prm.edges = edges; prm.W = W; prm.err = err; prm.P = g.P;
@@ -556,7 +573,8 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     prm.n_steps = (int)(PPG * nb * NUp + (L - 1));
     prm.naive = g.naive;
 
-    prm.wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
+    prm.wg = wg;
+    prm.rs = rs;
     const int blocks = wave_group_blocks(prm.wg);
     const size_t lds_block = wave_group_lds(prm.wg);
     if (DY == 0) return launch_adj_dy<T, 0>(prm, multiband, blocks, lds_block, s);

@@ -369,7 +369,9 @@ struct RankSplit {
 
 // host: split P pairs over `waves` waves of G lane groups each.  `resident` is the number of waves the launch keeps on the
 // chip at once (#CU * waves per CU); ranks are only used when the launch fills it (waves == resident) with whole workgroups.
-inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, const char *env_name) {
+// `table` (optional): the kernel family's own default shares, rows indexed by the number of ranks.
+inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, const char *env_name,
+                            const double (*table)[4] = nullptr) {
     RankSplit rs{};
     const int64_t per = (P + waves * G - 1) / (waves * G);
     rs.nranks = 1; rs.waves_per_rank = 0x7fffffff; rs.cnt[0] = (int)per; rs.base[0] = 0; rs.base[1] = per * waves * G;
@@ -379,7 +381,7 @@ inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, i
     // measured finishing times with equal shares, per number of ranks (see above); SK_RANK_W="50,30,20" overrides (per cent)
     static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
     double w[4];
-    for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
+    for (int r = 0; r < 4; ++r) w[r] = table ? table[nr][r] : dflt[nr][r];
     const char *e = getenv(env_name);
     if (!e || !*e) e = getenv("SK_RANK_W");
     if (e && *e) {
