@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-2 profiles (GPU box): rocprofv3 kernel trace + stats of bench.py on c3 / c5 / c4, then separate PMC passes
-# (counters never combined with API tracing) restricted to the dominant kernels.  Output: gpurun_out/r02p/
+# (counters never combined with API tracing) restricted to the dominant kernels.  Output: gpurun_out/r02q/
 set -u
-OUT=$PWD/gpurun_out/r02p; rm -rf $OUT; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/r02q; rm -rf $OUT; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
 cd /tmp
 for cfg in c3 c5 c4; do
   steps=5; [ $cfg = c4 ] && steps=2
