@@ -532,10 +532,12 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     const int wpc_env = env_int("SK_ADJ_WPC", 0);
-    const int wpc_cap = (wpc_env > 0 || DY == 2) ? 16 : 8;   // d = 2 (10 KB per wave): 13.1 ms at 16 (VGPRs allow 12) vs 13.6 at 8
+    // d = 2 (10 KB per wave): the VGPRs allow 12 resident waves per CU; launching 16 let the fourth workgroup of a CU start when
+    // the first ended (13.1 ms vs 13.6 at 8), 12 with shares by age rank is better still (C4 tiles: 9.06 -> 8.44 ms)
+    const int wpc_cap = wpc_env > 0 ? 16 : (DY == 2 ? 12 : 8);
     if (waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
-    // this kernel waits on memory every macro-step, so every resident wave the LDS ring allows is taken (8 at d = 1, up to
-    // 16 at d = 2); SK_ADJ_WPC overrides
+    // this kernel waits on memory every macro-step, so every resident wave the LDS ring and the registers allow is taken (8 at
+    // d = 1, 12 at d = 2); SK_ADJ_WPC overrides
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups: the same number of waves on every SIMD
     if (waves_per_cu < 1) waves_per_cu = 1;
@@ -547,7 +549,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     // shares by wave age rank when the launch fills the chip with four-wave workgroups and the largest share's span fits
     // the 32-bit buffer offsets; otherwise equal shares
     // (this kernel waits on HBM as much as on the vector unit: measured optimum 58 / 42 at d = 1, against 66 / 34 for the fused kernels)
-    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};   // (three and four ranks: not measured, equal)
+    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.25, 0.25, 0.25, 0.25}};   // (three ranks: d = 2, bound by the vector unit like the fused kernels; four: not measured, equal)
     WaveGroup wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
     RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, 256, "SK_ADJ_RANK_W", shares);
     if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_ADJ_RANK_W");
