@@ -42,8 +42,8 @@ struct WaveParams {
     int naive;
     double *edges;     // nullable [P, NNp + MMp]: K[MM][1..NNp] then K[1..MMp][NN] (EDGES variant; padded strip sizes)
     int k_f;           // coarse row inside the lane's block that holds the pair's last row
-    WaveGroup wg;
-    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's      // workgroups of independent waves (sk_wave_common.h)
+    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
+    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -37,8 +37,8 @@ struct AdjParams {
     int64_t ldb, ldwb;     // row strides in bytes
     int Mc, Nc;
     int NUp, nb, logL, PPG, n_steps, naive;
-    WaveGroup wg;
-    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's      // workgroups of independent waves (sk_wave_common.h)
+    WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
+    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's
 };
 
 // Prefetch distance of the increment lines, in macro-steps.  Memory operations of a macro-step are issued at its top in

@@ -34,6 +34,7 @@ struct DerivParams {
     int u_f, lam_f, sel_f;
     int pf;              // prefetch distance in macro-steps (3 or 5)
     WaveGroup wg;      // workgroups of independent waves (sk_wave_common.h)
+    RankSplit rs;      // pairs per wave by age rank (sk_wave_common.h); PPG / n_steps are the largest share's
 };
 
 // The increments of macro-step t+1 are requested from LDS early in macro-step t and waited for at its end: with
@@ -153,7 +154,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) 
         band = sig - ps * nb;
     }
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
-    const int64_t pair0 = (wave_id * G + (lane >> prm.logL)) * prm.PPG;
+    int PPG;               // this wave's pairs per lane group (by age rank, sk_wave_common.h), its first pair, the end of its rank
+    int64_t first_pair, P_end;
+    rank_share(prm.rs, wave_id, G, prm.P, PPG, first_pair, P_end);
+    const int n_steps = PPG * nb * NUp + (L - 1);
+    const int64_t pair0 = first_pair + (int64_t)(lane >> prm.logL) * PPG;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
     int slot_off = ((((-(u & 7)) % NSLOT) + NSLOT) % NSLOT) * SLOT_BYTES;   // ring slot (byte offset) of the line being read
     const unsigned rd_lane = lds0 + (unsigned)(lane >> 3) * 128u;
@@ -163,9 +168,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) 
 
     // ---- producer (DMA) state: one cursor, three buffer resources ----------------------------------------
     const int64_t pair_bytes = (int64_t)prm.Mc * prm.ldb;
-    const int64_t first_pair = wave_id * G * prm.PPG;
-    int64_t span = ((int64_t)prm.P - first_pair) * pair_bytes;
-    const int64_t wave_span = (int64_t)G * prm.PPG * pair_bytes;
+    int64_t span = (P_end - first_pair) * pair_bytes;
+    const int64_t wave_span = (int64_t)G * PPG * pair_bytes;
     span = span < wave_span ? span : wave_span;
     if (span < 0) span = 0;
     __amdgpu_buffer_rsrc_t rsrc[3];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) 
         st_m = (v0 - sg * NUp) / LINE_UNITS;
         const int ps0 = floor_div(sg, nb);
         st_band = sg - ps0 * nb;
-        st_off = (unsigned)((gc * prm.PPG + ps0) * (int)pair_bytes + (st_band * L + ip * LINE_UNITS) * ldb + st_m * 128 +
+        st_off = (unsigned)((gc * PPG + ps0) * (int)pair_bytes + (st_band * L + ip * LINE_UNITS) * ldb + st_m * 128 +
                             (lane & 7) * 16);
     }
     int fj = 0, fslot_off = 0;   // class and ring slot (byte offset) of the next fetch step (uniform)
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) 
         lds_read3_wait(gv, g0);
     }
 
-    for (int t = 0; t < prm.n_steps; ++t) {
+    for (int t = 0; t < n_steps; ++t) {
         issue_fetch();   // the line needed at macro-step t + PF
 
         if (u == 0) {
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_wave(const DerivParams prm) 
         }
 
         if (u == my_uf) {
-            if (band == nb - 1 && ps >= 0 && ps < prm.PPG && pair0 + ps < prm.P) {
+            if (band == nb - 1 && ps >= 0 && ps < PPG && pair0 + ps < P_end) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     double v = cand[s][0];
@@ -471,16 +475,27 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
     if (waves > max_waves) waves = max_waves;
-    int64_t PPG = (g.P + waves * G - 1) / (waves * G);
-    waves = (g.P + PPG * G - 1) / (PPG * G);
-    if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
     const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
     if (pair_bytes > (1LL << 30)) return SK_ERR_UNSUPPORTED;
-    if (PPG * G * pair_bytes >= (1LL << 31)) {
-        PPG = ((1LL << 31) - 1) / (G * pair_bytes);
-        if (PPG < 1) return SK_ERR_UNSUPPORTED;
+    // shares by wave age rank (see sk_wave_adj.hip's launcher); this kernel streams three increment arrays: the mild shares
+    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};
+    WaveGroup wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, 256, "SK_DERIV_RANK_W", shares);
+    if (rs.nranks > 1 && (int64_t)rs.cnt[0] * G * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_DERIV_RANK_W");
+    int64_t PPG = rs.cnt[0];
+    if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
+        if (PPG * G * pair_bytes >= (1LL << 31)) {
+            PPG = ((1LL << 31) - 1) / (G * pair_bytes);
+            if (PPG < 1) return SK_ERR_UNSUPPORTED;
+            waves = (g.P + PPG * G - 1) / (PPG * G);
+        }
+        wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_DERIV_RANK_W");
+        rs.cnt[0] = (int)PPG;
+        rs.base[1] = PPG * waves * G;
     }
+    if (PPG > 0x3fffffff / (nb * NUp)) return SK_ERR_UNSUPPORTED;
 
     DerivParams prm;
     prm.inc[0] = inc; prm.inc[1] = inc_d; prm.inc[2] = inc_dd;
@@ -493,7 +508,8 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
     prm.sel_f = (g.Nc - 1) % CW;
     prm.pf = PF;
 
-    prm.wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
+    prm.wg = wg;
+    prm.rs = rs;
     const int blocks = wave_group_blocks(prm.wg);
     const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
