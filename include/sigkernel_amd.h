@@ -354,6 +354,19 @@ int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc
 int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
                        int dyadic, int flags, float *out_k, float *out_kd, float *out_kdd, void *stream);
 
+/* ---- launch planning, host only (no device work; exposed so that the partition of the pairs can be tested without a GPU) ----
+ * The persistent kernels share P pairs among `waves` waves of G lane groups each; when a launch fills the chip with whole
+ * workgroups (waves == resident = n_cu * waves per CU) the shares depend on the wave's age rank.
+ * sk_plan_wave_shares: for every wave w, first[w] = the first pair of its lane group 0, ppg[w] = pairs per lane group (group g
+ * sweeps first + g * ppg ...), end[w] = the end of its rank's range (pairs >= end belong to other waves).  Returns the number
+ * of ranks (1 = equal shares) or a negative sk_status.
+ * sk_plan_group_chunks: the fused adjoints' split of an A x B Gram into chunks of one row a (PPG = the equal chunk size,
+ * max_groups = resident lane groups): for every lane group gi < n_groups its first pair, its slot in the partial-sum array
+ * (a * chunks_per_a + c) and its number of pairs.  Returns the number of ranks. */
+int sk_plan_wave_shares(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, int64_t *first, int64_t *end, int *ppg);
+int sk_plan_group_chunks(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, int64_t n_groups,
+                         int64_t *first, int64_t *slot, int *ppg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,8 @@ SIGNATURES = {
                                         _sz, _vp, _vp, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_adj_rescue_slot_bytes": (_sz, [_int, _int, _int]),
+    "sk_plan_wave_shares": (_int, [_i64, _int, _i64, _i64, _int, _int, _vp, _vp, _vp]),
+    "sk_plan_group_chunks": (_int, [_i64, _i64, _i64, _i64, _int, _int, _int, _i64, _vp, _vp, _vp]),
     "sk_adj_rescue_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, ctypes.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
     "sk_adj_rescue_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _vp, ctypes.c_double, _vp, _vp, _i64, _vp, _sz, _vp]),
     "sk_prep_paths_f64": (_int, [_vp, _i64, _int, _int, _int, _int, ctypes.c_double, _vp, _int, _int, _vp]),

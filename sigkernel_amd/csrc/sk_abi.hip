@@ -1,6 +1,7 @@
 // sk_abi.hip -- the extern "C" surface declared in include/sigkernel_amd.h.
 // Argument checking and kernel selection only; no torch types, no allocation, no synchronisation.
 #include "sk_internal.h"
+#include "sk_wave_common.h"
 
 using namespace sk;
 
@@ -127,7 +128,23 @@ int solve_fwd_sym(int kind, const double *Xr, const double *Xt, int64_t A, int M
 
 extern "C" {
 
-int sk_version(void) { return 200; }
+int sk_version(void) { return 201; }
+
+int sk_plan_wave_shares(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, int64_t *first, int64_t *end, int *ppg) {
+    if (P < 0 || G < 1 || waves < 1 || wpb < 1 || n_cu < 1 || !first || !end || !ppg) return SK_ERR_BAD_ARG;
+    const sk::RankSplit rs = sk::rank_split(P, G, waves, resident, wpb, n_cu, "SK_RANK_W");
+    for (int64_t w = 0; w < waves; ++w) sk::rank_share(rs, w, G, P, ppg[w], first[w], end[w]);
+    return rs.nranks;
+}
+
+int sk_plan_group_chunks(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, int64_t n_groups,
+                         int64_t *first, int64_t *slot, int *ppg) {
+    if (A < 1 || B < 0 || PPG < 1 || G < 1 || wpb < 1 || n_cu < 1 || !first || !slot || !ppg) return SK_ERR_BAD_ARG;
+    const sk::ChunkSplit cs = sk::chunk_split(A, B, PPG, max_groups, G, wpb, n_cu, "SK_RANK_W");
+    const int64_t P = B > 0 ? A * B : A;
+    for (int64_t gi = 0; gi < n_groups; ++gi) sk::chunk_share(cs, gi, A, B, P, first[gi], slot[gi], ppg[gi]);
+    return cs.nr;
+}
 
 const char *sk_status_string(int status) {
     switch (status) {

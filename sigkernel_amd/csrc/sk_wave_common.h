@@ -407,7 +407,7 @@ inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, i
 }
 
 // device: this wave's share -- pairs per lane group, first pair of its lane group 0, and the end of its rank's range
-__device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t wave_id, int G, int64_t P, int &ppg, int64_t &first, int64_t &end) {
+__host__ __device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t wave_id, int G, int64_t P, int &ppg, int64_t &first, int64_t &end) {
     int r = (int)(wave_id / rs.waves_per_rank);
     if (r >= rs.nranks) r = rs.nranks - 1;
     ppg = rs.cnt[0]; first = rs.base[0]; end = rs.base[1];
@@ -463,7 +463,7 @@ inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_gro
 }
 
 // device (per lane): lane group gi -> its first pair, its slot in the partial-sum array, and the pairs it sweeps
-__device__ __forceinline__ void chunk_share(const ChunkSplit &cs, int64_t gi, int64_t A, int64_t B, int64_t P, int64_t &first, int64_t &slot, int &ppg) {
+__host__ __device__ __forceinline__ void chunk_share(const ChunkSplit &cs, int64_t gi, int64_t A, int64_t B, int64_t P, int64_t &first, int64_t &slot, int &ppg) {
     if (B <= 0) { first = gi < P ? gi : P; slot = gi; ppg = 1; return; }   // paired batch: one pair per lane group
     int r = (int)(gi / cs.gpr);
     if (r >= cs.nr) r = cs.nr - 1;

@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 HEADER = os.path.join(ROOT, "include", "sigkernel_amd.h")
@@ -107,3 +109,73 @@ def test_the_hazard_lint_recognises_a_hazard():
 """
     good = bad.replace("\tv_mov_b64_e32 v[2:3], v[10:11]\n\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\tv_mov_b64_e32 v[2:3], v[10:11]")
     assert len(lint.scan(bad)) == 1 and len(lint.scan(good)) == 0
+
+
+def _wave_shares(P, G, waves, resident, wpb=4, n_cu=256):
+    import numpy as np
+    from sigkernel_amd import _lib
+    first, end, ppg = np.zeros(waves, np.int64), np.zeros(waves, np.int64), np.zeros(waves, np.int32)
+    nr = _lib.load().sk_plan_wave_shares(P, G, waves, resident, wpb, n_cu, first.ctypes.data, end.ctypes.data, ppg.ctypes.data)
+    return nr, first, end, ppg
+
+
+@pytest.mark.parametrize("P,G,wpc", [(262144, 1, 12), (262144, 1, 8), (4194304, 1, 12), (2098176, 1, 12), (65536, 1, 8), (1048576, 4, 8),
+                                     (100003, 2, 12), (12289, 1, 12), (3072 * 12 + 5, 1, 12), (3071, 1, 12), (1, 1, 12), (999983, 8, 16)])
+def test_shares_by_age_rank_partition_the_pairs(P, G, wpc, monkeypatch):
+    """sk_plan_wave_shares (the split the persistent kernels use): whatever the shares, every pair belongs to exactly
+    one lane group -- group g of wave w sweeps [first + g ppg, first + (g + 1) ppg) clipped to its rank's end."""
+    import numpy as np
+    for weights in (None, "34,33,33", "80,15,5", "50,50", "97,3", "25,25,25,25", "1,1,98"):
+        if weights is None:
+            monkeypatch.delenv("SK_RANK_W", raising=False)
+        else:
+            monkeypatch.setenv("SK_RANK_W", weights)
+        resident = 256 * wpc
+        waves = min((P + G - 1) // G, resident)
+        nr, first, end, ppg = _wave_shares(P, G, waves, resident)
+        assert nr >= 1
+        seen = np.zeros(P, np.int32)
+        for w in range(waves):
+            for g in range(G):
+                lo = min(first[w] + g * ppg[w], end[w])
+                hi = min(first[w] + (g + 1) * ppg[w], end[w])
+                if hi > lo:
+                    seen[lo:hi] += 1
+        assert seen.min() == 1 and seen.max() == 1, (weights, nr)
+        if nr > 1:      # the older the rank, the larger the share (default and the descending overrides)
+            per_rank = [int(ppg[r * 1024]) for r in range(nr)]
+            if weights in (None, "80,15,5", "97,3"):
+                assert per_rank == sorted(per_rank, reverse=True) and per_rank[0] > per_rank[-1]
+
+
+@pytest.mark.parametrize("A,B,max_groups,G", [(512, 512, 2048, 1), (1024, 2048, 2048, 1), (256, 2048, 2048, 1), (300, 2048, 2048, 1),
+                                              (2048, 2048, 2048, 1), (64, 96, 3072, 1), (1024, 64, 8192, 4), (7, 5, 2048, 1), (100, 0, 2048, 1)])
+def test_chunks_by_age_rank_partition_the_pairs(A, B, max_groups, G, monkeypatch):
+    """sk_plan_group_chunks (the fused adjoints' split): the chunks of every row a tile its B pairs exactly once and the slots
+    a * chunks + c are all distinct, whatever the shares."""
+    import numpy as np
+    from sigkernel_amd import _lib
+    PPG = B if B > 0 else 1
+    for d in range(1, max(B, 1) + 1):
+        if B > 0 and B % d == 0 and A * (B // d) <= max_groups:
+            PPG = d
+            break
+    n_groups = A * (B // PPG) if B > 0 else A
+    P = A * B if B > 0 else A
+    for weights in (None, "50,50", "90,10", "60,30,10", "34,33,33"):
+        if weights is None:
+            monkeypatch.delenv("SK_RANK_W", raising=False)
+        else:
+            monkeypatch.setenv("SK_RANK_W", weights)
+        first, slot, ppg = np.zeros(n_groups, np.int64), np.zeros(n_groups, np.int64), np.zeros(n_groups, np.int32)
+        nr = _lib.load().sk_plan_group_chunks(A, B, PPG, max_groups, G, 4, 256, n_groups, first.ctypes.data, slot.ctypes.data, ppg.ctypes.data)
+        assert nr >= 1
+        seen = np.zeros(P, np.int32)
+        for gi in range(n_groups):
+            lo, hi = int(first[gi]), int(first[gi]) + int(ppg[gi])
+            assert hi <= P
+            if B > 0:
+                assert lo // B == (hi - 1) // B == slot[gi] // (B // PPG)     # one row a per group, filed under that row
+            seen[lo:hi] += 1
+        assert seen.min() == 1 and seen.max() == 1, (weights, nr)
+        assert len(set(slot.tolist())) == n_groups and slot.max() == n_groups - 1
