@@ -28,5 +28,5 @@ for _ in range(10):
 if os.environ.get("SK_EXP_DUMP"):
     import ctypes
     sys.stdout.flush()
-    ctypes.CDLL(_lib.LIB_PATH).sk_exp_dump(4096)
+    ctypes.CDLL(_lib.LIB_PATH).sk_exp_dump(int(os.environ.get("SK_EXP_DUMP")))
 print("%-40s median %.3f ms  min %.3f ms   K[0,0] = %r  sum = %r" % (os.path.basename(sys.argv[1]), float(np.median(ts)), min(ts), float(K[0, 0]), float(K.sum())), flush=True)
