@@ -442,7 +442,7 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     // the HBM-bound streaming sweep gains nothing from even SIMD loads and is a few per cent faster with single-wave
     // workgroups (per 131072 pairs of 127 x 127: d = 0 2.70 vs 2.80 ms, with strip edges at d = 1 3.77 vs 3.98 ms)
     prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 1);
-    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, 256, "SK_WAVE_RANK_W");   // equal shares (single-wave workgroups: no fixed age order)
+    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, device_cu_count(), "SK_WAVE_RANK_W");   // equal shares (single-wave workgroups: no fixed age order)
     prm.rs.cnt[0] = (int)PPG;
     prm.rs.base[1] = PPG * waves * G;
     const int blocks = wave_group_blocks(prm.wg);

@@ -551,8 +551,8 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     // (this kernel waits on HBM as much as on the vector unit: measured optimum 58 / 42 at d = 1, against 66 / 34 for the fused kernels)
     static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.25, 0.25, 0.25, 0.25}};   // (three ranks: d = 2, bound by the vector unit like the fused kernels; four: not measured, equal)
     WaveGroup wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
-    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, 256, "SK_ADJ_RANK_W", shares);
-    if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_ADJ_RANK_W");
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W", shares);
+    if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W");
     int64_t PPG = rs.cnt[0];
     if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
@@ -562,7 +562,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
             waves = (g.P + PPG * G - 1) / (PPG * G);
         }
         wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
-        rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_ADJ_RANK_W");
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W");
         rs.cnt[0] = (int)PPG;
         rs.base[1] = PPG * waves * G;
     }

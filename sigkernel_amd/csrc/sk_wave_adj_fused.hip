@@ -473,7 +473,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     else if (rows_per_launch) {   // see launch_adj_fused_rbf_rows (sk_wave_adj_fused_rbf.hip)
         *rows_per_launch = 0;
         const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJF_WPB").wpb;
-        const int64_t gpr = 256LL * wpb * G;
+        const int64_t gpr = (int64_t)device_cu_count() * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
         const int64_t nch = B > 0 ? B / PPG : 1;
         if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
@@ -498,7 +498,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     prm.E = st.NNp + st.MMp;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.wg = wave_group(lds_bytes, waves, "SK_ADJF_WPB");
-    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, 256, "SK_ADJF_RANK_W");
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), "SK_ADJF_RANK_W");
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     switch (DY) {

@@ -554,7 +554,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         // the ranks: when the equal split does not give that, the caller sweeps the rows in several such launches.
         *rows_per_launch = 0;
         const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJR_WPB").wpb;
-        const int64_t gpr = 256LL * wpb * G;
+        const int64_t gpr = (int64_t)device_cu_count() * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
         const int64_t nch = B > 0 ? B / PPG : 1;
         if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
@@ -581,7 +581,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     prm.inv_sigma = inv_sigma;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + 1;    // + 1: node column 0 of the last pair completes one step later
     prm.wg = wave_group(lds_bytes, waves, "SK_ADJR_WPB");
-    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, 256, "SK_ADJR_RANK_W");
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), "SK_ADJR_RANK_W");
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     if (DY == 1) {

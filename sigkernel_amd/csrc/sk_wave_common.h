@@ -360,6 +360,19 @@ __device__ __forceinline__ int64_t wave_slot(const WaveGroup &wg, char *lds_bloc
 // (workgroup i, i + #CU, i + 2 #CU share a CU; verified from HW_ID on all 1024 SIMDs), so a wave's age rank is
 // blockIdx / #CU, and the launchers give rank r the fraction w[r] of the pairs, chosen so that all ranks finish together.
 // A wrong guess about placement costs speed, never correctness: the split is a partition of the pairs whatever the ranks.
+// compute units of the current device (256 on MI355X; the launchers size their persistent launches for that part, and on any
+// other count the shares below fall back to equal ones by themselves: the launch no longer consists of whole ranks)
+inline int device_cu_count() {
+    static int n[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (n[dev] == 0) {
+        int v = 0;
+        n[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+    }
+    return n[dev];
+}
+
 struct RankSplit {
     int nranks;              // 1: every wave gets cnt[0] pairs per lane group (the plain equal split)
     int waves_per_rank;      // #CU * waves per workgroup

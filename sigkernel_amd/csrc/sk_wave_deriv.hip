@@ -480,8 +480,8 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
     // shares by wave age rank (see sk_wave_adj.hip's launcher); this kernel streams three increment arrays: the mild shares
     static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};
     WaveGroup wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
-    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, 256, "SK_DERIV_RANK_W", shares);
-    if (rs.nranks > 1 && (int64_t)rs.cnt[0] * G * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_DERIV_RANK_W");
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W", shares);
+    if (rs.nranks > 1 && (int64_t)rs.cnt[0] * G * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W");
     int64_t PPG = rs.cnt[0];
     if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
@@ -491,7 +491,7 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
             waves = (g.P + PPG * G - 1) / (PPG * G);
         }
         wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
-        rs = rank_split(g.P, G, waves, -1, wg.wpb, 256, "SK_DERIV_RANK_W");
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W");
         rs.cnt[0] = (int)PPG;
         rs.base[1] = PPG * waves * G;
     }

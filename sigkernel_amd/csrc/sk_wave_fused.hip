@@ -700,7 +700,7 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     int64_t waves = (pl.P + pl.G - 1) / pl.G;
     if (waves > max_waves) waves = max_waves;
     prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
-    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, 256, "SK_FUSED_RANK_W");
+    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, device_cu_count(), "SK_FUSED_RANK_W");
     int64_t PPG = prm.rs.cnt[0];   // the largest share
     if (prm.rs.nranks == 1) {      // equal shares: no more waves than the pairs need
         waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);

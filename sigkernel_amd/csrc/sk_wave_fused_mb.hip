@@ -628,7 +628,7 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     const int64_t max_waves = 256LL * waves_per_cu;
     int64_t waves = P < max_waves ? P : max_waves;
     prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
-    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, 256, "SK_FUSEDMB_RANK_W");
+    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, device_cu_count(), "SK_FUSEDMB_RANK_W");
     int64_t PPW = prm.rs.cnt[0];   // the largest share
     if (prm.rs.nranks == 1) waves = (P + PPW - 1) / PPW;
     if (PPW > 0x3fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
