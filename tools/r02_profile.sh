@@ -5,8 +5,8 @@ set -u
 OUT=$PWD/gpurun_out/r02q; rm -rf $OUT; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
 cd /tmp
 for cfg in c3 c5 c4; do
-  steps=5; [ $cfg = c4 ] && steps=2
-  timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$cfg -o trace -- python $REPO/bench.py --config $cfg --steps $steps --warmup 1 --no-extras > $OUT/trace_$cfg.json 2> $OUT/trace_$cfg.err
+  steps=5; warm=1; [ $cfg = c4 ] && steps=2; [ $cfg = c3 ] && steps=40 && warm=10   # (short launches: the clocks take ~10 launches to settle)
+  timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$cfg -o trace -- python $REPO/bench.py --config $cfg --steps $steps --warmup $warm --no-extras > $OUT/trace_$cfg.json 2> $OUT/trace_$cfg.err
 done
 pmc() {  # tag regex bench-args...
   tag=$1; re=$2; shift 2
@@ -37,6 +37,11 @@ for cfg in ("c3","c5","c4"):
             print("  %-66s calls %5s  total %12s ns  avg %12s ns  %6s %%"%(short(r["Name"]),r["Calls"],r["TotalDurationNs"],r["AverageNs"],r["Percentage"]))
     try: print("  bench line:", open(os.path.join(out,"trace_%s.json"%cfg)).read()[:400])
     except Exception: pass
+    kt=glob.glob(os.path.join(out,"trace_"+cfg,"**","*kernel_trace.csv"),recursive=True)
+    if kt and f:
+        top=list(csv.DictReader(open(f[0])))[0]["Name"]
+        d=sorted((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6 for r in csv.DictReader(open(kt[0])) if r["Kernel_Name"]==top)
+        print("  per dispatch of the top kernel (ms): first-to-last sorted min %.3f  median %.3f  max %.3f  (n=%d; the first launches of a process run at lower clocks)"%(d[0],d[len(d)//2],d[-1],len(d)))
 for cfg in ("c5","c4","c3"):
     print("== %s: PMC, averages per dispatch and kernel =="%cfg)
     acc=defaultdict(lambda: defaultdict(list))
