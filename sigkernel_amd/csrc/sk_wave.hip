@@ -189,6 +189,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_wave(const WaveParams prm) {
 
         // -- row-unit start: left boundary K[i][0] = 1
         if (u == 0) {
+            asm volatile("");   // a real branch (if-converted: ten v_cndmask in every macro-step instead of five moves for one lane)
             corner = 1.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) left[i] = 1.0;

@@ -430,18 +430,21 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         // previous macro-step (below); the wait for the y units hands them over.
         if constexpr (!CUR) {
             if (tm == (RBF ? c_uk0 : c_u0)) {
+                asm volatile("");   // a real branch: if-converted, the five moves become ten v_cndmask in every macro-step
                 corner = 1.0;
 #pragma unroll
                 for (int i = 0; i < R; ++i) left[i] = 1.0;
             }
         } else {
             if (RBF && uk == 0) {
+                asm volatile("");
                 corner = 1.0;
 #pragma unroll
                 for (int i = 0; i < R; ++i) left[i] = 1.0;
             }
             if (u == 0) {
                 if (!RBF) {
+                    asm volatile("");
                     corner = 1.0;
 #pragma unroll
                     for (int i = 0; i < R; ++i) left[i] = 1.0;
