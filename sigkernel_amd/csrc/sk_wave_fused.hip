@@ -217,13 +217,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     const int lam7 = lam & 7;
     // Without edges nothing needs the per-lane cursors in every macro-step: the step counter is kept modulo NUp in scalar
     // registers (tm, tq) and a lane compares it with constants of its own -- u == 0 when tm == c_u0, uk == 0 when
-    // tm == c_uk0, the pair's K[MM][NN] is ready when tm == c_out -- and the y ring is walked by two running addresses
-    // (a_e, a_o: even / odd dimension rows, see lds_read_dims_issue).  Saves ~10 VALU instructions per macro-step.
+    // tm == c_uk0, the pair's K[MM][NN] is ready when tm == c_out -- and the y ring is walked by one running address (a_e:
+    // even dimension rows, the odd ones at a_e ^ 128, see lds_read_dims_issue).
     constexpr bool CUR = EDGES;   // per-lane (u, ps, uk, psk, yslab, ypar) cursors
     constexpr bool MID = false;   // fetch_next in the middle of a step instead of at its end (see there)
     // x rows may stay in flight across the loop edge -- not in the variant that is short of registers, where the allocator
     // moves the destinations of pending loads (tools/check_async_hazards.py)
-    constexpr bool INFLIGHT_X = !(KIND == 1 && DY == 0 && ND == 8);   // next step's LDS reads are issued mid-step (see fetch_next)
+    constexpr bool INFLIGHT_X = !(KIND == 1 && DY == 0 && ND == 8);
     int tm = 0, tq = 0;
     int c_u0 = lam % NUp, c_uk0 = (lam + LAG) % NUp;
     int c_out = lam == prm.lam_f ? (lam + LAG + prm.u_f) % NUp : -1;
