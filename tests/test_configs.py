@@ -512,3 +512,36 @@ def test_symmetric_gram_in_one_triangular_launch(monkeypatch):
     Xl = walk(gen, 5, 300, 3).to(DEV)
     Kl = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1).compute_Gram(Xl, Xl, sym=True)
     assert torch.equal(Kl, Kl.t()) and rel_err(Kl.cpu().numpy(), O.gram_forward(Xl.cpu(), Xl.cpu(), sigkernel_amd.RBFKernel(1.0), 1, nthreads=NT)) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_shares_by_wave_age_rank_do_not_change_any_result(monkeypatch):
+    """the launches hand the oldest wave of a SIMD the largest share of the pairs.  Whatever the shares, the pairs
+    are partitioned, so forward values (single- and multi-band) are bit-identical to those of equal shares; the fused adjoints
+    add their per-chunk partial sums in a different grouping, so gradients agree to rounding (sizes large enough for the shares
+    to be in force: >= 12 pairs per resident wave slot; 256 x 256 paths of 64 nodes fill the chip with 8 chunks per row)."""
+    gen = torch.Generator().manual_seed(7)
+    cases = [
+        (sigkernel_amd.LinearKernel(), 1, walk(gen, 384, 64, 8), walk(gen, 400, 64, 8)),        # fused forward, three ranks
+        (sigkernel_amd.RBFKernel(0.9), 2, walk(gen, 256, 64, 3), walk(gen, 256, 64, 3)),        # RBF, fused adjoint (chunks by rank)
+        (sigkernel_amd.RBFKernel(1.1), 1, walk(gen, 96, 300, 5), walk(gen, 400, 280, 5)),       # multi-band forward
+    ]
+    for kern, d, Xc, Yc in cases:
+        sk = sigkernel_amd.SigKernel(kern, dyadic_order=d)
+        X, Y = Xc.to(DEV), Yc.to(DEV)
+        w = torch.randn(X.shape[0], Y.shape[0], generator=gen, dtype=torch.float64).to(DEV)
+        out = []
+        for shares in ("50,50", None, "80,20"):
+            for var in ("SK_RANK_W",):
+                if shares is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, shares if d != 1 or type(kern) is not sigkernel_amd.LinearKernel else {"50,50": "34,33,33", "80,20": "70,20,10"}[shares])
+            Xg = X.clone().requires_grad_(True)
+            K = sk.compute_Gram(Xg, Y)
+            (K * w).sum().backward()
+            Kn = sk.compute_Gram(X, Y)
+            out.append((K.detach().clone(), Xg.grad.clone(), Kn.clone()))
+        for K, g, Kn in out[1:]:
+            assert torch.equal(K, out[0][0]) and torch.equal(Kn, out[0][2])
+            assert float((g - out[0][1]).abs().max()) <= 1e-12 * float(out[0][1].abs().max())
