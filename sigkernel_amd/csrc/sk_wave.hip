@@ -440,12 +440,26 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     prm.edges = strip_edges;
     prm.k_f = (g.Mc - 1) % RC;
 
-    // the HBM-bound streaming sweep gains nothing from even SIMD loads and is a few per cent faster with single-wave
-    // workgroups (per 131072 pairs of 127 x 127: d = 0 2.70 vs 2.80 ms, with strip edges at d = 1 3.77 vs 3.98 ms)
+    // Workgroups.  With equal shares the HBM-bound streaming sweep gains nothing from even SIMD loads and is a few per cent
+    // faster as single-wave workgroups (per 131072 pairs of 127 x 127: d = 0 2.70 vs 2.80 ms, with strip edges at d = 1 3.77
+    // vs 3.98 ms).  Where the launch fills the chip with TWO four-wave workgroups per CU, shares by wave age rank
+    // (sk_wave_common.h) beat that: 58 / 42 % 2.87 -> 2.67 ms, with strip edges 54 / 46 % 3.68 -> 3.57 ms (other residencies:
+    // not measured, single-wave workgroups as before).  SK_WAVE_WPB=1 restores those everywhere.
     prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 1);
-    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, device_cu_count(), "SK_WAVE_RANK_W");   // equal shares (single-wave workgroups: no fixed age order)
+    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, device_cu_count(), "SK_WAVE_RANK_W");   // equal shares
     prm.rs.cnt[0] = (int)PPG;
     prm.rs.base[1] = PPG * waves * G;
+    if (env_int("SK_WAVE_WPB", 4) == 4 && lds_bytes * 4 <= 160 * 1024) {
+        static const double plain[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
+        static const double edged[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.54, 0.46, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
+        const int64_t full = (g.P + G - 1) / G < max_waves ? (g.P + G - 1) / G : max_waves;
+        const RankSplit rs = rank_split(g.P, G, full, max_waves, 4, device_cu_count(), "SK_WAVE_RANK_W", strip_edges ? edged : plain);
+        if (rs.nranks == 2 && (int64_t)rs.cnt[0] * G * pair_bytes < (1LL << 31)) {
+            prm.rs = rs;
+            waves = full;
+            prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 4);
+        }
+    }
     const int blocks = wave_group_blocks(prm.wg);
     const size_t lds_block = wave_group_lds(prm.wg);
     switch (DY) {
