@@ -107,10 +107,14 @@ class ShardedGram(torch.autograd.Function):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         lo, hi, chunk = row_range(A, rank, world)
         if hi > lo and ctx.local is not None:
+            # the local graph is kept (retain_graph): a second backward through the same graph (retain_graph=True upstream,
+            # repeated autograd.grad) must give the same rows again -- the inner Function drops the kept edges after their
+            # first use and re-sweeps forward by itself from then on
             Xl, Kl = ctx.local
-            ctx.local = None
-            (gl,) = torch.autograd.grad(Kl, Xl, grad_output[lo:hi].to(dtype))
+            (gl,) = torch.autograd.grad(Kl, Xl, grad_output[lo:hi].to(dtype), retain_graph=True)
         else:
+            if hi > lo and ctx.needs_input_grad[0]:
+                raise RuntimeError("ShardedGram.backward: the local graph of this rank's rows is gone")
             gl = torch.zeros((hi - lo,) + tail, dtype=dtype, device=device)
         grad_X = _all_gather_rows(gl, A, chunk, group)
         if ctx.needs_input_grad[1]:      # the reference's 2x rule (sigkernel.py:410-412)

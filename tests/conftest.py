@@ -40,16 +40,23 @@ def golden_gram_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "gram_*.npz")))
 
 
-def grad_tol(name, key):
-    """Tolerance for a gradient of fixture `name` against the REFERENCE's value: 3x the error the analytic adjoint achieves
-    there (tests/golden/grad_errors.json, written by tests/golden/measure_grad_errors.py), never below north_star's 1e-6.
-    The reference differentiates by a forward difference with h = 1e-9, so the residual is its round-off noise
-    (tests/test_oracle.py::test_adjoint_vs_noise_free_reference_formula proves that); most entries land on the 1e-6 floor,
-    the sums over a whole symmetric Gram matrix (grad_xx_sum) reach 7e-6."""
+def reference_noise(name, key):
+    """Round-off noise the REFERENCE's gradient `key` of fixture `name` carries: its max-norm relative distance from the
+    reference's own formula evaluated in long double (tests/golden/grad_errors.json, written by
+    tests/golden/measure_grad_noise.py, which imports no implementation)."""
     import json
     with open(os.path.join(GOLDEN, "grad_errors.json")) as f:
-        achieved = json.load(f)[name][key]
-    return max(1e-6, 3.0 * achieved)
+        return float(json.load(f)[name][key]["reference_noise"])
+
+
+def grad_tol(name, key):
+    """Tolerance for a gradient against the REFERENCE's fixture value: north_star's 1e-6, or -- for the few entries whose
+    fixture itself is further than that from the reference's formula -- 1.25 x the reference's measured round-off noise.
+    The reference differentiates by a forward difference with h = 1e-9 in double (sigkernel.py:313-341, :472-500);
+    tests/test_oracle.py::test_every_gradient_fixture_vs_noise_free_reference_formula proves, per (fixture, key), that (i) the
+    analytic adjoint is within 1e-7 of that formula in long double and (ii) the fixture's distance from it is the recorded
+    noise -- so |implementation - fixture| <= noise + 1e-7 <= this tolerance, derived from the reference alone."""
+    return max(1e-6, 1.25 * reference_noise(name, key))
 
 
 def make_kernel(case):
