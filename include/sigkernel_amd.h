@@ -294,11 +294,13 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
  *   SK_FLAG_EXACT calls or shapes the fast kernels do not cover. */
 
 /* Device-side rescue of the fast adjoint: re-solves with stored grids exactly the pairs whose self-check residual
- * err[p] (as written by sk_solve_adj_*) exceeds `tol` or is NaN, overwriting their W (and out_final when non-NULL).
+ * err[p] (as written by sk_solve_adj_*) exceeds `tol`, overwriting their W (and out_final when non-NULL); a NaN residual
+ * (NaN / inf coordinates) is left alone -- the re-solve could only reproduce the NaN.
  * Enqueue it unconditionally right after sk_solve_adj_*: when no pair is flagged it reads P doubles and returns, so the
  * caller never has to read the residuals back (the reference has no such step: it stores both grids for every pair,
  * sigkernel.py:438-470).  workspace: k >= 1 slots of sk_adj_rescue_slot_bytes(Mc, Nc, dyadic) bytes; k slots re-solve k
- * flagged pairs concurrently. */
+ * flagged pairs concurrently.  sk_adj_rescue_slot_bytes is 0, and sk_adj_rescue_* returns SK_ERR_UNSUPPORTED, for grids
+ * whose three live diagonals exceed the LDS (more than ~6800 fine rows): no rescue exists there. */
 size_t sk_adj_rescue_slot_bytes(int Mc, int Nc, int dyadic);
 int sk_adj_rescue_f64(const double *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int dyadic, int scheme, const double *err,
                       double tol, double *out_final, double *W, int64_t ldw, void *workspace, size_t workspace_bytes, void *stream);

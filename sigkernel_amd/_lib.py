@@ -648,11 +648,16 @@ class HipBackend:
             if fast:
                 # pairs whose self-check residual is too large (exploding kernels) are re-solved with stored grids by a
                 # kernel that reads the residuals itself: nothing comes back to the host, the backward pass never synchronises
+                # (the stored-grid kernel keeps three diagonals of the fine grid in LDS: sk_adj_rescue_slot_bytes is 0 for the
+                # grids it cannot hold -- more than ~6800 fine rows -- and such pairs have no rescue: their residuals stay in
+                # `err` for the caller, NaN-marked W would be worse than the fast kernel's value)
                 ws2, nb2 = self._grid_scratch(P, Mc, Nc, dyadic, dev, self.RESCUE_SLOTS)
                 if nb2:
                     fr = getattr(lib, "sk_adj_rescue_" + _suffix(inc_c))
-                    _check(fr(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, _ptr(err), float(self.ADJ_RESIDUAL_TOL), _ptr(out),
-                              _ptr(Wp), ldw, _ptr(ws2), nb2, _stream(inc_c)), "sk_adj_rescue")
+                    rc = fr(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), scheme, _ptr(err), float(self.ADJ_RESIDUAL_TOL), _ptr(out),
+                            _ptr(Wp), ldw, _ptr(ws2), nb2, _stream(inc_c))
+                    if rc != 2:          # 2: the grid does not fit the stored-grid kernel's LDS -- no rescue available, not an error
+                        _check(rc, "sk_adj_rescue")
         W = Wp[..., :Nc]
         # the caching allocator keeps the scratch alive for the work queued on this same stream
         if return_residual:
@@ -664,14 +669,22 @@ class HipBackend:
 
     def _grid_scratch(self, P, Mc, Nc, dyadic, dev, max_slots):
         """(uint8 tensor, bytes) holding up to max_slots pairs of solution grids, within GRID_SCRATCH_BYTES (at least one slot;
-        (None, 0) when a single slot exceeds half of the free memory)."""
+        raises when a single slot exceeds half of the free memory even after releasing torch's cached blocks; (None, 0) when
+        the stored-grid kernel cannot hold the grid at all)."""
+        if not int(load().sk_adj_rescue_slot_bytes(Mc, Nc, int(dyadic))):
+            return None, 0
         slot = int(load().sk_adj_rescue_slot_bytes(Mc, Nc, int(dyadic)))
         n = max(1, min(int(max_slots), int(P), self.GRID_SCRATCH_BYTES // max(slot, 1)))
         free, _ = torch.cuda.mem_get_info(dev)
         if n * slot > 0.5 * free:
             n = int(0.5 * free // slot)
         if n < 1:
-            return None, 0
+            torch.cuda.empty_cache()      # blocks cached by torch's allocator do not show in mem_get_info: release them and look again
+            free, _ = torch.cuda.mem_get_info(dev)
+            n = int(0.5 * free // slot)
+        if n < 1:
+            raise RuntimeError("sigkernel_amd: no memory for one stored-grid scratch slot (%d bytes): pairs that fail the fast "
+                               "adjoint's self-check could not be re-solved" % slot)
         return torch.empty(n * slot, dtype=torch.uint8, device=dev), n * slot
 
     def deriv_increments(self, G0, G1, G2, eps):

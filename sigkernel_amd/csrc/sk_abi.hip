@@ -392,6 +392,7 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
 
 size_t sk_adj_rescue_slot_bytes(int Mc, int Nc, int dyadic) {
     if (Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
+    if (simple_lds_bytes(make_geom(1, Mc, Nc, dyadic, SK_SCHEME_DEFAULT)) > 160 * 1024) return 0;   // the stored-grid kernel cannot hold it
     return (size_t)2 * (size_t)((Mc << dyadic) + 1) * (size_t)((Nc << dyadic) + 1) * sizeof(double);
 }
 

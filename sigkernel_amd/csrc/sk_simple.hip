@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c
 }
 
 // Device-side rescue of the fast adjoint: every block scans 64 self-check residuals at a time and re-solves, with both
-// grids stored, exactly the pairs whose residual exceeds `tol` (or is NaN).  Launched unconditionally after the fast
+// grids stored, exactly the pairs whose residual exceeds `tol` (a NaN residual -- poisoned inputs -- is left alone).  Launched unconditionally after the fast
 // kernel: when nothing is flagged (the normal case) it reads P doubles and exits, so the host never has to look at the
 // residuals -- no device-to-host synchronisation in a backward pass.
 template <typename T>
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(WAVE) void k_adj_rescue(const T *__restrict__ inc_c
     double *Kr = Kf + gs;
     for (int64_t p0 = (int64_t)blockIdx.x * WAVE; p0 < P; p0 += (int64_t)gridDim.x * WAVE) {
         const int64_t p = p0 + threadIdx.x;
-        const bool bad = p < P && !(err[p] <= tol);
+        // a NaN residual means the inputs of the pair are already poisoned (NaN / inf coordinates): a stored-grid re-solve would
+        // spend milliseconds to produce NaN again -- leave the fast kernel's NaN in W and move on
+        const double e = p < P ? err[p] : 0.0;
+        const bool bad = p < P && e > tol;
         unsigned long long m = __ballot(bad);
         while (m) {
             const int b = __ffsll((long long)m) - 1;

@@ -216,6 +216,32 @@ def test_adjoint_self_check_triggers_the_stored_grid_resolve(be):
     assert rel_err(np.delete(W.cpu().numpy(), 2, axis=0), np.delete(want_w, 2, axis=0)) <= ADJ_TOL
 
 
+def test_adjoint_of_a_long_first_path_needs_no_rescue_kernel(be):
+    """More fine rows than the stored-grid rescue kernel can hold in LDS (three diagonals of MM + 1 doubles > 160 KB, i.e.
+    MM > 6826): the multi-band fast adjoint has no such limit, and the unconditional rescue launch must then be skipped,
+    not raise `unsupported`."""
+    rng = np.random.default_rng(11)
+    Mc, Nc, d = 3500, 24, 1                      # MM = 7000
+    assert int(_lib.load().sk_adj_rescue_slot_bytes(Mc, Nc, d)) == 0
+    inc = rng.normal(scale=0.01, size=(3, Mc, Nc))
+    want_k, want_w = O.adjoint_coarse(inc, d, nthreads=8)
+    k, W, res = be.solve_adj(padded(inc), d, return_residual=True)
+    assert float(res.max()) < 1e-9
+    assert rel_err(k.cpu().numpy(), want_k) <= FAST_TOL and rel_err(W.cpu().numpy(), want_w) <= ADJ_TOL
+
+
+def test_adjoint_rescue_leaves_poisoned_pairs_alone(be):
+    """A NaN coordinate gives a NaN residual: the rescue must not spend a stored-grid re-solve on it (the answer is NaN
+    either way) and the other pairs must be untouched."""
+    rng = np.random.default_rng(12)
+    inc = rng.normal(scale=0.02, size=(5, 40, 40))
+    inc[3, 7, 9] = np.nan
+    want_k, want_w = O.adjoint_coarse(np.delete(inc, 3, axis=0), 1, nthreads=8)
+    k, W, res = be.solve_adj(padded(inc), 1, return_residual=True)
+    assert np.isnan(res.cpu().numpy()[3]) and np.isnan(W.cpu().numpy()[3]).any()
+    assert rel_err(np.delete(W.cpu().numpy(), 3, axis=0), want_w) <= ADJ_TOL
+
+
 def test_fuzz_random_shapes_against_oracle(be):
     """120 random shapes (ragged, tiny, multi-band, every dyadic order the tiled kernels cover) through every fast kernel."""
     rng = np.random.default_rng(2024)
