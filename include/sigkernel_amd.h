@@ -60,6 +60,10 @@ typedef enum sk_status {
                                cover the shape/layout (used by tests and benchmarks)            */
 
 int sk_version(void);
+
+/* Development hook: the SK_* tuning knobs are parsed from the environment ONCE, when the library is loaded; tools that sweep a
+ * knob inside one process call this after changing it.  Not for product code (not thread-safe against concurrent launches). */
+void sk_reload_knobs(void);
 const char *sk_status_string(int status);
 /* Number of HIP devices visible, or a negative sk_status. */
 int sk_device_count(void);
@@ -129,10 +133,16 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  *   [A][B / *ppg_out][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
  *   dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == NULL: size query only.  err [P] zero-initialised: self-check residual
  *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2, default scheme, path dim <= 8, one band per pair with
- *   M <= lanes x rows per lane and N - 1 <= 2 NUp - 1; otherwise SK_ERR_UNSUPPORTED. */
+ *   M <= lanes x rows per lane and N - 1 <= 2 NUp - 1; otherwise SK_ERR_UNSUPPORTED.
+ *   ypart (nullable; Gram, path dim <= 4): the SECOND-argument sums of the same sweep, for compute_Gram(X, X, sym=True) with a
+ *   gradient (compute_mmd's K_XX, sigkernel.py:190), where only the pairs on and above the diagonal are solved and a pair (a, b)
+ *   also owes d1 k(x_b, x_a) = d2 k(x_a, x_b) to row b.  Viewed as [A*B][*ycols_out][6], node column c < N of pair (a, b) holds
+ *   S0 = [..][0] and S1 = [..][2 .. 2+D), WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1);
+ *   the caller weights the pairs and folds them over a.  ycols_out != NULL in the size query asks for that variant's sizes. */
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
-                             size_t gpart_doubles, double *err, int *ppg_out, int *rows_out, int *outw_out, void *stream);
+                             size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
+                             int *outw_out, int *ycols_out, void *stream);
 
 /* Second-argument adjoint (Gram only): dL/dY from W for the pairs (a, b), b >= b0 -- the counterpart of sk_static_adjoint_*
  * that the reference never needs (it returns no gradient for its second argument, sigkernel.py:343, :412).  It exists for

@@ -29,6 +29,7 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/sigkernel_amd.h one to one
 SIGNATURES = {
     "sk_version": (_int, []),
+    "sk_reload_knobs": (None, []),
     "sk_status_string": (ctypes.c_char_p, [_int]),
     "sk_device_count": (_int, []),
     "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
@@ -66,7 +67,7 @@ SIGNATURES = {
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
                                            _vp]),
     "sk_rbf_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp,
-                                        _sz, _vp, _vp, _vp, _vp, _vp]),
+                                        _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_adj_rescue_slot_bytes": (_sz, [_int, _int, _int]),
     "sk_plan_wave_shares": (_int, [_i64, _int, _i64, _i64, _int, _int, _vp, _vp, _vp]),
@@ -430,11 +431,14 @@ class HipBackend:
         g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
-        linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL."""
+        linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL.
+        yside (Gram, dim <= 4): a third result, the second-argument sums of the same sweep as a (A, B, N, 2 + D) tensor [S0, 0, S1]
+        per node of y_b, WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1) (see
+        second_argument_gradient)."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -442,26 +446,31 @@ class HipBackend:
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
             return None
+        if yside and (not gram or D > 4):
+            return None
         dev = X.device
         Mrows, Ncp = 256, (N + 15) // 16 * 16
         if scale is not None:
             scale = scale.double().contiguous()
         lib = load()
         P, Bk = (A * B, B) if gram else (A, 0)
-        ppg, rows, outw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        ppg, rows, outw, ycols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         with torch.cuda.device(dev):
             Xr = _prep_paths(X, False, False, 1.0, Mrows)
             Yt = _prep_paths(Y, False, True, 1.0, Ncp)
             args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_DEFAULT, float(sigma), _ptr(edges), _ptr(scale))
-            tail = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), _stream(X))
-            rc = lib.sk_rbf_adjoint_fused_f64(*args, None, 0, None, *tail)
+            tail = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None, _stream(X))
+            rc = lib.sk_rbf_adjoint_fused_f64(*args, None, 0, None, None, 0, *tail)
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
             gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
             err = torch.zeros(P, dtype=torch.float64, device=dev)
-            rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), *tail)
+            # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read
+            ypart = torch.empty(A, B, ycols.value, 6, dtype=torch.float64, device=dev) if yside else None
+            rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ypart),
+                                              ypart.numel() if yside else 0, *tail)
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused")
@@ -469,7 +478,21 @@ class HipBackend:
         T = gpart.sum(1)[:, :M]                                   # chunks of an a added in a fixed order
         cs, accd = T[..., 0:1], T[..., 2:2 + D]
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)     # sum_c V G (-2/sigma) (x_r - y_c)
+        if yside:
+            return g.to(X.dtype), res, ypart[:, :, :N, :2 + D]
         return g.to(X.dtype), res
+
+    @staticmethod
+    def second_argument_gradient(ysums, Y, sigma, weight, b0=0):
+        """dL/dY[b0:] (B-b0, N, D) from rbf_adjoint_fused(..., yside=True)'s sums (A, B, N, 2+D) and the per-pair upstream gradient
+        `weight` (A, B): sum_a weight[a, b] (-2/sigma) (y_b[c] S0[a, b, c] - S1[a, b, c]).  The pairs are folded over a in a fixed
+        order (one matrix product per b), so the result is reproducible."""
+        D = Y.shape[2]
+        w = weight[:, b0:].double()
+        ys = ysums[:, b0:]
+        folded = torch.einsum("ab,abck->bck", w, ys)              # (B-b0, N, 2+D)
+        g = (-2.0 / float(sigma)) * (Y[b0:].double() * folded[..., 0:1] - folded[..., 2:2 + D])
+        return g.to(Y.dtype)
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

@@ -1,5 +1,8 @@
 // sk_abi.hip -- the extern "C" surface declared in include/sigkernel_amd.h.
 // Argument checking and kernel selection only; no torch types, no allocation, no synchronisation.
+#include <atomic>
+#include <cstdlib>
+
 #include "sk_internal.h"
 #include "sk_wave_common.h"
 
@@ -126,13 +129,67 @@ int solve_fwd_sym(int kind, const double *Xr, const double *Xt, int64_t A, int M
 
 }  // namespace
 
+// ---- the one place that reads the environment: SK_* tuning knobs, parsed when the library is loaded ------------------------
+namespace sk {
+namespace {
+int knob_int(const char *name) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : 0;
+}
+RankW knob_shares(const char *name) {
+    RankW r{};
+    const char *e = getenv(name);
+    if (e && *e)
+        for (const char *q = e; *q && r.n < 4; ++r.n) {
+            r.w[r.n] = atof(q);
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    return r;
+}
+Knobs parse_knobs() {
+    Knobs k{};
+    k.wave_pf = knob_int("SK_WAVE_PF"); k.wave_wpc = knob_int("SK_WAVE_WPC"); k.wave_wpb = knob_int("SK_WAVE_WPB");
+    k.adj_wpc = knob_int("SK_ADJ_WPC"); k.adj_wpb = knob_int("SK_ADJ_WPB");
+    k.adjf_wpc = knob_int("SK_ADJF_WPC"); k.adjf_wpb = knob_int("SK_ADJF_WPB");
+    k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB"); k.adjr_all = knob_int("SK_ADJR_ALL");
+    k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
+    k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB");
+    k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB");
+    k.rank_w = knob_shares("SK_RANK_W"); k.wave_rank_w = knob_shares("SK_WAVE_RANK_W"); k.adj_rank_w = knob_shares("SK_ADJ_RANK_W");
+    k.adjf_rank_w = knob_shares("SK_ADJF_RANK_W"); k.adjr_rank_w = knob_shares("SK_ADJR_RANK_W");
+    k.deriv_rank_w = knob_shares("SK_DERIV_RANK_W"); k.fused_rank_w = knob_shares("SK_FUSED_RANK_W");
+    k.fusedmb_rank_w = knob_shares("SK_FUSEDMB_RANK_W");
+    return k;
+}
+Knobs g_knobs = parse_knobs();          // dynamic initialisation = library load
+std::atomic<int> g_cu_count[16];        // 0: not asked yet
+}  // namespace
+const Knobs &knobs() { return g_knobs; }
+int device_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int n = g_cu_count[dev].load(std::memory_order_relaxed);
+    if (n == 0) {       // (racing threads compute the same value)
+        int v = 0;
+        n = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+        g_cu_count[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+}  // namespace sk
+
 extern "C" {
 
-int sk_version(void) { return 201; }
+int sk_version(void) { return 300; }
+
+/* Development hook: parse the SK_* environment variables again (tools that sweep a knob inside one process).  Not
+ * thread-safe against concurrent launches; product code never calls it. */
+void sk_reload_knobs(void) { sk::g_knobs = sk::parse_knobs(); }
 
 int sk_plan_wave_shares(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, int64_t *first, int64_t *end, int *ppg) {
     if (P < 0 || G < 1 || waves < 1 || wpb < 1 || n_cu < 1 || !first || !end || !ppg) return SK_ERR_BAD_ARG;
-    const sk::RankSplit rs = sk::rank_split(P, G, waves, resident, wpb, n_cu, "SK_RANK_W");
+    const sk::RankSplit rs = sk::rank_split(P, G, waves, resident, wpb, n_cu, sk::RankW{});
     for (int64_t w = 0; w < waves; ++w) sk::rank_share(rs, w, G, P, ppg[w], first[w], end[w]);
     return rs.nranks;
 }
@@ -140,7 +197,7 @@ int sk_plan_wave_shares(int64_t P, int G, int64_t waves, int64_t resident, int w
 int sk_plan_group_chunks(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, int64_t n_groups,
                          int64_t *first, int64_t *slot, int *ppg) {
     if (A < 1 || B < 0 || PPG < 1 || G < 1 || wpb < 1 || n_cu < 1 || !first || !slot || !ppg) return SK_ERR_BAD_ARG;
-    const sk::ChunkSplit cs = sk::chunk_split(A, B, PPG, max_groups, G, wpb, n_cu, "SK_RANK_W");
+    const sk::ChunkSplit cs = sk::chunk_split(A, B, PPG, max_groups, G, wpb, n_cu, sk::RankW{});
     const int64_t P = B > 0 ? A * B : A;
     for (int64_t gi = 0; gi < n_groups; ++gi) sk::chunk_share(cs, gi, A, B, P, first[gi], slot[gi], ppg[gi]);
     return cs.nr;
@@ -369,14 +426,15 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
 
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
-                             size_t gpart_doubles, double *err, int *ppg_out, int *rows_out, int *outw_out, void *stream) {
+                             size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
+                             int *outw_out, int *ycols_out, void *stream) {
     if (!Xr || !Yt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
-    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err)) return SK_ERR_BAD_ARG;
+    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err) || (ypart && !gpart)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ppg_out, rows_out,
-                                outw_out, (hipStream_t)stream);
+    return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ypart, ypart_doubles,
+                                ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, (hipStream_t)stream);
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {

@@ -6,6 +6,23 @@
 
 namespace sk {
 
+// Tuning knobs: the SK_* environment variables are parsed ONCE, when the library is loaded (sk_abi.hip), into this immutable
+// struct; no launch path reads the environment (tests/test_abi.py greps the launch translation units for getenv).
+// 0 / n = 0 mean "the built-in default".  Tools that sweep a knob inside one process call sk_reload_knobs() after changing it.
+struct RankW { int n; double w[4]; };      // shares of the pairs by wave age rank, per cent; n = number of ranks given
+struct Knobs {
+    int wave_pf, wave_wpc, wave_wpb;
+    int adj_wpc, adj_wpb;
+    int adjf_wpc, adjf_wpb;
+    int adjr_wpc, adjr_wpb, adjr_all;
+    int deriv_pf, deriv_wpc, deriv_wpb;
+    int fused_wpc, fused_wpb;
+    int fusedmb_wpc, fusedmb_wpb;
+    RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
+};
+const Knobs &knobs();                      // sk_abi.hip
+int device_cu_count();                     // sk_abi.hip: compute units of the current device (256 on MI355X), cached per device
+
 // Geometry of one solve call; MM/NN are fine-grid cell counts.
 struct Geom {
     int64_t P;
@@ -119,7 +136,8 @@ int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_maj
 // ---- sk_wave_adj_fused_rbf.hip: adjoint with the RBF static kernel fused in (nodes, increments, contraction in the sweep) ----
 int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                         int *ppg_out, int *rows_out, int *outw_out, hipStream_t s);
+                         double *ypart, size_t ypart_doubles, int want_yside, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out,
+                         hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

@@ -384,7 +384,7 @@ int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t 
 template <typename T>
 int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *strip_edges, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    int PF = env_int("SK_WAVE_PF", 2);
+    int PF = knobs().wave_pf > 0 ? knobs().wave_pf : 2;
     if ((PF != 3 && PF != 4) || strip_edges) PF = 2;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
@@ -405,7 +405,7 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
 
     // persistent waves: enough of them to fill the chip, each streaming PPG pairs per lane group
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    const int wpc_env = env_int("SK_WAVE_WPC", 0);
+    const int wpc_env = knobs().wave_wpc;
     // d = 2 (10 KB of LDS per wave): 16 waves/CU 3.09 ms vs 3.43 ms at 8 on a C4 tile; d = 3 is better off with 8 (2.24 vs 2.36 ms)
     const int wpc_cap = (wpc_env > 0 || DY == 2) ? 16 : 8;
     if (waves_per_cu > wpc_cap) waves_per_cu = wpc_cap;
@@ -414,7 +414,7 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
+    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;   // one pair per lane group at least
     if (waves > max_waves) waves = max_waves;
     int64_t PPG = (g.P + waves * G - 1) / (waves * G);
@@ -445,19 +445,19 @@ int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, dou
     // vs 3.98 ms).  Where the launch fills the chip with TWO four-wave workgroups per CU, shares by wave age rank
     // (sk_wave_common.h) beat that: 58 / 42 % 2.87 -> 2.67 ms, with strip edges 54 / 46 % 3.68 -> 3.57 ms (other residencies:
     // not measured, single-wave workgroups as before).  SK_WAVE_WPB=1 restores those everywhere.
-    prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 1);
-    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, device_cu_count(), "SK_WAVE_RANK_W");   // equal shares
+    prm.wg = wave_group(lds_bytes, waves, knobs().wave_wpb, 1);
+    prm.rs = rank_split(g.P, G, waves, -1, prm.wg.wpb, device_cu_count(), knobs().wave_rank_w);   // equal shares
     prm.rs.cnt[0] = (int)PPG;
     prm.rs.base[1] = PPG * waves * G;
-    if (env_int("SK_WAVE_WPB", 4) == 4 && lds_bytes * 4 <= 160 * 1024) {
-        static const double plain[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
-        static const double edged[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.54, 0.46, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
+    if ((knobs().wave_wpb <= 0 || knobs().wave_wpb == 4) && lds_bytes * 4 <= 160 * 1024) {
+        static constexpr double plain[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
+        static constexpr double edged[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.54, 0.46, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}};
         const int64_t full = (g.P + G - 1) / G < max_waves ? (g.P + G - 1) / G : max_waves;
-        const RankSplit rs = rank_split(g.P, G, full, max_waves, 4, device_cu_count(), "SK_WAVE_RANK_W", strip_edges ? edged : plain);
+        const RankSplit rs = rank_split(g.P, G, full, max_waves, 4, device_cu_count(), knobs().wave_rank_w, strip_edges ? edged : plain);
         if (rs.nranks == 2 && (int64_t)rs.cnt[0] * G * pair_bytes < (1LL << 31)) {
             prm.rs = rs;
             waves = full;
-            prm.wg = wave_group(lds_bytes, waves, "SK_WAVE_WPB", 4);
+            prm.wg = wave_group(lds_bytes, waves, knobs().wave_wpb, 4);
         }
     }
     const int blocks = wave_group_blocks(prm.wg);

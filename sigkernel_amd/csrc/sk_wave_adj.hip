@@ -531,7 +531,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    const int wpc_env = env_int("SK_ADJ_WPC", 0);
+    const int wpc_env = knobs().adj_wpc;
     // d = 2 (10 KB per wave): the VGPRs allow 12 resident waves per CU; launching 16 let the fourth workgroup of a CU start when
     // the first ended (13.1 ms vs 13.6 at 8), 12 with shares by age rank is better still (C4 tiles: 9.06 -> 8.44 ms)
     const int wpc_cap = wpc_env > 0 ? 16 : (DY == 2 ? 12 : 8);
@@ -541,7 +541,7 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups: the same number of waves on every SIMD
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
+    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
     if (waves > max_waves) waves = max_waves;
     const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
@@ -549,10 +549,10 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
     // shares by wave age rank when the launch fills the chip with four-wave workgroups and the largest share's span fits
     // the 32-bit buffer offsets; otherwise equal shares
     // (this kernel waits on HBM as much as on the vector unit: measured optimum 58 / 42 at d = 1, against 66 / 34 for the fused kernels)
-    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.25, 0.25, 0.25, 0.25}};   // (three ranks: d = 2, bound by the vector unit like the fused kernels; four: not measured, equal)
-    WaveGroup wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
-    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W", shares);
-    if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W");
+    static constexpr double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.25, 0.25, 0.25, 0.25}};   // (three ranks: d = 2, bound by the vector unit like the fused kernels; four: not measured, equal)
+    WaveGroup wg = wave_group(lds_bytes, waves, knobs().adj_wpb);
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), knobs().adj_rank_w, shares);
+    if (rs.nranks > 1 && ((int64_t)rs.cnt[0] * G + 1) * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), knobs().adj_rank_w);
     int64_t PPG = rs.cnt[0];
     if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
@@ -561,8 +561,8 @@ int launch_adj_wave(const T *inc_c, int64_t ld, const Geom &g, const double *edg
             if (PPG < 1) return SK_ERR_UNSUPPORTED;
             waves = (g.P + PPG * G - 1) / (PPG * G);
         }
-        wg = wave_group(lds_bytes, waves, "SK_ADJ_WPB");
-        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_ADJ_RANK_W");
+        wg = wave_group(lds_bytes, waves, knobs().adj_wpb);
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), knobs().adj_rank_w);
         rs.cnt[0] = (int)PPG;
         rs.base[1] = PPG * waves * G;
     }

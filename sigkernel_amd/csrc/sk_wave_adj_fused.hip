@@ -463,8 +463,8 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
 
     // pairs per lane group: the smallest divisor of B that keeps the launch within the resident waves (8 per CU: the
     // kernel holds ~230 VGPRs, two waves per SIMD)
-    const int wpc = env_int("SK_ADJF_WPC", 8);
-    const int64_t max_groups = 256LL * wpc * G;
+    const int wpc = knobs().adjf_wpc > 0 ? knobs().adjf_wpc : 8;
+    const int64_t max_groups = (int64_t)device_cu_count() * wpc * G;
     int64_t PPG = B > 0 ? B : 1;   // paired: every pair has its own x, one pair per lane group.  Gram with more paths than
     for (int64_t d = 1; d <= B; ++d)   // resident lane groups: one whole row of the Gram per group, launched in several rounds
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
@@ -472,7 +472,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     if (force_nch > 0) PPG = B / force_nch;
     else if (rows_per_launch) {   // see launch_adj_fused_rbf_rows (sk_wave_adj_fused_rbf.hip)
         *rows_per_launch = 0;
-        const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJF_WPB").wpb;
+        const int wpb = wave_group(lds_bytes, max_groups / G, knobs().adjf_wpb).wpb;
         const int64_t gpr = (int64_t)device_cu_count() * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
         const int64_t nch = B > 0 ? B / PPG : 1;
@@ -497,8 +497,8 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     prm.PPG = (int)PPG;
     prm.E = st.NNp + st.MMp;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
-    prm.wg = wave_group(lds_bytes, waves, "SK_ADJF_WPB");
-    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), "SK_ADJF_RANK_W");
+    prm.wg = wave_group(lds_bytes, waves, knobs().adjf_wpb);
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), knobs().adjf_rank_w);
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     switch (DY) {

@@ -31,6 +31,22 @@ namespace {
 constexpr int RFD = 8;                 // dims carried by the staged arrays
 constexpr int RY_SLAB = RFD * 128;
 constexpr int RX_SLOTS = 2;
+constexpr int YW = 6;                  // doubles per (pair, node column) of the second-argument sums: S0, 0, S1[0..4)
+
+// One x window slab (per lane group, ring slot and lap): everything the 8 lanes that start a pair during the window need, in
+// ONE run of 16-byte DMA pieces:
+//   [0, 8 RC 64)            the x points of their node rows, position i = (lam & 7) RC + k <-> node row Mcp-1 - (lamj RC + i)
+//   [XR_UP, +64)            the node row above position 0 (the last row of the lane above the window's first lane)
+//   [XR_COL, +(4R+1) 16)    the pair's terminal COLUMN K[j][NN], j = MMp-(lamj+8)R-1 .. MMp-lamj R  (8R + 2 doubles)
+//   [XR_SC, +16)            the pair's upstream gradient, as the aligned 16 bytes that hold scale[pair]
+template <int RC, int R> struct XSlab {
+    static constexpr int XR_UP = 8 * RC * 64;
+    static constexpr int XR_COL = XR_UP + 64;
+    static constexpr int NPCOL = 4 * R + 1;
+    static constexpr int XR_SC = XR_COL + NPCOL * 16;
+    static constexpr int NPIECES = (XR_SC + 16) / 16;
+    static constexpr int BYTES = (XR_SC + 16 + 63) / 64 * 64;
+};
 
 struct AdjRbfParams {
     const double *Xr;      // [A][Mrows][8]  x_p (points), zero rows / dims beyond M / D
@@ -39,6 +55,8 @@ struct AdjRbfParams {
     const double *scale;   // [P] upstream gradient per pair, nullable
     double *Gpart;         // [P / PPG][L*RC + 1][OUTW]  per node row: cs, 0, accd[0..ND)
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
+    double *Ypart;         // YSIDE: [P][2 NUp][YW] per pair and node column of y_b: S0 = sum_r V G, S1 = sum_r V G x_r, both
+                           // WITHOUT the pair's upstream gradient (the caller weights the pairs when it folds them over a)
     int64_t P, B;
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
     ChunkSplit cs;         // chunk sizes by wave age rank; PPG / n_steps are the equal split's
@@ -71,15 +89,31 @@ __device__ __forceinline__ void lds_read_xpt(double (&x)[ND], unsigned a) {
         lds_read_row1<4>(x, a);
     }
 }
+// the five 16-byte pieces of the second-argument carry (piece m = component m of node columns c1, c2): 65 slots of 16 bytes per
+// piece -- one per lane, and slot 64, which nobody writes: the zero a group's top lane starts from
+constexpr int YC_PIECE = 65 * 16;
+__device__ __forceinline__ void lds_read_carry(d2_t (&v)[5], unsigned a) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1040\n\tds_read_b128 %2, %5 offset:2080\n\t"
+                 "ds_read_b128 %3, %5 offset:3120\n\tds_read_b128 %4, %5 offset:4160\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
+}
+__device__ __forceinline__ void lds_write_carry(unsigned a, const d2_t (&v)[5]) {
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1040\n\tds_write_b128 %0, %3 offset:2080\n\t"
+                 "ds_write_b128 %0, %4 offset:3120\n\tds_write_b128 %0, %5 offset:4160"
+                 : : "v"(a), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory");
+}
 
-template <int DY, int RC, bool FULLWAVE, int ND>
+template <int DY, int RC, bool FULLWAVE, int ND, bool YSIDE>
 __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_adj_fused_rbf(const AdjRbfParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
-    constexpr int XSLAB = RC * 512;
+    typedef XSlab<RC, R> XS;
+    constexpr int XSLAB = XS::BYTES;
     constexpr int OUTW = ND + 2;
     constexpr int ECG = (4 * S + 1) * 16;    // terminal-row chunk of one lane group (sk_wave_adj.hip)
     constexpr int NPC = 4 * S + 1;
+    static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
+    static_assert(!YSIDE || ND == 4, "the second-argument sums are built for paths of dim <= 4");
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
     const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
@@ -91,7 +125,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     const int lam = lane & (L - 1), grp = lane >> prm.logL;
     const int NUp = prm.NUp;
     const int Mcp = L * RC;
-    const int MM = prm.Mc << DY, MMp = Mcp << DY, NNp = (NUp * CW) << DY;
+    const int MMp = Mcp << DY, NNp = (NUp * CW) << DY;
     const int NSLAB = (L >> 3) + 2;
     const unsigned y_bytes = (unsigned)(NSLAB * RY_SLAB);
     const unsigned x_base0 = (unsigned)G * y_bytes;
@@ -119,12 +153,18 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     const int n_steps = PPG * NUp + (L - 1) + 1;   // + 1: node column 0 of the last pair completes one step later
     auto group_first = [&](int g) -> int64_t { return readlane64(pair0, g << prm.logL); };
     const bool is_top = lam == 0;
+    const bool is_bot = lam == L - 1;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
     const int JMAX = (L + NUp - 1) / NUp;
-    const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * RX_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
-                          (unsigned)((lam & 7) * RC * 64);
+    const unsigned my_slab = lds0 + x_base0 + (unsigned)((grp * RX_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB);
+    const unsigned my_x = my_slab + (unsigned)(lam7 * RC * 64);
+    const unsigned my_xup = my_slab + (unsigned)(lam7 == 0 ? XS::XR_UP : lam7 * RC * 64 - 64);   // the node row above this lane's first
+    const unsigned my_col = my_slab + (unsigned)(XS::XR_COL + (7 - lam7) * R * 8);                // doubles (7-lam7)R .. +5 of the column piece
+    const unsigned my_sc = my_slab + (unsigned)XS::XR_SC;
     const unsigned ec_base = lds0 + x_base0 + (unsigned)(G * RX_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
     const unsigned ec_slot = (unsigned)(G * ECG);
+    const unsigned yc_base = ec_base + 2u * ec_slot;                                     // YSIDE: the carry, 16 bytes per lane and piece
+    const unsigned yc_rd = yc_base + (unsigned)((is_top ? WAVE : lane - 1) << 4);        // what the lane above handed down (top lane: zero)
     bool row_ok[RC];   // this lane's coarse rows that exist (p_k < Mc)
 #pragma unroll
     for (int k = 0; k < RC; ++k) row_ok[k] = Mcp - 1 - (lam * RC + k) < prm.Mc;
@@ -155,25 +195,41 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         y_u0 += 8;
         if (y_u0 == NUp) { y_u0 = 0; y_pi += 1; }
     };
-    // x slabs: LDS position i = (lam & 7) * RC + k holds the x POINT of node row p = Mcp - 1 - (lamj*RC + i)
+    // x window slabs (XSlab): the points of the 8 lanes' node rows, the row above them, the pair's terminal column for their
+    // fine rows and its upstream gradient -- one run of 16-byte pieces per lane group and lap
+    const int E = NNp + MMp;
     int x_q0 = 0, x_lam0 = 0, x_slot = 0;
     auto issue_x = [&]() {
         for (int j = 0; j < JMAX; ++j) {
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = group_first(g) + pi;
-                if (pi < 0 || pi >= PPG || p >= prm.P) p = 0;
+                // out of the group's range: something valid -- and of the group's OWN a: the lanes reload their x points at every
+                // pair start, and the second-argument sums of a pair's node column 0 are completed one macro-step into the next
+                const int64_t gf = group_first(g);
+                int64_t p = gf + pi;
+                if (pi < 0 || pi >= PPG || p >= prm.P) p = gf < prm.P ? gf : 0;
                 const int64_t a = split_a(p);
                 char *dst = lds + x_base0 + ((g * RX_SLOTS + x_slot) * JMAX + j) * XSLAB;
+                const double *xa = prm.Xr + a * prm.Mrows * RFD;
+                const double *ecol = prm.edges + p * E + (NNp - 2 + MMp - (lamj + 8) * R);
+                const double *scp = prm.scale ? reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(prm.scale + p) & ~(uintptr_t)15) : prm.Xr;   // the aligned 16 bytes that hold scale[p]
 #pragma unroll
-                for (int c = 0; c < (XSLAB + 1023) / 1024; ++c)
-                    if (c * 1024 + lane * 16 < XSLAB) {
-                        const int i = c * 16 + (lane >> 2);
-                        const int row = Mcp - 1 - (lamj * RC + i);
-                        const double *src = prm.Xr + (a * prm.Mrows + row) * RFD + (lane & 3) * 2;
+                for (int c = 0; c < (XS::NPIECES + 63) / 64; ++c) {
+                    const int idx = c * 64 + lane;
+                    if (idx < XS::NPIECES) {
+                        const double *src;
+                        if (idx < 32 * RC + 4) {
+                            const int i = idx < 32 * RC ? (idx >> 2) : -1;
+                            src = xa + (Mcp - 1 - (lamj * RC + i)) * RFD + (idx & 3) * 2;
+                        } else if (idx < 32 * RC + 4 + XS::NPCOL) {
+                            src = ecol + 2 * (idx - (32 * RC + 4));
+                        } else {
+                            src = scp;
+                        }
                         __builtin_amdgcn_global_load_lds(src, (lds_void *)(dst + c * 1024), 16, 0, 0);
                     }
+                }
             }
         }
         x_slot = x_slot + 1 == RX_SLOTS ? 0 : x_slot + 1;
@@ -181,7 +237,6 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         if (x_lam0 == NUp) { x_lam0 = 0; x_q0 += 1; }
     };
     // terminal ROW of the pair the top lanes are in, one window ahead (sk_wave_adj.hip: issue_edge_chunk)
-    const int E = NNp + MMp;
     int ec_u0 = 0, ec_ps = 0, ec_fill = 0;
     auto issue_edge_chunk = [&]() {
         for (int c = 0; c * WAVE < G * NPC; ++c) {
@@ -198,29 +253,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         if (ec_u0 == NUp) { ec_u0 = 0; ec_ps += 1; }
     };
 
-    // ---- terminal COLUMN and the upstream gradient of the coming pair, one macro-step ahead (sk_wave_adj.hip) ------------
-    auto prefetch_edges = [&](int nu, int nps, double (&pcol)[R + 1], double &pscale) {
-        if (nu == 0) {
-            int64_t pr = pair0 + nps;
-            pr = pr < 0 ? 0 : (pr >= prm.P ? prm.P - 1 : pr);
-            const double *e = prm.edges + pr * E;
-            const int i0 = lam * RC * r;
-            const double *q = e + (NNp - 1);
-#pragma unroll
-            for (int i = 0; i < R; ++i) load_async(pcol[i], q + min(MM, MMp - (i0 + i)));
-            load_async(pcol[R], q + max(min(MM, MMp - (i0 + R)), 1));
-            if (prm.scale) load_async(pscale, prm.scale + pr);
-        }
-    };
-    auto fix_edges = [&](int nu, double (&pcol)[R + 1]) {
-        if (nu == 0 && lam * RC * r + R == MMp) pcol[R] = 1.0;
-    };
-
-    double xr[RC][ND];
+    double xr[RC][ND], xup[YSIDE ? ND : 1];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int j = 0; j < ND; ++j) xr[k][j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < (YSIDE ? ND : 1); ++j) xup[j] = 0.0;
     // accumulators per node row r_k = p_k + 1 (k < RC) and, [RC], node row p_{RC-1} (node row 0 on the bottom lane)
     double cs[RC + 1], accd[RC + 1][ND];
 #pragma unroll
@@ -247,13 +286,15 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     expc.init();
     double chk_val = 0.0;
     int64_t chk_pair = -1;
-    double s_pair = 0.0;    // upstream gradient of the pair being swept (0 outside the group's pairs)
-    double ncol[R + 1], nscale = 0.0;
-#pragma unroll
-    for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
+    // upstream gradient of the pair being swept: sx for what the step adds at node column c1, sx_d (its value one step ago) at
+    // c2 -- at the first step of a pair the c2 terms still belong to the pair before.  The weights themselves stay unscaled (the
+    // second-argument sums are weighted by the caller) and are SELECTED to zero outside the group's pairs.
+    double sx = 0.0, sx_d = 0.0;
+    int valid = 0;
+    double *yp_cur = nullptr, *yp_prev = nullptr;   // YSIDE: the Ypart blocks of this lane's pair and of the one before (null: none)
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite
-        const int total = (int)(G * y_bytes + G * RX_SLOTS * JMAX * XSLAB + 2 * G * ECG);
+        const int total = (int)(G * y_bytes + G * RX_SLOTS * JMAX * XSLAB + 2 * G * ECG + (YSIDE ? 5 * YC_PIECE : 0));
         const d2_t z = {0.0, 0.0};
         for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -261,55 +302,65 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     issue_y();
     issue_x();
     issue_edge_chunk();
-    {
-        double pcol[R + 1], pscale[1], tsc[1];
-#pragma unroll
-        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
-        async_begin(pscale[0]);
-        prefetch_edges(u, ps, pcol, pscale[0]);
-        async_wait<0>(ncol, pcol);
-        async_wait<0>(tsc, pscale);
-        fix_edges(u, ncol);
-        nscale = (u == 0 && ps >= 0 && ps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
-    }
-    issue_y();
-    issue_x();
 
-    for (int t = 0; t < n_steps; ++t) {
+    for (int t0 = 0; t0 < n_steps; t0 += 8) {
+        // window of 8 macro-steps: what it consumes was issued a window ago; what the next one consumes is issued now
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_y();
+        issue_x();
+        issue_edge_chunk();
+        const unsigned x_rd = (unsigned)(((t0 >> 3) % RX_SLOTS) * JMAX * XSLAB);
+        const unsigned ec_rd = ec_base + (unsigned)(((t0 >> 3) & 1) * ec_slot + grp * ECG);
+        const int t_end = t0 + 8 < n_steps ? t0 + 8 : n_steps;
+        for (int t = t0; t < t_end; ++t) {
         // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
         double trow_p[S], trow[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
-        lds_read_f64_run<S>(trow_p, ec_base + (unsigned)(((t >> 3) & 1) * ec_slot + grp * ECG + ((7 - (t & 7)) * S + 1) * 8));
+        lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
 
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
             chk_pair = -1;
         }
-        int nu = u + 1, nps = ps;
-        if (nu == NUp) { nu = 0; nps += 1; }
         const int uo = NUp - 1 - u;    // original unit: node columns c0 = 2uo, c1 = 2uo + 1 (c2 = 2uo + 2 is last step's c0)
 
-        // -- start of a (flipped) pair: boundaries, upstream gradient, this lane's x points
+        // -- start of a (flipped) pair: boundaries, terminal column, upstream gradient, this lane's x points
         if (u == 0) {
-            cornerR = 1.0;
-            cornerF = ncol[0];
-#pragma unroll
-            for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = ncol[i + 1]; }
-            s_pair = nscale;
-            const unsigned xa = my_x + (unsigned)(((t >> 3) % RX_SLOTS) * JMAX * XSLAB);
+            asm volatile("");
+            const int64_t pe = pair0 + ps;
+            valid = (ps >= 0 && ps < PPG && pe < prm.P) ? 1 : 0;
+            const unsigned xa = my_x + x_rd;
 #pragma unroll
             for (int k = 0; k < RC; ++k) lds_read_xpt<ND>(xr[k], xa + k * 64u);
+            if constexpr (YSIDE) {
+                lds_read_xpt<ND>(xup, my_xup + x_rd);
+                yp_prev = yp_cur;
+                yp_cur = valid ? prm.Ypart + pe * (int64_t)(2 * NUp * YW) : nullptr;
+            }
+            double col[6];
+            {
+                d2_t c3[3];
+                const unsigned ca_ = my_col + x_rd;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
+                col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+            }
+            // col[1 + m] = K[MMp - lam R - R + m][NN], m = 0..R: the lane's fine rows bottom to top; K[0][NN] = 1 is not stored
+            cornerR = 1.0;
+            cornerF = col[1 + R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
+            if (lam * R + R == MMp) leftF[R - 1] = 1.0;
+            const double sv = prm.scale ? lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u)) : 1.0;
+            sx = valid ? sv : 0.0;
         }
 
         // -- y points of the unit's two node columns
         d2_t yv[ND];
-        {
-            const unsigned ya = my_y + (unsigned)(yslab * RY_SLAB + ((u & 7) << 4));
-            lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
-        }
+        const unsigned ya = my_y + (unsigned)(yslab * RY_SLAB + ((u & 7) << 4));
+        lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         lds_take<S>(trow, trow_p);
-        if ((t & 7) == 0) issue_edge_chunk();
 
         // -- top rows of the two states
         double topR[S], topF[S];
@@ -318,7 +369,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             double tf = trow[S - 1 - i];
             if (i == S - 1 && u == NUp - 1) tf = 1.0;     // K[MM][0] = 1 is not stored
             if (FULLWAVE) {   // lane 0 keeps the `old` operand: the boundary (1 for the reverse state, the terminal row for K)
-                topR[i] = dpp_shr1(botR[i], 1.0);
+                topR[i] = dpp_shr1_one(botR[i]);
                 topF[i] = dpp_shr1(botF[i], tf);
             } else {
                 const double shR = dpp_shr1(botR[i], 1.0);
@@ -330,18 +381,11 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // what the lane above evaluated / weighted one macro-step ago, for this unit's two columns (garbage for a top lane:
         // its first coarse row is padding and masked)
         double Gabv[2], wup0[2];
-        Gabv[0] = dpp_shr1(lastOwn[0], 0.0);
-        Gabv[1] = dpp_shr1(lastOwn[1], 0.0);
-        wup0[0] = dpp_shr1(lastW[0], 0.0);
-        wup0[1] = dpp_shr1(lastW[1], 0.0);
+        Gabv[0] = dpp_shr1_zero(lastOwn[0]);
+        Gabv[1] = dpp_shr1_zero(lastOwn[1]);
+        wup0[0] = dpp_shr1_zero(lastW[0]);
+        wup0[1] = dpp_shr1_zero(lastW[1]);
         if (is_top) { wup0[0] = 0.0; wup0[1] = 0.0; }     // nothing above the first lane of a group contributes
-
-        // -- next step's column edges (asynchronous)
-        double pcol[R + 1], pscale[1];
-#pragma unroll
-        for (int i = 0; i <= R; ++i) async_begin(pcol[i]);
-        async_begin(pscale[0]);
-        prefetch_edges(nu, nps, pcol, pscale[0]);
 
         // -- nodes of this lane's rows at the two columns
         double Gown[RC][2];
@@ -411,25 +455,25 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         cornerR = topR[S - 1];
         cornerF = topF[S - 1];
 
-        // -- weights of the cells (original columns c0, c1), scaled by the pair's upstream gradient; zero outside the pair,
-        //    in padding rows / columns and outside the group's pairs (SELECTED: leftovers may hold anything, NaN included)
+        // -- weights of the cells (original columns c0, c1), WITHOUT the pair's upstream gradient; zero outside the pair, in
+        //    padding rows / columns and outside the group's pairs (SELECTED: leftovers may hold anything, NaN included)
         double wk[RC][2];
         {
-            const bool live = s_pair != 0.0;
-            const double wsc = sc * s_pair;
+            const bool live = valid != 0;
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
-                wk[k][0] = (live && row_ok[k] && c0_ok) ? acc[k][1] * wsc : 0.0;
-                wk[k][1] = (live && row_ok[k] && c1_ok) ? acc[k][0] * wsc : 0.0;
+                wk[k][0] = (live && row_ok[k] && c0_ok) ? acc[k][1] * sc : 0.0;
+                wk[k][1] = (live && row_ok[k] && c1_ok) ? acc[k][0] * sc : 0.0;
             }
         }
         // -- contraction: node rows r_k = p_k + 1 at node columns c1 (this unit's second) and c2 (the previous unit's first).
         //    The y points are read from the ring a second time: holding them across the sweep costs 4 ND VGPRs
         {
-            const unsigned ya = my_y + (unsigned)(yslab * RY_SLAB + ((u & 7) << 4));
             asm volatile("" ::: "memory");
             lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
+        d2_t car[5];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
+        if constexpr (YSIDE) lds_read_carry(car, yc_rd);
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
             const double u0 = k == 0 ? wup0[0] : wk[(k + RC - 1) % RC][0];     // cells of coarse row p_k + 1
@@ -439,18 +483,56 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double g2 = k == 0 ? GabvP : GownP[(k + RC - 1) % RC];       // G[r_k][c2]
             const double V1 = ((wk[k][0] + u1) - wk[k][1]) - u0;
             const double V2 = ((wk[k][1] + u2) - wkP[k]) - u1;
-            const double cv1 = V1 * g1, cv2 = V2 * g2;
+            const double cb1 = V1 * g1, cb2 = V2 * g2;
+            const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
             cs[k] += cv1 + cv2;
 #pragma unroll
             for (int j = 0; j < ND; ++j) accd[k][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[k][j]));
+            if constexpr (YSIDE) {     // x of node row r_k: the lane above's last row (k = 0) or this lane's row k - 1
+                car[0][0] += cb1; car[0][1] += cb2;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) {
+                    const double xj = k == 0 ? xup[j] : xr[(k + RC - 1) % RC][j];
+                    car[1 + j][0] = fma(cb1, xj, car[1 + j][0]);
+                    car[1 + j][1] = fma(cb2, xj, car[1 + j][1]);
+                }
+            }
         }
         {   // node row p_{RC-1} from its own cells only (V[0][c] = w[0][c] - w[0][c-1]): node row 0 on the bottom lane
             const double V1 = wk[RC - 1][1] - wk[RC - 1][0];
             const double V2 = wkP[RC - 1] - wk[RC - 1][1];
-            const double cv1 = V1 * Gown[RC - 1][1], cv2 = V2 * GownP[RC - 1];
+            const double cb1 = V1 * Gown[RC - 1][1], cb2 = V2 * GownP[RC - 1];
+            const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
             cs[RC] += cv1 + cv2;
 #pragma unroll
             for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+            if constexpr (YSIDE) {
+                // what this lane hands down: the sums over the node rows r_k so far
+                lds_write_carry(yc_base + (unsigned)(lane << 4), car);
+                if (is_bot) {   // the bottom lane completes them with node row 0 and stores the two columns of its pair
+                    asm volatile("");
+                    car[0][0] += cb1; car[0][1] += cb2;
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) {
+                        car[1 + j][0] = fma(cb1, xr[RC - 1][j], car[1 + j][0]);
+                        car[1 + j][1] = fma(cb2, xr[RC - 1][j], car[1 + j][1]);
+                    }
+                    // node column c1 = 2uo + 1 of this pair; c2 = 2uo + 2, which at the pair's first step (uo = NUp - 1) is
+                    // node column 0 of the pair BEFORE
+                    double *d1 = yp_cur ? yp_cur + (2 * uo + 1) * YW : nullptr;
+                    double *d2p = u == 0 ? yp_prev : (yp_cur ? yp_cur + (2 * uo + 2) * YW : nullptr);
+                    if (d1) {
+                        *reinterpret_cast<d2_t *>(d1) = d2_t{car[0][0], 0.0};
+                        *reinterpret_cast<d2_t *>(d1 + 2) = d2_t{car[1][0], car[2][0]};
+                        *reinterpret_cast<d2_t *>(d1 + 4) = d2_t{car[3][0], car[4][0]};
+                    }
+                    if (d2p) {
+                        *reinterpret_cast<d2_t *>(d2p) = d2_t{car[0][1], 0.0};
+                        *reinterpret_cast<d2_t *>(d2p + 2) = d2_t{car[1][1], car[2][1]};
+                        *reinterpret_cast<d2_t *>(d2p + 4) = d2_t{car[3][1], car[4][1]};
+                    }
+                }
+            }
         }
         // -- histories for the next macro-step (and for the lane below, which reads lastOwn / lastW at its top)
         wupP = wup0[0];
@@ -461,9 +543,10 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         for (int j = 0; j < ND; ++j) yP[j] = yv[j][0];
         lastOwn[0] = Gown[RC - 1][0]; lastOwn[1] = Gown[RC - 1][1];
         lastW[0] = wk[RC - 1][0]; lastW[1] = wk[RC - 1][1];
+        sx_d = sx;
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P) {
+        if (u == NUp - 1 && prm.err && valid) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -472,22 +555,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         }
 
         // -- close the step
-        {
-            double tsc[1];
-            async_wait<0>(ncol, pcol);
-            async_wait<0>(tsc, pscale);
-            fix_edges(nu, ncol);
-            if (nu == 0) nscale = (nps >= 0 && nps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
-        }
-        u = nu;
-        ps = nps;
+        u += 1;
+        if (u == NUp) { u = 0; ps += 1; }
         if (((t + 1) & 7) == lam7) {
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
         }
-        if (((t + 1) & 7) == 0) {
-            issue_y();
-            issue_x();
         }
     }
     if (chk_pair >= 0)
@@ -511,9 +584,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE, int ND>
+template <int DY, int RC, bool FULLWAVE, int ND, bool YSIDE>
 int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND>;
+    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YSIDE>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -524,10 +597,13 @@ int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
 
 // gpart viewed as [A][B / PPG][*rows_out][*outw_out] and summed over the chunk axis gives, per node row r < M of x_a,
 // cs = that[a][r][0] and accd = that[a][r][2 .. 2 + D): dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == nullptr: query.
+// ypart (nullable; Gram, D <= 4): [A B][*ycols_out][6] per pair and node column c of y_b: S0 = that[..][0], S1 = that[..][2 .. 2 + D),
+// without the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1).
 namespace {
 int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                               double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                              int *ppg_out, int *rows_out, int *outw_out, int64_t *rows_per_launch, int64_t force_nch, hipStream_t s) {
+                              double *ypart, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out, int64_t *rows_per_launch,
+                              int64_t force_nch, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY < 1 || DY > 2 || B < 0 || g.naive || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges; the sweep uses the same lanes and units
@@ -535,16 +611,21 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
     if (g.Nc > 2 * NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
-    if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
+    if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC + 1) return SK_ERR_UNSUPPORTED;   // (+ 1: the node row above the first lane's)
     const int ND = D <= 4 ? 4 : 8;
-    if (ND == 8 && DY == 1 && !env_int("SK_ADJR_ALL", 0)) return SK_ERR_UNSUPPORTED;   // two coarse rows of 8 dims per lane: 77 VGPRs spilled
+    if (ND == 8 && DY == 1 && !knobs().adjr_all) return SK_ERR_UNSUPPORTED;   // two coarse rows of 8 dims per lane: 77 VGPRs spilled
+    const bool yside = ypart != nullptr || ycols_out != nullptr;
+    if (yside && (ND != 4 || B <= 0)) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16;
+    const int xslab = DY == 1 ? XSlab<2, 4>::BYTES : XSlab<1, 4>::BYTES;
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * xslab) + (size_t)2 * G * (4 * S + 1) * 16 +
+                             (ypart ? 5 * YC_PIECE : 0);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
-    const int wpc = env_int("SK_ADJR_WPC", 8);
-    const int64_t max_groups = 256LL * wpc * G;
+    const int n_cu = device_cu_count();
+    const int wpc = knobs().adjr_wpc > 0 ? knobs().adjr_wpc : 8;
+    const int64_t max_groups = (int64_t)n_cu * wpc * G;
     int64_t PPG = B > 0 ? B : 1;
     for (int64_t d = 1; d <= B; ++d)
         if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
@@ -553,8 +634,8 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         // Shares by wave age rank (ChunkSplit) need a launch that fills the chip exactly, with the chunks of an a a multiple of
         // the ranks: when the equal split does not give that, the caller sweeps the rows in several such launches.
         *rows_per_launch = 0;
-        const int wpb = wave_group(lds_bytes, max_groups / G, "SK_ADJR_WPB").wpb;
-        const int64_t gpr = (int64_t)device_cu_count() * wpb * G;
+        const int wpb = wave_group(lds_bytes, max_groups / G, knobs().adjr_wpb).wpb;
+        const int64_t gpr = (int64_t)n_cu * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
         const int64_t nch = B > 0 ? B / PPG : 1;
         if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
@@ -570,43 +651,53 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC + 1;
     if (outw_out) *outw_out = OUTW;
+    if (ycols_out) *ycols_out = 2 * NUp;
     if (!gpart) return SK_OK;
     if (gpart_doubles < (size_t)groups * (L * RC + 1) * OUTW) return SK_ERR_WORKSPACE;
     const int64_t waves = (groups + G - 1) / G;
 
     AdjRbfParams prm;
-    prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.err = err;
+    prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.err = err; prm.Ypart = ypart;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.PPG = (int)PPG;
     prm.inv_sigma = inv_sigma;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + 1;    // + 1: node column 0 of the last pair completes one step later
-    prm.wg = wave_group(lds_bytes, waves, "SK_ADJR_WPB");
-    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), "SK_ADJR_RANK_W");
+    prm.wg = wave_group(lds_bytes, waves, knobs().adjr_wpb);
+    prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, n_cu, knobs().adjr_rank_w);
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
-    if (DY == 1) {
-        if (ND == 4) return full ? launch_adjr<1, 2, true, 4>(prm, lds_block, s) : launch_adjr<1, 2, false, 4>(prm, lds_block, s);
-        return full ? launch_adjr<1, 2, true, 8>(prm, lds_block, s) : launch_adjr<1, 2, false, 8>(prm, lds_block, s);
+    if (ypart) {
+        if (DY == 1) return full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);
+        return full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
     }
-    if (ND == 4) return full ? launch_adjr<2, 1, true, 4>(prm, lds_block, s) : launch_adjr<2, 1, false, 4>(prm, lds_block, s);
-    return full ? launch_adjr<2, 1, true, 8>(prm, lds_block, s) : launch_adjr<2, 1, false, 8>(prm, lds_block, s);
+    if (DY == 1) {
+        if (ND == 4) return full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
+        return full ? launch_adjr<1, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 8, false>(prm, lds_block, s);
+    }
+    if (ND == 4) return full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
+    return full ? launch_adjr<2, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 8, false>(prm, lds_block, s);
 }
 }  // namespace
 
 int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                         int *ppg_out, int *rows_out, int *outw_out, hipStream_t s) {
-    int ppg = 0, rows = 0, outw = 0;
+                         double *ypart, size_t ypart_doubles, int want_yside, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out,
+                         hipStream_t s) {
+    int ppg = 0, rows = 0, outw = 0, ycols = 0;
     int64_t per_launch = 0;
-    int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, &ppg, &rows, &outw, &per_launch, 0, s);
+    const bool yside = want_yside || ypart;
+    int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, nullptr, &ppg, &rows, &outw,
+                                       yside ? &ycols : nullptr, &per_launch, 0, s);
     if (rc != SK_OK) return rc;
     if (ppg_out) *ppg_out = ppg;
     if (rows_out) *rows_out = rows;
     if (outw_out) *outw_out = outw;
+    if (ycols_out) *ycols_out = ycols;
     if (!gpart) return SK_OK;
+    if (ypart && ypart_doubles < (size_t)g.P * ycols * YW) return SK_ERR_WORKSPACE;
     if (per_launch <= 0 || B <= 0)
-        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, gpart, gpart_doubles, err, nullptr, nullptr, nullptr,
-                                         nullptr, B > 0 ? B / ppg : 0, s);
+        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, gpart, gpart_doubles, err, ypart, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that gpart keeps one layout)
     const int64_t nch = B / ppg;
     const int64_t slot = (int64_t)rows * outw;
@@ -619,7 +710,8 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
         gs.P = An * B;
         rc = launch_adj_fused_rbf_rows(Xr + a0 * Mrows * RFD, Yt, An, B, Mrows, Ncp, D, gs, inv_sigma, edges + a0 * B * Epair,
                                        scale ? scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
-                                       err ? err + a0 * B : nullptr, nullptr, nullptr, nullptr, nullptr, nch, s);
+                                       err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * YW : nullptr, nullptr, nullptr,
+                                       nullptr, nullptr, nullptr, nch, s);
         if (rc != SK_OK) return rc;
     }
     return SK_OK;

@@ -1,7 +1,5 @@
 // sk_wave_common.h -- device helpers shared by the tiled wavefront kernels (sk_wave.hip, sk_wave_adj.hip).
 #pragma once
-#include <cstdlib>
-
 #include "sk_internal.h"
 
 namespace sk {
@@ -18,6 +16,21 @@ __device__ __forceinline__ double dpp_shr1(double v, double fill) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// lane l receives lane l-1's value; lane 0 receives 0.0 (bound_ctrl: no `old` operand to set up, two instructions in all)
+__device__ __forceinline__ double dpp_shr1_zero(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// lane l receives lane l-1's value; lane 0 receives 1.0 (the low word by bound_ctrl, the high word from `old`: three instructions)
+__device__ __forceinline__ double dpp_shr1_one(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0x3ff00000, hi, 0x138, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -247,11 +260,7 @@ template <int DY> struct Tile {
     static constexpr int R = RC << DY;                         // fine rows per lane
 };
 
-// Tuning knobs are read from the environment at launch (see the launchers).
-inline int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
+// (tuning knobs: struct Knobs / knobs() in sk_internal.h)
 
 // ---- hand-managed asynchronous global loads (sk_wave_adj.hip, sk_wave_adj_fused.hip) ----------------------------------
 // Asynchronous 8-byte global loads into registers.  The compiler must never touch a destination register between the
@@ -334,8 +343,8 @@ struct WaveGroup {
 };
 
 // host: waves per workgroup, and a resident-waves-per-CU figure rounded to whole workgroups
-inline WaveGroup wave_group(size_t lds_per_wave, int64_t n_waves, const char *env_name, int dflt = 4) {
-    int wpb = env_int(env_name, dflt);
+inline WaveGroup wave_group(size_t lds_per_wave, int64_t n_waves, int knob, int dflt = 4) {
+    int wpb = knob > 0 ? knob : dflt;
     if (wpb < 1) wpb = 1;
     if (wpb > 4) wpb = 4;
     while (wpb > 1 && (size_t)wpb * lds_per_wave > 160 * 1024) --wpb;
@@ -360,17 +369,15 @@ __device__ __forceinline__ int64_t wave_slot(const WaveGroup &wg, char *lds_bloc
 // (workgroup i, i + #CU, i + 2 #CU share a CU; verified from HW_ID on all 1024 SIMDs), so a wave's age rank is
 // blockIdx / #CU, and the launchers give rank r the fraction w[r] of the pairs, chosen so that all ranks finish together.
 // A wrong guess about placement costs speed, never correctness: the split is a partition of the pairs whatever the ranks.
-// compute units of the current device (256 on MI355X; the launchers size their persistent launches for that part, and on any
-// other count the shares below fall back to equal ones by themselves: the launch no longer consists of whole ranks)
-inline int device_cu_count() {
-    static int n[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (n[dev] == 0) {
-        int v = 0;
-        n[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
-    }
-    return n[dev];
+// (device_cu_count(): 256 on MI355X; the launchers size their persistent launches by it, and on a launch that does not consist
+// of whole ranks the shares below fall back to equal ones by themselves)
+// a family's SK_*_RANK_W (else the global SK_RANK_W) replaces the default shares when it names exactly nr ranks
+inline void rank_override(const RankW &family, int nr, double (&w)[4]) {
+    const RankW &o = family.n > 0 ? family : knobs().rank_w;
+    double tot = 0;
+    for (int r = 0; r < o.n && r < 4; ++r) tot += o.w[r];
+    if (o.n == nr && tot > 0)
+        for (int r = 0; r < nr; ++r) w[r] = o.w[r] / tot;
 }
 
 struct RankSplit {
@@ -383,7 +390,7 @@ struct RankSplit {
 // host: split P pairs over `waves` waves of G lane groups each.  `resident` is the number of waves the launch keeps on the
 // chip at once (#CU * waves per CU); ranks are only used when the launch fills it (waves == resident) with whole workgroups.
 // `table` (optional): the kernel family's own default shares, rows indexed by the number of ranks.
-inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, const char *env_name,
+inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, const RankW &family,
                             const double (*table)[4] = nullptr) {
     RankSplit rs{};
     const int64_t per = (P + waves * G - 1) / (waves * G);
@@ -392,17 +399,10 @@ inline RankSplit rank_split(int64_t P, int G, int64_t waves, int64_t resident, i
     const int nr = wpr > 0 ? (int)(waves / wpr) : 0;
     if (waves != resident || nr < 2 || nr > 4 || (int64_t)nr * wpr != waves) return rs;
     // measured finishing times with equal shares, per number of ranks (see above); SK_RANK_W="50,30,20" overrides (per cent)
-    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+    static constexpr double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
     double w[4];
     for (int r = 0; r < 4; ++r) w[r] = table ? table[nr][r] : dflt[nr][r];
-    const char *e = getenv(env_name);
-    if (!e || !*e) e = getenv("SK_RANK_W");
-    if (e && *e) {
-        double v[4] = {0, 0, 0, 0}, tot = 0;
-        int n = 0;
-        for (const char *q = e; *q && n < 4; ++n) { v[n] = atof(q); tot += v[n]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        if (n == nr && tot > 0) for (int r = 0; r < nr; ++r) w[r] = v[r] / tot;
-    }
+    rank_override(family, nr, w);
     const int64_t T = (P + wpr * G - 1) / (wpr * G);   // pairs per lane group summed over the ranks of one SIMD slot
     if (T < 4 * nr) return rs;                          // too few pairs for the split to matter
     int64_t used = 0;
@@ -442,7 +442,7 @@ struct ChunkSplit {
     int off[4];          // first pair (within the B of an a) of rank r's chunks
 };
 
-inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, const char *env_name) {
+inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, const RankW &family) {
     ChunkSplit cs{};
     const int64_t nch = B > 0 ? B / PPG : 1;
     cs.nr = 1; cs.cpr = (int)nch; cs.nch = (int)nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = (int)PPG; cs.off[0] = 0;
@@ -450,17 +450,10 @@ inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_gro
     if (B <= 0 || gpr <= 0 || A * nch != max_groups || max_groups % gpr) return cs;
     const int nr = (int)(max_groups / gpr);
     if (nr < 2 || nr > 4 || nch % nr || PPG < 4 * nr) return cs;
-    static const double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+    static constexpr double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
     double w[4];
     for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
-    const char *e = getenv(env_name);
-    if (!e || !*e) e = getenv("SK_RANK_W");
-    if (e && *e) {
-        double v[4] = {0, 0, 0, 0}, tot = 0;
-        int n = 0;
-        for (const char *q = e; *q && n < 4; ++n) { v[n] = atof(q); tot += v[n]; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        if (n == nr && tot > 0) for (int r = 0; r < nr; ++r) w[r] = v[r] / tot;
-    }
+    rank_override(family, nr, w);
     const int cpr = (int)(nch / nr);
     const int64_t T = B / cpr;            // pairs of one a per "column" of ranks: sum of the sizes
     int64_t used = 0;

@@ -439,7 +439,7 @@ template <typename T>
 int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld, const Geom &g, T *out_k, T *out_kd,
                       T *out_kdd, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    const int PF = env_int("SK_DERIV_PF", 3) == 5 ? 5 : 3;   // prefetch distance (macro-steps)
+    const int PF = knobs().deriv_pf == 5 ? 5 : 3;   // prefetch distance (macro-steps)
     const int DY = g.dyadic;
     if (DY > (sizeof(T) == 8 ? 2 : 1)) return SK_ERR_UNSUPPORTED;   // register budget: S = CW << DY columns x 3 states
     if (((reinterpret_cast<uintptr_t>(inc) | reinterpret_cast<uintptr_t>(inc_d) | reinterpret_cast<uintptr_t>(inc_dd)) & 15) ||
@@ -468,20 +468,20 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
     if (waves_per_cu > 8) waves_per_cu = 8;
-    const int wpc_env = env_int("SK_DERIV_WPC", 0);
+    const int wpc_env = knobs().deriv_wpc;
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
+    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (g.P + G - 1) / G;
     if (waves > max_waves) waves = max_waves;
     const int64_t pair_bytes = (int64_t)g.Mc * ld * (int64_t)sizeof(T);
     if (pair_bytes > (1LL << 30)) return SK_ERR_UNSUPPORTED;
     // shares by wave age rank (see sk_wave_adj.hip's launcher); this kernel streams three increment arrays: the mild shares
-    static const double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};
-    WaveGroup wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
-    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W", shares);
-    if (rs.nranks > 1 && (int64_t)rs.cnt[0] * G * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W");
+    static constexpr double shares[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.58, 0.42, 0, 0}, {1 / 3., 1 / 3., 1 / 3., 0}, {0.25, 0.25, 0.25, 0.25}};
+    WaveGroup wg = wave_group(lds_bytes, waves, knobs().deriv_wpb);
+    RankSplit rs = rank_split(g.P, G, waves, max_waves, wg.wpb, device_cu_count(), knobs().deriv_rank_w, shares);
+    if (rs.nranks > 1 && (int64_t)rs.cnt[0] * G * pair_bytes >= (1LL << 31)) rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), knobs().deriv_rank_w);
     int64_t PPG = rs.cnt[0];
     if (rs.nranks == 1) {
         waves = (g.P + PPG * G - 1) / (PPG * G);
@@ -490,8 +490,8 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
             if (PPG < 1) return SK_ERR_UNSUPPORTED;
             waves = (g.P + PPG * G - 1) / (PPG * G);
         }
-        wg = wave_group(lds_bytes, waves, "SK_DERIV_WPB");
-        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), "SK_DERIV_RANK_W");
+        wg = wave_group(lds_bytes, waves, knobs().deriv_wpb);
+        rs = rank_split(g.P, G, waves, -1, wg.wpb, device_cu_count(), knobs().deriv_rank_w);
         rs.cnt[0] = (int)PPG;
         rs.base[1] = PPG * waves * G;
     }

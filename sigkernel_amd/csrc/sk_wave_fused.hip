@@ -690,24 +690,25 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND>;
     // persistent waves: all of them must be resident at once, so the variant's VGPR count caps the waves per SIMD
     // (512 VGPRs per lane and SIMD; a variant over 168 holds two waves per SIMD, not three)
-    static int vgprs = 0;
-    if (vgprs == 0) {
+    // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
+    // thread-safely, at the variant's first launch -- not mutable library state)
+    static const int vgprs = [&] {
         hipFuncAttributes attr;
-        vgprs = hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 128;
-    }
+        return hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 128;
+    }();
     int waves_per_cu = pl.waves_per_cu;
     const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
     if (waves_per_cu > by_regs) waves_per_cu = by_regs;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
+    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (pl.P + pl.G - 1) / pl.G;
     if (waves > max_waves) waves = max_waves;
-    prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
-    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, device_cu_count(), "SK_FUSED_RANK_W");
+    prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
+    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, device_cu_count(), knobs().fused_rank_w);
     int64_t PPG = prm.rs.cnt[0];   // the largest share
     if (prm.rs.nranks == 1) {      // equal shares: no more waves than the pairs need
         waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);
-        prm.wg = wave_group(pl.lds_bytes, waves, "SK_FUSED_WPB");
+        prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
     }
     if (PPG > 0x3fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
     prm.PPG = (int)PPG;
@@ -772,7 +773,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
-    const int wpc_env = env_int("SK_FUSED_WPC", 0);
+    const int wpc_env = knobs().fused_wpc;
     // measured on the headline (512 x 512 pairs, len 128, dim 8, d = 1) with four-wave workgroups, i.e. the same number of
     // waves on every SIMD: 8 waves/CU 5.66 ms, 12: 5.30, 13: 6.65 (single-wave workgroups, whose placement is uneven:
     // 8: 7.58, 10: 6.31, 12: 6.77).  d = 0 (four coarse rows per lane): 4: 4.60 ms, 8: 3.33, 12: 3.32; d = 2: 8: 3.31,

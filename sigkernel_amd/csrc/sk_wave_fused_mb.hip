@@ -618,18 +618,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
 template <typename TO, int DY, bool Y32, int KIND, int FD>
 int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
     auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD>;
-    static int vgprs = 0;
-    if (vgprs == 0) {
+    // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
+    // thread-safely, at the variant's first launch -- not mutable library state)
+    static const int vgprs = [&] {
         hipFuncAttributes attr;
-        vgprs = hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
-    }
+        return hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
+    }();
     const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
     if (waves_per_cu > by_regs) waves_per_cu = by_regs;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = 256LL * waves_per_cu;
+    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = P < max_waves ? P : max_waves;
-    prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
-    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, device_cu_count(), "SK_FUSEDMB_RANK_W");
+    prm.wg = wave_group(lds_bytes, waves, knobs().fusedmb_wpb);
+    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, device_cu_count(), knobs().fusedmb_rank_w);
     int64_t PPW = prm.rs.cnt[0];   // the largest share
     if (prm.rs.nranks == 1) waves = (P + PPW - 1) / PPW;
     if (PPW > 0x3fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
@@ -637,7 +638,7 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     prm.PPW = (int)PPW;
     prm.n_steps = (int)(PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0));
     prm.ws = ws;
-    if (prm.rs.nranks == 1) prm.wg = wave_group(lds_bytes, waves, "SK_FUSEDMB_WPB");
+    if (prm.rs.nranks == 1) prm.wg = wave_group(lds_bytes, waves, knobs().fusedmb_wpb);
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
@@ -668,7 +669,7 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false) {
     pl.lds_bytes = (size_t)(MB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
     pl.ws_stride = (int64_t)(pl.NUp + 8) * (pl.S + (kind == 1 ? 2 : 0));   // the row + a chunk of ones
     int wpc = (int)((160 * 1024) / pl.lds_bytes);
-    const int wpc_env = env_int("SK_FUSEDMB_WPC", 0);
+    const int wpc_env = knobs().fusedmb_wpc;
     if (wpc > 12) wpc = 12;
     if (wpc_env > 0) wpc = wpc < wpc_env ? wpc : wpc_env;
     else if (wpc > 4) wpc &= ~3;
@@ -698,7 +699,7 @@ int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y3
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
     const MbPlan pl = mb_plan(kind, Mc, Nc, dyadic, D);
     if (!pl.ok || P <= 0) return 0;
-    const int64_t max_waves = 256LL * 16;   // an upper bound on the resident waves whatever the variant's register count
+    const int64_t max_waves = (int64_t)device_cu_count() * 16;   // an upper bound on the resident waves whatever the variant's register count
     const int64_t waves = P < max_waves ? P : max_waves;
     return (size_t)waves * (size_t)pl.ws_stride * sizeof(double);
 }

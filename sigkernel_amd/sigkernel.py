@@ -337,6 +337,68 @@ def _same_storage(Xd, Yd):
     return Xd.shape == Yd.shape and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()
 
 
+def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, budget):
+    """dL/dX of compute_Gram(X, X, sym=True) from the triangular row blocks through the FUSED RBF adjoint with the
+    second-argument sums (sk_rbf_adjoint_fused_f64 with ypart): per row block r0:r1 ONE launch over the solved pairs
+    (a in r0:r1, b >= r0) gives the first-argument rows r0:r1 and, per pair, the sums that what the unsolved mirror pairs
+    (b, a), b >= r1, owe to rows r1: is folded from (d1 K(x_b, x_a) = d2 K(x_a, x_b): the scheme is symmetric).  Neither the
+    increments nor W exist in HBM.  None when the kernel does not cover the case, the forward kept no edges, or some pair failed
+    its self-check (looked at ONCE, for all blocks); the caller then takes the unfused triangular route."""
+    if not (_fused_rbf_adjoint_ok(be, static_kernel, Xd, Xd, dyadic, naive, True) and Xd.dtype == torch.float64
+            and hasattr(be, "second_argument_gradient")):
+        return None
+    A, M = Xd.shape[0], Xd.shape[1]
+    sigma = float(static_kernel.sigma)
+    grad = torch.zeros_like(Xd)
+    residuals = []
+    for r0, r1, kept in sym_blocks:
+        if not kept or len(kept) != 1 or kept[0][2] is None or kept[0][:2] != (0, r1 - r0):
+            return None
+        Xc = Xd[r0:].contiguous()
+        nb = Xc.shape[0]
+        # rows per launch by the memory of the second-argument sums (48 bytes per pair and node column)
+        per_row = 64 * nb * (M + 16)
+        edges = kept[0][2]
+        per = edges.numel() // (r1 - r0)
+        for a0, a1 in _tiles(r1 - r0, per_row, budget):
+            Xt = Xd[r0 + a0:r0 + a1].contiguous()
+            res = be.rbf_adjoint_fused(Xt, Xc, sigma, dyadic, edges[a0 * per:a1 * per], go[r0 + a0:r0 + a1, r0:].reshape(-1).contiguous(),
+                                       gram=True, yside=r1 < A)
+            if res is None:
+                return None
+            grad[r0 + a0:r0 + a1] += res[0]
+            residuals.append(res[1])
+            if r1 < A:   # upstream gradient of the mirror pair (b, a) is go[b, a]
+                grad[r1:] += be.second_argument_gradient(res[2], Xc, sigma, go[r0:, r0 + a0:r0 + a1].t(), r1 - r0)
+            del res
+    worst = torch.stack([r.reshape(()) for r in residuals]).max()
+    if not bool(worst <= be.ADJ_RESIDUAL_TOL):      # also False for NaN
+        return None
+    return grad
+
+
+def _sym_unfused_gradient(be, kind, param, Xd, go, dyadic, naive, sym_blocks, budget):
+    """The same through sk_static_increments -> sk_solve_adj -> sk_static_adjoint (first argument) + sk_static_adjoint2 (second
+    argument of the SAME W, weighted by the transposed upstream gradient); owns the stored-grid rescue."""
+    A, M, N = Xd.shape[0], Xd.shape[1], Xd.shape[1]
+    grad_X = torch.zeros_like(Xd)
+    for r0, r1, kept in sym_blocks:
+        Xr, Xc = Xd[r0:r1].contiguous(), Xd[r0:].contiguous()
+        go_blk = go[r0:r1, r0:].contiguous()
+        go_t = go[r0:, r0:r1].t().contiguous()         # [a, b] -> upstream gradient of the mirror pair (b, a)
+        per_row = 3 * Xc.shape[0] * M * N * Xd.element_size()
+        for a0, a1, edges in _edge_tiles(kept, r1 - r0, per_row, budget):
+            Xt = Xr[a0:a1].contiguous()
+            inc = be.static_increments(kind, param, Xt, Xc, True)
+            _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
+            del inc
+            grad_X[r0 + a0:r0 + a1] += be.static_adjoint(kind, param, Xt, Xc, W, go_blk[a0:a1].contiguous(), True)
+            if r1 < A:
+                grad_X[r1:] += be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
+            del W
+    return grad_X
+
+
 class _SigKernelGram(torch.autograd.Function):
     """Gram matrix k_sig(x_i, y_j) -- the reference's ``_SigKernelGram`` (sigkernel.py:347-416)."""
 
@@ -393,20 +455,11 @@ class _SigKernelGram(torch.autograd.Function):
             go = grad_output.to(X.dtype).contiguous()
             kind, param = _fused_static(sk, True)
             budget = _budget(X.device, ctx.workspace_bytes)
-            for r0, r1, kept in ctx.sym_blocks:
-                Xr, Xc = Xd[r0:r1].contiguous(), Xd[r0:].contiguous()
-                go_blk = go[r0:r1, r0:].contiguous()
-                go_t = go[r0:, r0:r1].t().contiguous()         # [a, b] -> upstream gradient of the mirror pair (b, a)
-                per_row = 3 * Xc.shape[0] * M * N * X.element_size()
-                for a0, a1, edges in _edge_tiles(kept, r1 - r0, per_row, budget):
-                    Xt = Xr[a0:a1].contiguous()
-                    inc = be.static_increments(kind, param, Xt, Xc, True)
-                    _, W = be.solve_adj(inc, d, naive, edges=edges) if edges is not None else be.solve_adj(inc, d, naive)
-                    del inc
-                    grad_X[r0 + a0:r0 + a1] += be.static_adjoint(kind, param, Xt, Xc, W, go_blk[a0:a1].contiguous(), True)
-                    if r1 < A:
-                        grad_X[r1:] += be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
-                    del W
+            g_fused = _sym_fused_gradient(be, sk, Xd, go, d, naive, ctx.sym_blocks, budget)
+            if g_fused is not None:
+                grad_X = g_fused
+            else:
+                grad_X = _sym_unfused_gradient(be, kind, param, Xd, go, d, naive, ctx.sym_blocks, budget)
             ctx.sym_blocks = None
         elif M >= 2 and N >= 2 and A > 0 and B > 0:
             go = grad_output.to(X.dtype).contiguous()

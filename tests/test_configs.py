@@ -447,6 +447,44 @@ def test_fused_rbf_adjoint_against_the_unfused_route(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_fused_rbf_adjoint_second_argument_sums():
+    """The same sweep's SECOND-argument sums (sk_rbf_adjoint_fused_f64 with ypart: per pair and node column of y_b, carried
+    down the lanes and stored by the bottom lane) folded with an arbitrary per-pair weight, against sk_static_adjoint2 on the
+    unfused route's W, on 60 random shapes (dyadic 1..2, dims 1..4, partial lane groups, b0 > 0); and the first-argument
+    gradient of the same launch against the plain one."""
+    be = _lib.get_backend()
+    rng = np.random.default_rng(7)
+    n = 0
+    for it in range(60):
+        d = int(rng.integers(1, 3))
+        cap = 64 * (4 >> d)
+        M = int(rng.integers(2, cap + 1)) if it % 4 else cap
+        N = int(rng.integers(2, 150)) if it % 5 else M
+        A, B, D = int(rng.integers(1, 20)), int(rng.integers(1, 30)), int(rng.integers(1, 5))
+        sig = float(rng.uniform(0.5, 1.5))
+        gen = torch.Generator().manual_seed(900 + it)
+        X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+        go = torch.randn(A * B, generator=gen, dtype=torch.float64).to(DEV) if it % 3 else None
+        w2 = torch.randn(A, B, generator=gen, dtype=torch.float64).to(DEV)
+        b0 = int(rng.integers(0, B))
+        res = be.solve_fwd_fused_rbf(X, Y, sig, d, False, True, keep_edges=True)
+        assert res is not None and res[1] is not None
+        got = be.rbf_adjoint_fused(X, Y, sig, d, res[1], go, gram=True, yside=True)
+        if got is None:
+            continue
+        plain = be.rbf_adjoint_fused(X, Y, sig, d, res[1], go, gram=True)
+        assert rel_err(got[0].cpu().numpy(), plain[0].cpu().numpy()) <= 1e-12, (it, d, A, B, M, N, D)
+        inc = be.static_increments(1, sig, X, Y, True)
+        _, W = be.solve_adj(inc, d, False, edges=res[1])
+        want = be.static_adjoint2(1, sig, X, Y, W, w2, b0)
+        gy = be.second_argument_gradient(got[2], Y, sig, w2, b0)
+        assert gy.shape == want.shape
+        assert rel_err(gy.cpu().numpy(), want.cpu().numpy()) <= max(1e-10, 10 * float(got[1])), (it, d, A, B, M, N, D, b0)
+        n += 1
+    assert n >= 40
+
+
+@pytest.mark.gpu
 def test_fused_rbf_adjoint_is_what_the_api_runs(monkeypatch):
     """compute_Gram / compute_kernel gradients with RBFKernel on paths of dim <= 4 go through the fused adjoint and agree with the
     unfused route and with the oracle's closed form; compute_mmd (triangular K_XX + fused K_XY) agrees with the reference fixture."""

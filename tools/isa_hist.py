@@ -17,14 +17,22 @@ def main():
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     body = lines[start:end + 1]
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\S+):", l)] if m}
-    best = (0, 0, 0)
+    loops = []
     for i, l in enumerate(body):
         m = re.match(r"\s+s_cbranch\S*\s+(\.LBB\S+)|\s+s_branch\s+(\.LBB\S+)", l)
         if m:
             tgt = labels.get(m.group(1) or m.group(2))
-            if tgt is not None and tgt < i and i - tgt > best[0]:
-                best = (i - tgt, tgt, i)
-    _, lo, hi = best
+            if tgt is not None and tgt < i:
+                loops.append((i - tgt, tgt, i))
+    # the hot loop: the SMALLEST loop that still holds most of the kernel's fp64 arithmetic (--outer: the largest loop)
+    def nf64(lo, hi):
+        return sum(1 for l in body[lo:hi + 1] if re.match(r"\s+v_\S*f64", l))
+    tot64 = nf64(0, len(body) - 1)
+    loops.sort()
+    if "--outer" in sys.argv or not loops:
+        _, lo, hi = loops[-1] if loops else (0, 0, len(body) - 1)
+    else:
+        _, lo, hi = next((lp for lp in loops if nf64(lp[1], lp[2]) >= 0.6 * tot64), loops[-1])
     h = collections.Counter()
     for l in body[lo:hi + 1]:
         m = re.match(r"\s+([a-z_0-9]+)", l)
