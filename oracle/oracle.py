@@ -50,6 +50,9 @@ def _load():
                                                      d, d, d, d, ctypes.c_int]
         lib.sk_oracle_solve_deriv_coarse.restype = ctypes.c_int
         lib.sk_oracle_max_threads.restype = ctypes.c_int
+        lib.sk_oracle_gram_pipeline.argtypes = [d, ctypes.c_int64, ctypes.c_int, d, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, d, ctypes.c_int]
+        lib.sk_oracle_gram_pipeline.restype = ctypes.c_int
         _lib = lib
     return _lib
 
@@ -163,6 +166,20 @@ def gram_forward(X, Y, static_kernel, dyadic, naive=False, nthreads=1):
     """_SigKernelGram.forward (sigkernel.py:350-401): torch (A,M,D),(B,N,D) -> numpy (A,B)."""
     G = static_kernel.Gram_matrix(X.detach().double().cpu(), Y.detach().double().cpu()).numpy()
     return solve_coarse(increments(G), dyadic, naive, nthreads=nthreads)
+
+
+def gram_pipeline(X, Y, kind, param, dyadic, naive=False, nthreads=1):
+    """The all-cores CPU baseline of bench.py: static kernel (kind 0 linear / 1 rbf with sigma = param), increments and PDE
+    solve per pair inside one OpenMP region (sk_oracle_gram_pipeline).  numpy (A,M,D), (B,N,D) -> (A,B)."""
+    X, Y = _c(X), _c(Y)
+    A, M, D = X.shape
+    B, N = Y.shape[0], Y.shape[1]
+    out = np.empty((A, B), dtype=np.float64)
+    rc = _load().sk_oracle_gram_pipeline(_p(X), A, M, _p(Y), B, N, D, int(kind), float(param), int(dyadic), int(naive), _p(out),
+                                         int(nthreads))
+    if rc:
+        raise RuntimeError("sk_oracle_gram_pipeline failed (%d)" % rc)
+    return out
 
 
 def gram_grad_points(X, Y, static_kernel, dyadic, naive=False, nthreads=1):

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #ifdef _OPENMP
+#include <math.h>
 #include <omp.h>
 #endif
 
@@ -133,6 +134,62 @@ int sk_oracle_solve_coarse(const double *inc_c, int64_t P, int Mc, int Nc, int d
             if (out_final) out_final[l] = prev[NN];
         }
         free(rows);
+    }
+    return fail;
+}
+
+/* The whole Gram pipeline per pair inside ONE parallel region -- the all-cores CPU baseline of bench.py (not a parity
+ * path): static kernel of the pair (static_kernels.py:26-33 linear <x, y>; :58-73 rbf exp(-(|x|^2 + |y|^2 - 2<x, y>) / sigma)),
+ * its 4-corner increments (sigkernel.py:362-363) and the PDE solve (cython_backend.pyx:101-117), with every scratch buffer
+ * allocated and first touched by the thread that uses it.  sk_oracle_solve_coarse alone leaves the static kernel and the
+ * increments serial, which is why a baseline built from it scales 5x on 128 threads.
+ * X [A, M, D], Y [B, N, D] row-major; kind 0 linear, 1 rbf (param = sigma); out [A, B].  Returns 0, 1 on bad arguments. */
+int sk_oracle_gram_pipeline(const double *X, int64_t A, int M, const double *Y, int64_t B, int N, int D, int kind, double param,
+                            int dyadic, int naive, double *out, int nthreads)
+{
+    if (A < 0 || B < 0 || M < 2 || N < 2 || D < 1 || dyadic < 0 || dyadic > 20 || (kind != 0 && kind != 1)) return 1;
+    const int Mc = M - 1, Nc = N - 1, MM = Mc << dyadic, NN = Nc << dyadic;
+    const double r = (double)(1 << dyadic);
+    int fail = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        double *G = (double *)malloc(sizeof(double) * ((size_t)M * N + (size_t)Mc * Nc + 2 * (size_t)(NN + 1) + M + N));
+        if (!G) {
+#pragma omp atomic write
+            fail = 1;
+        }
+        double *inc = G ? G + (size_t)M * N : NULL, *rows = G ? inc + (size_t)Mc * Nc : NULL;
+        double *xs = G ? rows + 2 * (size_t)(NN + 1) : NULL, *ys = G ? xs + M : NULL;
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t l = 0; l < A * B; ++l) {
+            if (!G) continue;
+            const double *x = X + (l / B) * (int64_t)M * D, *y = Y + (l % B) * (int64_t)N * D;
+            if (kind == 1) {
+                for (int p = 0; p < M; ++p) { double s = 0.; for (int k = 0; k < D; ++k) s += x[p * D + k] * x[p * D + k]; xs[p] = s; }
+                for (int q = 0; q < N; ++q) { double s = 0.; for (int k = 0; k < D; ++k) s += y[q * D + k] * y[q * D + k]; ys[q] = s; }
+            }
+            for (int p = 0; p < M; ++p)
+                for (int q = 0; q < N; ++q) {
+                    double s = 0.;
+                    for (int k = 0; k < D; ++k) s += x[p * D + k] * y[q * D + k];
+                    G[(size_t)p * N + q] = kind == 0 ? s : exp(-((-2. * s + xs[p]) + ys[q]) / param);
+                }
+            for (int p = 0; p < Mc; ++p)
+                for (int q = 0; q < Nc; ++q)
+                    inc[(size_t)p * Nc + q] = ((G[(size_t)(p + 1) * N + q + 1] + G[(size_t)p * N + q]) - G[(size_t)(p + 1) * N + q]) -
+                                              G[(size_t)p * N + q + 1];
+            double *prev = rows, *cur = rows + (NN + 1);
+            for (int j = 0; j <= NN; ++j) prev[j] = 1.;
+            for (int i = 0; i < MM; ++i) {
+                cur[0] = 1.;
+                for (int j = 0; j < NN; ++j)
+                    cur[j + 1] = sk_cell(cur[j], prev[j + 1], prev[j], sk_fine_inc(inc, Nc, dyadic, r, i, j), naive);
+                double *t = prev; prev = cur; cur = t;
+            }
+            out[l] = prev[NN];
+        }
+        free(G);
     }
     return fail;
 }

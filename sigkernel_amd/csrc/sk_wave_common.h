@@ -5,7 +5,10 @@
 namespace sk {
 namespace {
 
+#ifndef SK_WAVE_DEFINED
+#define SK_WAVE_DEFINED
 constexpr int WAVE = 64;
+#endif
 constexpr int LINE_UNITS = 8;  // 16-byte units per 128-byte line
 
 typedef __attribute__((address_space(3))) void lds_void;

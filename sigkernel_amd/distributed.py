@@ -14,9 +14,11 @@ Works with any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo
 import torch
 import torch.distributed as dist
 
-from .sigkernel import _SigKernelGram, k_kgrad
+from . import _lib
+from .sigkernel import (_SigKernelGram, _budget, _fused_linear_adjoint_ok, _fused_static, _gram_block, _sym_fused_gradient,
+                        _sym_unfused_gradient, k_kgrad)
 
-__all__ = ["row_range", "sharded_gram", "ShardedGram", "sharded_kgrad"]
+__all__ = ["row_range", "sharded_gram", "ShardedGram", "ShardedSymGram", "sharded_kgrad"]
 
 
 def row_range(n_rows, rank, world):
@@ -63,17 +65,7 @@ def _folded_symmetric_gram(X, static_kernel, dyadic_order, naive, workspace_byte
             if hi > lo:
                 strips[slot, : hi - lo, lo:] = _SigKernelGram.apply(Xd[lo:hi].contiguous(), Xd[lo:].contiguous(), static_kernel,
                                                                     dyadic_order, False, naive, workspace_bytes)
-    full = torch.empty(world * 2, bs, A, dtype=X.dtype, device=X.device)     # rank-major concatenation along dim 0
-    _gather(full, strips, group)
-    full = full.reshape(world, 2, bs, A)
-    K = torch.empty(2 * world * bs, A, dtype=X.dtype, device=X.device)
-    for r in range(world):
-        K[r * bs:(r + 1) * bs] = full[r, 0]
-        K[(2 * world - 1 - r) * bs:(2 * world - r) * bs] = full[r, 1]
-    K = K[:A]
-    iu = torch.triu_indices(A, A, offset=1, device=X.device)
-    K[iu[1], iu[0]] = K[iu[0], iu[1]]
-    return K
+    return _assemble_folded(strips, A, bs, world, group)
 
 
 class ShardedGram(torch.autograd.Function):
@@ -122,15 +114,103 @@ class ShardedGram(torch.autograd.Function):
         return grad_X, None, None, None, None, None, None, None
 
 
+def _folded_blocks(A, rank, world):
+    """The two row blocks of rank `rank` when the rows are cut into 2 x world blocks and folded: blocks r and 2R-1-r."""
+    bs = -(-A // (2 * world))
+    return bs, [(min(blk * bs, A), min((blk + 1) * bs, A)) for blk in (rank, 2 * world - 1 - rank)]
+
+
+def _assemble_folded(strips, A, bs, world, group):
+    """All-gather of every rank's two zero-padded strips (2, bs, A) -> the full, exactly symmetric (A, A) matrix."""
+    full = torch.empty(world * 2, bs, A, dtype=strips.dtype, device=strips.device)     # rank-major concatenation along dim 0
+    _gather(full, strips, group)
+    full = full.reshape(world, 2, bs, A)
+    K = torch.empty(2 * world * bs, A, dtype=strips.dtype, device=strips.device)
+    for r in range(world):
+        K[r * bs:(r + 1) * bs] = full[r, 0]
+        K[(2 * world - 1 - r) * bs:(2 * world - r) * bs] = full[r, 1]
+    K = K[:A]
+    iu = torch.triu_indices(A, A, offset=1, device=strips.device)
+    K[iu[1], iu[0]] = K[iu[0], iu[1]]
+    return K
+
+
+def _all_reduce_sum(t, group):
+    if t.is_cuda and dist.get_backend(group) == "gloo":      # (test configuration: several ranks sharing one GPU)
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class ShardedSymGram(torch.autograd.Function):
+    """compute_Gram(X, X, sym=True) WITH a gradient (compute_mmd's K_XX, sigkernel.py:190) over a process group: the triangle,
+    folded over the ranks like `_folded_symmetric_gram` -- rank r solves row blocks r and 2R-1-r against the columns from the
+    block's first row on, (2R+1)/(2R)^2 of the square.  In backward a solved pair (a, b) gives its first-argument gradient to
+    row a and, through the second-argument sums of the same adjoint sweep, what the unsolved mirror pair (b, a) owes to row b
+    (sigkernel._sym_fused_gradient); rows of grad_X therefore receive contributions from several ranks, and the path has a
+    real exchange step: ONE all-reduce (sum) of the (A, M, D) gradient -- 4 MB at BASELINE configs[3] -- over RCCL."""
+
+    @staticmethod
+    def forward(ctx, X, static_kernel, dyadic_order, _naive_solver, workspace_bytes, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        be = _lib.get_backend()
+        A = X.shape[0]
+        bs, blocks = _folded_blocks(A, rank, world)
+        Xd = X.detach().contiguous()
+        strips = torch.zeros(2, bs, A, dtype=X.dtype, device=X.device)
+        kept_blocks = []
+        for slot, (lo, hi) in enumerate(blocks):
+            if hi > lo:
+                kept = []
+                strips[slot, : hi - lo, lo:] = _gram_block(be, static_kernel, Xd[lo:hi].contiguous(), Xd[lo:].contiguous(),
+                                                           dyadic_order, _naive_solver, workspace_bytes, 3, kept)
+                kept_blocks.append((lo, hi, kept))
+        ctx.save_for_backward(X)
+        ctx.args = (static_kernel, dyadic_order, _naive_solver, workspace_bytes, group)
+        ctx.blocks = kept_blocks
+        return _assemble_folded(strips, A, bs, world, group)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (X,) = ctx.saved_tensors
+        static_kernel, d, naive, workspace_bytes, group = ctx.args
+        be = _lib.get_backend()
+        Xd = X.detach().contiguous()
+        go = grad_output.to(X.dtype).contiguous()
+        budget = _budget(X.device, workspace_bytes)
+        grad = _sym_fused_gradient(be, static_kernel, Xd, go, d, naive, ctx.blocks, budget)
+        if grad is None:
+            kind, param = _fused_static(static_kernel, True)
+            grad = _sym_unfused_gradient(be, kind, param, Xd, go, d, naive, ctx.blocks, budget)
+        ctx.blocks = [(lo, hi, []) for lo, hi, _ in ctx.blocks]      # a second backward sweeps forward again by itself
+        grad = _all_reduce_sum(grad.contiguous(), group)
+        # X is both arguments: the reference's 2x rule (sigkernel.py:410-412)
+        return 2 * grad, None, None, None, None, None
+
+
 def sharded_gram(sigkernel, X, Y, sym=False, group=None):
     """Full (A, B) Gram matrix on every rank; each rank solves only its rows."""
     if not dist.is_initialized():
         raise RuntimeError("sharded_gram needs torch.distributed to be initialised (one process per GPU)")
     same = X.shape == Y.shape and X.data_ptr() == Y.data_ptr() and X.stride() == Y.stride()
+    if dist.get_world_size(group) == 1 and sym and same:      # nothing to fold: the single-GPU Function owns the symmetric shortcuts
+        return _SigKernelGram.apply(X, Y, sigkernel.static_kernel, sigkernel.dyadic_order, sym, sigkernel._naive_solver,
+                                    sigkernel.workspace_bytes)
     if (sym and same and not X.requires_grad and dist.get_world_size(group) > 1 and X.shape[0] >= 2 and X.shape[1] >= 2):
         return _folded_symmetric_gram(X, sigkernel.static_kernel, sigkernel.dyadic_order, sigkernel._naive_solver,
                                       sigkernel.workspace_bytes, group)
-    return ShardedGram.apply(X, Y, sigkernel.static_kernel, sigkernel.dyadic_order, sym, sigkernel._naive_solver,
+    be = _lib.get_backend()
+    sk = sigkernel.static_kernel
+    if (sym and same and X.requires_grad and dist.get_world_size(group) > 1 and X.shape[0] >= 2 and X.shape[1] >= 2
+            and _fused_static(sk, True) is not None and hasattr(be, "static_adjoint2")
+            and not _fused_linear_adjoint_ok(be, sk, X, Y, sigkernel.dyadic_order, sigkernel._naive_solver, True)
+            and X.shape[2] <= 32):
+        # the triangle WITH a gradient: folded row blocks, second-argument sums, one all-reduce of the gradient
+        return ShardedSymGram.apply(X, sk, sigkernel.dyadic_order, sigkernel._naive_solver, sigkernel.workspace_bytes, group)
+    return ShardedGram.apply(X, Y, sk, sigkernel.dyadic_order, sym, sigkernel._naive_solver,
                              sigkernel.workspace_bytes, group)
 
 

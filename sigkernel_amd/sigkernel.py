@@ -296,6 +296,8 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of
     # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
     T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= _SYM_MIN_CELLS) else 1
+    if T > 1 and A >= 64 * T and keep_blocks is not None:
+        T *= 2        # big batches with the fused adjoint: 16 row blocks solve 53 % of the square instead of 56 % (C4: -1 %)
     if keep_blocks is not None and T > 1:
         # with the adjoint in the blocks too, small blocks lose more to launches and pipeline fill than the triangle saves
         # (measured: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms): at least _SYM_MIN_ROWS rows each

@@ -35,6 +35,17 @@ class OracleBackend:
         (g,) = torch.autograd.grad(G, Xg, dG)
         return g
 
+    def static_adjoint2(self, kind, param, X, Y, W, scale, b0=0):
+        """dL/dY[b0:] of the Gram pairs (a, b): autograd through the static kernel w.r.t. its second argument."""
+        import sigkernel_amd
+        k = sigkernel_amd.LinearKernel() if kind == 0 else sigkernel_amd.RBFKernel(param)
+        Yg = Y.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            G = k.Gram_matrix(X, Yg)
+        dG = self.increments_adjoint(W, scale)
+        (g,) = torch.autograd.grad(G, Yg, dG)
+        return g[b0:]
+
     def increments_adjoint(self, W, scale=None):
         dG = torch.from_numpy(O.increments_adjoint(W.detach().double().numpy())).to(W.dtype)
         if scale is not None:

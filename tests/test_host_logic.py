@@ -45,6 +45,55 @@ def test_gram_xx_two_times_rule_and_mmd(oracle_backend, name):
     assert rel_err(Xg.grad.numpy(), c["grad_mmd"]) <= grad_tol(name, "grad_mmd")
 
 
+@pytest.mark.parametrize("name", ["gram_c2mini_rbf_d1", "gram_c3mini_lin_d1"])
+def test_symmetric_gram_triangular_blocks_with_gradient(oracle_backend, name, monkeypatch):
+    """compute_Gram(X, X, sym=True) with a gradient in row blocks (only the pairs on and above the diagonal are solved; the
+    mirror pairs' share comes from the second-argument contraction): same values and gradients as the reference's fixtures,
+    also for a non-symmetric upstream gradient against the full sym=False computation."""
+    from sigkernel_amd import sigkernel as S
+    monkeypatch.setattr(S, "_SYM_TILES", 3)
+    monkeypatch.setattr(S, "_SYM_MIN_CELLS", 0.0)
+    monkeypatch.setattr(S, "_SYM_MIN_ROWS", 1)
+    monkeypatch.setattr(S, "_gram_symmetric", S._gram_symmetric)
+    c = golden(name)
+    X = torch.from_numpy(c["X"])
+    # force the block route even for 5..6 paths: the A >= 8 T rule is for launch overheads, not correctness
+    orig = S._gram_symmetric
+
+    def blocks(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes, keep_blocks=None):
+        monkeypatch.setattr(S, "_SYM_TILES", 3)
+        A = Xd.shape[0]
+        if keep_blocks is None:
+            return orig(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes, keep_blocks)
+        K = torch.empty(A, A, dtype=Xd.dtype)
+        step = -(-A // 3)
+        for r0 in range(0, A, step):
+            r1 = min(r0 + step, A)
+            kept = []
+            blk = S._gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes, 3, kept)
+            keep_blocks.append((r0, r1, kept))
+            K[r0:r1, r0:] = blk
+            if r1 < A:
+                K[r1:, r0:r1] = blk[:, r1 - r0:].t()
+        iu = torch.triu_indices(A, A, offset=1)
+        K[iu[1], iu[0]] = K[iu[0], iu[1]]
+        return K
+    monkeypatch.setattr(S, "_gram_symmetric", blocks)
+    sk = _sk(c)
+    Xg = X.clone().requires_grad_(True)
+    G = sk.compute_Gram(Xg, Xg, sym=True)
+    assert rel_err(G.detach().numpy(), c["gram_xx_sym"]) <= 1e-12
+    G.sum().backward()
+    assert rel_err(Xg.grad.numpy(), c["grad_xx_sum"]) <= grad_tol(name, "grad_xx_sum")
+    w = torch.randn(X.shape[0], X.shape[0], generator=torch.Generator().manual_seed(1), dtype=torch.float64)   # not symmetric
+    X1 = X.clone().requires_grad_(True)
+    (sk.compute_Gram(X1, X1, sym=True) * w).sum().backward()
+    monkeypatch.setattr(S, "_gram_symmetric", orig)
+    X2 = X.clone().requires_grad_(True)
+    (sk.compute_Gram(X2, X2, sym=False) * w).sum().backward()
+    assert rel_err(X1.grad.numpy(), X2.grad.numpy()) <= 1e-12
+
+
 @pytest.mark.parametrize("name", golden_gram_cases())
 def test_paired_kernel(oracle_backend, name):
     c = golden(name)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""(GPU box, ONE GPU) Per-rank compute time of strong-scaled BASELINE configs[3] -- compute_mmd(X, Y).backward(), 2048 x 2048
+paths of length 64, dim 4, RBF, dyadic 2 -- for R = 1, 2, 4, 8 ranks: every rank's share is run through the PRODUCT code
+(sigkernel_amd.distributed: row shard of K_XY, folded triangular blocks of K_XX with the all-reduced gradient, folded K_YY)
+one after the other on this GPU, with the collectives replaced by local copies of the same size.  No scaling curve can be
+measured on a 1-GPU lease; what this gives is max_r t_r(R), i.e. the speed-up the kernels and the host layer allow before
+communication (three all-gathers of <= 4 MB + one all-reduce of 4 MB per step, timed separately at world 1 over RCCL).
+
+    python tools/r03_shard_times.py [out.json]
+"""
+import json, os, sys, time, types
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sigkernel_amd
+from sigkernel_amd import distributed as D
+
+A, M, Dm, d = 2048, 64, 4, 2
+g = torch.Generator().manual_seed(0)
+mk = lambda: (torch.cumsum(torch.randn(A, M, Dm, generator=g, dtype=torch.float64), 1) / np.sqrt(M * Dm)).cuda()
+X, Y = mk(), mk()
+
+state = {"rank": 0, "world": 1}
+real_dist = D.dist
+shim = types.SimpleNamespace(
+    get_world_size=lambda group=None: state["world"], get_rank=lambda group=None: state["rank"],
+    is_initialized=lambda: True, get_backend=lambda group=None: "shim", ReduceOp=real_dist.ReduceOp, group=real_dist.group)
+
+
+def fake_gather(out, inp, group):          # every rank's slot receives THIS rank's block: same bytes moved, no peer
+    n = inp.shape[0]
+    for r in range(state["world"]):
+        out[r * n:(r + 1) * n].copy_(inp)
+
+
+D.dist = shim
+D._gather = fake_gather
+D._all_reduce_sum = lambda t, group: t
+sk_dist = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), d, process_group="shim")
+sk_one = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), d)       # R = 1: what bench.py --gpus 1 runs (no process group)
+
+
+def step():
+    Xg = X.detach().requires_grad_(True)
+    (sk_one if state["world"] == 1 else sk_dist).compute_mmd(Xg, Y).backward()
+    return Xg.grad
+
+
+res = {}
+for R in (1, 2, 4, 8):
+    state["world"] = R
+    times = []
+    for r in range(R):
+        state["rank"] = r
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 3 * 1e3)
+    res[R] = times
+    print("R=%d: per-rank ms %s  max %.1f" % (R, ["%.1f" % t for t in times], max(times)), flush=True)
+t1 = max(res[1])
+out = {"workload": "BASELINE configs[3], strong scaling: compute_mmd(X, Y).backward(), 2048 x 2048 paths, len 64, dim 4, RBF, dyadic 2, fp64",
+       "method": "each rank's share through sigkernel_amd.distributed on ONE MI355X, collectives replaced by local copies (tools/r03_shard_times.py); "
+                 "NOT a measured scaling curve",
+       "per_rank_ms": {str(R): res[R] for R in res},
+       "predicted_speedup_before_communication": {str(R): t1 / max(res[R]) for R in res}}
+# the collectives of one step at world 1 over RCCL: sizes as at R = 8
+try:
+    D.dist = real_dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+    real_dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    blk = torch.zeros(256, 2048, dtype=torch.float64, device="cuda"); full = torch.zeros(256, 2048, dtype=torch.float64, device="cuda")
+    gr = torch.zeros(2048, 64, 4, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        real_dist.all_gather_into_tensor(full, blk); real_dist.all_reduce(gr)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        real_dist.all_gather_into_tensor(full, blk); real_dist.all_gather_into_tensor(full, blk); real_dist.all_gather_into_tensor(full, blk)
+        real_dist.all_reduce(gr)
+    torch.cuda.synchronize()
+    out["collectives_ms_world1_rccl"] = (time.perf_counter() - t0) / 20 * 1e3
+    real_dist.destroy_process_group()
+except Exception as e:      # noqa: BLE001
+    out["collectives_ms_world1_rccl"] = "failed: %s" % e
+print(json.dumps(out))
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
