@@ -64,6 +64,9 @@ int sk_version(void);
 /* Development hook: the SK_* tuning knobs are parsed from the environment ONCE, when the library is loaded; tools that sweep a
  * knob inside one process call this after changing it.  Not for product code (not thread-safe against concurrent launches). */
 void sk_reload_knobs(void);
+
+/* kappa_d = 4^-d / sqrt(12), see sk_solve_fwd_linear_*. */
+double sk_linear_prescale(int dyadic);
 const char *sk_status_string(int status);
 /* Number of HIP devices visible, or a negative sk_status. */
 int sk_device_count(void);
@@ -121,7 +124,8 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
  *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED. */
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
-                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream);
+                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, const double *kfinal, double screen,
+                                double tol, void *rescue_ws, size_t rescue_ws_bytes, void *stream);
 
 /* Adjoint PDE AND RBFKernel chain rule in one kernel (csrc/sk_wave_adj_fused_rbf.hip): the reverse sweep evaluates the nodes
  * G = exp(-|x - y|^2 / sigma) itself, forms its increments as their 4-corner differences, recomputes K from the terminal edges a
@@ -142,7 +146,19 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
                              size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
-                             int *outw_out, int *ycols_out, void *stream);
+                             int *outw_out, int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
+                             size_t rescue_ws_bytes, void *stream);
+
+/* Device-side rescue of the two fused adjoints above (csrc/sk_adj_fused_rescue.hip) -- what makes a backward pass free of host
+ * synchronisation.  The fused adjoints recompute K backwards from its terminal edges, which loses accuracy like 1e-16 K^2 and is
+ * useless for exploding kernels; the reference stores both grids for every pair whatever K's size (sigkernel.py:438-470).
+ *   rescue_ws (sk_fused_rescue_workspace_bytes; NULL: no rescue -- the residuals in err are then the caller's to act on), with
+ *   kfinal [P] = the forward values K[MM][NN] (nullable): pairs with |kfinal| > screen are taken out of the sweep (their err entry
+ *   becomes -1) and their EXACT contribution (stored-grid adjoint + static-kernel chain rule) is added to the partial sums after it;
+ *   a chunk in which a pair that was not screened still ends with a residual above `tol` is recomputed exactly, all its pairs.
+ *   With kfinal the library initialises err itself.  When nothing is screened or fails (the normal case) the rescue reads P
+ *   doubles and returns.  `blocks` flagged chunks are processed concurrently (1..1024; the workspace grows with it). */
+size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks);
 
 /* Second-argument adjoint (Gram only): dL/dY from W for the pairs (a, b), b >= b0 -- the counterpart of sk_static_adjoint_*
  * that the reference never needs (it returns no gradient for its second argument, sigkernel.py:343, :412).  It exists for
@@ -207,17 +223,22 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
 /* Forward solve with the LINEAR static kernel fused in (csrc/sk_wave_fused.hip): the increments
  * s^2 <x[p+1]-x[p], y[q+1]-y[q]> are formed inside the sweep, nothing of size P*M*N ever exists in HBM.
  * Replaces, for LinearKernel, the whole of sigkernel.py:362-382 (Gram) / :216-234 (paired).
- *   dXr [A][Mrows][8] fp64: s^2 (x[p+1]-x[p]) for p < Mc, zero for the padding rows (Mrows >= 256 is always enough)
- *                           and padding dims (path dim <= 8);
+ *   dXr [A][Mrows][8] fp64: kappa s^2 (x[p+1]-x[p]) for p < Mc, kappa = sk_linear_prescale(dyadic) = 4^-d / sqrt(12) (the
+ *                           kernel's stencil coefficients take three operations per coarse cell on the pre-scaled increment);
+ *                           zero for the padding rows (Mrows >= 256 is always enough) and padding dims (path dim <= 8);
  *   dYt [Bn][8][Ncp] fp64: y[q+1]-y[q], dimension-major, zero-padded; Ncp = Nc rounded up to a multiple of 16;
  *   B > 0: Gram (Bn = B, pair (a,b) at a*B+b); B == 0: paired (Bn = A).  out_final [P].
  *   D = the path dimension (1..8): dimensions >= D of dXr / dYt must be zero; D <= 4 selects kernels that skip them.
+ *   queue: 64 bytes of device scratch for the launch's work counter (contents irrelevant, the library zeroes it on `stream`;
+ *          not shared with a launch that may run concurrently).  The waves of these persistent kernels take a fixed first share
+ *          of the pairs and draw the rest from that counter, so that they finish together whatever the SIMD arbitration, the
+ *          XCDs' clocks or other work on the chip do.  NULL: a static, equal partition (the results are the same bit for bit).
  * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M-1 > 256/128/64 for dyadic 0/1/2):
  * use sk_static_increments_* + sk_solve_fwd_*. */
 int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                            int dyadic, int scheme, double *out_final, void *stream);
+                            int dyadic, int scheme, double *out_final, void *queue, void *stream);
 int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                            int dyadic, int scheme, float *out_final, void *stream);
+                            int dyadic, int scheme, float *out_final, void *queue, void *stream);
 
 /* Forward solve with the RBF static kernel fused in (csrc/sk_wave_fused.hip, KIND 1): the nodes
  * G[p][q] = exp(-|x_p - y_q|^2 / sigma) are evaluated inside the sweep (one exp per coarse cell; a lane takes the node row
@@ -231,21 +252,21 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
  * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M > 256/128/64 for dyadic 0/1/2):
  * use sk_static_increments_* + sk_solve_fwd_*. */
 int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                         int dyadic, int scheme, double inv_sigma, double *out_final, void *stream);
+                         int dyadic, int scheme, double inv_sigma, double *out_final, void *queue, void *stream);
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                         int dyadic, int scheme, double inv_sigma, float *out_final, void *stream);
+                         int dyadic, int scheme, double inv_sigma, float *out_final, void *queue, void *stream);
 /* Symmetric Gram matrix of ONE path batch with the fused kernels above: only the A (A + 1) / 2 pairs on and above the diagonal are
  * solved (what the reference's CPU solver does for sym=True, cython_backend.pyx:74-97; its GPU path ignores `sym`), in ONE launch,
  * and each value is written to out[a][b] and out[b][a]: out [A][A] is exactly symmetric.  dXr / dXt (Xr / Xt): the row-major and
  * the dimension-major staging of the SAME paths, as sk_solve_fwd_linear_* (sk_solve_fwd_rbf_*) take them; Mc = Nc = M - 1. */
 int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                                int scheme, double *out, void *stream);
+                                int scheme, double *out, void *queue, void *stream);
 int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                                int scheme, float *out, void *stream);
+                                int scheme, float *out, void *queue, void *stream);
 int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, double *out, void *stream);
+                             int scheme, double inv_sigma, double *out, void *queue, void *stream);
 int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, float *out, void *stream);
+                             int scheme, double inv_sigma, float *out, void *queue, void *stream);
 
 /* Forward solve with the static kernel fused in for LONG or WIDE paths (csrc/sk_wave_fused_mb.hip): any number of bands per
  * pair (M - 1 beyond 256/128/64 at dyadic 0/1/2) and path dimensions up to 16 -- BASELINE configs[4] (len 512, dim 16,
@@ -272,12 +293,12 @@ int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void
 /* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
  * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream);
+                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *queue, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair for a later sk_solve_adj_* with SK_FLAG_EDGES_GIVEN
  * (`edges`: sk_strip_edges_bytes(P, Mc, Nc, dyadic, 8) bytes; fp64, dyadic 0..2). */
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                                  int dyadic, int scheme, double *out_final, double *edges, void *stream);
+                                  int dyadic, int scheme, double *out_final, double *edges, void *queue, void *stream);
 
 /* ---- adjoint solve ------------------------------------------------------------------------
  * W[p][a][b] = d K_p[MM][NN] / d inc_c[p][a][b] by the reference's variation-of-parameters

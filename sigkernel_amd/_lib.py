@@ -30,6 +30,7 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "sk_version": (_int, []),
     "sk_reload_knobs": (None, []),
+    "sk_linear_prescale": (ctypes.c_double, [_int]),
     "sk_status_string": (ctypes.c_char_p, [_int]),
     "sk_device_count": (_int, []),
     "sk_increments_f64": (_int, [_vp, _i64, _int, _int, _vp, _i64, _vp]),
@@ -48,26 +49,27 @@ SIGNATURES = {
     "sk_increments_adjoint_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _vp]),
     "sk_solve_fwd_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_f32": (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_solve_fwd_linear_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_static_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
     "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
     "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
                                        _vp, _sz, _vp]),
     "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _vp, _vp, _sz, _vp]),
-    "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
-    "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
-                                           _vp]),
+                                           _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
     "sk_rbf_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp,
-                                        _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+                                        _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
+    "sk_fused_rescue_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
     "sk_adj_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _int]),
     "sk_adj_rescue_slot_bytes": (_sz, [_int, _int, _int]),
     "sk_plan_wave_shares": (_int, [_i64, _int, _i64, _i64, _int, _int, _vp, _vp, _vp]),
@@ -173,6 +175,12 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _queue(dev):
+    """64 bytes of device scratch for one launch's work counter (the library zeroes it on the launch stream); the caching
+    allocator keeps it alive for the work queued on this stream and hands it out again afterwards."""
+    return torch.empty(8, dtype=torch.int64, device=dev)
+
+
 def _prep_paths(X, diff, dim_major, scale, rows, fd=8):
     """fp64, zero-padded staging of a path batch for the fused kernels in ONE launch (sk_prep_paths_*):
     X (A,M,D) -> [A][rows][fd] (dim_major=False) or [A][fd][rows] (dim_major=True) of scale*(x[p+1]-x[p]) (diff) or
@@ -243,7 +251,8 @@ class HipBackend:
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with torch.cuda.device(dev):
-            dXr = _prep_paths(X, True, False, float(scale) ** 2, Mrows)     # s^2 (x[p+1] - x[p]), [A][256][8]
+            kappa = float(lib.sk_linear_prescale(int(dyadic)))             # 4^-d / sqrt(12): see sk_solve_fwd_linear_*
+            dXr = _prep_paths(X, True, False, kappa * float(scale) ** 2, Mrows)   # kappa s^2 (x[p+1] - x[p]), [A][256][8]
             dYt = _prep_paths(Y, True, True, 1.0, Ncp)                      # y[q+1] - y[q], dimension-major [B][8][Ncp]
             if keep_edges and X.dtype == torch.float64 and 0 <= dyadic <= 2:
                 P = A * B if gram else A
@@ -251,13 +260,13 @@ class HipBackend:
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_linear_edges_f64(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D,
-                                                           int(dyadic), scheme, _ptr(out), _ptr(edges), _stream(X))
+                                                           int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(_queue(dev)), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_linear_edges")
             fn = getattr(lib, "sk_solve_fwd_linear_" + _suffix(X))
-            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, _ptr(out), _stream(X))
+            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, _ptr(out), _ptr(_queue(dev)), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_linear")
@@ -288,14 +297,14 @@ class HipBackend:
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic),
-                                                        scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _stream(X))
+                                                        scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _ptr(_queue(dev)), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_rbf_edges")
             fn = getattr(lib, "sk_solve_fwd_rbf_" + _suffix(X))
             rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, 1.0 / float(sigma),
-                    _ptr(out), _stream(X))
+                    _ptr(out), _ptr(_queue(dev)), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_rbf")
@@ -317,13 +326,14 @@ class HipBackend:
         lib = load()
         with torch.cuda.device(X.device):
             if kind == 0:
-                Xr, Xt = _prep_paths(X, True, False, float(param) ** 2, Mrows), _prep_paths(X, True, True, 1.0, Ncp)
+                kappa = float(lib.sk_linear_prescale(int(dyadic)))
+                Xr, Xt = _prep_paths(X, True, False, kappa * float(param) ** 2, Mrows), _prep_paths(X, True, True, 1.0, Ncp)
                 rc = getattr(lib, "sk_solve_fwd_linear_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic),
-                                                                           scheme, _ptr(out), _stream(X))
+                                                                           scheme, _ptr(out), _ptr(_queue(X.device)), _stream(X))
             else:
                 Xr, Xt = _prep_paths(X, False, False, 1.0, Mrows), _prep_paths(X, False, True, 1.0, Ncp)
                 rc = getattr(lib, "sk_solve_fwd_rbf_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme,
-                                                                        1.0 / float(param), _ptr(out), _stream(X))
+                                                                        1.0 / float(param), _ptr(out), _ptr(_queue(X.device)), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_*_sym")
@@ -381,12 +391,14 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_static")
         return out
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
-        gradient is only valid when the residual is <= ADJ_RESIDUAL_TOL (not NaN): the caller checks, without a
-        synchronisation per call, and takes the unfused route otherwise.  gram=False: paired batch, Y [A,N,D], scale [A]."""
+        gradient is only valid when the residual is <= ADJ_RESIDUAL_TOL (not NaN) -- unless `kfinal` (the forward values, one
+        per pair) is given: then the library's device-side rescue (sk_adj_fused_rescue.hip) takes exploding pairs out of the
+        sweep, solves them with stored grids and adds their exact share, and the gradient is valid as returned -- nothing for the
+        host to check, no synchronisation.  gram=False: paired batch, Y [A,N,D], scale [A]."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -406,22 +418,25 @@ class HipBackend:
             dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
             dYt = _prep_paths(Y, True, True, 1.0, Ncp)
             args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
-            rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), _stream(X))
+            rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), None, 0.0, 0.0, None, 0,
+                                                 _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
             tpart = torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
             err = torch.zeros(P, dtype=torch.float64, device=dev)
+            kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev)
             rc = lib.sk_linear_adjoint_fused_f64(*args, _ptr(tpart), tpart.numel(), _ptr(err), ctypes.byref(ppg), ctypes.byref(rows),
+                                                 _ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes,
                                                  _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused")
-        # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device.  Exploding kernels
-        # (residual above ADJ_RESIDUAL_TOL) are the caller's to handle -- the stored-grid rescue lives on the unfused route --
-        # and it looks at the residuals of a whole backward pass ONCE (see sigkernel._FusedResiduals).
+        # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device (diagnostics; with
+        # `kfinal` the rescue has already dealt with exploding pairs: entries of -1 are pairs it took out of the sweep)
         res = err.max()
+        self.last_fused_err = err
         T = tpart.sum(1).flip(1)[:, :Mc, :D]     # chunks of an a added in a fixed order; flipped rows back to p
         g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
         g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
@@ -431,11 +446,12 @@ class HipBackend:
         g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
-        linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL.
+        linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL, unless `kfinal` (forward values per
+        pair) arms the device-side rescue.
         yside (Gram, dim <= 4): a third result, the second-argument sums of the same sweep as a (A, B, N, 2 + D) tensor [S0, 0, S1]
         per node of y_b, WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1) (see
         second_argument_gradient)."""
@@ -459,7 +475,8 @@ class HipBackend:
             Xr = _prep_paths(X, False, False, 1.0, Mrows)
             Yt = _prep_paths(Y, False, True, 1.0, Ncp)
             args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_DEFAULT, float(sigma), _ptr(edges), _ptr(scale))
-            tail = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None, _stream(X))
+            head = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None)
+            tail = head + (None, 0.0, 0.0, None, 0, _stream(X))
             rc = lib.sk_rbf_adjoint_fused_f64(*args, None, 0, None, None, 0, *tail)
             if rc == 2:
                 return None
@@ -469,12 +486,15 @@ class HipBackend:
             err = torch.zeros(P, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read
             ypart = torch.empty(A, B, ycols.value, 6, dtype=torch.float64, device=dev) if yside else None
+            kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev)
+            tail = head + (_ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
             rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ypart),
                                               ypart.numel() if yside else 0, *tail)
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused")
         res = err.max()
+        self.last_fused_err = err
         T = gpart.sum(1)[:, :M]                                   # chunks of an a added in a fixed order
         cs, accd = T[..., 0:1], T[..., 2:2 + D]
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)     # sum_c V G (-2/sigma) (x_r - y_c)
@@ -493,6 +513,22 @@ class HipBackend:
         folded = torch.einsum("ab,abck->bck", w, ys)              # (B-b0, N, 2+D)
         g = (-2.0 / float(sigma)) * (Y[b0:].double() * folded[..., 0:1] - folded[..., 2:2 + D])
         return g.to(Y.dtype)
+
+    FUSED_SCREEN = 1e3        # |K[MM][NN]| above which a pair leaves the fused adjoint's sweep for the stored-grid rescue
+    FUSED_RESCUE_BLOCKS = 64  # flagged chunks re-solved concurrently
+
+    def _fused_rescue_args(self, kind, kfinal, P, Mc, Nc, dyadic, dev):
+        """(kfinal as fp64 [P] or None, workspace tensor or None, its bytes) for the fused adjoints' device-side rescue; no rescue
+        (None, None, 0) without forward values or for grids the stored-grid kernel cannot hold."""
+        if kfinal is None:
+            return None, None, 0
+        nbytes = int(load().sk_fused_rescue_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), self.FUSED_RESCUE_BLOCKS))
+        if not nbytes:
+            return None, None, 0
+        kf = kfinal.detach().reshape(-1).double().contiguous()
+        if kf.numel() != P:
+            raise ValueError("kfinal must hold one forward value per pair")
+        return kf, torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
 
     def static_adjoint(self, kind, param, X, Y, W, scale, gram):
         """dL/dX (A,M,D) from W = dL/d inc_c and the per-pair upstream gradient `scale`, for the fused static kernels

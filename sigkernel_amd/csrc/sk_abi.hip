@@ -117,14 +117,14 @@ int solve_fwd_static(int kind, double param, const double *Xr, const void *Yt, i
 // symmetric Gram of ONE path batch: only the A (A + 1) / 2 pairs on and above the diagonal are solved, each written twice
 template <typename TO>
 int solve_fwd_sym(int kind, const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                  int scheme, double inv_sigma, TO *out, void *stream) {
+                  int scheme, double inv_sigma, TO *out, void *queue, void *stream) {
     if (D < 1 || !Xr || !Xt || !out || A < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (kind == 1 && (!(inv_sigma > 0.0) || !(inv_sigma < 1e300))) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(A * (A + 1) / 2, Mc, Nc, dyadic, scheme);
-    if (kind == 0) return launch_fwd_fused_linear<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, out, nullptr, (hipStream_t)stream, 1);
-    return launch_fwd_fused_rbf<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, inv_sigma, out, nullptr, (hipStream_t)stream, 1);
+    if (kind == 0) return launch_fwd_fused_linear<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, out, nullptr, queue, (hipStream_t)stream, 1);
+    return launch_fwd_fused_rbf<TO>(Xr, Xt, A, A, Mrows, Ncp, D, g, inv_sigma, out, nullptr, queue, (hipStream_t)stream, 1);
 }
 
 }  // namespace
@@ -154,7 +154,7 @@ Knobs parse_knobs() {
     k.adjf_wpc = knob_int("SK_ADJF_WPC"); k.adjf_wpb = knob_int("SK_ADJF_WPB");
     k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB"); k.adjr_all = knob_int("SK_ADJR_ALL");
     k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
-    k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB");
+    k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB");
     k.rank_w = knob_shares("SK_RANK_W"); k.wave_rank_w = knob_shares("SK_WAVE_RANK_W"); k.adj_rank_w = knob_shares("SK_ADJ_RANK_W");
     k.adjf_rank_w = knob_shares("SK_ADJF_RANK_W"); k.adjr_rank_w = knob_shares("SK_ADJR_RANK_W");
@@ -186,6 +186,10 @@ int sk_version(void) { return 300; }
 /* Development hook: parse the SK_* environment variables again (tools that sweep a knob inside one process).  Not
  * thread-safe against concurrent launches; product code never calls it. */
 void sk_reload_knobs(void) { sk::g_knobs = sk::parse_knobs(); }
+
+/* kappa_d = 4^-d / sqrt(12): the factor the x differences handed to sk_solve_fwd_linear_* carry besides s^2 (it turns the
+ * stencil coefficients 1 + g/2 + g^2/12 and 1 - g^2/12 of the refined increment into 1 + g'(sqrt 3 + g') and 1 - g'^2). */
+double sk_linear_prescale(int dyadic) { return dyadic < 0 || dyadic > 16 ? 0.0 : 1.0 / ((double)(1LL << (2 * dyadic)) * 3.4641016151377544); }
 
 int sk_plan_wave_shares(int64_t P, int G, int64_t waves, int64_t resident, int wpb, int n_cu, int64_t *first, int64_t *end, int *ppg) {
     if (P < 0 || G < 1 || waves < 1 || wpb < 1 || n_cu < 1 || !first || !end || !ppg) return SK_ERR_BAD_ARG;
@@ -320,39 +324,39 @@ int sk_solve_fwd_f32(const float *inc_c, int64_t ld, int64_t P, int Mc, int Nc, 
 }
 
 int sk_solve_fwd_linear_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                            int dyadic, int scheme, double *out_final, void *stream) {
+                            int dyadic, int scheme, double *out_final, void *queue, void *stream) {
     if (D < 1 || !dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, queue, (hipStream_t)stream);
 }
 int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                            int dyadic, int scheme, float *out_final, void *stream) {
+                            int dyadic, int scheme, float *out_final, void *queue, void *stream) {
     if (D < 1 || !dXr || !dYt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_linear<float>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, nullptr, queue, (hipStream_t)stream);
 }
 
 int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                         int scheme, double inv_sigma, double *out_final, void *stream) {
+                         int scheme, double inv_sigma, double *out_final, void *queue, void *stream) {
     if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, queue, (hipStream_t)stream);
 }
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                         int scheme, double inv_sigma, float *out_final, void *stream) {
+                         int scheme, double inv_sigma, float *out_final, void *queue, void *stream) {
     if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<float>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, nullptr, queue, (hipStream_t)stream);
 }
 
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
@@ -377,64 +381,73 @@ int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void
 }
 
 int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                                int scheme, double *out, void *stream) {
-    return solve_fwd_sym<double>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, stream);
+                                int scheme, double *out, void *queue, void *stream) {
+    return solve_fwd_sym<double>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
 }
 int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                                int scheme, float *out, void *stream) {
-    return solve_fwd_sym<float>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, stream);
+                                int scheme, float *out, void *queue, void *stream) {
+    return solve_fwd_sym<float>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
 }
 int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, double *out, void *stream) {
-    return solve_fwd_sym<double>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, stream);
+                             int scheme, double inv_sigma, double *out, void *queue, void *stream) {
+    return solve_fwd_sym<double>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
 }
 int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, float *out, void *stream) {
-    return solve_fwd_sym<float>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, stream);
+                             int scheme, double inv_sigma, float *out, void *queue, void *stream) {
+    return solve_fwd_sym<float>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
 }
 
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *stream) {
+                               int dyadic, int scheme, double inv_sigma, double *out_final, double *edges, void *queue, void *stream) {
     if (D < 1 || !Xr || !Yt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(inv_sigma > 0.0) || !(inv_sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, edges, (hipStream_t)stream);
+    return launch_fwd_fused_rbf<double>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out_final, edges, queue, (hipStream_t)stream);
 }
 
 int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
-                                  int dyadic, int scheme, double *out_final, double *edges, void *stream) {
+                                  int dyadic, int scheme, double *out_final, double *edges, void *queue, void *stream) {
     if (D < 1 || !dXr || !dYt || !out_final || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, edges, (hipStream_t)stream);
+    return launch_fwd_fused_linear<double>(dXr, dYt, A, B, Mrows, Ncp, D, g, out_final, edges, queue, (hipStream_t)stream);
 }
 
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
-                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, void *stream) {
+                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, const double *kfinal, double screen,
+                                double tol, void *rescue_ws, size_t rescue_ws_bytes, void *stream) {
     if (!dXr || !dYt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
-    if (tpart && !err) return SK_ERR_BAD_ARG;
+    if ((tpart && !err) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
     return launch_adj_fused_linear(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, ppg_out, rows_out,
-                                   (hipStream_t)stream);
+                                   rescue_ws ? &fr : nullptr, (hipStream_t)stream);
 }
 
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
                              size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
-                             int *outw_out, int *ycols_out, void *stream) {
+                             int *outw_out, int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
+                             size_t rescue_ws_bytes, void *stream) {
     if (!Xr || !Yt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
-    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err) || (ypart && !gpart)) return SK_ERR_BAD_ARG;
+    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err) || (ypart && !gpart) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
     return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ypart, ypart_doubles,
-                                ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, (hipStream_t)stream);
+                                ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, rescue_ws ? &fr : nullptr, (hipStream_t)stream);
+}
+
+size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks) {
+    if ((kind != 0 && kind != 1) || P < 1 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
+    return fused_rescue_workspace_bytes(kind, P, Mc, Nc, dyadic, blocks);
 }
 
 size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, int elem_size) {

@@ -16,12 +16,31 @@ struct Knobs {
     int adjf_wpc, adjf_wpb;
     int adjr_wpc, adjr_wpb, adjr_all;
     int deriv_pf, deriv_wpc, deriv_wpb;
-    int fused_wpc, fused_wpb;
+    int fused_wpc, fused_wpb, fused_q_static;
     int fusedmb_wpc, fusedmb_wpb;
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
 };
 const Knobs &knobs();                      // sk_abi.hip
 int device_cu_count();                     // sk_abi.hip: compute units of the current device (256 on MI355X), cached per device
+
+// The fused adjoints' decomposition (sk_wave_common.h: chunk_split / chunk_share): a lane group sweeps one CHUNK of the B pairs
+// of one path x_a and leaves a partial sum in slot a * nch + c; chunks swept by the oldest waves are longer.
+struct ChunkSplit {
+    int nr;              // 1: nch equal chunks of size[0] pairs, group gi = a * nch + c
+    int cpr, nch;        // chunks of one a per rank; chunks of one a
+    int64_t gpr;         // lane groups per rank (= waves per rank * G)
+    int size[4];         // pairs in a chunk of rank r
+    int off[4];          // first pair (within the B of an a) of rank r's chunks
+};
+
+// Device-side rescue of the fused adjoints (sk_adj_fused_rescue.hip).
+// What the fused adjoint launchers need for it (nullptr: no rescue, the residuals are the caller's to look at):
+struct FusedRescue {
+    const double *kfinal;   // [P] forward values K[MM][NN], nullable: pairs with |K| > screen are skipped by the sweep and solved exactly
+    double screen, tol;     // tol: self-check residual above which a pair that was NOT screened makes its chunk be recomputed
+    void *ws;               // fused_rescue_workspace_bytes(kind, P, Mc, Nc, dyadic, blocks)
+    size_t ws_bytes;
+};
 
 // Geometry of one solve call; MM/NN are fine-grid cell counts.
 struct Geom {
@@ -110,11 +129,11 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, hipStream_t s, int tri = 0);
+                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0);
 
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri = 0);
+                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0);
 
 // ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
 template <typename TO>
@@ -126,7 +145,7 @@ int fused_mb_rows(int kind, int Mc, int dyadic);
 // ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
                             const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                            int *ppg_out, int *rows_out, hipStream_t s);
+                            int *ppg_out, int *rows_out, const FusedRescue *rescue, hipStream_t s);
 
 // ---- sk_prep.hip: fp64, zero-padded, row-major / dimension-major staging of the paths for the fused kernels ----
 template <typename T>
@@ -137,7 +156,14 @@ int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_maj
 int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
                          double *ypart, size_t ypart_doubles, int want_yside, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out,
-                         hipStream_t s);
+                         const FusedRescue *rescue, hipStream_t s);
+
+// ---- sk_adj_fused_rescue.hip: device-side rescue of the fused adjoints (exploding kernels) ----
+size_t fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks);
+int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, double screen, double *scale_eff, double *err, hipStream_t s);
+int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const double *scale, const double *err, double tol, double *part,
+                        double *ypart, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g, int rows, int outw, int ycols,
+                        double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

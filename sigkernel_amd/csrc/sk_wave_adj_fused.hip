@@ -367,7 +367,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         //    pairs sweep leftovers whose weights may be anything, NaN included: their w is SELECTED to zero, and the y values
         //    they multiply are finite because the rings were zero-filled before the first DMA (0 * NaN would poison the sum)
         {
-            const bool live = s_pair != 0.0;
+            const bool live = s_pair != 0.0 && s_pair == s_pair;   // (NaN: a pair the rescue's screen took out of the sweep)
             const double wsc = sc * s_pair;
 #pragma unroll
             for (int k = 0; k < RC; ++k) {
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         }
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P) {
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P && s_pair == s_pair) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -443,7 +443,8 @@ int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
 namespace {
 int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
                                  const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                                 int *ppg_out, int *rows_out, int64_t *rows_per_launch, int64_t *epair, int64_t force_nch, hipStream_t s) {
+                                 int *ppg_out, int *rows_out, int64_t *rows_per_launch, int64_t *epair, int64_t force_nch,
+                                 const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges
@@ -501,27 +502,47 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), knobs().adjf_rank_w);
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
+    int rc;
     switch (DY) {
-        case 0: return full ? launch_adjf<0, 2, true>(prm, lds_block, s) : launch_adjf<0, 2, false>(prm, lds_block, s);
-        case 1: return full ? launch_adjf<1, 2, true>(prm, lds_block, s) : launch_adjf<1, 2, false>(prm, lds_block, s);
-        default: return full ? launch_adjf<2, 1, true>(prm, lds_block, s) : launch_adjf<2, 1, false>(prm, lds_block, s);
+        case 0: rc = full ? launch_adjf<0, 2, true>(prm, lds_block, s) : launch_adjf<0, 2, false>(prm, lds_block, s); break;
+        case 1: rc = full ? launch_adjf<1, 2, true>(prm, lds_block, s) : launch_adjf<1, 2, false>(prm, lds_block, s); break;
+        default: rc = full ? launch_adjf<2, 1, true>(prm, lds_block, s) : launch_adjf<2, 1, false>(prm, lds_block, s); break;
     }
+    if (rc != SK_OK || !rescue || !rescue_ws) return rc;
+    return launch_fused_rescue(0, dXr, dYt, scale_orig, err, rescue->tol, tpart, nullptr, A, B, Mrows, Ncp, 8, g, L * RC, FD, 0, 0.0, prm.cs,
+                               groups, rescue_ws, rescue_ws_bytes, s);
 }
 }  // namespace
 
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
                             const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                            int *ppg_out, int *rows_out, hipStream_t s) {
+                            int *ppg_out, int *rows_out, const FusedRescue *rescue, hipStream_t s) {
     int ppg = 0, rows = 0;
     int64_t per_launch = 0, epair = 0;
-    int rc = launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, nullptr, 0, err, &ppg, &rows, &per_launch, &epair, 0, s);
+    int rc = launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, nullptr, 0, err, &ppg, &rows, &per_launch, &epair, 0,
+                                          nullptr, nullptr, nullptr, 0, s);
     if (rc != SK_OK) return rc;
     if (ppg_out) *ppg_out = ppg;
     if (rows_out) *rows_out = rows;
     if (!tpart) return SK_OK;
+    // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN)
+    const double *sweep_scale = scale;
+    void *rws = nullptr;
+    size_t rws_bytes = 0;
+    if (rescue && rescue->ws) {
+        const size_t head = sizeof(double) * (size_t)((g.P + 1) / 2 * 2);
+        if (rescue->ws_bytes <= head) return SK_ERR_WORKSPACE;
+        rws = (char *)rescue->ws + head;
+        rws_bytes = rescue->ws_bytes - head;
+        if (rescue->kfinal) {
+            rc = launch_fused_screen(rescue->kfinal, scale, g.P, rescue->screen, (double *)rescue->ws, err, s);
+            if (rc != SK_OK) return rc;
+            sweep_scale = (const double *)rescue->ws;
+        }
+    }
     if (per_launch <= 0 || B <= 0)
-        return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, nullptr, nullptr, nullptr, nullptr,
-                                            B > 0 ? B / ppg : 0, s);
+        return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, sweep_scale, tpart, tpart_doubles, err, nullptr, nullptr, nullptr,
+                                            nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that tpart keeps one layout)
     const int64_t nch = B / ppg, slot = (int64_t)rows * FD;
     if (tpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
@@ -529,9 +550,10 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
         const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;
         Geom gs = g;
         gs.P = An * B;
-        rc = launch_adj_fused_linear_rows(dXr + a0 * Mrows * FD, dYt, An, B, Mrows, Ncp, gs, edges + a0 * B * epair, scale ? scale + a0 * B : nullptr,
-                                          tpart + a0 * nch * slot, (size_t)(An * nch * slot), err ? err + a0 * B : nullptr, nullptr, nullptr,
-                                          nullptr, nullptr, nch, s);
+        rc = launch_adj_fused_linear_rows(dXr + a0 * Mrows * FD, dYt, An, B, Mrows, Ncp, gs, edges + a0 * B * epair,
+                                          sweep_scale ? sweep_scale + a0 * B : nullptr, tpart + a0 * nch * slot, (size_t)(An * nch * slot),
+                                          err ? err + a0 * B : nullptr, nullptr, nullptr, nullptr, nullptr, nch, rescue,
+                                          scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
         if (rc != SK_OK) return rc;
     }
     return SK_OK;

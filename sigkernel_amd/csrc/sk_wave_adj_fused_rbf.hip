@@ -353,7 +353,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
             if (lam * R + R == MMp) leftF[R - 1] = 1.0;
             const double sv = prm.scale ? lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u)) : 1.0;
+            if (sv != sv) valid = 0;      // NaN: a pair the rescue's screen took out of the sweep (sk_adj_fused_rescue.hip)
             sx = valid ? sv : 0.0;
+            if constexpr (YSIDE) { if (!valid) yp_cur = nullptr; }
         }
 
         // -- y points of the unit's two node columns
@@ -603,7 +605,8 @@ namespace {
 int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                               double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
                               double *ypart, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out, int64_t *rows_per_launch,
-                              int64_t force_nch, hipStream_t s) {
+                              int64_t force_nch, const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes,
+                              hipStream_t s) {
     const int DY = g.dyadic;
     if (DY < 1 || DY > 2 || B < 0 || g.naive || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges; the sweep uses the same lanes and units
@@ -666,28 +669,32 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, n_cu, knobs().adjr_rank_w);
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
+    int rc;
     if (ypart) {
-        if (DY == 1) return full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);
-        return full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
+        if (DY == 1) rc = full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);
+        else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
+    } else if (DY == 1) {
+        if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
+        else rc = full ? launch_adjr<1, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 8, false>(prm, lds_block, s);
+    } else {
+        if (ND == 4) rc = full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
+        else rc = full ? launch_adjr<2, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 8, false>(prm, lds_block, s);
     }
-    if (DY == 1) {
-        if (ND == 4) return full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
-        return full ? launch_adjr<1, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 8, false>(prm, lds_block, s);
-    }
-    if (ND == 4) return full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
-    return full ? launch_adjr<2, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 8, false>(prm, lds_block, s);
+    if (rc != SK_OK || !rescue || !rescue_ws) return rc;
+    return launch_fused_rescue(1, Xr, Yt, scale_orig, err, rescue->tol, gpart, ypart, A, B, Mrows, Ncp, D, g, L * RC + 1, OUTW, 2 * NUp, inv_sigma,
+                               prm.cs, groups, rescue_ws, rescue_ws_bytes, s);
 }
 }  // namespace
 
 int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                          double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
                          double *ypart, size_t ypart_doubles, int want_yside, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out,
-                         hipStream_t s) {
+                         const FusedRescue *rescue, hipStream_t s) {
     int ppg = 0, rows = 0, outw = 0, ycols = 0;
     int64_t per_launch = 0;
     const bool yside = want_yside || ypart;
     int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, nullptr, &ppg, &rows, &outw,
-                                       yside ? &ycols : nullptr, &per_launch, 0, s);
+                                       yside ? &ycols : nullptr, &per_launch, 0, nullptr, nullptr, nullptr, 0, s);
     if (rc != SK_OK) return rc;
     if (ppg_out) *ppg_out = ppg;
     if (rows_out) *rows_out = rows;
@@ -695,9 +702,24 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     if (ycols_out) *ycols_out = ycols;
     if (!gpart) return SK_OK;
     if (ypart && ypart_doubles < (size_t)g.P * ycols * YW) return SK_ERR_WORKSPACE;
+    // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN)
+    const double *sweep_scale = scale;
+    void *rws = nullptr;
+    size_t rws_bytes = 0;
+    if (rescue && rescue->ws) {
+        const size_t head = sizeof(double) * (size_t)((g.P + 1) / 2 * 2);
+        if (rescue->ws_bytes <= head) return SK_ERR_WORKSPACE;
+        rws = (char *)rescue->ws + head;
+        rws_bytes = rescue->ws_bytes - head;
+        if (rescue->kfinal) {
+            rc = launch_fused_screen(rescue->kfinal, scale, g.P, rescue->screen, (double *)rescue->ws, err, s);
+            if (rc != SK_OK) return rc;
+            sweep_scale = (const double *)rescue->ws;
+        }
+    }
     if (per_launch <= 0 || B <= 0)
-        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, gpart, gpart_doubles, err, ypart, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, s);
+        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, sweep_scale, gpart, gpart_doubles, err, ypart, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that gpart keeps one layout)
     const int64_t nch = B / ppg;
     const int64_t slot = (int64_t)rows * outw;
@@ -709,9 +731,9 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
         Geom gs = g;
         gs.P = An * B;
         rc = launch_adj_fused_rbf_rows(Xr + a0 * Mrows * RFD, Yt, An, B, Mrows, Ncp, D, gs, inv_sigma, edges + a0 * B * Epair,
-                                       scale ? scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
+                                       sweep_scale ? sweep_scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
                                        err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * YW : nullptr, nullptr, nullptr,
-                                       nullptr, nullptr, nullptr, nch, s);
+                                       nullptr, nullptr, nullptr, nch, rescue, scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
         if (rc != SK_OK) return rc;
     }
     return SK_OK;

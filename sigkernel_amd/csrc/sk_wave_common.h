@@ -437,13 +437,7 @@ __host__ __device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t
 // The fused adjoints split a Gram differently: a lane group sweeps one CHUNK of the B pairs of one path x_a and leaves a
 // partial sum in slot a * nch + c, which the host adds over c.  Chunks need not be equal for that, so the chunks swept by the
 // oldest waves are made longer: chunk c of every a belongs to rank c / cpr, and rank r's chunks hold size[r] pairs.
-struct ChunkSplit {
-    int nr;              // 1: nch equal chunks of size[0] pairs, group gi = a * nch + c
-    int cpr, nch;        // chunks of one a per rank; chunks of one a
-    int64_t gpr;         // lane groups per rank (= waves per rank * G)
-    int size[4];         // pairs in a chunk of rank r
-    int off[4];          // first pair (within the B of an a) of rank r's chunks
-};
+// (struct ChunkSplit: sk_internal.h)
 
 inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, const RankW &family) {
     ChunkSplit cs{};

@@ -35,7 +35,7 @@ constexpr int Y_SLAB_PITCH = FD * 128;   // 8 dimension rows of 8 units; no padd
 constexpr int X_SLOTS = 2;   // the window being consumed + the one in flight
 
 struct FusedParams {
-    const double *dXr;   // [A][Mrows][8]: s^2 (x[p+1]-x[p]), zero rows/dims beyond Mc / D
+    const double *dXr;   // [A][Mrows][8]: kappa s^2 (x[p+1]-x[p]), kappa = 4^-d / sqrt(12) (sk_linear_prescale); zero rows/dims beyond Mc / D
     const double *dYt;   // [Bn][8][Ncp]: y[q+1]-y[q], dimension-major, zero columns/dims beyond Nc / D
     void *out;           // [P] K[MM][NN]
     double *edges;       // EDGES variant: [P][NUp*S + L*R] terminal row and column in the strip layout (sk_wave.hip)
@@ -49,7 +49,13 @@ struct FusedParams {
     int tri;             // 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
                          // path batch (A = B); out is [A][A] and receives both (a, b) and (b, a)
     WaveGroup wg;
-    RankSplit rs;        // pairs per wave by age rank (sk_wave_common.h); PPG and n_steps are the largest share's
+    // The pairs of a launch are dealt to the waves as a stream of chunks (PairStream, below): chunk 0 of every wave is fixed --
+    // C0 pairs per lane group, wave w starts at pair w G C0 -- and the rest is drawn, 2^logC pairs per lane group at a time,
+    // from the launch's counter `queue` (zeroed by the launcher), so that the waves finish together whatever their SIMD's
+    // arbitration, their XCD's clock or what else runs on the chip.  queue == nullptr: C0 is the whole share, nothing is drawn.
+    unsigned long long *queue;
+    int64_t q_first;     // first pair handed out by the counter (= waves G C0)
+    int C0, logC;
 };
 
 template <int N>
@@ -231,11 +237,70 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     int c_u0m1 = (c_u0 + NUp - 1) % NUp;                                        // tm of the step BEFORE the lane starts a pair
     asm volatile("" : "+v"(c_u0), "+v"(c_uk0), "+v"(c_out), "+v"(c_kq), "+v"(c_kr), "+v"(c_u0m1));
     unsigned a_e;   // the odd rows are at a_e ^ 128: wave slices and slabs are 256-byte aligned, a slab row is 128 bytes
-    int PPG;               // this wave's pairs per lane group, the first pair of its group 0, the end of its rank's range
-    int64_t wave_first, P_end;
-    rank_share(prm.rs, wave_id, G, prm.P, PPG, wave_first, P_end);
-    const int n_steps = PPG * NUp + (L - 1) + LAG;
-    const int64_t pair0 = wave_first + (int64_t)grp * PPG;
+    // ---- the wave's stream of pairs: position i of lane group g is pair cb[k] + g size(k) + off, (k, off) = chunk and offset of i.
+    // Pair indices are 32-bit here (the launcher refuses P >= 2^31 - 2^20); NOPAIR marks "no such pair".
+    // (The chunk bases are wave-uniform, but the compiler cannot see that through the atomic: readfirstlane says so, or they
+    // live in VGPRs and every producer call computes its addresses with vector instructions.)
+    constexpr unsigned NOPAIR = 0xffffffffu;
+    const unsigned P32 = (unsigned)prm.P;
+    const int C0 = prm.C0, logC = prm.logC, CQ = 1 << logC;
+    unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * G * C0)), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
+    int have = 1;                     // chunks known so far
+    int t_end = 0x7fffffff;           // macro-steps this wave runs: known once a draw comes back empty
+    // (masks, not a chain of selects: hipcc turns `k == 0 ? cb0 : k == 1 ? cb1 : ...` into an indexed array in scratch memory)
+    auto ring_at = [&](int kk) __attribute__((always_inline)) -> unsigned {
+        return (cb0 & -(unsigned)(kk == 0)) | (cb1 & -(unsigned)(kk == 1)) | (cb2 & -(unsigned)(kk == 2)) | (cb3 & -(unsigned)(kk == 3));
+    };
+    auto chunk_of = [&](int i, int &off) __attribute__((always_inline)) -> int {
+        if (i < C0) { off = i; return 0; }
+        off = (i - C0) & (CQ - 1);
+        return 1 + ((i - C0) >> logC);
+    };
+    // pair at stream position i of lane group g (NOPAIR: none), and how many positions of its chunk follow it (left)
+    auto stream_pair_left = [&](int g, int i, int &left) __attribute__((always_inline)) -> unsigned {
+        left = 0;
+        if (i < 0) return NOPAIR;
+        int off;
+        const int k = chunk_of(i, off);
+        const int size = k == 0 ? C0 : CQ;
+        left = size - 1 - off;
+        const unsigned b = ring_at(k & 3);
+        const unsigned p = b + (unsigned)(g * size + off);
+        return (b >= P32 || p >= P32) ? NOPAIR : p;
+    };
+    auto stream_pair = [&](int g, int i) __attribute__((always_inline)) -> unsigned {      // wave-uniform arguments in the producers
+        int left;
+        return stream_pair_left(g, i, left);
+    };
+    auto lane_pair = [&](int i) __attribute__((always_inline)) -> unsigned {               // per-lane position, this lane's group
+        int left;
+        return stream_pair_left(grp, i, left);
+    };
+    // make sure the chunk of stream position f is known (the producers call this with the furthest position they touch)
+    auto ensure = [&](int f) __attribute__((always_inline)) {
+        int off;
+        const int kf = chunk_of(f, off);
+        while (have <= kf) {
+            unsigned b = NOPAIR;
+            if (prm.queue && t_end == 0x7fffffff) {
+                unsigned long long v = 0;
+                if (lane == 0) v = atomicAdd(prm.queue, (unsigned long long)(G * CQ));
+                const unsigned long long q = (unsigned long long)prm.q_first +
+                                             (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+                b = q < (unsigned long long)P32 ? (unsigned)q : NOPAIR;
+            }
+            if (b == NOPAIR && t_end == 0x7fffffff)
+                t_end = (C0 + (have - 1) * CQ) * NUp + (L - 1) + LAG;   // the stream ends where chunk `have` would begin
+            const int kk = have & 3;
+            const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
+            cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));
+            cb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb1 & ~m1) | (b & m1)));
+            cb2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb2 & ~m2) | (b & m2)));
+            cb3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb3 & ~m3) | (b & m3)));
+            have += 1;
+        }
+    };
     const bool is_top = lam == 0;
     const unsigned my_y = lds0 + (unsigned)grp * y_bytes;
     const unsigned y_lim = my_y + y_bytes;
@@ -266,10 +331,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
     };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
-    auto issue_y = [&]() {                            // ring slot, parity of the virtual slab number
+    auto issue_y = [&]() __attribute__((always_inline)) {                            // ring slot, parity of the virtual slab number
+        ensure(y_pi);
         for (int g = 0; g < G; ++g) {
-            int64_t p = wave_first + (int64_t)g * PPG + y_pi;
-            if (y_pi >= PPG || p >= P_end) p = 0;    // past the end: fetch something valid, never consumed
+            const unsigned sp = stream_pair(g, y_pi);
+            const int64_t p = sp == NOPAIR ? 0 : (int64_t)sp;   // past the end: fetch something valid, never consumed
             const int64_t b = split_b(p);
             const int krow = (lane >> 3) ^ ((y_par + g) & 1);   // odd slabs (per group): dimension rows swapped in pairs
             const double *src = prm.dYt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
@@ -283,13 +349,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // x slabs for the lanes that start a pair during macro-steps [t0, t0+8): lanes lam0 + j*NUp .. +7 start pair
     // t0/NUp - j, rows (lam0 + j*NUp .. +7)*RC of its x
     int x_q0 = 0, x_lam0 = 0, x_slot = 0;   // next window: t0 / NUp, t0 % NUp, ring slot
-    auto issue_x = [&]() {
+    auto issue_x = [&]() __attribute__((always_inline)) {
+        ensure(x_q0);
         for (int j = 0; j < JMAX; ++j) {
             const int lamj = x_lam0 + j * NUp, pi = x_q0 - j;
             if (lamj >= L) break;
             for (int g = 0; g < G; ++g) {
-                int64_t p = wave_first + (int64_t)g * PPG + pi;
-                if (pi < 0 || pi >= PPG || p >= P_end) p = 0;
+                const unsigned sp = stream_pair(g, pi);
+                const int64_t p = sp == NOPAIR ? 0 : (int64_t)sp;
                 const int64_t a = split_a(p);
                 const char *src = reinterpret_cast<const char *>(prm.dXr + (a * prm.Mrows + (int64_t)lamj * RC) * FD);
                 char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
@@ -346,17 +413,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // Everything the per-step edge bookkeeping compares against is loop-invariant and PER LANE, and is kept in VGPRs (the
     // asm pins): as wave-uniform values it filled the scalar file and came back through v_readlane in every macro-step.
     const int EP = EDGES ? (prm.e_NUp * S + prm.e_L * R) : 0;
-    int nvalid;   // pairs of this lane's group that exist: psk in [0, nvalid)
-    {
-        const int64_t left_pairs = P_end - pair0;
-        nvalid = left_pairs <= 0 ? 0 : (left_pairs < PPG ? (int)left_pairs : PPG);
-    }
     int erow_lim = EDGES && lam == prm.lam_f ? prm.e_NUp : 0;          // this lane holds the terminal row: units below this
     int ecol_uf = EDGES && lam < prm.e_L ? prm.u_f : -1;               // the unit whose block holds the terminal column
     int ecol_off = EDGES ? prm.e_NUp * S + lam * R : 0;
-    asm volatile("" : "+v"(nvalid), "+v"(erow_lim), "+v"(ecol_uf), "+v"(ecol_off));
-    double *ep_cur = EDGES ? prm.edges + (pair0 + psk) * EP : nullptr;   // edge block of the pair the sweep is in
-    double *e_ptr = ep_cur;                                              // ... of the values held for the next step's stores
+    asm volatile("" : "+v"(erow_lim), "+v"(ecol_uf), "+v"(ecol_off));
+    double *ep_cur = nullptr;   // EDGES: edge block of the pair the sweep is in (null: no such pair), set where psk changes
+    int ep_left = 0;            // ... and how many more pairs of this lane's chunk follow it: consecutive stream positions of a
+                                // chunk are consecutive pairs, so the pointer just advances; only a chunk's first pair is looked
+                                // up (with chunks of CQ pairs and L skewed lanes that is L / (CQ NUp) lookups per macro-step)
+    unsigned ep_p = NOPAIR;     // ... its index
+    auto sweep_pair_is = [&](int pk) __attribute__((always_inline)) {
+        if (EDGES) {
+            if (ep_left > 0) {
+                ep_left -= 1;
+                ep_p = (ep_p != NOPAIR && ep_p + 1u < P32) ? ep_p + 1u : NOPAIR;
+                ep_cur += EP;
+            } else {
+                asm volatile("");
+                ep_p = stream_pair_left(grp, pk, ep_left);
+                ep_cur = prm.edges + (int64_t)(ep_p != NOPAIR ? ep_p : 0u) * EP;
+            }
+        }
+    };
+    double *e_ptr = nullptr;    // ... of the values held for the next step's stores
     double erow[S];
     int erow_at = -1, ecol_at = -1;
     const int k_f = (prm.Mc - 1) % RC;
@@ -380,6 +459,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_y();
     issue_x();
+    sweep_pair_is(psk);
     if constexpr (!CUR) {
         if (c_u0 == 0) {   // lanes that start a pair in macro-step 0 (their K state is 1.0 already)
             load_x_rows(my_x);
@@ -388,7 +468,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         }
     }
     if (AHEAD) read_y();
-    for (int t = 0; t < n_steps; ++t) {
+    for (int t = 0; t < t_end; ++t) {
         if (EDGES) {   // the edge values of the previous macro-step, straight from the state registers
             double *const ep = e_ptr;
             if (erow_at >= 0) {
@@ -548,7 +628,18 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
 #pragma unroll
             for (int q = 0; q < CW; ++q) {
                 const double g = ginc[k][q];
-                if (NAIVE) {
+                if constexpr (!RBF) {
+                    // LINEAR: the staged x differences carry kappa = 4^-d / sqrt(12) (sk_linear_prescale), so g is kappa times the
+                    // increment and 1 + inc/2 4^-d + inc^2 4^-2d / 12 = 1 + g (sqrt 3 + g), 1 - inc^2 4^-2d / 12 = 1 - g g:
+                    // three operations per coarse cell instead of four
+                    if (NAIVE) {
+                        ca[k][q] = fma(g, 1.7320508075688772, 1.0);
+                        cbm[k][q] = 1.0;
+                    } else {
+                        ca[k][q] = fma(g, g + 1.7320508075688772, 1.0);
+                        cbm[k][q] = fma(-g, g, 1.0);
+                    }
+                } else if (NAIVE) {
                     ca[k][q] = fma(g, c_half, 1.0);
                     cbm[k][q] = 1.0;
                 } else {
@@ -583,7 +674,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (!FULLWAVE) corner = top[S - 1];
 
         if (EDGES) {
-            const bool pair_ok = (unsigned)psk < (unsigned)nvalid;
+            const bool pair_ok = ep_p != NOPAIR;
             e_ptr = ep_cur;
             erow_at = (pair_ok && uk < erow_lim) ? uk * S : -1;
             ecol_at = (pair_ok && uk == ecol_uf) ? ecol_off : -1;
@@ -601,7 +692,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (CUR ? uk == my_uf : tm == c_out) {
             int pv = CUR ? psk : tq + c_kq + (tm + c_kr >= NUp ? 1 : 0);
             asm volatile("" : "+v"(pv));   // keeps the pair tests inside this (rarely taken) branch instead of in every step
-            if ((unsigned)pv < (unsigned)nvalid) {
+            const unsigned pair_u = lane_pair(pv);
+            const int64_t pair_v = (int64_t)pair_u;
+            if (pair_u != NOPAIR) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -613,11 +706,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                     }
                 if (prm.tri) {      // the pair and its mirror image
                     int64_t a, b;
-                    tri_split(pair0 + pv, prm.B, a, b);
+                    tri_split(pair_v, prm.B, a, b);
                     static_cast<TO *>(prm.out)[a * prm.B + b] = (TO)v;
                     static_cast<TO *>(prm.out)[b * prm.B + a] = (TO)v;
                 } else {
-                    static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
+                    static_cast<TO *>(prm.out)[pair_v] = (TO)v;
                 }
             }
         }
@@ -633,7 +726,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             if (uk == NUp) {
                 uk = 0;
                 psk += 1;
-                if (EDGES) ep_cur += EP;
+                sweep_pair_is(psk);
             }
         }
         if constexpr (CUR) u += 1;
@@ -643,7 +736,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             if (u == NUp) {
                 u = 0;
                 ps += 1;
-                if (EDGES && !RBF) ep_cur += EP;
+                if (!RBF) sweep_pair_is(ps);
             }
         }
         if (CUR && !RBF) { uk = u; psk = ps; }
@@ -703,16 +796,34 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (pl.P + pl.G - 1) / pl.G;
     if (waves > max_waves) waves = max_waves;
-    prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
-    prm.rs = rank_split(pl.P, pl.G, waves, max_waves, prm.wg.wpb, device_cu_count(), knobs().fused_rank_w);
-    int64_t PPG = prm.rs.cnt[0];   // the largest share
-    if (prm.rs.nranks == 1) {      // equal shares: no more waves than the pairs need
-        waves = (pl.P + PPG * pl.G - 1) / (PPG * pl.G);
-        prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
+    int64_t per = (pl.P + waves * pl.G - 1) / (waves * pl.G);      // the equal share, pairs per lane group
+    if (per > 0x1fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
+    // drawn chunks: small, but never so small that more than three of them are in flight between the producers' frontier and
+    // the last lane of the sweep (the kernel keeps a ring of four chunk bases)
+    if (pl.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;           // (pair indices are 32-bit inside the kernel)
+    const int span = (pl.L - 1 + pl.lag + 24) / pl.NUp + 2;
+    int logC = 0;
+    while ((span >> logC) + 1 > 3) ++logC;
+    const int pct = knobs().fused_q_static > 0 ? (knobs().fused_q_static > 100 ? 100 : knobs().fused_q_static) : 35;
+    // ... and not smaller than needed either: ~24 draws per lane group balance a launch to a per cent or two, while every
+    // chunk costs each lane one look-up of its first pair (the variants that keep edges do that in the macro-step path)
+    while ((per * (100 - pct) / 100) >> (logC + 1) >= 24 && logC < 8) ++logC;
+    if (prm.queue && waves == max_waves && per >= (8 << logC) && pct < 100) {
+        // the launch fills the chip: `pct` per cent of the equal share is dealt out up front, the rest is drawn from the counter
+        prm.C0 = (int)(per * pct / 100);
+        prm.logC = logC;
+        prm.q_first = waves * pl.G * (int64_t)prm.C0;
+        if (hipMemsetAsync(prm.queue, 0, sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
+    } else {
+        waves = (pl.P + per * pl.G - 1) / (per * pl.G);            // no more waves than the pairs need
+        prm.queue = nullptr;
+        prm.C0 = (int)per;
+        prm.logC = logC;      // (the chunks after the first are all empty here, but the ring must not wrap onto the first)
+        prm.q_first = pl.P;
     }
-    if (PPG > 0x3fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
-    prm.PPG = (int)PPG;
-    prm.n_steps = (int)(PPG * pl.NUp + (pl.L - 1)) + pl.lag;
+    prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
+    prm.PPG = (int)per;
+    prm.n_steps = 0;
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
@@ -750,7 +861,7 @@ int launch_fused_dy(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) 
 // SK_ERR_UNSUPPORTED outside the kernel's scope.
 template <typename TO, int KIND>
 int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                     double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri = 0) {
+                     double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0) {
     if (tri && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
     const int DY = g.dyadic;
     if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
@@ -791,6 +902,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.inv_sigma = inv_sigma;
     prm.dims = D;
     prm.tri = tri;
+    prm.queue = (unsigned long long *)queue;
     prm.e_NUp = NUp;
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
@@ -815,23 +927,23 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
 
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, hipStream_t s, int tri) {
-    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, s, tri);
+                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri) {
+    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, queue, s, tri);
 }
 // Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, hipStream_t s, int tri) {
-    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, s, tri);
+                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri) {
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, queue, s, tri);
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double *,
-                                             double *, hipStream_t, int);
+                                             double *, void *, hipStream_t, int);
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, float *,
-                                            double *, hipStream_t, int);
+                                            double *, void *, hipStream_t, int);
 template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, double *,
-                                          double *, hipStream_t, int);
+                                          double *, void *, hipStream_t, int);
 template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, float *,
-                                         double *, hipStream_t, int);
+                                         double *, void *, hipStream_t, int);
 
 }  // namespace sk

@@ -171,7 +171,9 @@ class ShardedSymGram(torch.autograd.Function):
         ctx.save_for_backward(X)
         ctx.args = (static_kernel, dyadic_order, _naive_solver, workspace_bytes, group)
         ctx.blocks = kept_blocks
-        return _assemble_folded(strips, A, bs, world, group)
+        K = _assemble_folded(strips, A, bs, world, group)
+        ctx.K = K.detach()        # forward values: what arms the fused adjoint's device-side rescue
+        return K
 
     @staticmethod
     def backward(ctx, grad_output):
@@ -181,7 +183,7 @@ class ShardedSymGram(torch.autograd.Function):
         Xd = X.detach().contiguous()
         go = grad_output.to(X.dtype).contiguous()
         budget = _budget(X.device, workspace_bytes)
-        grad = _sym_fused_gradient(be, static_kernel, Xd, go, d, naive, ctx.blocks, budget)
+        grad = _sym_fused_gradient(be, static_kernel, Xd, go, d, naive, ctx.blocks, budget, getattr(ctx, "K", None))
         if grad is None:
             kind, param = _fused_static(static_kernel, True)
             grad = _sym_unfused_gradient(be, kind, param, Xd, go, d, naive, ctx.blocks, budget)

@@ -125,41 +125,38 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     return g
 
 
-def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget):
+def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals=None):
     """dL/dX for all rows through the fused adjoints -- sk_linear_adjoint_fused_f64 / sk_rbf_adjoint_fused_f64: adjoint PDE and
     the static kernel's chain rule in one kernel, from the paths and the forward's terminal edges; no matrix of size pairs x M x N
-    -- one launch per row tile.  None when the kernel does not cover the case or some pair failed its self-check (exploding
-    kernels: the residuals of all tiles are looked at ONCE, here -- the only host synchronisation of a backward pass); the
-    caller then takes the unfused route, tiled by ITS transient memory."""
+    -- one launch per row tile.  None when the kernel does not cover the case (the caller then takes the unfused route, tiled by
+    ITS transient memory).  Exploding kernels are the library's business: with the forward values (Kvals, or what the forward
+    re-run here returns) the launch takes such pairs out of the sweep and adds their exact, stored-grid share on the device
+    (csrc/sk_adj_fused_rescue.hip) -- nothing is read back, a backward pass has no host synchronisation."""
     A, M = Xd.shape[0], Xd.shape[1]
     linear = type(static_kernel) is LinearKernel
     param = _fused_static(static_kernel, gram)[1]
     per_row = (64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M      # edges and partial sums only
     grad = torch.empty_like(Xd)
-    residuals = []
     for a0, a1, edges in _edge_tiles(kept, A, per_row, budget):
         Xt = Xd[a0:a1].contiguous()
         Yt = Yd if gram else Yd[a0:a1].contiguous()
+        Kt = None if Kvals is None else Kvals[a0:a1]
         if edges is None or Xd.dtype != torch.float64:     # fp32 paths are swept in fp64: edges of the up-cast paths
             fwd = be.solve_fwd_fused_linear if linear else be.solve_fwd_fused_rbf
             res = fwd(Xt.double(), Yt.double(), param, dyadic, naive, gram, keep_edges=True)
             edges = res[1] if res is not None else None
+            Kt = res[0] if res is not None else None
         if edges is None:
             return None
         adj = be.linear_adjoint_fused if linear else be.rbf_adjoint_fused
-        res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram)
+        res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram, kfinal=Kt)
         if res is None:
             return None
         grad[a0:a1] = res[0]
-        residuals.append(res[1])
-    if residuals:
-        worst = torch.stack([r.reshape(()) for r in residuals]).max()
-        if not bool(worst <= be.ADJ_RESIDUAL_TOL):      # also False for NaN
-            return None
     return grad
 
 
-def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, workspace_bytes):
+def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, workspace_bytes, Kvals=None):
     """dL/dX (A,M,D) of a Gram block (gram=True: go (A,B)) or a paired batch (go (A,)): the fused linear / RBF adjoint when it
     applies, else the unfused routes tiled over rows by their transient memory (3 (Linear/RBF) or 8 (generic) arrays of the
     size of the tile's increments).  kept: what forward left for the tiles ([(a0, a1, edges)] or None)."""
@@ -167,7 +164,7 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
     budget = _budget(Xd.device, workspace_bytes)
     if (_fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
             or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
-        g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget)
+        g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals)
         if g is not None:
             return g
     fused = _fused_static(static_kernel, gram) is not None
@@ -206,6 +203,7 @@ class _SigKernel(torch.autograd.Function):
         Xd, Yd = X.detach(), Y.detach()
         K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False)
         if K is not None:
+            ctx.K = K.detach() if X.requires_grad else None     # forward values: what arms the fused adjoint's device-side rescue
             return K
         K = torch.empty(A, dtype=X.dtype, device=X.device)
         per_row = 2 * M * N * X.element_size()
@@ -224,7 +222,7 @@ class _SigKernel(torch.autograd.Function):
         if M >= 2 and N >= 2 and A > 0:
             go = grad_output.to(X.dtype).contiguous()
             grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, False, None,
-                                    ctx.workspace_bytes)
+                                    ctx.workspace_bytes, getattr(ctx, "K", None))
         return grad_X, None, None, None, None, None
 
 
@@ -339,20 +337,19 @@ def _same_storage(Xd, Yd):
     return Xd.shape == Yd.shape and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()
 
 
-def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, budget):
+def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, budget, Kvals=None):
     """dL/dX of compute_Gram(X, X, sym=True) from the triangular row blocks through the FUSED RBF adjoint with the
     second-argument sums (sk_rbf_adjoint_fused_f64 with ypart): per row block r0:r1 ONE launch over the solved pairs
     (a in r0:r1, b >= r0) gives the first-argument rows r0:r1 and, per pair, the sums that what the unsolved mirror pairs
     (b, a), b >= r1, owe to rows r1: is folded from (d1 K(x_b, x_a) = d2 K(x_a, x_b): the scheme is symmetric).  Neither the
-    increments nor W exist in HBM.  None when the kernel does not cover the case, the forward kept no edges, or some pair failed
-    its self-check (looked at ONCE, for all blocks); the caller then takes the unfused triangular route."""
+    increments nor W exist in HBM, and exploding pairs are rescued on the device (Kvals: the forward's (A, A) values).  None when
+    the kernel does not cover the case or the forward kept no edges; the caller then takes the unfused triangular route."""
     if not (_fused_rbf_adjoint_ok(be, static_kernel, Xd, Xd, dyadic, naive, True) and Xd.dtype == torch.float64
             and hasattr(be, "second_argument_gradient")):
         return None
     A, M = Xd.shape[0], Xd.shape[1]
     sigma = float(static_kernel.sigma)
     grad = torch.zeros_like(Xd)
-    residuals = []
     for r0, r1, kept in sym_blocks:
         if not kept or len(kept) != 1 or kept[0][2] is None or kept[0][:2] != (0, r1 - r0):
             return None
@@ -364,18 +361,15 @@ def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, bu
         per = edges.numel() // (r1 - r0)
         for a0, a1 in _tiles(r1 - r0, per_row, budget):
             Xt = Xd[r0 + a0:r0 + a1].contiguous()
+            Kt = None if Kvals is None else Kvals[r0 + a0:r0 + a1, r0:]
             res = be.rbf_adjoint_fused(Xt, Xc, sigma, dyadic, edges[a0 * per:a1 * per], go[r0 + a0:r0 + a1, r0:].reshape(-1).contiguous(),
-                                       gram=True, yside=r1 < A)
+                                       gram=True, yside=r1 < A, kfinal=Kt)
             if res is None:
                 return None
             grad[r0 + a0:r0 + a1] += res[0]
-            residuals.append(res[1])
             if r1 < A:   # upstream gradient of the mirror pair (b, a) is go[b, a]
                 grad[r1:] += be.second_argument_gradient(res[2], Xc, sigma, go[r0:, r0 + a0:r0 + a1].t(), r1 - r0)
             del res
-    worst = torch.stack([r.reshape(()) for r in residuals]).max()
-    if not bool(worst <= be.ADJ_RESIDUAL_TOL):      # also False for NaN
-        return None
     return grad
 
 
@@ -412,7 +406,7 @@ class _SigKernelGram(torch.autograd.Function):
         ctx.save_for_backward(X, Y)
         ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver = static_kernel, dyadic_order, _naive_solver
         ctx.workspace_bytes = workspace_bytes
-        ctx.sym_blocks = ctx.kept_edges = None
+        ctx.sym_blocks = ctx.kept_edges = ctx.K = None
         if M < 2 or N < 2 or A == 0 or B == 0:   # single points: k = 1; an empty batch: an empty matrix
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
@@ -429,8 +423,10 @@ class _SigKernelGram(torch.autograd.Function):
                     and not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
                     and hasattr(be, "static_adjoint2") and X.shape[2] <= (8 if type(static_kernel) is LinearKernel else 32)):
                 ctx.sym_blocks = []
-                return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes,
-                                       ctx.sym_blocks)
+                K = _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes,
+                                    ctx.sym_blocks)
+                ctx.K = K.detach()
+                return K
         fused = _fused_static(static_kernel, True) is not None
         # with a gradient pending, tile like backward will, so that the caching allocator can reuse the same blocks
         rows_factor = (3 if fused else 8) if X.requires_grad else None
@@ -439,6 +435,7 @@ class _SigKernelGram(torch.autograd.Function):
         if sym and _same_storage(Xd, Yd):   # all pairs were solved (fused adjoint ahead): still hand back an exactly symmetric matrix
             iu = torch.triu_indices(A, A, offset=1, device=K.device)
             K[iu[1], iu[0]] = K[iu[0], iu[1]]
+        ctx.K = K.detach() if X.requires_grad else None     # forward values: what arms the fused adjoints' device-side rescue
         return K
 
     @staticmethod
@@ -457,7 +454,7 @@ class _SigKernelGram(torch.autograd.Function):
             go = grad_output.to(X.dtype).contiguous()
             kind, param = _fused_static(sk, True)
             budget = _budget(X.device, ctx.workspace_bytes)
-            g_fused = _sym_fused_gradient(be, sk, Xd, go, d, naive, ctx.sym_blocks, budget)
+            g_fused = _sym_fused_gradient(be, sk, Xd, go, d, naive, ctx.sym_blocks, budget, getattr(ctx, "K", None))
             if g_fused is not None:
                 grad_X = g_fused
             else:
@@ -467,7 +464,7 @@ class _SigKernelGram(torch.autograd.Function):
             go = grad_output.to(X.dtype).contiguous()
             kept, ctx.kept_edges = getattr(ctx, "kept_edges", None), None
             grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, True, kept,
-                                    ctx.workspace_bytes)
+                                    ctx.workspace_bytes, getattr(ctx, "K", None))
         # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
         # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
         if ctx.needs_input_grad[1]:

@@ -58,13 +58,15 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_deriv_f64(p, None, p, 0, 1, 4, 4, 0, 0, p, p, p, None) == 1
     assert lib.sk_deriv_increments_f64(p, p, p, 0.0, 1, 4, 4, p, p, p, 0, None) == 1              # eps must be positive
     assert lib.sk_linear_adjoint_f64(p, 2, p, 0, None, 1, 1, 4, 4, 2, p, None) == 1               # ldy < Nc
-    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 4, 4, 16, 3, 1, 0, 0.0, p, None) == 1           # 1/sigma must be positive
-    assert lib.sk_solve_fwd_rbf_f64(p, None, 1, 1, 256, 4, 4, 16, 3, 1, 0, 1.0, p, None) == 1
-    assert lib.sk_solve_fwd_rbf_f32(p, p, 1, 1, 256, 4, 4, 16, 3, 3, 0, 1.0, p, None) == 2           # dyadic 3: not covered
-    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 3, 1, 0, 1.0, p, None) == 2      # 129 node rows: two bands
-    assert lib.sk_solve_fwd_linear_f64(p, p, 1, 1, 256, 4, 4, 16, 0, 1, 0, p, None) == 1                 # path dimension 0
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, -1, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, None, None, None) == 1  # B < 0
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 3, 0, p, None, None, 0, None, None, None, None) == 2   # dyadic 3
+    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 4, 4, 16, 3, 1, 0, 0.0, p, None, None) == 1           # 1/sigma must be positive
+    assert lib.sk_solve_fwd_rbf_f64(p, None, 1, 1, 256, 4, 4, 16, 3, 1, 0, 1.0, p, None, None) == 1
+    assert lib.sk_solve_fwd_rbf_f32(p, p, 1, 1, 256, 4, 4, 16, 3, 3, 0, 1.0, p, None, None) == 2           # dyadic 3: not covered
+    assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 3, 1, 0, 1.0, p, None, None) == 2      # 129 node rows: two bands
+    assert lib.sk_solve_fwd_linear_f64(p, p, 1, 1, 256, 4, 4, 16, 0, 1, 0, p, None, None) == 1                 # path dimension 0
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, -1, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 1  # B < 0
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 3, 0, p, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 2   # dyadic 3
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 1, 0, p, None, p, 64, p, None, None, p, 1e3, 1e-8, None, 0, None) == 1   # forward values without a rescue workspace
+    assert lib.sk_fused_rescue_workspace_bytes(1, 100, 63, 63, 2, 4) > 0 and lib.sk_fused_rescue_workspace_bytes(2, 100, 63, 63, 2, 4) == 0
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
@@ -179,3 +181,21 @@ def test_chunks_by_age_rank_partition_the_pairs(A, B, max_groups, G, monkeypatch
             seen[lo:hi] += 1
         assert seen.min() == 1 and seen.max() == 1, (weights, nr)
         assert len(set(slot.tolist())) == n_groups and slot.max() == n_groups - 1
+
+
+def test_launch_paths_read_no_environment_and_assume_no_cu_count():
+    """SURVEY 8(b) "stateless and re-entrant": the SK_* tuning knobs are parsed ONCE, when the library is loaded (sk_abi.hip:
+    parse_knobs), into an immutable struct -- no launch translation unit may call getenv; and none may hard-code MI355X's 256
+    compute units (device_cu_count() asks the runtime) or keep a mutable function-local static."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "sigkernel_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        text = open(path).read()
+        code = "\n".join(l.split("//")[0] for l in text.split("\n"))
+        name = os.path.basename(path)
+        if name != "sk_abi.hip":
+            assert "getenv" not in code, name
+        assert "256LL" not in code, name
+        for m in re.finditer(r"\bstatic\s+(?!const\b|constexpr\b|inline\b|_assert)(\w+)", code):
+            assert False, "%s: mutable static `%s`" % (name, m.group(0))

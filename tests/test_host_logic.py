@@ -175,8 +175,9 @@ def test_input_validation(oracle_backend):
 
 
 class _FusedFake:
-    """The oracle-backed fake with a fused linear adjoint whose self-check residual the test controls: exercises the
-    once-per-backward residual check and the re-tiled fallback of sigkernel._rows_gradient on CPU."""
+    """The oracle-backed fake with a fused linear adjoint that declines the case (returns None, as the HIP one does outside its
+    scope): exercises the re-tiled fallback of sigkernel._rows_gradient on CPU.  (Exploding kernels are no longer a reason to
+    fall back: the library rescues such pairs on the device, sk_adj_fused_rescue.hip.)"""
 
     def __init__(self, base, residual):
         self._base, self._residual, self.fused_calls, self.tile_rows = base, residual, 0, []
@@ -188,9 +189,10 @@ class _FusedFake:
     def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram, keep_edges=False):
         return None          # forward takes the tiled route; the fused adjoint asks for edges itself
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
         self.fused_calls += 1
-        return torch.full_like(X, float("nan")), torch.tensor(self._residual, dtype=torch.float64)
+        self.got_kfinal = kfinal is not None
+        return None
 
     def static_increments(self, kind, param, X, Y, gram):
         self.tile_rows.append(X.shape[0])
@@ -198,8 +200,8 @@ class _FusedFake:
 
 
 def test_failed_fused_adjoint_falls_back_tiled_by_the_unfused_budget():
-    """when the fused linear adjoint's self-check fails (or the kernel does not cover the case) the backward pass
-    must take the unfused route in tiles sized for THAT route's transient memory, and look at the residuals only once."""
+    """when the fused linear adjoint does not cover the case the backward pass must take the unfused route in tiles
+    sized for THAT route's transient memory; and the fused adjoint must be handed the forward values that arm its rescue."""
     from sigkernel_amd import _lib, sigkernel as skmod
     from fake_backend import OracleBackend
     c = golden("gram_c3mini_lin_d1")
@@ -219,6 +221,6 @@ def test_failed_fused_adjoint_falls_back_tiled_by_the_unfused_budget():
         (K * w).sum().backward()
     finally:
         _lib.set_backend(prev)
-    assert fake.fused_calls >= 1                                   # tried (in its own, larger tiles), residual 1.0 > 1e-8 -> fallback
+    assert fake.fused_calls >= 1 and fake.got_kfinal               # tried (in its own, larger tiles), declined -> fallback
     assert fake.tile_rows and max(fake.tile_rows) <= 2 and sum(fake.tile_rows) == A, fake.tile_rows
     assert rel_err(Xg.grad.numpy(), c["grad_w"]) <= grad_tol("gram_c3mini_lin_d1", "grad_w")

@@ -5,11 +5,11 @@ or writes a destination register while the load is still in flight.
 
     python tools/check_async_hazards.py [file.hip ...]      exit status 1 if any hazard is found
 
-Model: a linear walk over each function in layout order.  A VMEM load makes its destination VGPRs pending until an
-s_waitcnt whose vmcnt(N) leaves at most N loads outstanding (loads return in order); a ds_read until lgkmcnt(0).
-Compiler-generated loads are tracked too (harmless: the compiler waits before using them).  Layout order is not
-control flow, so this is a lint, not a proof -- but every real instance seen so far (copies of a pending register
-hoisted above the wait) shows up in it.
+Model: a walk over each function in layout order, restarted with nothing pending after every unconditional branch.  A VMEM
+load makes its destination VGPRs pending until an s_waitcnt whose vmcnt(N) leaves at most N loads outstanding (loads return
+in order); a ds_read until lgkmcnt(0).  Compiler-generated loads are tracked too (harmless: the compiler waits before using
+them).  Layout order is not control flow, so this is a lint, not a proof -- but every real instance seen so far (copies of a
+pending register hoisted above the wait) shows up in it.
 """
 import os
 import re
@@ -40,39 +40,75 @@ def all_regs(line):
     return out
 
 
-def scan(asm_text):
-    hazards = []
-    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
-        name, body = m.group(1), m.group(2)
-        vm = []      # pending VMEM loads, oldest first: (dest regs, text)
-        lgkm = []    # pending LDS reads
-        for raw in body.split("\n"):
-            l = raw.strip()
-            if not l or l.startswith(";") or (l.startswith(".") and not l.startswith(".LBB")):
-                continue
-            l = l.split(";")[0].strip()
-            op = l.split()[0]
-            if op == "s_waitcnt":
-                mv = re.search(r"vmcnt\((\d+)\)", l)
-                if mv:
-                    n = int(mv.group(1))
-                    vm = vm[len(vm) - n:] if n < len(vm) else vm
-                    if n == 0:
-                        vm = []
-                if "lgkmcnt(0)" in l:
-                    lgkm = []
-                continue
+def _blocks(body):
+    """Basic blocks of one function: [(label or None, [instruction lines])] in layout order."""
+    blocks, cur, label = [], [], None
+    for raw in body.split("\n"):
+        l = raw.strip()
+        if not l or l.startswith(";"):
+            continue
+        m = re.match(r"(\.LBB\w+):", l)
+        if m:
+            if cur or label is not None:
+                blocks.append((label, cur))
+            cur, label = [], m.group(1)
+            continue
+        if l.startswith("."):
+            continue
+        l = l.split(";")[0].strip()
+        cur.append(l)
+        op = l.split()[0]
+        if op.startswith("s_branch") or op.startswith("s_cbranch") or op == "s_endpgm":
+            blocks.append((label, cur))
+            cur, label = [], None
+    if cur or label is not None:
+        blocks.append((label, cur))
+    return blocks
+
+
+def _transfer(lines, vm, lgkm, hazards, name):
+    """Walk one block from the pending state (vm: in-order list, lgkm: list); append hazards when `hazards` is a list."""
+    vm, lgkm = list(vm), list(lgkm)
+    for l in lines:
+        op = l.split()[0]
+        if op == "s_waitcnt":
+            mv = re.search(r"vmcnt\((\d+)\)", l)
+            if mv:
+                n = int(mv.group(1))
+                vm = vm[len(vm) - n:] if n < len(vm) else vm
+                if n == 0:
+                    vm = []
+            if "lgkmcnt(0)" in l:
+                lgkm = []
+            continue
+        if hazards is not None:
             touched = all_regs(l)
             for dest, text in vm + lgkm:
                 if touched & dest:
                     hazards.append((name, text, l))
-            is_lds_dma = (" lds" in l and op.startswith("buffer_load")) or op.startswith("global_load_lds")
-            if (op.startswith("global_load") or op.startswith("buffer_load") or op.startswith("flat_load")) and not is_lds_dma:
-                vm.append((regs(l.split()[1].rstrip(",")), l))
-            elif is_lds_dma or op.startswith("global_store") or op.startswith("buffer_store") or "atomic" in op:
-                vm.append((set(), l))      # counts in vmcnt, no destination
-            elif op.startswith("ds_read"):
-                lgkm.append((regs(l.split()[1].rstrip(",")), l))
+        is_lds_dma = (" lds" in l and op.startswith("buffer_load")) or op.startswith("global_load_lds")
+        if (op.startswith("global_load") or op.startswith("buffer_load") or op.startswith("flat_load")) and not is_lds_dma:
+            vm.append((frozenset(regs(l.split()[1].rstrip(","))), l))
+        elif is_lds_dma or op.startswith("global_store") or op.startswith("buffer_store") or "atomic" in op:
+            vm.append((frozenset(), l))      # counts in vmcnt, no destination
+        elif op.startswith("ds_read"):
+            lgkm.append((frozenset(regs(l.split()[1].rstrip(","))), l))
+    return vm, lgkm
+
+
+def scan(asm_text):
+    """A walk over every function in layout order, block by block.  Layout order is not control flow: after an unconditional
+    branch (or s_endpgm) nothing falls through, so the walk restarts with nothing pending -- round 3: a loop whose latch is laid
+    out between its pre-header and its header was otherwise flagged for the latch's read-ahead following the pre-header's."""
+    hazards = []
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+        name = m.group(1)
+        vm, lgkm = [], []
+        for _, lines in _blocks(m.group(2)):
+            vm, lgkm = _transfer(lines, vm, lgkm, hazards, name)
+            last = lines[-1].split()[0] if lines else ""
+            if last.startswith("s_branch") or last == "s_endpgm":
+                vm, lgkm = [], []
     return hazards
 
 

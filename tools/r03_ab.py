@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Same-box A/B of the round-2 build (build_ab/r02: package + library of commit 7529476, made by hand in the build container)
+against the working tree: box-to-box variance is +-3 %, so only timings from ONE call compare.
+usage: r03_ab.py [c3|c4fwd|c4|c5|c2 ...]   (each build runs in its own process, alternating, three rounds)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--one":
+    which, cfg = sys.argv[2], sys.argv[3]
+    sys.path.insert(0, os.path.join(ROOT, "build_ab", "r02") if which == "r02" else ROOT)
+    import numpy as np, torch
+    import sigkernel_amd
+    gen = torch.Generator().manual_seed(0)
+    def walk(A, M, D, dt=torch.float64): return (torch.cumsum(torch.randn(A, M, D, generator=gen, dtype=torch.float64), dim=1) / np.sqrt(M * D)).to(dt).cuda()
+    if cfg == "c3":
+        X, Y = walk(512, 128, 8), walk(512, 128, 8); sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1); fn = lambda: sk.compute_Gram(X, Y)
+    elif cfg == "c2":
+        X = walk(128, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1); fn = lambda: sk.compute_Gram(X, X, sym=True)
+    elif cfg == "c5":
+        X, Y = walk(256, 512, 16, torch.float32), walk(256, 512, 16, torch.float32); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
+    elif cfg == "c4fwd":
+        X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
+    else:
+        X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
+        def fn():
+            Xg = X.detach().requires_grad_(True); sk.compute_mmd(Xg, Y).backward(); return Xg.grad
+    n = 30 if cfg in ("c3", "c2") else 6
+    for _ in range(max(3, n // 3)): out = fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    print("%-4s %-6s median %.4f ms  min %.4f ms  checksum %r" % (which, cfg, float(np.median(ts)), min(ts), float(out.double().sum())), flush=True)
+    sys.exit(0)
+for cfg in sys.argv[1:] or ["c3"]:
+    for rnd in range(3):
+        for which in ("r02", "new"):
+            subprocess.run([sys.executable, __file__, "--one", which, cfg])
