@@ -155,7 +155,7 @@ Knobs parse_knobs() {
     k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB"); k.adjr_all = knob_int("SK_ADJR_ALL");
     k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
-    k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB");
+    k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");
     k.rank_w = knob_shares("SK_RANK_W"); k.wave_rank_w = knob_shares("SK_WAVE_RANK_W"); k.adj_rank_w = knob_shares("SK_ADJ_RANK_W");
     k.adjf_rank_w = knob_shares("SK_ADJF_RANK_W"); k.adjr_rank_w = knob_shares("SK_ADJR_RANK_W");
     k.deriv_rank_w = knob_shares("SK_DERIV_RANK_W"); k.fused_rank_w = knob_shares("SK_FUSED_RANK_W");

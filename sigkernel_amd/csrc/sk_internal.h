@@ -17,7 +17,7 @@ struct Knobs {
     int adjr_wpc, adjr_wpb, adjr_all;
     int deriv_pf, deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static;
-    int fusedmb_wpc, fusedmb_wpb;
+    int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
 };
 const Knobs &knobs();                      // sk_abi.hip

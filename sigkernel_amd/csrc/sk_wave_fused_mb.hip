@@ -47,7 +47,10 @@ struct FusedMbParams {
     double inv_sigma;
     int64_t ws_stride;  // doubles per wave
     WaveGroup wg;
-    RankSplit rs;        // pairs per wave by age rank; PPW / n_steps are the largest share's
+    // the wave's stream of pairs (as in sk_wave_fused.hip): C0 pairs fixed per wave, then one pair at a time drawn from `queue`
+    unsigned long long *queue;   // the launch's counter (zeroed by the launcher; inside the workspace), nullptr: equal static shares
+    int64_t q_first;
+    int C0;
 };
 
 // 16-byte asynchronous global load past the L1 (sc0 sc1: the line was written by another lane of this wave a few
@@ -221,15 +224,44 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         ypar = s0 & 1;
     }
     const int lam7 = lam & 7;
-    int PPW;               // this wave's pairs (by age rank, sk_wave_common.h), its first pair, the end of its rank's range
-    int64_t pair0, P_end;
-    rank_share(prm.rs, wave_id, 1, prm.P, PPW, pair0, P_end);
-    const int n_steps = PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0);
-    int nvalid;   // pairs of this wave that exist
-    {
-        const int64_t left_pairs = P_end - pair0;
-        nvalid = left_pairs <= 0 ? 0 : (left_pairs < PPW ? (int)left_pairs : PPW);
-    }
+    // ---- the wave's stream of pairs: positions 0 .. C0-1 are pairs wave_id C0 + i; every later position is one pair drawn from the
+    // launch's counter (a pair is nb NUp >= 160 macro-steps long, the lanes' skew 63: at most two pairs are in flight, plus
+    // the producers' look-ahead -- a ring of four).  Pair indices are 32-bit; NOPAIR = none.
+    constexpr unsigned NOPAIR = 0xffffffffu;
+    const unsigned P32 = (unsigned)prm.P;
+    const int C0 = prm.C0;
+    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * C0));
+    unsigned cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR, cb0 = NOPAIR;   // drawn pair of position C0 + j in cb[j & 3]
+    int have = 0;                     // drawn positions known so far
+    int t_end = 0x7fffffff;
+    const int tail = (MB_L - 1) + (KIND == 1 ? 1 : 0);
+    auto stream_pair = [&](int i) __attribute__((always_inline)) -> unsigned {
+        if (i < 0) return NOPAIR;
+        if (i < C0) { const unsigned p = base0 + (unsigned)i; return p < P32 ? p : NOPAIR; }
+        const int kk = (i - C0) & 3;
+        return (cb0 & -(unsigned)(kk == 0)) | (cb1 & -(unsigned)(kk == 1)) | (cb2 & -(unsigned)(kk == 2)) | (cb3 & -(unsigned)(kk == 3));
+    };
+    auto ensure = [&](int f) __attribute__((always_inline)) {
+        while (C0 + have <= f) {
+            unsigned b = NOPAIR;
+            if (prm.queue && t_end == 0x7fffffff) {
+                unsigned long long v = 0;
+                if (lam == 0) v = atomicAdd(prm.queue, 1ULL);
+                const unsigned long long q = (unsigned long long)prm.q_first +
+                                             (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+                b = q < (unsigned long long)P32 ? (unsigned)q : NOPAIR;
+            }
+            if (b == NOPAIR && t_end == 0x7fffffff) t_end = (C0 + have) * prm.nb * prm.NUp + tail;
+            const int kk = have & 3;
+            const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
+            cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));
+            cb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb1 & ~m1) | (b & m1)));
+            cb2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb2 & ~m2) | (b & m2)));
+            cb3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb3 & ~m3) | (b & m3)));
+            have += 1;
+        }
+    };
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
     const unsigned my_x = lds0 + X_BASE + (unsigned)((lam & 7) * RC * XROW);
 
@@ -250,8 +282,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     // y slab s = virtual units [8s, 8s+8): unit offset y_u0 in the row, of pair-in-wave y_pi (every band re-reads its pair's y)
     int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
-        int64_t p = pair0 + y_pi;
-        if (y_pi >= PPW || p >= P_end) p = 0;    // past the end: fetch something valid, never consumed
+        ensure(y_pi);
+        const unsigned spy = stream_pair(y_pi);
+        const int64_t p = spy == NOPAIR ? 0 : (int64_t)spy;    // past the end: fetch something valid, never consumed
         const int64_t b = split_b(p);
         if constexpr (Y32) {
             const double *row0 = prm.Yt + b * (FDY + 1) * (int64_t)prm.Ncp;
@@ -282,8 +315,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     // consumes during the window: positions x_lam0 .. x_lam0+7 of the wave's global row (lane 0's unit IS the window's offset)
     int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
     auto issue_x = [&]() {
-        int64_t p = pair0 + x_pi;
-        if (x_pi >= PPW || p >= P_end) p = 0;
+        ensure(x_pi);
+        const unsigned spx = stream_pair(x_pi);
+        const int64_t p = spx == NOPAIR ? 0 : (int64_t)spx;
         const int64_t a = split_a(p);
         const int lamj = x_lam0 < L ? x_lam0 : 0;     // nobody starts: fetch something valid
         const char *src = reinterpret_cast<const char *>(prm.Xr + (a * prm.Mrows + (int64_t)(x_band * L + lamj) * RC + (RBF ? 1 : 0)) * FD);
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     issue_x();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    for (int t = 0; t < n_steps; ++t) {
+    for (int t = 0; t < t_end; ++t) {
         // -- lane 0: the boundary entry of its unit u (K row for the sweep of uk, node pair at the columns of unit u), from
         //    the chunk the window's LDS-DMA brought in; no wait here (see lds_read_pend)
         d2_t pend[NP], bnd[NP];
@@ -560,7 +594,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (uk == my_uf) {
             int pv = psk, bv = bandk;
             asm volatile("" : "+v"(pv), "+v"(bv));
-            if (bv == prm.band_f && (unsigned)pv < (unsigned)nvalid) {
+            const unsigned pair_v = bv == prm.band_f ? stream_pair(pv) : NOPAIR;
+            if (pair_v != NOPAIR) {
                 double v = cand[0][0];
 #pragma unroll
                 for (int k = 0; k < RC; ++k)
@@ -570,7 +605,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                static_cast<TO *>(prm.out)[pair0 + pv] = (TO)v;
+                static_cast<TO *>(prm.out)[pair_v] = (TO)v;
             }
         }
 
@@ -629,16 +664,27 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     if (waves_per_cu < 1) waves_per_cu = 1;
     const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = P < max_waves ? P : max_waves;
+    if (P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;            // (pair indices are 32-bit inside the kernel)
+    int64_t per = (P + waves - 1) / waves;                       // the equal share, pairs per wave
+    if (per > 0x1fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double) + 64) return SK_ERR_WORKSPACE;
+    const int pct = knobs().fusedmb_q_static > 0 ? (knobs().fusedmb_q_static > 100 ? 100 : knobs().fusedmb_q_static) : 50;
+    if (waves == max_waves && per >= 8 && pct < 100) {
+        // the launch fills the chip: `pct` per cent of the equal share is dealt out up front, the rest is drawn pair by pair
+        prm.C0 = (int)(per * pct / 100);
+        prm.queue = reinterpret_cast<unsigned long long *>(ws + (size_t)waves * (size_t)prm.ws_stride);
+        prm.q_first = waves * (int64_t)prm.C0;
+        if (hipMemsetAsync(prm.queue, 0, sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
+    } else {
+        waves = (P + per - 1) / per;
+        prm.C0 = (int)per;
+        prm.queue = nullptr;
+        prm.q_first = P;
+    }
     prm.wg = wave_group(lds_bytes, waves, knobs().fusedmb_wpb);
-    prm.rs = rank_split(P, 1, waves, max_waves, prm.wg.wpb, device_cu_count(), knobs().fusedmb_rank_w);
-    int64_t PPW = prm.rs.cnt[0];   // the largest share
-    if (prm.rs.nranks == 1) waves = (P + PPW - 1) / PPW;
-    if (PPW > 0x3fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double)) return SK_ERR_WORKSPACE;
-    prm.PPW = (int)PPW;
-    prm.n_steps = (int)(PPW * prm.nb * prm.NUp + (MB_L - 1) + (KIND == 1 ? 1 : 0));
+    prm.PPW = (int)per;
+    prm.n_steps = 0;
     prm.ws = ws;
-    if (prm.rs.nranks == 1) prm.wg = wave_group(lds_bytes, waves, knobs().fusedmb_wpb);
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
@@ -701,7 +747,7 @@ size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic,
     if (!pl.ok || P <= 0) return 0;
     const int64_t max_waves = (int64_t)device_cu_count() * 16;   // an upper bound on the resident waves whatever the variant's register count
     const int64_t waves = P < max_waves ? P : max_waves;
-    return (size_t)waves * (size_t)pl.ws_stride * sizeof(double);
+    return (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the launch's work counter
 }
 // rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
 int fused_mb_rows(int kind, int Mc, int dyadic) {

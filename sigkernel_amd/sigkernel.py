@@ -63,9 +63,12 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
             and not os.environ.get("SK_NO_FUSED_RBF")):
         kind, param = 1, float(static_kernel.sigma)
         res = be.solve_fwd_fused_rbf(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
-    if res is None and kind is not None and not keep_edges and hasattr(be, "solve_fwd_fused_static") \
-            and not os.environ.get("SK_NO_FUSED_MB"):
+    if res is None and kind is not None and hasattr(be, "solve_fwd_fused_static") and not os.environ.get("SK_NO_FUSED_MB"):
+        # several bands per pair / wide paths: the multi-band fused kernel.  It keeps no edges: with a gradient pending the values
+        # still come from it (nothing of size pairs x M x N in HBM) and the adjoint sweeps forward by itself later
         res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram)
+        if res is not None and keep_edges:
+            res = (res, None)
     return res
 
 
@@ -99,6 +102,10 @@ def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
             and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF"))
 
 
+def _upcast_tile(X, dyadic):
+    return X.dtype == torch.float32 and dyadic == 2
+
+
 def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=None):
     """dL/dX for one tile on the unfused routes: increments -> adjoint PDE (W = dK/d inc_c) -> chain through the static kernel.
 
@@ -108,6 +115,11 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     this replaces the reference's h = 1e-9 finite difference (sigkernel.py:313-341, :472-500)."""
     fused = _fused_static(static_kernel, gram)
     if fused is not None and hasattr(be, "static_adjoint"):
+        if _upcast_tile(Xt, dyadic) and edges is None:
+            # fp32 paths at dyadic 2: the streaming adjoint exists for fp64 there.  The whole tile in fp64 -- increments formed
+            # from the up-cast paths, adjoint, chain rule -- instead of fp32 increments up-cast in 4 GB chunks (round 2: 3x slower)
+            g = _tile_gradient(be, static_kernel, Xt.double(), Yt.double(), go.double(), dyadic, naive, gram)
+            return g.to(Xt.dtype)
         inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
         if inc is not None:
             _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
@@ -168,7 +180,8 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
         if g is not None:
             return g
     fused = _fused_static(static_kernel, gram) is not None
-    per_row = (3 if fused else 8) * (Yd.shape[0] if gram else 1) * M * N * Xd.element_size()
+    esize = 8 if (fused and _upcast_tile(Xd, dyadic)) else Xd.element_size()
+    per_row = (3 if fused else 8) * (Yd.shape[0] if gram else 1) * M * N * esize
     grad = torch.empty_like(Xd)
     for a0, a1, edges in _edge_tiles(kept, A, per_row, budget, strict=True):
         grad[a0:a1] = _tile_gradient(be, static_kernel, Xd[a0:a1].contiguous(), Yd if gram else Yd[a0:a1].contiguous(),
@@ -377,6 +390,9 @@ def _sym_unfused_gradient(be, kind, param, Xd, go, dyadic, naive, sym_blocks, bu
     """The same through sk_static_increments -> sk_solve_adj -> sk_static_adjoint (first argument) + sk_static_adjoint2 (second
     argument of the SAME W, weighted by the transposed upstream gradient); owns the stored-grid rescue."""
     A, M, N = Xd.shape[0], Xd.shape[1], Xd.shape[1]
+    if _upcast_tile(Xd, dyadic) and all(not kept or all(e[2] is None for e in kept) for _, _, kept in sym_blocks):
+        # fp32 paths at dyadic 2 without kept edges: the whole route in fp64 (see _tile_gradient)
+        return _sym_unfused_gradient(be, kind, param, Xd.double(), go.double(), dyadic, naive, sym_blocks, budget).to(Xd.dtype)
     grad_X = torch.zeros_like(Xd)
     for r0, r1, kept in sym_blocks:
         Xr, Xc = Xd[r0:r1].contiguous(), Xd[r0:].contiguous()
