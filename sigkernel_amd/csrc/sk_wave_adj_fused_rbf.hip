@@ -505,9 +505,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double V2 = wkP[RC - 1] - wk[RC - 1][1];
             const double cb1 = V1 * Gown[RC - 1][1], cb2 = V2 * GownP[RC - 1];
             const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
-            cs[RC] += cv1 + cv2;
+            if (is_bot) {
+                asm volatile("");
+                cs[RC] += cv1 + cv2;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+                for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+            }
             if constexpr (YSIDE) {
                 // what this lane hands down: the sums over the node rows r_k so far
                 lds_write_carry(yc_base + (unsigned)(lane << 4), car);
