@@ -6,7 +6,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     which, cfg = sys.argv[2], sys.argv[3]
-    sys.path.insert(0, os.path.join(ROOT, "build_ab", "r02") if which == "r02" else ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "build_ab", which) if which != "new" else ROOT)
     import numpy as np, torch
     import sigkernel_amd
     gen = torch.Generator().manual_seed(0)
@@ -34,5 +34,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 for cfg in sys.argv[1:] or ["c3"]:
     for rnd in range(3):
-        for which in ("r02", "new"):
+        for which in (os.environ.get("SK_AB_BASE", "r02"), "new"):
             subprocess.run([sys.executable, __file__, "--one", which, cfg])
