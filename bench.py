@@ -335,12 +335,13 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
             (lambda: _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True))
         # Linear / RBF within the fused kernels' scope: one launch does static kernel + increments + PDE for the whole Gram;
         # nothing of size pairs x M x N touches HBM, so the ceiling is fp64 vector issue.  FMA-class lane operations per pair:
-        # 3 per fine cell (stencil) + per coarse cell 4 (coefficients) + the static kernel (linear: D FMAs; rbf: 2 D for
-        # the distance, 19 for exp, 4 for the 4-corner difference).
+        # 3 per fine cell (stencil) + per coarse cell 3 (linear) / 4 (rbf) coefficient operations + the static kernel (linear:
+        # D FMAs; rbf: 2 D for the distance, 19 for exp, 4 for the 4-corner difference).
         ms = time_launches(run_fused, reps)
         avg = float(np.mean(ms))
         pairs_f = A * (A + 1) // 2 if sym else A * B        # sym: the pairs on and above the diagonal, one launch
-        per_coarse = 4 + (D if kname == "linear" else 2 * D + 23)
+        # (linear, round 3: three coefficient operations per coarse cell on the pre-scaled increment, sk_linear_prescale)
+        per_coarse = (3 + D) if kname == "linear" else (4 + 2 * D + 23)
         ops = pairs_f * (cells_per_entry * 3 + Mc * Nc * per_coarse)
         tflops = 2 * ops / (avg * 1e-3) / 1e12
         kern = "sk_solve_fwd_%s_%s (k_fwd_fused: static kernel + increments + PDE in one launch)" % (kname, "f64" if s == 8 else "f32")
@@ -350,7 +351,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
             "kernel": kern, "pairs_per_launch": pairs_f, "fp64_lane_ops_per_launch": ops, "avg_launch_ms": avg,
             "min_launch_ms": float(np.min(ms)),
             "cells_per_s": pairs_f * cells_per_entry / (avg * 1e-3),
-            "note": "algorithmic FMA-class operations (stencil 3/cell, coefficients 4/coarse cell, static kernel) x 2 flop over the "
+            "note": "algorithmic FMA-class operations (stencil 3/cell, coefficients 3 (linear) or 4 (rbf) per coarse cell, static kernel) x 2 flop over the "
                     "launch time, against the fp64 vector peak; the increment matrix is never materialised, HBM traffic is the "
                     "paths (MBs).  tools/ubench/fma_rate measures 63 TFLOP/s of independent v_fma_f64 on this part "
                     "(profiles/r02_fma_rate.txt)",

@@ -55,3 +55,8 @@ for cfg in ("c5","c4","c3"):
 if os.path.exists(os.path.join(out,"failed.txt")): print(open(os.path.join(out,"failed.txt")).read())
 PY
 cat $OUT/summary.txt | head -150
+# the HBM-streaming solver's own PMC pass, the per-rank shard times, this round's bench lines
+bash tools/pmc_fwd.sh r03fwd > $OUT/pmc_fwd_solver.txt 2>&1
+timeout 900 python tools/r03_shard_times.py $OUT/c4_shard_times.json > $OUT/shard.log 2>&1
+for cfg in c3 c2 c4 c5; do timeout 900 python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; done
+python tools/r03_ab.py c3 c4 > $OUT/ab_r02_vs_r03.txt 2>&1
