@@ -32,52 +32,6 @@ def _budget(device, requested):
     return _DEFAULT_WORKSPACE
 
 
-_SYM_STREAMS = int(os.environ.get("SK_SYM_STREAMS", "2"))   # side streams the row blocks of a symmetric Gram alternate on
-_side_pool = {}
-
-
-class _BlockStreams:
-    """Row blocks of a symmetric Gram, launched round-robin on side streams: every block is a persistent launch sized to the
-    whole chip, so on ONE stream the chip idles through each launch's drain and the next one's fill; on alternating streams the
-    next block's workgroups take the CUs the moment the previous block's let go of them.  Fork / join by events only (no host
-    synchronisation; capturable in a hipGraph).  n <= 1 or a CPU tensor: everything stays on the current stream."""
-
-    def __init__(self, device, n=None):
-        n = _SYM_STREAMS if n is None else n
-        self.streams = []
-        if device.type == "cuda" and n > 1:
-            key = (device.index, n)
-            if key not in _side_pool:
-                _side_pool[key] = [torch.cuda.Stream(device) for _ in range(n)]
-            self.streams = _side_pool[key]
-            self.cur = torch.cuda.current_stream(device)
-        self.n = max(1, len(self.streams))
-
-    def fork(self):
-        """Everything queued on the current stream so far happens before the blocks."""
-        for st in self.streams:
-            st.wait_stream(self.cur)
-        return self
-
-    def on(self, i):
-        """Context manager: block i's stream."""
-        if not self.streams:
-            import contextlib
-            return contextlib.nullcontext()
-        return torch.cuda.stream(self.streams[i % self.n])
-
-    def hand_over(self, *tensors):
-        """Tensors a block allocated on its side stream and the current stream goes on using after join()."""
-        if self.streams:
-            for t in tensors:
-                if t is not None:
-                    t.record_stream(self.cur)
-
-    def join(self):
-        for st in self.streams:
-            self.cur.wait_stream(st)
-
-
 def _tiles(n_rows, bytes_per_row, budget):
     rows = int(max(1, min(n_rows, budget // max(1, bytes_per_row))))
     return [(a, min(a + rows, n_rows)) for a in range(0, n_rows, rows)]
@@ -360,22 +314,16 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
         # (measured: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms): at least _SYM_MIN_ROWS rows each
         T = max(1, min(T, A // _SYM_MIN_ROWS))
     step = -(-A // T)
-    bs = _BlockStreams(Xd.device, None if T > 1 else 1).fork()
-    try:
-        for i, r0 in enumerate(range(0, A, step)):
-            r1 = min(r0 + step, A)
-            kept = [] if keep_blocks is not None else None
-            with bs.on(i):
-                blk = _gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes,
-                                  3 if keep_blocks is not None else None, kept)
-                if keep_blocks is not None:
-                    keep_blocks.append((r0, r1, kept))
-                    bs.hand_over(*[e[2] for e in kept])
-                K[r0:r1, r0:] = blk          # (the blocks write disjoint parts of K)
-                if r1 < A:
-                    K[r1:, r0:r1] = blk[:, r1 - r0:].t()
-    finally:
-        bs.join()
+    for r0 in range(0, A, step):
+        r1 = min(r0 + step, A)
+        kept = [] if keep_blocks is not None else None
+        blk = _gram_block(be, static_kernel, Xd[r0:r1].contiguous(), Xd[r0:].contiguous(), dyadic_order, naive, workspace_bytes,
+                          3 if keep_blocks is not None else None, kept)
+        if keep_blocks is not None:
+            keep_blocks.append((r0, r1, kept))
+        K[r0:r1, r0:] = blk
+        if r1 < A:
+            K[r1:, r0:r1] = blk[:, r1 - r0:].t()
     # the diagonal blocks were solved in full: symmetrise them to the upper triangle too
     iu = torch.triu_indices(A, A, offset=1, device=Xd.device)
     K[iu[1], iu[0]] = K[iu[0], iu[1]]
@@ -414,44 +362,28 @@ def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, bu
         return None
     A, M = Xd.shape[0], Xd.shape[1]
     sigma = float(static_kernel.sigma)
+    grad = torch.zeros_like(Xd)
     for r0, r1, kept in sym_blocks:
         if not kept or len(kept) != 1 or kept[0][2] is None or kept[0][:2] != (0, r1 - r0):
             return None
-    bs = _BlockStreams(Xd.device, None if len(sym_blocks) > 1 else 1)
-    grads = [torch.zeros_like(Xd) for _ in range(bs.n)]    # one accumulator per stream: the blocks' rows overlap
-    ok = True
-    bs.fork()
-    try:
-        for i, (r0, r1, kept) in enumerate(sym_blocks):
-            with bs.on(i):
-                grad = grads[i % bs.n]
-                Xc = Xd[r0:].contiguous()
-                nb = Xc.shape[0]
-                # rows per launch by the memory of the second-argument sums (48 bytes per pair and node column)
-                per_row = 64 * nb * (M + 16)
-                edges = kept[0][2]
-                per = edges.numel() // (r1 - r0)
-                for a0, a1 in _tiles(r1 - r0, per_row, budget // bs.n):
-                    Xt = Xd[r0 + a0:r0 + a1].contiguous()
-                    Kt = None if Kvals is None else Kvals[r0 + a0:r0 + a1, r0:]
-                    res = be.rbf_adjoint_fused(Xt, Xc, sigma, dyadic, edges[a0 * per:a1 * per],
-                                               go[r0 + a0:r0 + a1, r0:].reshape(-1).contiguous(), gram=True, yside=r1 < A, kfinal=Kt)
-                    if res is None:
-                        ok = False
-                        break
-                    grad[r0 + a0:r0 + a1] += res[0]
-                    if r1 < A:   # upstream gradient of the mirror pair (b, a) is go[b, a]
-                        grad[r1:] += be.second_argument_gradient(res[2], Xc, sigma, go[r0:, r0 + a0:r0 + a1].t(), r1 - r0)
-                    del res
-            if not ok:
-                break
-    finally:
-        bs.join()
-    if not ok:
-        return None
-    for g in grads[1:]:
-        grads[0] += g
-    return grads[0]
+        Xc = Xd[r0:].contiguous()
+        nb = Xc.shape[0]
+        # rows per launch by the memory of the second-argument sums (48 bytes per pair and node column)
+        per_row = 64 * nb * (M + 16)
+        edges = kept[0][2]
+        per = edges.numel() // (r1 - r0)
+        for a0, a1 in _tiles(r1 - r0, per_row, budget):
+            Xt = Xd[r0 + a0:r0 + a1].contiguous()
+            Kt = None if Kvals is None else Kvals[r0 + a0:r0 + a1, r0:]
+            res = be.rbf_adjoint_fused(Xt, Xc, sigma, dyadic, edges[a0 * per:a1 * per], go[r0 + a0:r0 + a1, r0:].reshape(-1).contiguous(),
+                                       gram=True, yside=r1 < A, kfinal=Kt)
+            if res is None:
+                return None
+            grad[r0 + a0:r0 + a1] += res[0]
+            if r1 < A:   # upstream gradient of the mirror pair (b, a) is go[b, a]
+                grad[r1:] += be.second_argument_gradient(res[2], Xc, sigma, go[r0:, r0 + a0:r0 + a1].t(), r1 - r0)
+            del res
+    return grad
 
 
 def _sym_unfused_gradient(be, kind, param, Xd, go, dyadic, naive, sym_blocks, budget):

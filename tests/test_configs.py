@@ -322,45 +322,6 @@ def test_forward_and_training_step_replay_from_a_hip_graph(kind, D):
 
 
 @pytest.mark.gpu
-def test_symmetric_row_blocks_on_side_streams_match_one_stream_and_replay_from_a_graph(monkeypatch):
-    """compute_mmd(X, Y).backward() with the triangular K_XX in row blocks that alternate on side streams (sigkernel._BlockStreams):
-    bit-identical to the same blocks on the current stream alone, and -- fork / join being events only -- still capturable."""
-    from sigkernel_amd import sigkernel as S
-    monkeypatch.setattr(S, "_SYM_MIN_CELLS", 0.0)
-    gen = torch.Generator().manual_seed(77)
-    X, Y = walk(gen, 96, 24, 4).to(DEV), walk(gen, 80, 20, 4).to(DEV)
-    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
-    out = {}
-    for n in (1, 3):
-        monkeypatch.setattr(S, "_SYM_STREAMS", n)
-        Xg = X.clone().requires_grad_(True)
-        loss = sk.compute_mmd(Xg, Y)
-        loss.backward()
-        out[n] = (loss.detach().clone(), Xg.grad.clone())
-    assert torch.equal(out[1][0], out[3][0])
-    assert float((out[1][1] - out[3][1]).abs().max()) <= 1e-14 * float(out[1][1].abs().max())   # (the accumulators are summed in another order)
-    Xc = X.cpu().numpy()
-    ref = torch.from_numpy(2.0 * O.gram_grad_weighted(Xc, Xc, np.full((96, 96), 1.0), ("rbf", 1.0), 2, nthreads=NT))   # the reference's 2x rule
-    Xs = X.clone().requires_grad_(True)
-    sk.compute_Gram(Xs, Xs, sym=True).sum().backward()
-    assert float((Xs.grad.cpu() - ref).abs().max() / ref.abs().max()) <= 1e-10
-    sX = X.clone().requires_grad_(True)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(2):
-            sk.compute_mmd(sX, Y).backward()
-            sX.grad = None
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        sk.compute_mmd(sX, Y).backward()
-    graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(sX.grad, out[3][1])
-
-
-@pytest.mark.gpu
 def test_headline_with_a_second_stream_busy_same_bits_little_slowdown():
     """The fused forward draws its pairs from a per-launch queue, so work someone else has on the chip shifts shares instead of
     stretching the tail: with a second stream kept busy by small launches the headline Gram is bit-identical and < 10 % slower."""
