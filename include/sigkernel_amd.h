@@ -149,6 +149,23 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
                              int *outw_out, int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
                              size_t rescue_ws_bytes, void *stream);
 
+/* The fused RBF adjoint for LONG or WIDE paths (csrc/sk_wave_adj_fused_mb.hip): any number of bands per pair, path dimensions up to
+ * 16 -- BASELINE configs[4]'s shape with a gradient runs in sk_solve_fwd_static_* (edges) + this kernel with nothing of size P*M*N
+ * in HBM.  Replaces sigkernel.py:419-502 + :404-416 for RBFKernel there, i.e. sk_static_increments + sk_solve_fwd + sk_solve_adj +
+ * sk_static_adjoint.
+ *   sk_rbf_adjoint_fused_mb_layout: *mrows = rows of Xr per path, gpart = [P][*rows][*outw] doubles, *edge_doubles per pair,
+ *   *workspace_bytes (one band-boundary row per resident wave); SK_ERR_UNSUPPORTED outside the scope (dyadic 1..2, D <= 16, second
+ *   path of >= ~160 points).
+ *   Xr [A][Mrows][fd] / Yt [Bn][fd][Ncp]: the fp64 POINT arrays of sk_solve_fwd_static_* (kind 1, yt_f32 = 0), fd = 8 or 16;
+ *   edges: what sk_solve_fwd_static_* kept;  scale [P] nullable.  gpart receives, per PAIR and node row r < M, cs = [..][0] and
+ *   accd = [..][2 .. 2+D): summed over the pairs of an x_a, dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  err [P] zero-initialised:
+ *   self-check residual as for sk_solve_adj_* (a pair whose scale is NaN is skipped and its sums stored as zeros). */
+int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
+                                   size_t *workspace_bytes);
+int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+                                int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
+                                size_t gpart_doubles, double *err, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Device-side rescue of the two fused adjoints above (csrc/sk_adj_fused_rescue.hip) -- what makes a backward pass free of host
  * synchronisation.  The fused adjoints recompute K backwards from its terminal edges, which loses accuracy like 1e-16 K^2 and is
  * useless for exploding kernels; the reference stores both grids for every pair whatever K's size (sigkernel.py:438-470).
@@ -281,14 +298,17 @@ int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int 
  * sk_static_increments_* + sk_solve_fwd_*, or swap the arguments -- the kernel is symmetric). */
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
+/* edges (nullable; kind 1, dyadic 1..2): also keep every pair's terminal row and column -- of the grid PADDED to the bands and units
+ * of sk_rbf_adjoint_fused_mb_f64, whose padding carries no increments -- *edge_doubles (sk_rbf_adjoint_fused_mb_layout) doubles per
+ * pair: what that adjoint recomputes K from.  Mrows must then be the layout's *mrows. */
 int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
-                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
-                            void *stream);
+                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, double *edges, void *workspace,
+                            size_t workspace_bytes, void *stream);
 /* f32: yt_f32 = 1 (kind 1, fd = 16 only): Yt holds the fp32 points packed as sk_prep_paths_f32 layout 2 writes them -- half
  * the LDS ring, twice the resident waves at 16 dimensions; arithmetic stays fp64.  yt_f32 = 0: Yt is the fp64 array above. */
 int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows,
-                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace,
-                            size_t workspace_bytes, void *stream);
+                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, double *edges,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same, also keeping the terminal row/column of every pair (layout and size: sk_strip_edges_bytes) for a later
  * sk_solve_adj_* with SK_FLAG_EDGES_GIVEN on the increments of the same paths (sk_static_increments_*, kind 1). */

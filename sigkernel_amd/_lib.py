@@ -56,9 +56,12 @@ SIGNATURES = {
     "sk_solve_fwd_static_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
     "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
     "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
-                                       _vp, _sz, _vp]),
-    "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _vp, _vp, _sz, _vp]),
+    "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
+                                       _vp, _vp, _vp, _sz, _vp]),
+    "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
+                                           _vp, _sz, _vp, _vp, _sz, _vp]),
     "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
@@ -339,7 +342,18 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_*_sym")
         return out
 
-    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False):
+    @staticmethod
+    def _adjoint_mb_layout(P, Mc, Nc, dyadic, D):
+        """(mrows, rows, outw, edge_doubles, workspace_bytes) of sk_rbf_adjoint_fused_mb_f64, or None outside its scope."""
+        mrows, rows, outw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        ed, wsb = ctypes.c_int64(0), ctypes.c_size_t(0)
+        rc = load().sk_rbf_adjoint_fused_mb_layout(P, Mc, Nc, int(dyadic), D, ctypes.byref(mrows), ctypes.byref(rows), ctypes.byref(outw),
+                                                   ctypes.byref(ed), ctypes.byref(wsb))
+        if rc != 0:
+            return None
+        return mrows.value, rows.value, outw.value, int(ed.value), int(wsb.value)
+
+    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False, keep_edges=False):
         """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for
         pairs that need several bands of a wavefront and for path dims up to 16 (sk_solve_fwd_static_*, csrc/sk_wave_fused_mb.hip):
         nothing of size pairs x M x N in HBM.  None outside the kernel's scope (dyadic > 2, dim > 16, naive scheme, second path
@@ -360,9 +374,16 @@ class HipBackend:
             if _swapped or not int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Nc, Mc, int(dyadic), D)):
                 return None
             Kt = self.solve_fwd_fused_static(kind, param, Y, X, dyadic, naive, gram, _swapped=True)
-            return None if Kt is None else (Kt.t().contiguous() if gram else Kt)
+            Kt = None if Kt is None else (Kt.t().contiguous() if gram else Kt)
+            return (Kt, None) if (keep_edges and Kt is not None) else Kt
         fd = 8 if D <= 8 else 16
         Mrows = int(lib.sk_solve_fwd_static_rows(int(kind), Mc, int(dyadic)))
+        # keep_edges (RBF, dyadic 1..2): the terminal row / column of every pair in the layout sk_rbf_adjoint_fused_mb_f64 reads
+        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D) if (keep_edges and kind == 1 and not _swapped) else None
+        edges = None
+        if lay is not None:
+            Mrows = lay[0]
+            edges = torch.empty(P * lay[3], dtype=torch.float64, device=X.device)
         NUp = ((Nc + 1 + int(kind)) // 2 + 7) // 8 * 8
         Ncp = 2 * NUp
         dev = X.device
@@ -382,14 +403,55 @@ class HipBackend:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             if X.dtype == torch.float32:
                 rc = lib.sk_solve_fwd_static_f32(int(kind), float(param), _ptr(Xr), _ptr(Yt), int(y32), A, B if gram else 0, Mrows, Mc,
-                                                 Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
+                                                 Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(edges), _ptr(ws), nbytes,
+                                                 _stream(X))
             else:
                 rc = lib.sk_solve_fwd_static_f64(int(kind), float(param), _ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp,
-                                                 D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(ws), nbytes, _stream(X))
+                                                 D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(edges), _ptr(ws), nbytes, _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_static")
-        return out
+        return (out, edges) if keep_edges else out
+
+    def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True):
+        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel on LONG or WIDE paths
+        straight from the paths and the terminal edges solve_fwd_fused_static(keep_edges=True) kept: adjoint PDE, node evaluation and
+        chain rule in one multi-band kernel (sk_rbf_adjoint_fused_mb_f64; fp64 sweep whatever the dtype of X; dim <= 16, dyadic
+        1..2, any M, N >= ~160).  None outside that scope."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if D > 16 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0 or edges is None:
+            return None
+        P, Bk = (A * B, B) if gram else (A, 0)
+        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D)
+        if lay is None or edges.numel() != P * lay[3]:
+            return None
+        mrows, rows, outw, _, nbytes = lay
+        fd = outw - 2
+        Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
+        dev = X.device
+        if scale is not None:
+            scale = scale.double().contiguous()
+        with torch.cuda.device(dev):
+            Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
+            Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
+            gpart = torch.empty(P, rows, outw, dtype=torch.float64, device=dev)
+            err = torch.zeros(P, dtype=torch.float64, device=dev)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = load().sk_rbf_adjoint_fused_mb_f64(_ptr(Xr), _ptr(Yt), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
+                                                    float(sigma), _ptr(edges), _ptr(scale), _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ws),
+                                                    nbytes, _stream(X))
+            if rc == 2:
+                return None
+            _check(rc, "sk_rbf_adjoint_fused_mb")
+        self.last_fused_err = err
+        T = gpart.view(A, B if gram else 1, rows, outw)[:, :, :M].sum(1)     # the pairs of an a added in a fixed order
+        cs, accd = T[..., 0:1], T[..., 2:2 + D]
+        g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
+        return g.to(X.dtype), err.max()
 
     def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel straight from the paths

@@ -104,14 +104,15 @@ int solve_fwd_edges(const T *inc_c, int64_t ld, int64_t P, int Mc, int Nc, int d
 
 template <typename TO>
 int solve_fwd_static(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Mc,
-                     int Nc, int Ncp, int D, int fd, int dyadic, int scheme, TO *out_final, void *ws, size_t ws_bytes, void *stream) {
+                     int Nc, int Ncp, int D, int fd, int dyadic, int scheme, TO *out_final, double *edges, void *ws, size_t ws_bytes,
+                     void *stream) {
     if (D < 1 || !Xr || !Yt || !out_final || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
     if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_fwd_fused_mb<TO>(kind, Xr, Yt, yt_f32, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, out_final, ws, ws_bytes,
-                                   (hipStream_t)stream);
+    return launch_fwd_fused_mb<TO>(kind, Xr, Yt, yt_f32, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, out_final, edges, ws,
+                                   ws_bytes, (hipStream_t)stream);
 }
 
 // symmetric Gram of ONE path batch: only the A (A + 1) / 2 pairs on and above the diagonal are solved, each written twice
@@ -153,6 +154,7 @@ Knobs parse_knobs() {
     k.adj_wpc = knob_int("SK_ADJ_WPC"); k.adj_wpb = knob_int("SK_ADJ_WPB");
     k.adjf_wpc = knob_int("SK_ADJF_WPC"); k.adjf_wpb = knob_int("SK_ADJF_WPB");
     k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB"); k.adjr_all = knob_int("SK_ADJR_ALL");
+    k.adjmb_wpc = knob_int("SK_ADJMB_WPC"); k.adjmb_wpb = knob_int("SK_ADJMB_WPB");
     k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");
@@ -368,15 +370,15 @@ int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
     return fused_mb_rows(kind, Mc, dyadic);
 }
 int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
-                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, void *workspace, size_t workspace_bytes,
-                            void *stream) {
-    return solve_fwd_static<double>(kind, param, Xr, Yt, 0, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+                            int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, double *edges, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    return solve_fwd_static<double>(kind, param, Xr, Yt, 0, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, edges, workspace,
                                     workspace_bytes, stream);
 }
 int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows,
-                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, void *workspace,
-                            size_t workspace_bytes, void *stream) {
-    return solve_fwd_static<float>(kind, param, Xr, Yt, yt_f32, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, workspace,
+                            int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, double *edges,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    return solve_fwd_static<float>(kind, param, Xr, Yt, yt_f32, A, B, Mrows, Mc, Nc, Ncp, D, fd, dyadic, scheme, out_final, edges, workspace,
                                    workspace_bytes, stream);
 }
 
@@ -443,6 +445,25 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
     const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
     return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ypart, ypart_doubles,
                                 ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, rescue_ws ? &fr : nullptr, (hipStream_t)stream);
+}
+
+int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
+                                   size_t *workspace_bytes) {
+    if (P < 1 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    return adj_fused_mb_layout(P, Mc, Nc, dyadic, D, mrows, rows, outw, edge_doubles, nullptr, nullptr, workspace_bytes) ? SK_OK
+                                                                                                                        : SK_ERR_UNSUPPORTED;
+}
+
+int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+                                int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
+                                size_t gpart_doubles, double *err, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!Xr || !Yt || !edges || !gpart || !err || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (!(sigma > 0.0) || !(sigma < 1e300)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_adj_fused_rbf_mb(Xr, Yt, A, B, Mrows, Ncp, D, fd, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, workspace,
+                                   workspace_bytes, (hipStream_t)stream);
 }
 
 size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks) {

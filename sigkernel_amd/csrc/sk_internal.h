@@ -15,6 +15,7 @@ struct Knobs {
     int adj_wpc, adj_wpb;
     int adjf_wpc, adjf_wpb;
     int adjr_wpc, adjr_wpb, adjr_all;
+    int adjmb_wpc, adjmb_wpb;     // sk_wave_adj_fused_mb.hip
     int deriv_pf, deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static;
     int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;
@@ -138,9 +139,16 @@ int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
 // ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
 template <typename TO>
 int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D,
-                        int fd, const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s);
+                        int fd, const Geom &g, double inv_sigma, TO *out, double *edges, void *ws, size_t ws_bytes, hipStream_t s);
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
-int fused_mb_rows(int kind, int Mc, int dyadic);
+int fused_mb_rows(int kind, int Mc, int dyadic, bool edges = false);
+
+// ---- sk_wave_adj_fused_mb.hip: the fused RBF adjoint for pairs of several bands / path dims up to 16 ----
+bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles, int *nb,
+                         int *nup, size_t *ws_bytes);
+int launch_adj_fused_rbf_mb(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
+                            double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
+                            void *ws, size_t ws_bytes, hipStream_t s);
 
 // ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,

@@ -40,6 +40,9 @@ struct FusedMbParams {
     const double *Xr;   // [A][Mrows][FD]: KIND 0: s^2 (x[p+1]-x[p]);  KIND 1: x[p]; zero rows / dims beyond the path
     const double *Yt;   // [Bn][FD][Ncp]: KIND 0: y[q+1]-y[q];  KIND 1: y[q]; dimension-major, zero-padded
     void *out;          // [P]
+    double *edges;      // EDGES: [P][NUp S + nb 64 R] the terminal row K[MMp][1..NNp] and column K[1..MMp][NNp] of the PADDED grid (whose
+                        // padding carries no increments: K[MMp][j] = K[MM][min(j, NN)] and likewise down the column), for
+                        // sk_rbf_adjoint_fused_mb_f64
     double *ws;         // per wave: [NUp + 8][E] band-boundary row + a chunk of ones, E = S doubles of K (+ 2 node values, KIND 1) per unit
     int64_t P, B;       // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired
     int Mrows, Ncp, Mc, Nc, NUp, nb, PPW, n_steps;
@@ -170,7 +173,7 @@ __device__ __forceinline__ void lds_pend_take(d2_t (&o)[NP], d2_t (&t)[NP]) { as
 // products are exact in fp64 and the cancellation costs nothing the inputs could resolve; the fp64-ring variants keep the
 // direct sum over (x - y)^2.  The slab pitch (9 x 128 bytes) is an odd multiple of 128, so lanes 8 apart (same unit of
 // neighbouring slabs) hit different halves of the bank row without the parity swizzle of the fp64 ring.
-template <typename TO, int DY, bool Y32, int KIND, int FD>
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams prm) {
     constexpr bool NAIVE = false;   // the _naive_solver scheme is not built for this kernel
     constexpr int FDY = Y32 ? FD / 2 : FD;   // rows of a y slab
@@ -544,6 +547,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                     ginc[k][q] = g;
                 }
         }
+        if constexpr (EDGES) {   // no increments in the padding: the terminal edges of the padded grid are then the clamped ones
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
+                    if (!((bandk * L + lam) * RC + k < prm.Mc && 2 * uk + q < prm.Nc)) ginc[k][q] = 0.0;
+        }
         double ca[RC][CW], cbm[RC][CW];
 #pragma unroll
         for (int k = 0; k < RC; ++k)
@@ -588,6 +598,27 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
 #pragma unroll
             for (int cc = 0; cc < S; cc += 2) lds_write_b128(ea + cc * 8u, d2_t{bot[cc], bot[cc + 1]});
             if (RBF) lds_write_b128(ea + S * 8u, d2_t{own[RC - 1][2], own[RC - 1][3]});
+        }
+
+        if constexpr (EDGES) {
+            // terminal row: the bottom lane's last fine row in the last band; terminal column: every lane's rows after the last unit
+            if ((is_bot && bandk == nb - 1) || uk == NUp - 1) {
+                int pv = psk;
+                asm volatile("" : "+v"(pv));
+                const unsigned pair_e = stream_pair(pv);
+                if (pair_e != NOPAIR && uk >= 0) {
+                    double *e = prm.edges + (int64_t)pair_e * ((int64_t)NUp * S + (int64_t)nb * L * R);
+                    if (is_bot && bandk == nb - 1) {
+#pragma unroll
+                        for (int cc = 0; cc < S; cc += 2) *reinterpret_cast<d2_t *>(e + (int64_t)uk * S + cc) = d2_t{bot[cc], bot[cc + 1]};
+                    }
+                    if (uk == NUp - 1) {
+                        double *ec = e + (int64_t)NUp * S + (int64_t)(bandk * L + lam) * R;
+#pragma unroll
+                        for (int rr = 0; rr < R; rr += 2) *reinterpret_cast<d2_t *>(ec + rr) = d2_t{left[rr], left[rr + 1]};
+                    }
+                }
+            }
         }
 
         // -- K[MM][NN] of a pair
@@ -650,9 +681,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool Y32, int KIND, int FD>
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false>
 int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD>;
+    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD, EDGES>;
     // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
     // thread-safely, at the variant's first launch -- not mutable library state)
     static const int vgprs = [&] {
@@ -699,7 +730,7 @@ struct MbPlan {
     bool ok;
 };
 
-MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false) {
+MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bool edges = false) {
     MbPlan pl{};
     pl.ok = false;
     if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16 || (kind != 0 && kind != 1)) return pl;
@@ -709,7 +740,7 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false) {
     const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (pl.NUp < MB_L + 16) return pl;                      // band boundary slack (see the header)
-    pl.nb = (Mc + MB_L * pl.RC - 1) / (MB_L * pl.RC);
+    pl.nb = (Mc + (edges ? 1 : 0) + MB_L * pl.RC - 1) / (MB_L * pl.RC);   // edges: the bands of sk_wave_adj_fused_mb.hip (node rows)
     const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
     const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
     pl.lds_bytes = (size_t)(MB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
@@ -729,6 +760,19 @@ template <typename TO, int DY, int KIND>
 int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y32, int64_t P, double *ws, size_t ws_bytes,
                  hipStream_t s) {
     if (naive) return SK_ERR_UNSUPPORTED;   // the _naive_solver scheme is not built for this kernel (streaming route instead)
+    if (prm.edges) {   // with the terminal edges: RBF at dyadic 1..2, what sk_rbf_adjoint_fused_mb_f64 sweeps
+        if constexpr (KIND == 1 && DY >= 1) {
+            if (y32) {
+                if constexpr (sizeof(TO) == 4) {
+                    if (pl.fd == 16) return launch_mb_one<TO, DY, true, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+                }
+                return SK_ERR_UNSUPPORTED;
+            }
+            if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+            return launch_mb_one<TO, DY, false, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+        }
+        return SK_ERR_UNSUPPORTED;
+    }
     if (y32) {   // fp32 y ring: built where it pays (RBF points of fp32 inputs, 16 dims)
         if constexpr (KIND == 1 && sizeof(TO) == 4) {
             if (pl.fd == 16) return launch_mb_one<TO, DY, true, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
@@ -750,24 +794,24 @@ size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic,
     return (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the launch's work counter
 }
 // rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
-int fused_mb_rows(int kind, int Mc, int dyadic) {
+int fused_mb_rows(int kind, int Mc, int dyadic, bool edges) {
     const int RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
-    const int nb = (Mc + MB_L * RC - 1) / (MB_L * RC);
+    const int nb = (Mc + (edges ? 1 : 0) + MB_L * RC - 1) / (MB_L * RC);
     return nb * MB_L * RC + 8;
 }
 
 template <typename TO>
 int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D,
-                        int fd, const Geom &g, double inv_sigma, TO *out, void *ws, size_t ws_bytes, hipStream_t s) {
+                        int fd, const Geom &g, double inv_sigma, TO *out, double *edges, void *ws, size_t ws_bytes, hipStream_t s) {
     // yt_f32: Yt holds fp32 values packed two dimensions per 16-byte unit (sk_prep_paths_* layout 2): byte for byte a
     // dimension-major fp64 array of fd / 2 rows, which is how the kernel addresses it
     const double *Yt = static_cast<const double *>(Yt_any);
     const bool y32 = yt_f32 != 0;
-    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32);
+    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32, edges != nullptr);
     if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
-    if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < fused_mb_rows(kind, g.Mc, g.dyadic)) return SK_ERR_UNSUPPORTED;
+    if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < fused_mb_rows(kind, g.Mc, g.dyadic, edges != nullptr)) return SK_ERR_UNSUPPORTED;
     FusedMbParams prm{};
-    prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
+    prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.edges = edges; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb; prm.inv_sigma = inv_sigma; prm.ws_stride = pl.ws_stride;
     const int row_unit = (g.Mc - 1) / pl.RC;      // lane-row that holds the last coarse row
     prm.u_f = (g.Nc - 1) / 2;
@@ -791,8 +835,8 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f
 }
 
 template int launch_fwd_fused_mb<double>(int, const double *, const void *, int, int64_t, int64_t, int, int, int, int, const Geom &, double,
-                                         double *, void *, size_t, hipStream_t);
+                                         double *, double *, void *, size_t, hipStream_t);
 template int launch_fwd_fused_mb<float>(int, const double *, const void *, int, int64_t, int64_t, int, int, int, int, const Geom &, double,
-                                        float *, void *, size_t, hipStream_t);
+                                        float *, double *, void *, size_t, hipStream_t);
 
 }  // namespace sk

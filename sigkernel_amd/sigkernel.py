@@ -66,9 +66,9 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
     if res is None and kind is not None and hasattr(be, "solve_fwd_fused_static") and not os.environ.get("SK_NO_FUSED_MB"):
         # several bands per pair / wide paths: the multi-band fused kernel.  It keeps no edges: with a gradient pending the values
         # still come from it (nothing of size pairs x M x N in HBM) and the adjoint sweeps forward by itself later
-        res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram)
-        if res is not None and keep_edges:
-            res = (res, None)
+        # (with a gradient pending: RBF at dyadic 1..2 keeps the edges sk_rbf_adjoint_fused_mb_f64 reads; otherwise none, and the
+        # adjoint sweeps forward by itself later)
+        res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
     return res
 
 
@@ -100,6 +100,14 @@ def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
     return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused") and not naive and float(static_kernel.sigma) > 0
             and X.shape[2] <= 4 and dyadic in (1, 2) and X.shape[1] <= 64 * (4 >> dyadic) and Y.shape[1] >= 2
             and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF"))
+
+
+def _fused_rbf_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
+    """Whether sk_rbf_adjoint_fused_mb_f64 is worth trying: exactly RBFKernel, default scheme, dyadic 1..2, path dim <= 16, a second
+    path long enough for the band pipeline (the kernel has the last word)."""
+    return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused_mb") and not naive and float(static_kernel.sigma) > 0
+            and X.shape[2] <= 16 and dyadic in (1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
+            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF") and not os.environ.get("SK_NO_FUSED_MB"))
 
 
 def _upcast_tile(X, dyadic):
@@ -147,6 +155,27 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
     A, M = Xd.shape[0], Xd.shape[1]
     linear = type(static_kernel) is LinearKernel
     param = _fused_static(static_kernel, gram)[1]
+    mb = not linear and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
+    if mb:
+        # long / wide paths: sk_solve_fwd_static_* (edges) + sk_rbf_adjoint_fused_mb_f64; per pair 8 (MM + NN) bytes of edges and
+        # (M + 128) (fd + 2) doubles of partial sums
+        per_row = (Yd.shape[0] if gram else 1) * (8 * ((M + Yd.shape[1]) << dyadic) + 8 * 18 * (M + 128) + 4096)
+        grad = torch.empty_like(Xd)
+        for a0, a1, edges in _edge_tiles(kept, A, per_row, budget, strict=True):
+            Xt = Xd[a0:a1].contiguous()
+            Yt = Yd if gram else Yd[a0:a1].contiguous()
+            got = go if go is None else go[a0:a1].reshape(-1).contiguous()
+            res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram) if edges is not None else None
+            if res is None:    # no edges kept, or kept by another kernel in its own layout
+                fw = be.solve_fwd_fused_static(1, param, Xt, Yt, dyadic, naive, gram, keep_edges=True)
+                edges = fw[1] if fw is not None else None
+                if edges is None:
+                    return None
+                res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram)
+                if res is None:
+                    return None
+            grad[a0:a1] = res[0]
+        return grad
     per_row = (64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M      # edges and partial sums only
     grad = torch.empty_like(Xd)
     for a0, a1, edges in _edge_tiles(kept, A, per_row, budget):
@@ -175,7 +204,8 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
     A, M, N = Xd.shape[0], Xd.shape[1], Yd.shape[1]
     budget = _budget(Xd.device, workspace_bytes)
     if (_fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
-            or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
+            or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
+            or _fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
         g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals)
         if g is not None:
             return g
