@@ -153,18 +153,24 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
  * 16 -- BASELINE configs[4]'s shape with a gradient runs in sk_solve_fwd_static_* (edges) + this kernel with nothing of size P*M*N
  * in HBM.  Replaces sigkernel.py:419-502 + :404-416 for RBFKernel there, i.e. sk_static_increments + sk_solve_fwd + sk_solve_adj +
  * sk_static_adjoint.
- *   sk_rbf_adjoint_fused_mb_layout: *mrows = rows of Xr per path, gpart = [P][*rows][*outw] doubles, *edge_doubles per pair,
- *   *workspace_bytes (one band-boundary row per resident wave); SK_ERR_UNSUPPORTED outside the scope (dyadic 1..2, D <= 16, second
- *   path of >= ~160 points).
- *   Xr [A][Mrows][fd] / Yt [Bn][fd][Ncp]: the fp64 POINT arrays of sk_solve_fwd_static_* (kind 1, yt_f32 = 0), fd = 8 or 16;
- *   edges: what sk_solve_fwd_static_* kept;  scale [P] nullable.  gpart receives, per PAIR and node row r < M, cs = [..][0] and
- *   accd = [..][2 .. 2+D): summed over the pairs of an x_a, dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  err [P] zero-initialised:
+ *   sk_rbf_adjoint_fused_mb_layout: *mrows = rows of Xr per path, gpart = [P][*rows][*outw] doubles, n0 = [P][*ncols] doubles,
+ *   *edge_doubles per pair, *workspace_bytes (one band-boundary row per resident wave); SK_ERR_UNSUPPORTED outside the scope
+ *   (dyadic 1..2, D <= 16, second path of >= ~160 points).
+ *   Xr [A][Mrows][fd] / Yt [Bn][fd][Ncp]: the fp64 POINT arrays of sk_solve_fwd_static_* (kind 1), fd = 8 or 16; yt_f32 = 1 (fd = 16,
+ *   fp32 inputs): Yt is the packed fp32 array sk_solve_fwd_static_f32 takes -- half the LDS ring, two waves per SIMD at 16 dimensions;
+ *   edges: what sk_solve_fwd_static_* kept;  scale [P] nullable.  gpart receives, per PAIR and node row 1 <= r < M, cs = [..][0]
+ *   and accd = [..][2 .. 2+D): summed over the pairs of an x_a, dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  Node row 0 (gpart's
+ *   row 0 is written by the rescue only: zero it) comes as per-column weights n0[pair][c], c < N: cs += sum_c n0, accd += sum_c n0 y_b[c].
+ *   rescue_ws / kfinal / screen / tol: the device-side rescue described below (sk_fused_rescue_workspace_bytes(1, ...)), with yt64 =
+ *   the fp64 Yt [Bn][fd][Ncp] (the same array as Yt unless yt_f32).  err [P] zero-initialised:
  *   self-check residual as for sk_solve_adj_* (a pair whose scale is NaN is skipped and its sums stored as zeros). */
-int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
-                                   size_t *workspace_bytes);
-int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols,
+                                   int64_t *edge_doubles, size_t *workspace_bytes);
+int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
                                 int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
-                                size_t gpart_doubles, double *err, void *workspace, size_t workspace_bytes, void *stream);
+                                size_t gpart_doubles, double *n0, size_t n0_doubles, double *err, void *workspace, size_t workspace_bytes,
+                                const double *yt64, const double *kfinal, double screen, double tol, void *rescue_ws, size_t rescue_ws_bytes,
+                                void *stream);
 
 /* Device-side rescue of the two fused adjoints above (csrc/sk_adj_fused_rescue.hip) -- what makes a backward pass free of host
  * synchronisation.  The fused adjoints recompute K backwards from its terminal edges, which loses accuracy like 1e-16 K^2 and is
@@ -298,9 +304,10 @@ int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int 
  * sk_static_increments_* + sk_solve_fwd_*, or swap the arguments -- the kernel is symmetric). */
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
-/* edges (nullable; kind 1, dyadic 1..2): also keep every pair's terminal row and column -- of the grid PADDED to the bands and units
- * of sk_rbf_adjoint_fused_mb_f64, whose padding carries no increments -- *edge_doubles (sk_rbf_adjoint_fused_mb_layout) doubles per
- * pair: what that adjoint recomputes K from.  Mrows must then be the layout's *mrows. */
+/* edges (nullable; kind 1, dyadic 1..2): also keep, of the grid PADDED to the bands and units of sk_rbf_adjoint_fused_mb_f64 (padding
+ * carries no increments), the bottom row of every band of 64 lanes (the last one is the pair's terminal row) and the terminal column
+ * -- *edge_doubles (sk_rbf_adjoint_fused_mb_layout) doubles per pair: what that adjoint recomputes K from, band by band.  Mrows must
+ * then be the layout's *mrows. */
 int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc,
                             int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, double *edges, void *workspace,
                             size_t workspace_bytes, void *stream);

@@ -59,9 +59,9 @@ SIGNATURES = {
                                        _vp, _vp, _sz, _vp]),
     "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _vp, _vp, _vp, _sz, _vp]),
-    "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
-    "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
-                                           _vp, _sz, _vp, _vp, _sz, _vp]),
+    "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
+                                           _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
     "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
@@ -344,14 +344,14 @@ class HipBackend:
 
     @staticmethod
     def _adjoint_mb_layout(P, Mc, Nc, dyadic, D):
-        """(mrows, rows, outw, edge_doubles, workspace_bytes) of sk_rbf_adjoint_fused_mb_f64, or None outside its scope."""
-        mrows, rows, outw = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        """(mrows, rows, outw, edge_doubles, workspace_bytes, ncols) of sk_rbf_adjoint_fused_mb_f64, or None outside its scope."""
+        mrows, rows, outw, ncols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         ed, wsb = ctypes.c_int64(0), ctypes.c_size_t(0)
         rc = load().sk_rbf_adjoint_fused_mb_layout(P, Mc, Nc, int(dyadic), D, ctypes.byref(mrows), ctypes.byref(rows), ctypes.byref(outw),
-                                                   ctypes.byref(ed), ctypes.byref(wsb))
+                                                   ctypes.byref(ncols), ctypes.byref(ed), ctypes.byref(wsb))
         if rc != 0:
             return None
-        return mrows.value, rows.value, outw.value, int(ed.value), int(wsb.value)
+        return mrows.value, rows.value, outw.value, int(ed.value), int(wsb.value), ncols.value
 
     def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False, keep_edges=False):
         """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for
@@ -413,7 +413,9 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_static")
         return (out, edges) if keep_edges else out
 
-    def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True):
+    FUSED_RESCUE_BLOCKS_MB = 8   # (a stored pair of 2044 x 2044 grids is 67 MB)
+
+    def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True, kfinal=None):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel on LONG or WIDE paths
         straight from the paths and the terminal edges solve_fwd_fused_static(keep_edges=True) kept: adjoint PDE, node evaluation and
         chain rule in one multi-band kernel (sk_rbf_adjoint_fused_mb_f64; fp64 sweep whatever the dtype of X; dim <= 16, dyadic
@@ -429,7 +431,7 @@ class HipBackend:
         lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D)
         if lay is None or edges.numel() != P * lay[3]:
             return None
-        mrows, rows, outw, _, nbytes = lay
+        mrows, rows, outw, _, nbytes, ncols = lay
         fd = outw - 2
         Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
         dev = X.device
@@ -437,19 +439,34 @@ class HipBackend:
             scale = scale.double().contiguous()
         with torch.cuda.device(dev):
             Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
-            Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
+            y32 = fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
+            if y32:      # fp32 points, two dimensions per 16-byte unit + a row of fp64 norms: half the LDS ring (as the forward)
+                Yt = torch.empty(B, fd // 2 + 1, Ncp, 2, dtype=torch.float32, device=dev)
+                _check(load().sk_prep_paths_f32(_ptr(Y), B, N, D, 0, 2, 1.0, _ptr(Yt), Ncp, fd, _stream(X)), "sk_prep_paths (packed fp32)")
+            else:
+                Yt = _prep_paths(Y, False, True, 1.0, Ncp, fd)
             gpart = torch.empty(P, rows, outw, dtype=torch.float64, device=dev)
+            gpart[:, 0].zero_()                      # node row 0: only the rescue writes there (the sweep's share comes through n0)
+            n0 = torch.empty(P, ncols, dtype=torch.float64, device=dev)
             err = torch.zeros(P, dtype=torch.float64, device=dev)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            rc = load().sk_rbf_adjoint_fused_mb_f64(_ptr(Xr), _ptr(Yt), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
-                                                    float(sigma), _ptr(edges), _ptr(scale), _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ws),
-                                                    nbytes, _stream(X))
+            kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev, self.FUSED_RESCUE_BLOCKS_MB)
+            Yt64 = None if rws is None else (_prep_paths(Y, False, True, 1.0, Ncp, fd) if y32 else Yt)
+            rc = load().sk_rbf_adjoint_fused_mb_f64(_ptr(Xr), _ptr(Yt), int(y32), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
+                                                    float(sigma), _ptr(edges), _ptr(scale), _ptr(gpart), gpart.numel(), _ptr(n0), n0.numel(),
+                                                    _ptr(err), _ptr(ws), nbytes, _ptr(Yt64), _ptr(kf), float(self.FUSED_SCREEN),
+                                                    float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused_mb")
         self.last_fused_err = err
         T = gpart.view(A, B if gram else 1, rows, outw)[:, :, :M].sum(1)     # the pairs of an a added in a fixed order
-        cs, accd = T[..., 0:1], T[..., 2:2 + D]
+        cs, accd = T[..., 0:1].clone(), T[..., 2:2 + D].clone()
+        # node row 0: per-column weights, contracted with the points of y_b here
+        n0v = n0.view(A, B if gram else 1, ncols)[:, :, :N]
+        cs[:, 0, 0] += n0v.sum((1, 2))
+        Yd = Y.double()
+        accd[:, 0] += torch.einsum("abc,bcd->ad", n0v, Yd) if gram else torch.einsum("ac,acd->ad", n0v[:, 0], Yd)
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), err.max()
 
@@ -579,12 +596,12 @@ class HipBackend:
     FUSED_SCREEN = 1e3        # |K[MM][NN]| above which a pair leaves the fused adjoint's sweep for the stored-grid rescue
     FUSED_RESCUE_BLOCKS = 64  # flagged chunks re-solved concurrently
 
-    def _fused_rescue_args(self, kind, kfinal, P, Mc, Nc, dyadic, dev):
+    def _fused_rescue_args(self, kind, kfinal, P, Mc, Nc, dyadic, dev, blocks=None):
         """(kfinal as fp64 [P] or None, workspace tensor or None, its bytes) for the fused adjoints' device-side rescue; no rescue
         (None, None, 0) without forward values or for grids the stored-grid kernel cannot hold."""
         if kfinal is None:
             return None, None, 0
-        nbytes = int(load().sk_fused_rescue_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), self.FUSED_RESCUE_BLOCKS))
+        nbytes = int(load().sk_fused_rescue_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), blocks or self.FUSED_RESCUE_BLOCKS))
         if not nbytes:
             return None, None, 0
         kf = kfinal.detach().reshape(-1).double().contiguous()
@@ -722,6 +739,11 @@ class HipBackend:
         The fast kernel recomputes K backwards instead of storing it and reports a per-pair residual; pairs whose
         residual exceeds ADJ_RESIDUAL_TOL (K exploding beyond ~1e4) are re-solved by the stored-grid kernel.
         `edges` (from solve_fwd_keep_edges on the same increments) skips the forward sweep; `final` is then None."""
+        if edges is not None:
+            # edges kept by another kernel in its own layout (sk_solve_fwd_static_* keeps sk_rbf_adjoint_fused_mb_f64's): sweep forward here
+            P_ = inc_c.numel() // (inc_c.shape[-2] * inc_c.shape[-1])
+            if edges.numel() * 8 != int(load().sk_strip_edges_bytes(P_, inc_c.shape[-2], inc_c.shape[-1], int(dyadic), inc_c.element_size())):
+                edges = None
         if (inc_c.dtype == torch.float32 and dyadic == 2 and edges is None and not (flags & (FLAG_SIMPLE | FLAG_EXACT))):
             # the fused adjoint has no fp32 variant at dyadic 2 (16-column blocks do not fit the register file) and the
             # stored-grid kernel is ~100x slower: run the fp64 kernel on up-cast increments, in pair chunks of bounded size

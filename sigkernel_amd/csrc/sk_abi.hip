@@ -447,23 +447,27 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
                                 ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, rescue_ws ? &fr : nullptr, (hipStream_t)stream);
 }
 
-int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
-                                   size_t *workspace_bytes) {
+int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols,
+                                   int64_t *edge_doubles, size_t *workspace_bytes) {
     if (P < 1 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
-    return adj_fused_mb_layout(P, Mc, Nc, dyadic, D, mrows, rows, outw, edge_doubles, nullptr, nullptr, workspace_bytes) ? SK_OK
-                                                                                                                        : SK_ERR_UNSUPPORTED;
+    return adj_fused_mb_layout(P, Mc, Nc, dyadic, D, mrows, rows, outw, ncols, edge_doubles, nullptr, nullptr, workspace_bytes)
+               ? SK_OK : SK_ERR_UNSUPPORTED;
 }
 
-int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
                                 int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
-                                size_t gpart_doubles, double *err, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!Xr || !Yt || !edges || !gpart || !err || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+                                size_t gpart_doubles, double *n0, size_t n0_doubles, double *err, void *workspace, size_t workspace_bytes,
+                                const double *yt64, const double *kfinal, double screen, double tol, void *rescue_ws, size_t rescue_ws_bytes,
+                                void *stream) {
+    if ((kfinal && !rescue_ws) || (rescue_ws && !yt64)) return SK_ERR_BAD_ARG;
+    if (!Xr || !Yt || !edges || !gpart || !n0 || !err || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (!(sigma > 0.0) || !(sigma < 1e300)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
-    return launch_adj_fused_rbf_mb(Xr, Yt, A, B, Mrows, Ncp, D, fd, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, workspace,
-                                   workspace_bytes, (hipStream_t)stream);
+    const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
+    return launch_adj_fused_rbf_mb(Xr, Yt, yt_f32, A, B, Mrows, Ncp, D, fd, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, n0, n0_doubles, err,
+                                   workspace, workspace_bytes, rescue_ws ? &fr : nullptr, yt64, (hipStream_t)stream);
 }
 
 size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks) {

@@ -41,6 +41,9 @@ struct FusedRescueParams {
     double *Ypart;             // rbf, nullable: [P][ycols][6]
     int64_t A, B, P, n_groups;
     int Mrows, Ncp, Mc, Nc, D, dyadic, rows, outw, ycols;
+    int fd;                    // dims carried by Xs / Ys (8; 8 or 16 for sk_wave_adj_fused_mb.hip)
+    double *N0;                // sk_wave_adj_fused_mb.hip, nullable: [P][n0cols] node row 0 weights of the sweep, cleared for a failed pair
+    int n0cols;
     double inv_sigma;
     ChunkSplit cs;
     double *ws;                // per block: inc [Mc][Nc], W [Mc][Nc], G [M][N] (rbf), Kf, Kr
@@ -51,8 +54,9 @@ struct FusedRescueParams {
 __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slot, double *lds, double *wsb) {
     const int Mc = prm.Mc, Nc = prm.Nc, M = Mc + 1, N = Nc + 1, d = prm.dyadic;
     const int64_t a = prm.B > 0 ? p / prm.B : p, b = prm.B > 0 ? p % prm.B : p;
-    const double *xs = prm.Xs + a * (int64_t)prm.Mrows * 8;      // row r: xs[r * 8 + k]
-    const double *ys = prm.Ys + b * (int64_t)8 * prm.Ncp;        // column c: ys[k * Ncp + c]
+    const int fd = prm.fd;
+    const double *xs = prm.Xs + a * (int64_t)prm.Mrows * fd;     // row r: xs[r * fd + k]
+    const double *ys = prm.Ys + b * (int64_t)fd * prm.Ncp;       // column c: ys[k * Ncp + c]
     double *inc = wsb, *W = inc + (int64_t)Mc * Nc, *G = W + (int64_t)Mc * Nc;
     double *Kf = G + (prm.kind == 1 ? (int64_t)M * N : 0), *Kr = Kf + (int64_t)((Mc << d) + 1) * ((Nc << d) + 1);
     const double s = prm.scale ? prm.scale[p] : 1.0;
@@ -61,15 +65,15 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
         for (int c = lane; c < Mc * Nc; c += WAVE) {
             const int pp = c / Nc, q = c - pp * Nc;
             double g = 0.0;
-            for (int k = 0; k < 8; ++k) g = fma(xs[pp * 8 + k], ys[(int64_t)k * prm.Ncp + q], g);
+            for (int k = 0; k < fd; ++k) g = fma(xs[pp * fd + k], ys[(int64_t)k * prm.Ncp + q], g);
             inc[c] = g;
         }
     } else {
         for (int c = lane; c < M * N; c += WAVE) {
             const int r = c / N, q = c - r * N;
             double d2 = 0.0;
-            for (int k = 0; k < 8; ++k) {
-                const double df = xs[r * 8 + k] - ys[(int64_t)k * prm.Ncp + q];
+            for (int k = 0; k < fd; ++k) {
+                const double df = xs[r * fd + k] - ys[(int64_t)k * prm.Ncp + q];
                 d2 = fma(df, df, d2);
             }
             G[c] = exp(-d2 * prm.inv_sigma);
@@ -97,7 +101,7 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
             return (((w_at(r - 1, c - 1) + w_at(r, c)) - w_at(r - 1, c)) - w_at(r, c - 1)) * G[r * N + c];
         };
         for (int r = lane; r < M; r += WAVE) {      // first argument: per node row, cs = sum_c V G, accd = sum_c V G y_c
-            double cs = 0.0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double cs = 0.0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = 0; c < N; ++c) {
                 const double v = VG(r, c);
                 cs += v;
@@ -113,7 +117,7 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
                 for (int r = 0; r < M; ++r) {
                     const double v = VG(r, c);
                     s0 += v;
-                    for (int k = 0; k < 4; ++k) s1[k] = fma(v, xs[r * 8 + k], s1[k]);
+                    for (int k = 0; k < 4; ++k) s1[k] = fma(v, xs[r * fd + k], s1[k]);
                 }
                 double *dst = prm.Ypart + (p * prm.ycols + c) * 6;
                 dst[0] = s0; dst[1] = 0.0;
@@ -146,6 +150,8 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
         double *slot = prm.part + slot_i * (int64_t)prm.rows * prm.outw;
         if (failed) {      // a pair the screen let through failed after the fact: the whole chunk again, exactly
             for (int c = threadIdx.x; c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
+            if (prm.N0)    // (one pair per chunk there)
+                for (int c = threadIdx.x; c < prm.n0cols; c += WAVE) prm.N0[first * prm.n0cols + c] = 0.0;
             __syncthreads();
         }
         for (int i = 0; i < ppg && first + i < prm.P; ++i) {
@@ -175,7 +181,8 @@ int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, do
 
 int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const double *scale, const double *err, double tol, double *part,
                         double *ypart, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g, int rows, int outw, int ycols,
-                        double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s) {
+                        double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s, int fd, double *n0,
+                        int n0cols) {
     const size_t lds = simple_lds_bytes(g);
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     const size_t per_block = sizeof(double) * fused_rescue_block_doubles(kind, g.Mc, g.Nc, g.dyadic);
@@ -188,6 +195,7 @@ int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const doub
     prm.A = A; prm.B = B; prm.P = g.P; prm.n_groups = n_groups; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.D = D;
     prm.dyadic = g.dyadic; prm.rows = rows; prm.outw = outw; prm.ycols = ycols; prm.inv_sigma = inv_sigma; prm.cs = cs;
     prm.ws = (double *)ws; prm.ws_block = (int64_t)(per_block / sizeof(double));
+    prm.fd = fd; prm.N0 = n0; prm.n0cols = n0cols;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_fused_rescue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_fused_rescue, dim3((unsigned)blocks), dim3(WAVE), lds, s, prm);
     return check_launch();

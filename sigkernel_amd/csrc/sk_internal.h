@@ -144,11 +144,12 @@ size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic,
 int fused_mb_rows(int kind, int Mc, int dyadic, bool edges = false);
 
 // ---- sk_wave_adj_fused_mb.hip: the fused RBF adjoint for pairs of several bands / path dims up to 16 ----
-bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles, int *nb,
-                         int *nup, size_t *ws_bytes);
-int launch_adj_fused_rbf_mb(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
-                            double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                            void *ws, size_t ws_bytes, hipStream_t s);
+bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols, int64_t *edge_doubles,
+                         int *nb, int *nup, size_t *ws_bytes);
+int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
+                            double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *n0,
+                            size_t n0_doubles, double *err, void *ws, size_t ws_bytes, const FusedRescue *rescue, const double *Yt64,
+                            hipStream_t s);
 
 // ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
@@ -171,7 +172,8 @@ size_t fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dya
 int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, double screen, double *scale_eff, double *err, hipStream_t s);
 int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const double *scale, const double *err, double tol, double *part,
                         double *ypart, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g, int rows, int outw, int ycols,
-                        double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s);
+                        double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s, int fd = 8, double *n0 = nullptr,
+                        int n0cols = 0);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

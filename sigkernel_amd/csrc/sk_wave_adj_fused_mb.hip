@@ -8,18 +8,19 @@
 // sk_wave_fused_mb.hip: one 64-lane wavefront sweeps one pair at a time, band after band (band 0 = the LAST rows of the pair:
 // the sweep is flipped), lane `lam` runs `lam` macro-steps behind lane 0.  What is new:
 //
-//   * Band boundary.  What lane 0 takes from "the lane above" -- the bottom fine row of both states, the last node row's two
-//     values and the last coarse row's two weights -- is what lane 63 had for the same unit one band earlier: 2 S + 4 doubles per
-//     unit, staged in LDS, written through to the wave's row in global memory (L2) every 8 macro-steps and brought back by
-//     LDS-DMA one window ahead (sk_wave_fused_mb.hip).  In band 0 the entries come from a constant chunk (ones for the reverse
-//     state, zero weights) and the forward state's top row is the pair's terminal ROW, fetched in chunks as in
-//     sk_wave_adj.hip.
+//   * Band boundary.  What lane 0 takes from "the lane above" -- the bottom fine row of the reverse state, the last node row's
+//     two values and the last coarse row's two weights -- is what lane 63 had for the same unit one band earlier: S + 4 doubles
+//     per unit, staged in LDS, written through to the wave's row in global memory (L2) every 8 macro-steps and brought back by
+//     LDS-DMA one window ahead (sk_wave_fused_mb.hip); in band 0 the entries come from a constant chunk (ones, zero weights).
+//     The FORWARD state does not cross bands: the forward pass kept the bottom row of every band (the terminal row being the
+//     last), lane 0 takes its top row from there (chunks as in sk_wave_adj.hip), so the backward recompute of K restarts from
+//     exact values every 64 R fine rows and its error is that of a single band whatever the path length.
 //   * Accumulators per (pair, band).  A lane's node rows change with the band, so its 1 + D sums per node row are written out
 //     when it enters the next band -- to Gpart[pair][node row][2 + FD] -- one macro-step late: node column 0 of a band is
 //     completed during the first macro-step of the next one (sk_wave_adj_fused_rbf.hip), and that part still belongs to the
 //     rows being left.  The caller adds the pairs of an x_a.
 //
-// Scope: fp64, dyadic 1..2, path dim <= 16, N - 1 <= 2 NUp - 2 with NUp >= 80 units, M + 1 <= 64 RC nb.
+// Scope: fp64 sweep, dyadic 1..2, path dim <= 16, N - 1 <= 2 NUp - 1 with NUp >= 80 units, any M (M + 1 <= 64 RC nb).
 // Replaces, for RBFKernel on long or wide paths, sk_static_increments + sk_solve_fwd(EDGES) + sk_solve_adj + sk_static_adjoint,
 // i.e. sigkernel.py:419-502 (prep_backward) + :404-416.
 #include "sk_wave_common.h"
@@ -32,10 +33,12 @@ constexpr int AMB_X_SLOTS = 2;
 
 struct AdjMbParams {
     const double *Xr;      // [A][Mrows][FD]  x_p (points), zero rows / dims beyond M / D
-    const double *Yt;      // [B][FD][Ncp]    y_q, dimension-major, zero-padded
-    const double *edges;   // [P][NNp + MMp]  K[MMp][1..NNp], K[1..MMp][NNp] of the padded grid (sk_solve_fwd_static_* with edges)
+    const double *Yt;      // [B][FD][Ncp]    y_q, dimension-major, zero-padded;  Y32: [B][FD/2 + 1][Ncp] fp32 points packed two
+                           // dimensions per 16-byte unit + a row of |y_q|^2 in fp64 (sk_prep_paths_f32 layout 2, as sk_wave_fused_mb.hip)
+    const double *edges;   // [P][nb NNp + MMp]  K[MMp - b 64 R][1..NNp] (b < nb), K[1..MMp][NNp] of the padded grid (sk_solve_fwd_static_* with edges)
     const double *scale;   // [P] upstream gradient per pair, nullable
-    double *Gpart;         // [P][Mcp + 1][FD + 2] per node row: cs, 0, accd[0..FD)
+    double *Gpart;         // [P][Mcp + 1][FD + 2] per node row >= 1: cs, 0, accd[0..FD)  (row 0 is not written: N0)
+    double *N0;            // [P][2 NUp] node row 0: per node column c the weight V[0][c] G[0][c] s_ab; the caller contracts it with y_b
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
     double *ws;            // per wave: [NUp + 8][E] band-boundary row + the constant chunk of band 0
     int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired
@@ -95,8 +98,11 @@ __device__ __forceinline__ void amb_read_xrow(double (&x)[ND], unsigned a) {
     }
 }
 
-template <int DY, int RC, int FD>
-__global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams prm) {
+// Y32 (fp32 inputs): the y ring holds the caller's fp32 points, half the bytes -- at FD = 16 what lets two waves share a SIMD -- and the
+// squared distance is formed as the forward kernel forms it there, |x|^2 + |y|^2 - 2 <x, y> (static_kernels.py:70-73): FD FMAs per
+// node, exact products of fp32 values.  Everything is still computed in fp64.
+template <int DY, int RC, int FD, bool Y32>
+__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD == 16 && (DY == 1 || !Y32)) ? 1 : 2))) void k_adj_fused_rbf_mb(const AdjMbParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY;
     static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
@@ -106,9 +112,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
     //                    [the pair's terminal COLUMN for their fine rows: 8 R + 2 doubles][the 16 bytes that hold scale[pair]]
     constexpr int XR_COL = 8 * RC * XROW, NPCOL = 4 * R + 1, XR_SC = XR_COL + NPCOL * 16;
     constexpr int NPIECES = XR_SC / 16 + 1, XSLAB = (XR_SC + 16 + 63) / 64 * 64;
-    constexpr int YSLAB = FD * 128, NSLAB = L / 8 + 2, NDMA_Y = YSLAB / 1024;
-    // band boundary entry of one unit: botR[S], botF[S], the last node row's two values, the last coarse row's two weights
-    constexpr int E = 2 * S + 4, NPB = E / 2, CHUNK = 8 * E * 8, CPIECES = CHUNK / 16;
+    constexpr int FDY = Y32 ? FD / 2 : FD;   // rows of a y slab
+    constexpr int YSLAB = FDY * 128 + (Y32 ? 128 : 0), NSLAB = L / 8 + 2, NDMA_Y = FDY * 128 / 1024;
+    static_assert(!Y32 || FD == 16, "the fp32 ring is built for 16 dimensions");
+    // band boundary entry of one unit: botR[S], the last node row's two values, the last coarse row's two weights (the forward state
+    // restarts from the row the forward pass kept for the band: no error carried from band to band)
+    constexpr int E = S + 4, NPB = E / 2, CHUNK = 8 * E * 8, CPIECES = CHUNK / 16;
     constexpr int NPC = 4 * S + 1, ECG = NPC * 16;   // terminal-row chunk (sk_wave_adj.hip)
     constexpr int OUTW = FD + 2;
     constexpr unsigned X_BASE = NSLAB * YSLAB, BI_BASE = X_BASE + AMB_X_SLOTS * XSLAB, BO_BASE = BI_BASE + 2 * CHUNK,
@@ -123,9 +132,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
     const int NUp = prm.NUp, nb = prm.nb;
     const int Mcp = nb * L * RC;
     const int MMp = Mcp << DY, NNp = (NUp * CW) << DY;
-    const int EE = NNp + MMp;   // edge doubles per pair
+    const int EE = nb * NNp + MMp;   // edge doubles per pair
     const double sc = 1.0 / (double)(1 << (2 * DY));
     const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double two_inv_sigma = 2.0 * prm.inv_sigma;
     const bool is_bot = lam == L - 1;
     const int lam7 = lam & 7;
 
@@ -178,11 +188,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
         const unsigned spy = pair_at(y_pi);
         const int64_t b = split_b(spy == NOPAIR ? 0 : (int64_t)spy);
         const int uo = NUp - 1 - (y_u0 + (lam & 7));
+        if constexpr (Y32) {
+            const double *row0 = prm.Yt + b * (FDY + 1) * (int64_t)prm.Ncp;
+            __builtin_amdgcn_global_load_lds(row0 + ((lam >> 3) * (int64_t)prm.Ncp + (int64_t)uo * 2), (lds_void *)(lds + y_slot * YSLAB), 16, 0, 0);
+            if (lam < 8)   // the |y|^2 row: 128 bytes
+                __builtin_amdgcn_global_load_lds(row0 + (FDY * (int64_t)prm.Ncp + (int64_t)uo * 2), (lds_void *)(lds + y_slot * YSLAB + FDY * 128), 16,
+                                                 0, 0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NDMA_Y; ++c) {
-            const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);     // odd slabs: dimension rows swapped in pairs
-            const double *src = prm.Yt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)uo * 2);
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+            for (int c = 0; c < NDMA_Y; ++c) {
+                const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);     // odd slabs: dimension rows swapped in pairs
+                const double *src = prm.Yt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)uo * 2);
+                __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+            }
         }
         y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
         y_par ^= 1;
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
         const int lamj = x_lam0 < L ? x_lam0 : 0;        // nobody starts: fetch something valid
         const int gl0 = x_band * L + lamj;
         const double *xa = prm.Xr + a * prm.Mrows * FD;
-        const double *ecol = prm.edges + p * EE + (NNp - 2 + MMp - (gl0 + 8) * R);
+        const double *ecol = prm.edges + p * EE + (nb * NNp - 2 + MMp - (gl0 + 8) * R);
         const double *scp = prm.scale ? reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(prm.scale + p) & ~(uintptr_t)15) : prm.Xr;
         char *dst = lds + X_BASE + x_slot * XSLAB;
 #pragma unroll
@@ -231,9 +249,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
                 __builtin_amdgcn_global_load_lds(sb, (lds_void *)(lds + BI_BASE + x_slot * CHUNK + c * 1024), 16, 0, 17);
             }
         }
-        if (x_band == 0 && lam < NPC) {   // terminal ROW K[MMp][.] for lane 0's 8 units (sk_wave_adj.hip: issue_edge_chunk)
+        if (lam < NPC) {   // the band's top row of K (band 0: the terminal row) for lane 0's 8 units (sk_wave_adj.hip: issue_edge_chunk)
             const int k = NNp - (x_lam0 + LINE_UNITS) * S - 2 + 2 * lam;
-            if (k >= 0) __builtin_amdgcn_global_load_lds(prm.edges + p * EE + k, (lds_void *)(lds + EC_BASE + x_slot * ECG), 16, 0, 0);
+            if (k >= 0)
+                __builtin_amdgcn_global_load_lds(prm.edges + p * EE + (int64_t)x_band * NNp + k, (lds_void *)(lds + EC_BASE + x_slot * ECG), 16, 0, 0);
         }
         x_slot ^= 1;
         x_lam0 += 8;
@@ -260,25 +279,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
     };
 
     // ---- state ------------------------------------------------------------------------------------------------------------
-    double xr[RC][FD];
+    double xr[RC][FD], xsn[RC];   // Y32: xsn = -|x_row|^2 / sigma
 #pragma unroll
-    for (int k = 0; k < RC; ++k)
+    for (int k = 0; k < RC; ++k) {
+        xsn[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < FD; ++j) xr[k][j] = 0.0;
-    // accumulators per node row r_k = p_k + 1 (k < RC) and, [RC], node row p_{RC-1}: node row 0 on the bottom lane of the last band
-    double cs[RC + 1], accd[RC + 1][FD];
+    }
+    // accumulators per node row r_k = p_k + 1 (k < RC).  A macro-step's terms are added ONE STEP LATER, when both node columns they
+    // belong to -- c1 of the step before (cv1p) and c2 = that step's first column (cv2) -- are the two columns of ONE unit of the y
+    // ring, the previous one: one read per dimension pair, no column history in registers
+    double cs[RC], accd[RC][FD], cv1p[RC];
 #pragma unroll
-    for (int k = 0; k <= RC; ++k) {
+    for (int k = 0; k < RC; ++k) {
         cs[k] = 0.0;
+        cv1p[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < FD; ++j) accd[k][j] = 0.0;
     }
-    double GownP[RC], GabvP = 0.0, lastOwn[2] = {0.0, 0.0}, yP[FD];
+    double GownP[RC], GabvP = 0.0, lastOwn[2] = {0.0, 0.0};
     double wkP[RC], wupP = 0.0, lastW[2] = {0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < RC; ++k) { GownP[k] = 0.0; wkP[k] = 0.0; }
-#pragma unroll
-    for (int j = 0; j < FD; ++j) yP[j] = 0.0;
+    unsigned yq_e = lds0, yq_o = lds0;     // the previous unit's y (even / odd dimension rows)
     double leftR[R], botR[S], cornerR = 1.0;
     double leftF[R], botF[S], cornerF = 1.0;
 #pragma unroll
@@ -295,7 +318,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
 #pragma unroll
     for (int k = 0; k < RC; ++k) row_ok[k] = false;
     double *gp_cur = nullptr, *gp_prev = nullptr;     // Gpart row r_0 of this lane in the band being swept / the band before (null: none)
-    bool n0_cur = false, n0_prev = false;             // bottom lane in the last band: it also owns node row 0
+    double *n0_cur = nullptr, *n0_prev = nullptr;     // bottom lane in the last band: it also owns node row 0 -- N0 row of the pair
 
     {   // lanes ahead of their first band read slabs no DMA has written yet: make those finite
         const d2_t z = {0.0, 0.0};
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
     for (int c = 0; c < (CPIECES + 63) / 64; ++c) {
         const int idx = c * 64 + lam;
         if (idx < CPIECES) {
-            const double v = (idx * 2) % E >= 2 * S + 2 ? 0.0 : 1.0;
+            const double v = (idx * 2) % E >= S + 2 ? 0.0 : 1.0;
             amb_store_through(wsrow + (int64_t)NUp * E + idx * 2, d2_t{v, v});
         }
     }
@@ -335,10 +358,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
 #pragma unroll
             for (int i = 0; i < NPB; ++i) amb_begin(pend[i]);
             amb_read_pend<0>(pend[0], ba); amb_read_pend<16>(pend[1], ba); amb_read_pend<32>(pend[2], ba); amb_read_pend<48>(pend[3], ba);
-            amb_read_pend<64>(pend[4], ba); amb_read_pend<80>(pend[5], ba);
-            if constexpr (NPB > 6) {
-                amb_read_pend<96>(pend[6], ba); amb_read_pend<112>(pend[7], ba); amb_read_pend<128>(pend[8], ba); amb_read_pend<144>(pend[9], ba);
-            }
+            if constexpr (NPB > 4) { amb_read_pend<64>(pend[4], ba); amb_read_pend<80>(pend[5], ba); }
         }
         double trow_p[S], trow[S];
 #pragma unroll
@@ -363,6 +383,15 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
             const unsigned xa = my_x + x_rd;
 #pragma unroll
             for (int k = 0; k < RC; ++k) amb_read_xrow<FD>(xr[k], xa + k * XROW);
+            if constexpr (Y32) {
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    double q2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) q2 = fma(xr[k][j], xr[k][j], q2);
+                    xsn[k] = -q2 * prm.inv_sigma;
+                }
+            }
             double col[6];
             {
                 d2_t c3[3];
@@ -382,53 +411,89 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
             gp_prev = gp_cur;
             n0_prev = n0_cur;
             gp_cur = valid ? prm.Gpart + (pe * (int64_t)(Mcp + 1) + (Mcp - gl * RC)) * OUTW : nullptr;
-            n0_cur = valid && is_bot && band == nb - 1;
+            n0_cur = (valid && is_bot && band == nb - 1) ? prm.N0 + pe * (int64_t)(2 * NUp) : nullptr;
             if (sv != sv) valid = 0;      // NaN: a pair the rescue's screen took out of the sweep (its sums are stored as zeros)
             sx = valid ? sv : 0.0;
         }
 
-        // -- y points of the unit's two node columns
-        d2_t yv[FD];
-        const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
-        amb_read_ydims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+        // -- top rows of the two states: the lane above's bottom row; lane 0: the boundary entry (reverse state: ones in band 0),
+        //    in band 0 the pair's terminal row for the forward state
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
         lds_take<S>(trow, trow_p);
-
-        // -- top rows of the two states: the lane above's bottom row; lane 0: the boundary entry (reverse state: ones in band 0),
-        //    in band 0 the pair's terminal row for the forward state
         double topR[S], topF[S];
-        const bool band0 = band == 0;
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             double tf = trow[S - 1 - i];
-            if (i == S - 1 && u == NUp - 1) tf = 1.0;     // K[MM][0] = 1 is not stored
-            tf = band0 ? tf : bnd[(S + i) >> 1][(S + i) & 1];
+            if (i == S - 1 && u == NUp - 1) tf = 1.0;     // K[.][0] = 1 is not stored
             topR[i] = dpp_shr1(botR[i], bnd[i >> 1][i & 1]);
             topF[i] = dpp_shr1(botF[i], tf);
         }
         // what the lane above evaluated / weighted one macro-step ago, for this unit's two columns; lane 0: what lane 63 had for
         // this unit one band earlier (band 0: nothing above contributes: zero weights, its first coarse row is padding)
         double Gabv[2], wup0[2];
-        Gabv[0] = dpp_shr1(lastOwn[0], bnd[S][0]);
-        Gabv[1] = dpp_shr1(lastOwn[1], bnd[S][1]);
-        wup0[0] = dpp_shr1(lastW[0], bnd[S + 1][0]);
-        wup0[1] = dpp_shr1(lastW[1], bnd[S + 1][1]);
+        Gabv[0] = dpp_shr1(lastOwn[0], bnd[S / 2][0]);
+        Gabv[1] = dpp_shr1(lastOwn[1], bnd[S / 2][1]);
+        wup0[0] = dpp_shr1(lastW[0], bnd[S / 2 + 1][0]);
+        wup0[1] = dpp_shr1(lastW[1], bnd[S / 2 + 1][1]);
 
-        // -- nodes of this lane's rows at the two columns
+        // -- nodes of this lane's rows at the unit's two node columns, eight dimensions of y at a time
+        const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
+        const unsigned ya_e = Y32 ? ya : ya + (unsigned)(ypar << 7), ya_o = Y32 ? ya + 128u : ya + (unsigned)((ypar ^ 1) << 7);
         double Gown[RC][2];
+        if constexpr (Y32) {
+            d2_t raw[FDY];
+            d2_t ysq_p, ysq;
+            amb_begin(ysq_p);
+            amb_read_pend<FDY * 128>(ysq_p, ya);          // |y|^2 of the two columns
+            amb_read_ydims<FDY>(raw, ya_e, ya_o);         // (its lgkmcnt(0) covers the read above)
+            amb_take(ysq, ysq_p);
+            double xy[RC][CW];
 #pragma unroll
-        for (int k = 0; k < RC; ++k)
+            for (int k = 0; k < RC; ++k)
 #pragma unroll
-            for (int q = 0; q < CW; ++q) {
-                double d2 = 0.0;
+                for (int q = 0; q < CW; ++q) xy[k][q] = 0.0;
 #pragma unroll
-                for (int j = 0; j < FD; ++j) {
-                    const double df = xr[k][j] - yv[j][q];
-                    d2 = fma(df, df, d2);
+            for (int jp = 0; jp < FDY; ++jp) {
+                const f4_t f = __builtin_bit_cast(f4_t, raw[jp]);
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+                    const double y0 = (double)f[q], y1 = (double)f[2 + q];
+#pragma unroll
+                    for (int k = 0; k < RC; ++k) xy[k][q] = fma(xr[k][2 * jp + 1], y1, fma(xr[k][2 * jp], y0, xy[k][q]));
                 }
-                Gown[k][q] = exp_nonpos(fma(-d2, prm.inv_sigma, d2 * 0.0), expc);
             }
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q)   // -(|x|^2 + |y|^2 - 2<x,y>) / sigma (an infinite coordinate gives inf - inf = NaN as in the reference)
+                    Gown[k][q] = exp_nonpos(fma(xy[k][q], two_inv_sigma, xsn[k] - ysq[q] * prm.inv_sigma), expc);
+        } else {
+            double d2[RC][CW];
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) d2[k][q] = 0.0;
+#pragma unroll
+            for (int h = 0; h < FD / 8; ++h) {
+                d2_t yh[8];
+                amb_read_ydims<8>(yh, ya_e + h * 1024u, ya_o + h * 1024u);
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const double df = xr[k][8 * h + j] - yh[j][q];
+                            d2[k][q] = fma(df, df, d2[k][q]);
+                        }
+            }
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q) Gown[k][q] = exp_nonpos(fma(-d2[k][q], prm.inv_sigma, d2[k][q] * 0.0), expc);
+        }
         // -- increments of the RC x 2 coarse cells, the reference's order ((G11 + G00) - G10) - G01 (sigkernel.py:362-363);
         //    padding rows / columns carry none
         const bool c0_ok = 2 * uo < prm.Nc, c1_ok = 2 * uo + 1 < prm.Nc;
@@ -498,20 +563,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
         if (is_bot) {
             const unsigned ea = lds0 + BO_BASE + (unsigned)((u & 7) * (E * 8));
 #pragma unroll
-            for (int cc = 0; cc < S; cc += 2) {
-                lds_write_b128(ea + cc * 8u, d2_t{botR[cc], botR[cc + 1]});
-                lds_write_b128(ea + (S + cc) * 8u, d2_t{botF[cc], botF[cc + 1]});
-            }
-            lds_write_b128(ea + 2 * S * 8u, d2_t{Gown[RC - 1][0], Gown[RC - 1][1]});
-            lds_write_b128(ea + (2 * S + 2) * 8u, d2_t{wk[RC - 1][0], wk[RC - 1][1]});
+            for (int cc = 0; cc < S; cc += 2) lds_write_b128(ea + cc * 8u, d2_t{botR[cc], botR[cc + 1]});
+            lds_write_b128(ea + S * 8u, d2_t{Gown[RC - 1][0], Gown[RC - 1][1]});
+            lds_write_b128(ea + (S + 2) * 8u, d2_t{wk[RC - 1][0], wk[RC - 1][1]});
         }
-        // -- contraction: node rows r_k = p_k + 1 at node columns c1 (this unit's second) and c2 (the previous unit's first).
-        //    The y points are read from the ring a second time: holding them across the sweep costs 4 FD VGPRs
-        {
-            asm volatile("" ::: "memory");
-            amb_read_ydims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
-        }
-        double cv1[RC + 1], cv2[RC + 1];
+        // -- contraction: node rows r_k = p_k + 1 at node columns c1 (this unit's second) and c2 (the previous unit's first)
+        double cv1[RC], cv2[RC];
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
             const double u0 = k == 0 ? wup0[0] : wk[(k + RC - 1) % RC][0];     // cells of coarse row p_k + 1
@@ -524,54 +581,75 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_rbf_mb(const AdjMbParams
             cv1[k] = V1 * g1 * sx;
             cv2[k] = V2 * g2 * sx_d;
         }
-        {   // node row p_{RC-1} from its own cells only (V[0][c] = w[0][c] - w[0][c-1]): node row 0 on the bottom lane of the last band
+        // node row p_{RC-1} from its own cells only (V[0][c] = w[0][c] - w[0][c-1]): node row 0 on the bottom lane of the last band.
+        // Its weights go out per node column (N0); the c2 term of a band's first macro-step is node column 0 of the band BEFORE
+        if (n0_cur || (u == 0 && n0_prev)) {
+            asm volatile("");
             const double V1 = wk[RC - 1][1] - wk[RC - 1][0];
             const double V2 = wkP[RC - 1] - wk[RC - 1][1];
-            cv1[RC] = n0_cur ? V1 * Gown[RC - 1][1] * sx : 0.0;
-            cv2[RC] = (u == 0 ? n0_prev : n0_cur) ? V2 * GownP[RC - 1] * sx_d : 0.0;
+            const double c1v = V1 * Gown[RC - 1][1] * sx, c2v = V2 * GownP[RC - 1] * sx_d;
+            if (n0_cur) n0_cur[2 * uo + 1] = c1v;
+            if (u == 0) {
+                if (n0_prev) n0_prev[0] = c2v;
+            } else if (n0_cur) {
+                n0_cur[2 * uo + 2] = c2v;
+            }
+        }
+        // the terms of the PREVIOUS macro-step's c1 and of this step's c2: the two columns of the previous unit
+#pragma unroll
+        for (int k = 0; k < RC; ++k) cs[k] += cv1p[k] + cv2[k];
+        if constexpr (Y32) {
+            d2_t raw[FDY];
+            amb_read_ydims<FDY>(raw, yq_e, yq_o);
+#pragma unroll
+            for (int jp = 0; jp < FDY; ++jp) {
+                const f4_t f = __builtin_bit_cast(f4_t, raw[jp]);
+                const double a0 = (double)f[0], a1 = (double)f[1], b0 = (double)f[2], b1 = (double)f[3];
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    accd[k][2 * jp] = fma(cv1p[k], a1, fma(cv2[k], a0, accd[k][2 * jp]));
+                    accd[k][2 * jp + 1] = fma(cv1p[k], b1, fma(cv2[k], b0, accd[k][2 * jp + 1]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < FD / 8; ++h) {
+                d2_t yh[8];
+                amb_read_ydims<8>(yh, yq_e + h * 1024u, yq_o + h * 1024u);
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) accd[k][8 * h + j] = fma(cv1p[k], yh[j][1], fma(cv2[k], yh[j][0], accd[k][8 * h + j]));
+            }
         }
         if (u == 0) {
-            // the c2 terms of a band's first macro-step complete node column 0 of the band BEFORE: add them to the sums of the
-            // rows being left, write those out, and start over for the new rows
+            // a band's first macro-step: with the above the sums of the rows being left are complete -- write them out, start over
             asm volatile("");
             if (gp_prev) {
 #pragma unroll
-                for (int k = 0; k <= RC; ++k) {
-                    if (k == RC && !n0_prev) break;
+                for (int k = 0; k < RC; ++k) {
                     double *dst = gp_prev - (int64_t)k * OUTW;
-                    *reinterpret_cast<d2_t *>(dst) = d2_t{cs[k] + cv2[k], 0.0};
+                    *reinterpret_cast<d2_t *>(dst) = d2_t{cs[k], 0.0};
 #pragma unroll
-                    for (int j = 0; j < FD; j += 2)
-                        *reinterpret_cast<d2_t *>(dst + 2 + j) = d2_t{fma(cv2[k], yP[j], accd[k][j]), fma(cv2[k], yP[j + 1], accd[k][j + 1])};
+                    for (int j = 0; j < FD; j += 2) *reinterpret_cast<d2_t *>(dst + 2 + j) = d2_t{accd[k][j], accd[k][j + 1]};
                 }
             }
 #pragma unroll
-            for (int k = 0; k <= RC; ++k) {
+            for (int k = 0; k < RC; ++k) {
                 cs[k] = 0.0;
-                cv2[k] = 0.0;
 #pragma unroll
                 for (int j = 0; j < FD; ++j) accd[k][j] = 0.0;
             }
         }
 #pragma unroll
-        for (int k = 0; k < RC; ++k) {
-            cs[k] += cv1[k] + cv2[k];
-#pragma unroll
-            for (int j = 0; j < FD; ++j) accd[k][j] = fma(cv1[k], yv[j][1], fma(cv2[k], yP[j], accd[k][j]));
-        }
-        if (n0_cur) {
-            asm volatile("");
-            cs[RC] += cv1[RC] + cv2[RC];
-#pragma unroll
-            for (int j = 0; j < FD; ++j) accd[RC][j] = fma(cv1[RC], yv[j][1], fma(cv2[RC], yP[j], accd[RC][j]));
-        }
+        for (int k = 0; k < RC; ++k) cv1p[k] = cv1[k];
+        yq_e = ya_e;
+        yq_o = ya_o;
         // -- histories for the next macro-step (and for the lane below, which reads lastOwn / lastW at its top)
         wupP = wup0[0];
         GabvP = Gabv[0];
 #pragma unroll
         for (int k = 0; k < RC; ++k) { wkP[k] = wk[k][0]; GownP[k] = Gown[k][0]; }
-#pragma unroll
-        for (int j = 0; j < FD; ++j) yP[j] = yv[j][0];
         lastOwn[0] = Gown[RC - 1][0]; lastOwn[1] = Gown[RC - 1][1];
         lastW[0] = wk[RC - 1][0]; lastW[1] = wk[RC - 1][1];
         sx_d = sx;
@@ -613,7 +691,7 @@ struct AmbPlan {
     bool ok;
 };
 
-AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D) {
+AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D, bool y32 = false) {
     AmbPlan pl{};
     pl.ok = false;
     if (dyadic < 1 || dyadic > 2 || D < 1 || D > 16) return pl;
@@ -624,27 +702,30 @@ AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D) {
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (pl.NUp < AMB_L + 16) return pl;                      // band boundary slack
     pl.nb = (Mc + 1 + AMB_L * pl.RC - 1) / (AMB_L * pl.RC);  // the node rows must fit the lanes (the first lane-row is padding)
-    const int R = 4, E = 2 * pl.S + 4;
+    const int R = 4, E = pl.S + 4;
     const size_t xslab = ((size_t)8 * pl.RC * pl.fd * 8 + (4 * R + 1) * 16 + 16 + 63) / 64 * 64;
-    pl.lds_bytes = (size_t)(AMB_L / 8 + 2) * pl.fd * 128 + AMB_X_SLOTS * xslab + (size_t)3 * 8 * E * 8 + (size_t)2 * (4 * pl.S + 1) * 16;
+    pl.lds_bytes = (size_t)(AMB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + AMB_X_SLOTS * xslab + (size_t)3 * 8 * E * 8 + (size_t)2 * (4 * pl.S + 1) * 16;
     pl.ws_stride = (int64_t)(pl.NUp + 8) * E;
-    pl.edge_doubles = (int64_t)pl.NUp * pl.S + (int64_t)pl.nb * AMB_L * R;
+    pl.edge_doubles = (int64_t)pl.nb * pl.NUp * pl.S + (int64_t)pl.nb * AMB_L * R;
     pl.ok = true;
     return pl;
 }
 
-template <int DY, int RC, int FD>
+template <int DY, int RC, int FD, bool Y32 = false>
 int launch_amb(AdjMbParams prm, const AmbPlan &pl, void *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_adj_fused_rbf_mb<DY, RC, FD>;
+    auto kern = k_adj_fused_rbf_mb<DY, RC, FD, Y32>;
     static const int vgprs = [&] {
         hipFuncAttributes attr;
         return hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
     }();
-    int wpc = (int)((160 * 1024) / pl.lds_bytes);
+    // resident waves per CU: whole workgroups of wpb waves by LDS, by registers, at most two per SIMD
+    const int wpb0 = wave_group(pl.lds_bytes, 1 << 20, knobs().adjmb_wpb).wpb;
+    int wpc = (int)((160 * 1024) / (pl.lds_bytes * wpb0)) * wpb0;
     const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
     if (wpc > by_regs) wpc = by_regs;
     if (knobs().adjmb_wpc > 0 && wpc > knobs().adjmb_wpc) wpc = knobs().adjmb_wpc;
     if (wpc > 8) wpc = 8;
+    if (wpc >= wpb0) wpc = wpc / wpb0 * wpb0;
     if (wpc < 1) wpc = 1;
     const int64_t max_waves = (int64_t)device_cu_count() * wpc;
     int64_t waves = prm.P < max_waves ? prm.P : max_waves;
@@ -666,15 +747,16 @@ int launch_amb(AdjMbParams prm, const AmbPlan &pl, void *ws, size_t ws_bytes, hi
 }  // namespace
 
 // Layout query of sk_rbf_adjoint_fused_mb_f64 (0 / false outside the kernel's scope): rows of Xr the caller provides per path,
-// node rows and doubles per node row of gpart, edge doubles per pair (what sk_solve_fwd_static_* writes with `edges`), bands,
-// units, workspace bytes.
-bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles, int *nb,
-                         int *nup, size_t *ws_bytes) {
+// node rows and doubles per node row of gpart, node columns of n0, edge doubles per pair (what sk_solve_fwd_static_* writes with
+// `edges`), bands, units, workspace bytes.
+bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols, int64_t *edge_doubles,
+                         int *nb, int *nup, size_t *ws_bytes) {
     const AmbPlan pl = amb_plan(Mc, Nc, dyadic, D);
     if (!pl.ok || P <= 0) return false;
     if (mrows) *mrows = pl.nb * AMB_L * pl.RC + 8;
     if (rows) *rows = pl.nb * AMB_L * pl.RC + 1;
     if (outw) *outw = pl.fd + 2;
+    if (ncols) *ncols = 2 * pl.NUp;
     if (edge_doubles) *edge_doubles = pl.edge_doubles;
     if (nb) *nb = pl.nb;
     if (nup) *nup = pl.NUp;
@@ -683,22 +765,47 @@ bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrow
     return true;
 }
 
-int launch_adj_fused_rbf_mb(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
-                            double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                            void *ws, size_t ws_bytes, hipStream_t s) {
+int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
+                            double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *n0,
+                            size_t n0_doubles, double *err, void *ws, size_t ws_bytes, const FusedRescue *rescue, const double *Yt64,
+                            hipStream_t s) {
     if (g.naive || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
-    const AmbPlan pl = amb_plan(g.Mc, g.Nc, g.dyadic, D);
-    if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
+    const double *Yt = static_cast<const double *>(Yt_any);
+    const bool y32 = yt_f32 != 0;
+    const AmbPlan pl = amb_plan(g.Mc, g.Nc, g.dyadic, D, y32);
+    if (!pl.ok || fd != pl.fd || (y32 && pl.fd != 16)) return SK_ERR_UNSUPPORTED;
     if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < pl.nb * AMB_L * pl.RC + 1) return SK_ERR_UNSUPPORTED;
-    if (g.Nc > 2 * pl.NUp - 2) return SK_ERR_UNSUPPORTED;
+    if (g.Nc > 2 * pl.NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
     const int64_t rows = (int64_t)pl.nb * AMB_L * pl.RC + 1;
-    if (gpart_doubles < (size_t)(g.P * rows * (pl.fd + 2))) return SK_ERR_WORKSPACE;
+    if (gpart_doubles < (size_t)(g.P * rows * (pl.fd + 2)) || n0_doubles < (size_t)(g.P * 2 * pl.NUp)) return SK_ERR_WORKSPACE;
     AdjMbParams prm{};
-    prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.err = err;
+    prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.N0 = n0; prm.err = err;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb;
     prm.inv_sigma = inv_sigma;
-    if (g.dyadic == 1) return pl.fd == 8 ? launch_amb<1, 2, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<1, 2, 16>(prm, pl, ws, ws_bytes, s);
-    return pl.fd == 8 ? launch_amb<2, 1, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16>(prm, pl, ws, ws_bytes, s);
+    // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN: the
+    // sweep stores zeros for them), and their exact, stored-grid share is added to gpart afterwards -- one pair per chunk here
+    void *rws = nullptr;
+    size_t rws_bytes = 0;
+    if (rescue && rescue->ws && Yt64) {
+        const size_t head = sizeof(double) * (size_t)((g.P + 1) / 2 * 2);
+        if (rescue->ws_bytes <= head) return SK_ERR_WORKSPACE;
+        rws = (char *)rescue->ws + head;
+        rws_bytes = rescue->ws_bytes - head;
+        if (rescue->kfinal) {
+            const int rc = launch_fused_screen(rescue->kfinal, scale, g.P, rescue->screen, (double *)rescue->ws, err, s);
+            if (rc != SK_OK) return rc;
+            prm.scale = (const double *)rescue->ws;
+        }
+    }
+    int rc;
+    if (y32) rc = g.dyadic == 1 ? launch_amb<1, 2, 16, true>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16, true>(prm, pl, ws, ws_bytes, s);
+    else if (g.dyadic == 1) rc = pl.fd == 8 ? launch_amb<1, 2, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<1, 2, 16>(prm, pl, ws, ws_bytes, s);
+    else rc = pl.fd == 8 ? launch_amb<2, 1, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16>(prm, pl, ws, ws_bytes, s);
+    if (rc != SK_OK || !rws) return rc;
+    ChunkSplit cs{};          // one pair per chunk, slot = pair
+    cs.nr = 1; cs.nch = (int)(B > 0 ? B : 1); cs.cpr = cs.nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = 1; cs.off[0] = 0;
+    return launch_fused_rescue(1, Xr, Yt64, scale, err, rescue->tol, gpart, nullptr, A, B, Mrows, Ncp, D, g, (int)rows, pl.fd + 2, 0, inv_sigma, cs,
+                               g.P, rws, rws_bytes, s, pl.fd, n0, 2 * pl.NUp);
 }
 
 }  // namespace sk

@@ -40,9 +40,10 @@ struct FusedMbParams {
     const double *Xr;   // [A][Mrows][FD]: KIND 0: s^2 (x[p+1]-x[p]);  KIND 1: x[p]; zero rows / dims beyond the path
     const double *Yt;   // [Bn][FD][Ncp]: KIND 0: y[q+1]-y[q];  KIND 1: y[q]; dimension-major, zero-padded
     void *out;          // [P]
-    double *edges;      // EDGES: [P][NUp S + nb 64 R] the terminal row K[MMp][1..NNp] and column K[1..MMp][NNp] of the PADDED grid (whose
-                        // padding carries no increments: K[MMp][j] = K[MM][min(j, NN)] and likewise down the column), for
-                        // sk_rbf_adjoint_fused_mb_f64
+    double *edges;      // EDGES: [P][nb NUp S + nb 64 R] of the PADDED grid (whose padding carries no increments: K[MMp][j] = K[MM][min(j, NN)]
+                        // and likewise down the column): the rows K[MMp - b 64 R][1..NNp], b = 0..nb-1 -- the terminal row and the bottom
+                        // row of every other band, from which sk_rbf_adjoint_fused_mb_f64 restarts its backward recompute of K band by
+                        // band -- then the terminal column K[1..MMp][NNp]
     double *ws;         // per wave: [NUp + 8][E] band-boundary row + a chunk of ones, E = S doubles of K (+ 2 node values, KIND 1) per unit
     int64_t P, B;       // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired
     int Mrows, Ncp, Mc, Nc, NUp, nb, PPW, n_steps;
@@ -601,19 +602,21 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         }
 
         if constexpr (EDGES) {
-            // terminal row: the bottom lane's last fine row in the last band; terminal column: every lane's rows after the last unit
-            if ((is_bot && bandk == nb - 1) || uk == NUp - 1) {
+            // the bottom fine row of every band (row nb-1-band of the pair's block: the LAST band's is the terminal row), from the
+            // bottom lane; the terminal column: every lane's rows after the last unit
+            if (is_bot || uk == NUp - 1) {
                 int pv = psk;
                 asm volatile("" : "+v"(pv));
                 const unsigned pair_e = stream_pair(pv);
                 if (pair_e != NOPAIR && uk >= 0) {
-                    double *e = prm.edges + (int64_t)pair_e * ((int64_t)NUp * S + (int64_t)nb * L * R);
-                    if (is_bot && bandk == nb - 1) {
+                    double *e = prm.edges + (int64_t)pair_e * ((int64_t)nb * NUp * S + (int64_t)nb * L * R);
+                    if (is_bot) {
+                        double *er = e + ((int64_t)(nb - 1 - bandk) * NUp + uk) * S;
 #pragma unroll
-                        for (int cc = 0; cc < S; cc += 2) *reinterpret_cast<d2_t *>(e + (int64_t)uk * S + cc) = d2_t{bot[cc], bot[cc + 1]};
+                        for (int cc = 0; cc < S; cc += 2) *reinterpret_cast<d2_t *>(er + cc) = d2_t{bot[cc], bot[cc + 1]};
                     }
                     if (uk == NUp - 1) {
-                        double *ec = e + (int64_t)NUp * S + (int64_t)(bandk * L + lam) * R;
+                        double *ec = e + (int64_t)nb * NUp * S + (int64_t)(bandk * L + lam) * R;
 #pragma unroll
                         for (int rr = 0; rr < R; rr += 2) *reinterpret_cast<d2_t *>(ec + rr) = d2_t{left[rr], left[rr + 1]};
                     }

@@ -165,13 +165,14 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
             Xt = Xd[a0:a1].contiguous()
             Yt = Yd if gram else Yd[a0:a1].contiguous()
             got = go if go is None else go[a0:a1].reshape(-1).contiguous()
-            res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram) if edges is not None else None
+            Kt = None if Kvals is None else Kvals[a0:a1]
+            res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=Kt) if edges is not None else None
             if res is None:    # no edges kept, or kept by another kernel in its own layout
                 fw = be.solve_fwd_fused_static(1, param, Xt, Yt, dyadic, naive, gram, keep_edges=True)
                 edges = fw[1] if fw is not None else None
                 if edges is None:
                     return None
-                res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram)
+                res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=fw[0])
                 if res is None:
                     return None
             grad[a0:a1] = res[0]
@@ -465,7 +466,10 @@ class _SigKernelGram(torch.autograd.Function):
             # with a gradient: the triangular forward AND a triangular adjoint (a pair above the diagonal also stands for
             # its mirror image, through the second-argument contraction of the same W) -- fused static kernels only
             # (the fused linear adjoint is faster on all pairs than the unfused one on the triangle: 14 vs 20 ms at the C3 shape)
-            if (X.requires_grad and Y.requires_grad and _fused_static(static_kernel, True) is not None
+            # (long / wide RBF paths: the multi-band fused adjoint on ALL pairs beats the unfused triangle -- C5's shape 0.29 s against 0.46 s)
+            mb_only = (_fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
+                       and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
+            if (X.requires_grad and Y.requires_grad and _fused_static(static_kernel, True) is not None and not mb_only
                     and not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
                     and hasattr(be, "static_adjoint2") and X.shape[2] <= (8 if type(static_kernel) is LinearKernel else 32)):
                 ctx.sym_blocks = []

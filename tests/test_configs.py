@@ -589,6 +589,111 @@ def test_fused_multiband_scope_and_c5_route(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------
+# the multi-band fused RBF adjoint (sk_rbf_adjoint_fused_mb_f64, csrc/sk_wave_adj_fused_mb.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,A,B,M,N,D", [(2, 3, 4, 150, 170, 3), (2, 2, 3, 60, 200, 10), (1, 3, 2, 300, 180, 5), (2, 2, 2, 129, 161, 16),
+                                         (1, 2, 2, 130, 300, 12), (2, 5, 7, 64, 165, 4), (2, 2, 3, 65, 162, 8), (1, 2, 2, 257, 161, 2)])
+def test_multiband_fused_rbf_adjoint_vs_oracle(d, A, B, M, N, D):
+    """Long / wide paths: terminal edges from sk_solve_fwd_static_* and the multi-band fused adjoint against the oracle's closed
+    form (O.gram_grad_weighted), row by row -- band boundaries (M = 64 k + 1, 129, 257), one band, 1..3 bands, dims up to 16,
+    N at the edge of a unit row (odd / even Nc)."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    k = sigkernel_amd.RBFKernel(0.7)
+    res = be.solve_fwd_fused_static(1, 0.7, Xc.to(DEV), Yc.to(DEV), d, False, True, keep_edges=True)
+    assert res is not None and res[1] is not None
+    K, edges = res
+    assert rel_err(K.cpu().numpy(), O.gram_forward(Xc, Yc, k, d, nthreads=NT)) <= 1e-11
+    out = be.rbf_adjoint_fused_mb(Xc.to(DEV), Yc.to(DEV), 0.7, d, edges, w.reshape(-1).to(DEV), gram=True)
+    assert out is not None
+    got, resid = out[0].cpu().numpy(), float(out[1])
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, d, nthreads=NT)
+    assert resid <= _lib.HipBackend.ADJ_RESIDUAL_TOL
+    scale = np.abs(want).max()
+    for r in range(M):
+        assert np.abs(got[:, r] - want[:, r]).max() <= 1e-10 * scale, (r, np.abs(got[:, r] - want[:, r]).max() / scale)
+    # paired batch through the same kernel
+    n = min(A, B)
+    resp = be.solve_fwd_fused_static(1, 0.7, Xc[:n].to(DEV), Yc[:n].to(DEV), d, False, False, keep_edges=True)
+    outp = be.rbf_adjoint_fused_mb(Xc[:n].to(DEV), Yc[:n].to(DEV), 0.7, d, resp[1], w.diagonal()[:n].contiguous().to(DEV), gram=False)
+    for i in range(n):
+        wi = O.gram_grad_weighted(Xc[i:i + 1], Yc[i:i + 1], w[i:i + 1, i:i + 1].numpy(), k, d)[0]
+        assert np.abs(outp[0][i].cpu().numpy() - wi).max() <= 1e-10 * max(np.abs(wi).max(), 1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("screen", [1e3, 1e300])
+def test_multiband_fused_adjoint_rescues_an_exploding_pair_on_the_device(screen, monkeypatch):
+    """Failure injection on long paths: x_2 and y_5 are the same straight line, k(x_2, y_5) ~ 1e6 and more.  With the screen the
+    pair leaves the sweep (residual -1) and its exact stored-grid share is added to its slot on the device; with the screen off it
+    fails its self-check and its slot -- node row 0 weights included -- is recomputed.  Every gradient row matches the oracle."""
+    be = _lib.get_backend()
+    monkeypatch.setattr(type(be), "FUSED_SCREEN", screen)
+    gen = torch.Generator().manual_seed(43)
+    A, B, M, N, D = 4, 7, 90, 165, 5
+    Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
+    Xc[2] = torch.arange(M, dtype=torch.float64)[:, None] * 0.2 * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    Yc[5] = torch.arange(N, dtype=torch.float64)[:, None] * 0.2 * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    k = sigkernel_amd.RBFKernel(2.0)
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    Kw = O.gram_forward(Xc, Yc, k, 2, nthreads=NT)
+    assert np.sum(np.abs(Kw) > 1e3) == 1 and abs(Kw[2, 5]) > 1e5, np.sort(np.abs(Kw).ravel())[-3:]
+    Xg, Yd, wd = Xc.to(DEV).requires_grad_(True), Yc.to(DEV), w.to(DEV)
+    torch.cuda.set_sync_debug_mode("warn")
+    import warnings
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            (sigkernel_amd.SigKernel(k, 2).compute_Gram(Xg, Yd) * wd).sum().backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert not [r for r in rec if "synchroniz" in str(r.message).lower()]
+    err = be.last_fused_err.cpu().numpy().reshape(A, B)
+    assert (err[2, 5] == -1.0) if screen < 1e100 else (err[2, 5] > _lib.HipBackend.ADJ_RESIDUAL_TOL or err[2, 5] != err[2, 5])
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, 2, nthreads=NT)
+    got = Xg.grad.cpu().numpy()
+    for a in range(A):
+        assert rel_err(got[a], want[a]) <= 2 * _lib.HipBackend.ADJ_RESIDUAL_TOL, (a, rel_err(got[a], want[a]))
+
+
+@pytest.mark.gpu
+def test_c5_route_with_a_gradient_materialises_nothing(monkeypatch):
+    """BASELINE configs[4]'s shape (len 512, dim 16, RBF, dyadic 2, fp32) WITH a gradient: sk_solve_fwd_static_f32 keeps the edges,
+    sk_rbf_adjoint_fused_mb_f64 (fp32 ring) sweeps back -- sk_static_increments, sk_solve_adj and sk_static_adjoint are never
+    called, nothing of size pairs x M x N exists; the gradient matches the oracle to fp32 resolution (~1e-7) and, on fp64 tensors of
+    the same shape, to 5e-10: the backward recompute of K runs from the terminal column across all 2044 fine columns (it restarts
+    from exact values at every band of rows, not along a row), and its rounding error grows with that width -- 1e-12 at C4's 252
+    columns, 1e-11 at 660, 2e-10 here; north_star asks for 1e-6.  compute_mmd (the symmetric Grams included) goes the same way."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(18)
+    X, Y = walk(gen, 3, 512, 16, torch.float32), walk(gen, 4, 512, 16, torch.float32)
+    w = torch.randn(3, 4, generator=gen, dtype=torch.float64)
+    k = sigkernel_amd.RBFKernel(1.0)
+    sk = sigkernel_amd.SigKernel(k, 2)
+    boom = lambda name: (lambda self, *a, **kw: (_ for _ in ()).throw(AssertionError(name + " called")))
+    for name in ("static_increments", "solve_adj", "static_adjoint", "solve_fwd_keep_edges"):
+        monkeypatch.setattr(type(be), name, boom(name))
+    want = O.gram_grad_weighted(X.double(), Y.double(), w.numpy(), k, 2, nthreads=NT)
+    for dt, tol in ((torch.float32, 2e-6), (torch.float64, 5e-10)):
+        Xg = X.to(dt).to(DEV).requires_grad_(True)
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        (sk.compute_Gram(Xg, Y.to(dt).to(DEV)) * w.to(dt).to(DEV)).sum().backward()
+        # edges, partial sums, and the rescue's stored grids for 8 pairs at a time (8 x 67 MB, whatever the batch)
+        assert torch.cuda.max_memory_allocated() - base < 900 << 20
+        assert rel_err(Xg.grad.double().cpu().numpy(), want) <= tol, (dt, rel_err(Xg.grad.double().cpu().numpy(), want))
+    Xg = X.double().to(DEV).requires_grad_(True)
+    sk.compute_mmd(Xg, Y.double().to(DEV)).backward()
+    Xc, Yc = X.double(), Y.double()
+    g_xx = 2.0 * O.gram_grad_weighted(Xc, Xc, (np.ones((3, 3)) - np.eye(3)) / 6.0, k, 2, nthreads=NT)   # unbiased: off-diagonal mean, 2x rule
+    g_xy = O.gram_grad_weighted(Xc, Yc, np.full((3, 4), -2.0 / 12.0), k, 2, nthreads=NT)
+    assert rel_err(Xg.grad.cpu().numpy(), g_xx + g_xy) <= 5e-10
+
+
+# ---------------------------------------------------------------------------------------------
 # the fused RBF adjoint (sk_rbf_adjoint_fused_f64, csrc/sk_wave_adj_fused_rbf.hip)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
