@@ -466,7 +466,8 @@ class HipBackend:
         n0v = n0.view(A, B if gram else 1, ncols)[:, :, :N]
         cs[:, 0, 0] += n0v.sum((1, 2))
         Yd = Y.double()
-        accd[:, 0] += torch.einsum("abc,bcd->ad", n0v, Yd) if gram else torch.einsum("ac,acd->ad", n0v[:, 0], Yd)
+        # (one small product per y_b, then the sum over b: the flat (A x BN) (BN x D) product runs at 75 GFLOP/s in rocBLAS)
+        accd[:, 0] += torch.bmm(n0v.transpose(0, 1), Yd).sum(0) if gram else torch.einsum("ac,acd->ad", n0v[:, 0], Yd)
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), err.max()
 

@@ -132,6 +132,30 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *wsb = prm.ws + (int64_t)blockIdx.x * prm.ws_block;
     const int64_t A = prm.B > 0 ? prm.P / prm.B : prm.P;
+    if (prm.cs.nr == 1 && prm.cs.size[0] == 1 && prm.n_groups == prm.P) {
+        // one pair per chunk, slot = pair (sk_wave_adj_fused_mb.hip: tens of thousands of chunks): the lanes look at 64 residuals at a
+        // time, the wave stops only for the flagged ones
+        for (int64_t base = (int64_t)blockIdx.x * WAVE; base < prm.P; base += (int64_t)gridDim.x * WAVE) {
+            const int64_t p = base + threadIdx.x;
+            const double e = p < prm.P ? prm.err[p] : 0.0;
+            unsigned long long todo = __ballot(e > prm.tol || e < 0.0);
+            while (todo) {
+                const int l = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int64_t pp = base + l;
+                const bool failed = prm.err[pp] > prm.tol;
+                double *slot = prm.part + pp * (int64_t)prm.rows * prm.outw;
+                if (failed) {
+                    for (int c = threadIdx.x; c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
+                    if (prm.N0)
+                        for (int c = threadIdx.x; c < prm.n0cols; c += WAVE) prm.N0[pp * prm.n0cols + c] = 0.0;
+                    __syncthreads();
+                }
+                rescue_pair(prm, pp, slot, lds, wsb);
+            }
+        }
+        return;
+    }
     for (int64_t gi = blockIdx.x; gi < prm.n_groups; gi += gridDim.x) {
         int64_t first, slot_i;
         int ppg;
