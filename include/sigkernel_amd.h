@@ -149,6 +149,19 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
                              int *outw_out, int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
                              size_t rescue_ws_bytes, void *stream);
 
+/* k, d/dgamma k, d2/dgamma2 k with the static kernel fused in (csrc/sk_wave_deriv_fused.hip): the three increment arrays of k_kgrad
+ * (sigkernel.py:526-541) are formed inside the solver from the point arrays of x, x + eps gamma, x + 2 eps gamma and y, in the
+ * operand order of sk_static_deriv_increments_* (bit-identical increments), and never exist in HBM.  Replaces
+ * sk_static_deriv_increments_* + sk_solve_deriv_* (cuda_backend.py:165-223, sigkernel.py:526-566) for LinearKernel (kind 0) and
+ * RBFKernel (kind 1, param = sigma).
+ *   X0r, X1r, X2r [A][Mrows][fd], Yt [Bn][fd][Ncp]: fp64 POINT arrays as sk_prep_paths_* builds them (fd = 8 for D <= 8, else 16;
+ *   Mrows >= *mrows of sk_solve_deriv_static_workspace_bytes; Ncp >= 2 NUp, NUp = ceil8((Nc + 2) / 2) >= 64);  B > 0: Gram, B == 0:
+ *   paired;  out_* [P].  SK_ERR_UNSUPPORTED (workspace_bytes 0): dyadic > 2, D > 16, second path shorter than 126 points. */
+size_t sk_solve_deriv_static_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows);
+int sk_solve_deriv_static_f64(int kind, double param, const double *X0r, const double *X1r, const double *X2r, const double *Yt, int64_t A,
+                              int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, double eps, double *out_k,
+                              double *out_kd, double *out_kdd, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The fused RBF adjoint for LONG or WIDE paths (csrc/sk_wave_adj_fused_mb.hip): any number of bands per pair, path dimensions up to
  * 16 -- BASELINE configs[4]'s shape with a gradient runs in sk_solve_fwd_static_* (edges) + this kernel with nothing of size P*M*N
  * in HBM.  Replaces sigkernel.py:419-502 + :404-416 for RBFKernel there, i.e. sk_static_increments + sk_solve_fwd + sk_solve_adj +

@@ -59,6 +59,9 @@ SIGNATURES = {
                                        _vp, _vp, _sz, _vp]),
     "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                        _vp, _vp, _vp, _sz, _vp]),
+    "sk_solve_deriv_static_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _vp]),
+    "sk_solve_deriv_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
+                                         ctypes.c_double, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
                                            _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
@@ -864,6 +867,41 @@ class HipBackend:
             _check(fn(int(kind), float(param), _ptr(X0), _ptr(X1), _ptr(X2), _ptr(Y), A, B, M, N, D, float(eps), _ptr(out[0]),
                       _ptr(out[1]), _ptr(out[2]), ld, _stream(X0)), "sk_static_deriv_increments")
         return out[..., : N - 1]
+
+    def solve_deriv_fused(self, kind, param, X0, X1, X2, Y, dyadic, eps):
+        """(k, d/dgamma k, d2/dgamma2 k), (A,B) each, straight from the paths X0 = X, X1 = X + eps*gamma, X2 = X + 2*eps*gamma and Y:
+        the three increment arrays are formed inside the solver (sk_solve_deriv_static_f64, csrc/sk_wave_deriv_fused.hip) with the
+        arithmetic of static_deriv_increments and never exist in HBM.  None outside its scope (fp64, dim <= 16, dyadic <= 2, second
+        path of 126 points or more)."""
+        for t, n in ((X0, "X0"), (X1, "X1"), (X2, "X2"), (Y, "Y")):
+            _dev(t, n)
+        A, M, D = X0.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if X0.dtype != torch.float64 or D > 16 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or A == 0 or B == 0:
+            return None
+        if kind == 1 and not float(param) > 0:
+            return None
+        lib = load()
+        mrows = ctypes.c_int(0)
+        nbytes = int(lib.sk_solve_deriv_static_workspace_bytes(A * B, Mc, Nc, int(dyadic), D, ctypes.byref(mrows)))
+        if not nbytes:
+            return None
+        fd = 8 if D <= 8 else 16
+        Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
+        dev = X0.device
+        out = torch.empty(3, A, B, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            Xr = [_prep_paths(x.contiguous(), False, False, 1.0, mrows.value, fd) for x in (X0, X1, X2)]
+            Yt = _prep_paths(Y.contiguous(), False, True, 1.0, Ncp, fd)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.sk_solve_deriv_static_f64(int(kind), float(param), _ptr(Xr[0]), _ptr(Xr[1]), _ptr(Xr[2]), _ptr(Yt), A, B, mrows.value, Mc, Nc,
+                                               Ncp, D, fd, int(dyadic), SCHEME_DEFAULT, float(eps), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                               _ptr(ws), nbytes, _stream(X0))
+        if rc == 2:
+            return None
+        _check(rc, "sk_solve_deriv_static")
+        return out[0], out[1], out[2]
 
     def solve_deriv(self, inc3, dyadic, flags=0):
         """inc3 [3, ..., Mc, Nc] (increments of k, d/dgamma, d2/dgamma2) -> (k, k_gamma, k_gamma_gamma), [...] each."""

@@ -155,6 +155,7 @@ Knobs parse_knobs() {
     k.adjf_wpc = knob_int("SK_ADJF_WPC"); k.adjf_wpb = knob_int("SK_ADJF_WPB");
     k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB"); k.adjr_all = knob_int("SK_ADJR_ALL");
     k.adjmb_wpc = knob_int("SK_ADJMB_WPC"); k.adjmb_wpb = knob_int("SK_ADJMB_WPB");
+    k.derivf_wpc = knob_int("SK_DERIVF_WPC"); k.derivf_wpb = knob_int("SK_DERIVF_WPB");
     k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");
@@ -445,6 +446,25 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
     const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
     return launch_adj_fused_rbf(Xr, Yt, A, B, Mrows, Ncp, D, g, 1.0 / sigma, edges, scale, gpart, gpart_doubles, err, ypart, ypart_doubles,
                                 ycols_out != nullptr, ppg_out, rows_out, outw_out, ycols_out, rescue_ws ? &fr : nullptr, (hipStream_t)stream);
+}
+
+size_t sk_solve_deriv_static_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows) {
+    if (P < 1 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return 0;
+    return deriv_fused_workspace_bytes(P, Mc, Nc, dyadic, D, mrows);
+}
+
+int sk_solve_deriv_static_f64(int kind, double param, const double *X0r, const double *X1r, const double *X2r, const double *Yt, int64_t A,
+                              int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, double eps, double *out_k,
+                              double *out_kd, double *out_kdd, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!X0r || !X1r || !X2r || !Yt || !out_k || !out_kd || !out_kdd || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 ||
+        dyadic > 16 || !(eps > 0))
+        return SK_ERR_BAD_ARG;
+    if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
+    if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    return launch_deriv_fused(kind, X0r, X1r, X2r, Yt, A, B, Mrows, Ncp, D, fd, g, kind == 1 ? 1.0 / param : 0.0, eps, out_k, out_kd, out_kdd,
+                              workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int sk_rbf_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols,

@@ -16,6 +16,7 @@ struct Knobs {
     int adjf_wpc, adjf_wpb;
     int adjr_wpc, adjr_wpb, adjr_all;
     int adjmb_wpc, adjmb_wpb;     // sk_wave_adj_fused_mb.hip
+    int derivf_wpc, derivf_wpb;   // sk_wave_deriv_fused.hip
     int deriv_pf, deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static;
     int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;
@@ -142,6 +143,12 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt, int yt_f32, 
                         int fd, const Geom &g, double inv_sigma, TO *out, double *edges, void *ws, size_t ws_bytes, hipStream_t s);
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int fused_mb_rows(int kind, int Mc, int dyadic, bool edges = false);
+
+// ---- sk_wave_deriv_fused.hip: k, d/dgamma, d2/dgamma2 with the static kernel fused in (no increment arrays in HBM) ----
+size_t deriv_fused_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows);
+int launch_deriv_fused(int kind, const double *X0r, const double *X1r, const double *X2r, const double *Yt, int64_t A, int64_t B, int Mrows,
+                       int Ncp, int D, int fd, const Geom &g, double inv_sigma, double eps, double *out_k, double *out_kd, double *out_kdd,
+                       void *ws, size_t ws_bytes, hipStream_t s);
 
 // ---- sk_wave_adj_fused_mb.hip: the fused RBF adjoint for pairs of several bands / path dims up to 16 ----
 bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols, int64_t *edge_doubles,

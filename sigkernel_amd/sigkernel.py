@@ -548,6 +548,12 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
     for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
         Xt, gt = Xd[a0:a1], gd[a0:a1]
         X1, X2 = Xt + eps * gt, Xt + 2. * eps * gt                                   # sigkernel.py:530, :537
+        if fused is not None and hasattr(be, "solve_deriv_fused") and not os.environ.get("SK_NO_FUSED_DERIV"):
+            # static kernel, finite differences, increments AND the three-state sweep in one kernel (sk_solve_deriv_static_f64)
+            res = be.solve_deriv_fused(fused[0], fused[1], Xt.contiguous(), X1, X2, Yd.contiguous(), dyadic_order, eps)
+            if res is not None:
+                out[0, a0:a1], out[1, a0:a1], out[2, a0:a1] = res
+                continue
         inc3 = None
         if fused is not None:    # static kernel + finite differences + increments in one pass (sk_static_deriv_increments_*)
             inc3 = be.static_deriv_increments(fused[0], fused[1], Xt.contiguous(), X1, X2, Yd.contiguous(), eps)

@@ -332,3 +332,55 @@ def test_gpu_api_larger_problem_against_oracle_and_linearity():
     assert rel_err(k2, k) <= 1e-13
     assert rel_err(kd2, 2 * kd) <= 1e-8
     assert rel_err(kdd2, 4 * kdd) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused derivative solver (sk_solve_deriv_static_f64, csrc/sk_wave_deriv_fused.hip)
+# ---------------------------------------------------------------------------------------------
+FUSED_DERIV_SHAPES = [(1, 3, 2, 130, 128, 5), (0, 2, 3, 100, 140, 8), (2, 2, 2, 70, 127, 3), (1, 2, 3, 128, 158, 16), (1, 4, 3, 50, 127, 4),
+                      (0, 3, 2, 64, 126, 7), (1, 3, 4, 40, 170, 3), (0, 2, 3, 70, 200, 8), (1, 3, 2, 130, 180, 5), (2, 2, 2, 20, 161, 2),
+                      (1, 2, 2, 65, 300, 12), (0, 5, 7, 129, 165, 4), (2, 2, 3, 70, 170, 9), (1, 2, 2, 193, 150, 3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_gpu_fused_derivative_solver_is_bit_identical_to_the_unfused_route(kind, monkeypatch):
+    """Static kernel, finite differences, increments and the three-state sweep in ONE kernel: the increments are formed in the
+    operand order of sk_static_deriv_increments_* and swept with the stencil of sk_solve_deriv_*'s fast kernel, so the three outputs
+    are BIT-identical to the unfused route -- one band and several, the boundary through L2 (rows of >= 80 units) and through the LDS
+    ring (64 <= units < 80, not a multiple of 32 included), dims up to 16, dyadic 0..2 -- and sk_static_deriv_increments is never
+    called (nothing of size pairs x M x N in HBM)."""
+    import sigkernel_amd
+    from sigkernel_amd import _lib
+    be = _lib.get_backend()
+    kern = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.8)
+    for d, A, B, M, N, D in FUSED_DERIV_SHAPES:
+        gen = torch.Generator().manual_seed(M + N)
+        X, Y = walk(gen, A, M, D).cuda(), walk(gen, B, N, D).cuda()
+        g = torch.randn(A, M, D, generator=gen, dtype=torch.float64).cuda()
+        sk = sigkernel_amd.SigKernel(kern, d)
+        monkeypatch.setenv("SK_NO_FUSED_DERIV", "1")
+        want = sk.compute_kernel_and_derivatives_Gram(X, Y, g)
+        monkeypatch.delenv("SK_NO_FUSED_DERIV")
+        with monkeypatch.context() as m:
+            m.setattr(type(be), "static_deriv_increments", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("increments materialised")))
+            got = sk.compute_kernel_and_derivatives_Gram(X, Y, g)
+        for a, b, name in zip(got, want, ("k", "k_gamma", "k_gamma_gamma")):
+            assert torch.equal(a, b), ((d, A, B, M, N, D), name, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+def test_gpu_fused_derivative_solver_against_the_oracle():
+    """The same route against the CPU oracle's k_kgrad (the reference's stencil and pre-processing): two bands, LDS boundary.
+    k_gamma at 1e-8 here: a last-bit difference between the device's exp and libm's in an RBF node is amplified by 1/eps = 1e4 (the
+    module docstring's argument; 1e-9 holds for the linear kernel)."""
+    import sigkernel_amd
+    from oracle import oracle as O
+    gen = torch.Generator().manual_seed(19)
+    X, Y = walk(gen, 6, 100, 4), walk(gen, 5, 130, 4)
+    g = torch.randn(6, 100, 4, generator=gen, dtype=torch.float64) / 8
+    for kern in (sigkernel_amd.LinearKernel(), sigkernel_amd.RBFKernel(0.9)):
+        k, kd, kdd = (t.cpu().numpy() for t in sigkernel_amd.SigKernel(kern, 1).compute_kernel_and_derivatives_Gram(X.cuda(), Y.cuda(), g.cuda()))
+        ek, ekd, ekdd = O.kgrad(X, Y, g, kern, 1, nthreads=8)
+        tol_kd = TOL_KD if isinstance(kern, sigkernel_amd.LinearKernel) else 1e-8
+        assert rel_err(k, ek) <= TOL_K and rel_err(kd, ekd) <= tol_kd and rel_err(kdd, ekdd) <= 1e-5, (rel_err(k, ek), rel_err(kd, ekd), rel_err(kdd, ekdd))
