@@ -185,6 +185,20 @@ int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const void *Yt, int yt_f32, in
                                 const double *yt64, const double *kfinal, double screen, double tol, void *rescue_ws, size_t rescue_ws_bytes,
                                 void *stream);
 
+/* The same for LinearKernel on long / wide paths (csrc/sk_wave_adj_fused_mb.hip: k_adj_fused_linear_mb): increments from the path
+ * differences, W contracted with the y differences on the spot.  Replaces sigkernel.py:419-502 + :404-416 there, i.e.
+ * sk_static_increments + sk_solve_fwd + sk_solve_adj + sk_linear_adjoint.
+ *   dXr [A][Mrows][fd] = s^2 (x[p+1]-x[p]), dYt [Bn][fd][Ncp] = y[q+1]-y[q] (sk_solve_fwd_static_*'s kind-0 arrays; Ncp >= 2 NUp,
+ *   NUp = ceil8((Nc + 1) / 2) >= 80);  edges: what sk_solve_fwd_static_* (kind 0, edges, Mrows = *mrows) kept, *edge_doubles per pair;
+ *   gpart [P][*rows][*outw = fd]: per PAIR and FLIPPED coarse row (row *rows - 1 - p holds coarse row p); summed over the pairs of an
+ *   x_a and flipped back it is the T of sk_linear_adjoint_*: dL/dx[m] = s^2 (T[m-1] - T[m]).  Rescue arguments as above.  dyadic 0..2. */
+int sk_linear_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
+                                      size_t *workspace_bytes);
+int sk_linear_adjoint_fused_mb_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+                                   int dyadic, int scheme, const double *edges, const double *scale, double *gpart, size_t gpart_doubles,
+                                   double *err, void *workspace, size_t workspace_bytes, const double *kfinal, double screen, double tol,
+                                   void *rescue_ws, size_t rescue_ws_bytes, void *stream);
+
 /* Device-side rescue of the two fused adjoints above (csrc/sk_adj_fused_rescue.hip) -- what makes a backward pass free of host
  * synchronisation.  The fused adjoints recompute K backwards from its terminal edges, which loses accuracy like 1e-16 K^2 and is
  * useless for exploding kernels; the reference stores both grids for every pair whatever K's size (sigkernel.py:438-470).
@@ -317,7 +331,7 @@ int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int 
  * sk_static_increments_* + sk_solve_fwd_*, or swap the arguments -- the kernel is symmetric). */
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
-/* edges (nullable; kind 1, dyadic 1..2): also keep, of the grid PADDED to the bands and units of sk_rbf_adjoint_fused_mb_f64 (padding
+/* edges (nullable; kind 1 at dyadic 1..2, kind 0 at dyadic 0..2): also keep, of the grid PADDED to the bands and units of sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64 (padding
  * carries no increments), the bottom row of every band of 64 lanes (the last one is the pair's terminal row) and the terminal column
  * -- *edge_doubles (sk_rbf_adjoint_fused_mb_layout) doubles per pair: what that adjoint recomputes K from, band by band.  Mrows must
  * then be the layout's *mrows. */

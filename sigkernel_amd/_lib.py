@@ -62,6 +62,9 @@ SIGNATURES = {
     "sk_solve_deriv_static_workspace_bytes": (_sz, [_i64, _int, _int, _int, _int, _vp]),
     "sk_solve_deriv_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,
                                          ctypes.c_double, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sk_linear_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "sk_linear_adjoint_fused_mb_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp,
+                                              _sz, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
     "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
                                            _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
@@ -346,10 +349,15 @@ class HipBackend:
         return out
 
     @staticmethod
-    def _adjoint_mb_layout(P, Mc, Nc, dyadic, D):
-        """(mrows, rows, outw, edge_doubles, workspace_bytes, ncols) of sk_rbf_adjoint_fused_mb_f64, or None outside its scope."""
+    def _adjoint_mb_layout(P, Mc, Nc, dyadic, D, kind=1):
+        """(mrows, rows, outw, edge_doubles, workspace_bytes, ncols) of sk_rbf_adjoint_fused_mb_f64 (kind 1) / sk_linear_adjoint_fused_mb_f64
+        (kind 0; ncols = 0), or None outside its scope."""
         mrows, rows, outw, ncols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         ed, wsb = ctypes.c_int64(0), ctypes.c_size_t(0)
+        if kind == 0:
+            rc = load().sk_linear_adjoint_fused_mb_layout(P, Mc, Nc, int(dyadic), D, ctypes.byref(mrows), ctypes.byref(rows), ctypes.byref(outw),
+                                                          ctypes.byref(ed), ctypes.byref(wsb))
+            return None if rc != 0 else (mrows.value, rows.value, outw.value, int(ed.value), int(wsb.value), 0)
         rc = load().sk_rbf_adjoint_fused_mb_layout(P, Mc, Nc, int(dyadic), D, ctypes.byref(mrows), ctypes.byref(rows), ctypes.byref(outw),
                                                    ctypes.byref(ncols), ctypes.byref(ed), ctypes.byref(wsb))
         if rc != 0:
@@ -381,8 +389,9 @@ class HipBackend:
             return (Kt, None) if (keep_edges and Kt is not None) else Kt
         fd = 8 if D <= 8 else 16
         Mrows = int(lib.sk_solve_fwd_static_rows(int(kind), Mc, int(dyadic)))
-        # keep_edges (RBF, dyadic 1..2): the terminal row / column of every pair in the layout sk_rbf_adjoint_fused_mb_f64 reads
-        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D) if (keep_edges and kind == 1 and not _swapped) else None
+        # keep_edges (RBF at dyadic 1..2, Linear): every band's bottom row and the terminal column of every pair, in the layout
+        # sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64 read
+        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D, int(kind)) if (keep_edges and not _swapped) else None
         edges = None
         if lay is not None:
             Mrows = lay[0]
@@ -417,6 +426,48 @@ class HipBackend:
         return (out, edges) if keep_edges else out
 
     FUSED_RESCUE_BLOCKS_MB = 8   # (a stored pair of 2044 x 2044 grids is 67 MB)
+
+    def linear_adjoint_fused_mb(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
+        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel on LONG or WIDE paths
+        straight from the paths and the edges solve_fwd_fused_static(0, ..., keep_edges=True) kept (sk_linear_adjoint_fused_mb_f64; fp64
+        sweep; dim <= 16, dyadic 0..2, any M, N >= ~160).  None outside that scope."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B, N = Y.shape[0], Y.shape[1]
+        Mc, Nc = M - 1, N - 1
+        if D > 16 or dyadic not in (0, 1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or edges is None:
+            return None
+        P, Bk = (A * B, B) if gram else (A, 0)
+        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D, 0)
+        if lay is None or edges.numel() != P * lay[3]:
+            return None
+        mrows, rows, fd, _, nbytes, _ = lay
+        Ncp = 2 * (((Nc + 1) // 2 + 7) // 8 * 8)
+        dev = X.device
+        if scale is not None:
+            scale = scale.double().contiguous()
+        with torch.cuda.device(dev):
+            dXr = _prep_paths(X, True, False, float(param) ** 2, mrows, fd)
+            dYt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
+            tpart = torch.empty(P, rows, fd, dtype=torch.float64, device=dev)
+            err = torch.zeros(P, dtype=torch.float64, device=dev)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev, self.FUSED_RESCUE_BLOCKS_MB)
+            rc = load().sk_linear_adjoint_fused_mb_f64(_ptr(dXr), _ptr(dYt), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
+                                                       _ptr(edges), _ptr(scale), _ptr(tpart), tpart.numel(), _ptr(err), _ptr(ws), nbytes, _ptr(kf),
+                                                       float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
+            if rc == 2:
+                return None
+            _check(rc, "sk_linear_adjoint_fused_mb")
+        self.last_fused_err = err
+        T = tpart.view(A, B if gram else 1, rows, fd).sum(1).flip(1)[:, :Mc, :D]    # the pairs of an a in a fixed order; flipped rows back to p
+        g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
+        g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
+        g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
+        if float(param) != 1.0:
+            g = g * (float(param) ** 2)
+        return g.to(X.dtype), err.max()
 
     def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True, kfinal=None):
         """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel on LONG or WIDE paths

@@ -490,6 +490,27 @@ int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const void *Yt, int yt_f32, in
                                    workspace, workspace_bytes, rescue_ws ? &fr : nullptr, yt64, (hipStream_t)stream);
 }
 
+int sk_linear_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
+                                      size_t *workspace_bytes) {
+    if (P < 1 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    return adj_fused_mb_layout(P, Mc, Nc, dyadic, D, mrows, rows, outw, nullptr, edge_doubles, nullptr, nullptr, workspace_bytes, 0)
+               ? SK_OK : SK_ERR_UNSUPPORTED;
+}
+
+int sk_linear_adjoint_fused_mb_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd,
+                                   int dyadic, int scheme, const double *edges, const double *scale, double *gpart, size_t gpart_doubles,
+                                   double *err, void *workspace, size_t workspace_bytes, const double *kfinal, double screen, double tol,
+                                   void *rescue_ws, size_t rescue_ws_bytes, void *stream) {
+    if (kfinal && !rescue_ws) return SK_ERR_BAD_ARG;
+    if (!dXr || !dYt || !edges || !gpart || !err || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
+    const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
+    return launch_adj_fused_linear_mb(dXr, dYt, A, B, Mrows, Ncp, D, fd, g, edges, scale, gpart, gpart_doubles, err, workspace, workspace_bytes,
+                                      rescue_ws ? &fr : nullptr, (hipStream_t)stream);
+}
+
 size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks) {
     if ((kind != 0 && kind != 1) || P < 1 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return 0;
     return fused_rescue_workspace_bytes(kind, P, Mc, Nc, dyadic, blocks);

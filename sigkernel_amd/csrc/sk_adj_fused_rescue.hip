@@ -88,11 +88,11 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
     adj_pair<double>(inc, Nc, Mc, Nc, d, 0, lds, Kf, Kr, nullptr, W, Nc);
     if (prm.kind == 0) {
         // T[a][pp][k] += s sum_q W[pp][q] dy[q][k], kept at flipped row rows - 1 - pp (sk_wave_adj_fused.hip)
-        for (int c = lane; c < Mc * 8; c += WAVE) {
-            const int pp = c >> 3, k = c & 7;
+        for (int c = lane; c < Mc * fd; c += WAVE) {
+            const int pp = c / fd, k = c - pp * fd;
             double t = 0.0;
             for (int q = 0; q < Nc; ++q) t = fma(W[(int64_t)pp * Nc + q], ys[(int64_t)k * prm.Ncp + q], t);
-            slot[(int64_t)(prm.rows - 1 - pp) * 8 + k] += s * t;
+            slot[(int64_t)(prm.rows - 1 - pp) * fd + k] += s * t;
         }
     } else {
         // V[r][c] = w[r-1][c-1] + w[r][c] - w[r-1][c] - w[r][c-1] (w = W inside the grid, 0 outside): d k / d G[r][c]

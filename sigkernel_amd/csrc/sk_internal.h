@@ -152,7 +152,10 @@ int launch_deriv_fused(int kind, const double *X0r, const double *X1r, const dou
 
 // ---- sk_wave_adj_fused_mb.hip: the fused RBF adjoint for pairs of several bands / path dims up to 16 ----
 bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols, int64_t *edge_doubles,
-                         int *nb, int *nup, size_t *ws_bytes);
+                         int *nb, int *nup, size_t *ws_bytes, int kind = 1);
+int launch_adj_fused_linear_mb(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
+                               const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err, void *ws,
+                               size_t ws_bytes, const FusedRescue *rescue, hipStream_t s);
 int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
                             double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *n0,
                             size_t n0_doubles, double *err, void *ws, size_t ws_bytes, const FusedRescue *rescue, const double *Yt64,

@@ -684,6 +684,390 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- the LINEAR static kernel on long paths: the same stream, a much lighter step -----------------------------------------------------
+// Increments straight from the path differences (no nodes), W contracted on the spot with the y differences of its own unit
+// (sk_wave_adj_fused.hip): T[pair][coarse row][:] = s_ab sum_q W[p][q] (y[q+1] - y[q]), no coupling to the lane above -- the band
+// boundary entry is the reverse state's bottom row alone (S doubles), and a lane's sums go out when it enters the next band.
+// Gpart: [P][Mcp][FD], FLIPPED coarse rows (row f = Mcp - 1 - p, the layout of sk_wave_adj_fused.hip); Xr = s^2 (x[p+1] - x[p]),
+// Yt = y[q+1] - y[q] dimension-major; edges from sk_solve_fwd_static_* (kind 0) with edges.
+template <int DY, int RC, int FD>
+__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD == 16 && DY == 0) ? 1 : 2))) void k_adj_fused_linear_mb(const AdjMbParams prm) {
+    constexpr int CW = 2;
+    constexpr int R = RC << DY, S = CW << DY;
+    static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
+    constexpr int L = AMB_L;
+    constexpr int XROW = FD * 8, PPR = FD / 2;
+    constexpr int XR_COL = 8 * RC * XROW, NPCOL = 4 * R + 1, XR_SC = XR_COL + NPCOL * 16;
+    constexpr int NPIECES = XR_SC / 16 + 1, XSLAB = (XR_SC + 16 + 63) / 64 * 64;
+    constexpr int YSLAB = FD * 128, NSLAB = L / 8 + 2, NDMA_Y = YSLAB / 1024;
+    constexpr int E = S, NPB = E / 2, CHUNK = 8 * E * 8, CPIECES = CHUNK / 16;     // boundary entry: botR[S]
+    constexpr int NPC = 4 * S + 1, ECG = NPC * 16;
+    constexpr int OUTW = FD;
+    constexpr unsigned X_BASE = NSLAB * YSLAB, BI_BASE = X_BASE + AMB_X_SLOTS * XSLAB, BO_BASE = BI_BASE + 2 * CHUNK,
+                       EC_BASE = BO_BASE + CHUNK, LDS_END = EC_BASE + 2 * ECG;
+    extern __shared__ __attribute__((aligned(16))) char lds_block[];
+    char *lds;
+    const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
+    if (wave_id < 0) return;
+    const unsigned lds0 = lds_offset(lds);
+
+    const int lam = threadIdx.x & (WAVE - 1);
+    const int NUp = prm.NUp, nb = prm.nb;
+    const int Mcp = nb * L * RC;
+    const int MMp = Mcp << DY, NNp = (NUp * CW) << DY;
+    const int EE = nb * NNp + MMp;
+    const double sc = 1.0 / (double)(1 << (2 * DY));
+    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const bool is_bot = lam == L - 1;
+    const int lam7 = lam & 7;
+
+    int u, band, ps;
+    {
+        const int sig = floor_div(-lam, NUp);
+        u = -lam - sig * NUp;
+        ps = floor_div(sig, nb);
+        band = sig - ps * nb;
+    }
+    int yslab, ypar;
+    {
+        const int s0 = floor_div(-lam, 8);
+        yslab = ((s0 % NSLAB) + NSLAB) % NSLAB;
+        ypar = s0 & 1;
+    }
+    constexpr unsigned NOPAIR = 0xffffffffu;
+    const unsigned P32 = (unsigned)prm.P;
+    const int per = prm.per;
+    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * per));
+    auto pair_at = [&](int i) __attribute__((always_inline)) -> unsigned {
+        if (i < 0 || i >= per) return NOPAIR;
+        const unsigned p = base0 + (unsigned)i;
+        return p < P32 ? p : NOPAIR;
+    };
+    const int t_end = per * nb * NUp + (L - 1) + 1;   // + 1: the last band's sums go out at the first macro-step after it
+
+    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
+    auto split_b = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+    };
+    auto split_a = [&](int64_t p) -> int64_t {
+        if (prm.B <= 0) return p;
+        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+    };
+    double *const wsrow = prm.ws + wave_id * prm.ws_stride;
+    const unsigned my_x = lds0 + X_BASE + (unsigned)(lam7 * RC * XROW);
+    const unsigned my_col = lds0 + X_BASE + (unsigned)(XR_COL + (7 - lam7) * R * 8);
+    const unsigned my_sc = lds0 + X_BASE + (unsigned)XR_SC;
+
+    int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
+    auto issue_y = [&]() {
+        const unsigned spy = pair_at(y_pi);
+        const int64_t b = split_b(spy == NOPAIR ? 0 : (int64_t)spy);
+        const int uo = NUp - 1 - (y_u0 + (lam & 7));
+#pragma unroll
+        for (int c = 0; c < NDMA_Y; ++c) {
+            const int krow = (c * 8 + (lam >> 3)) ^ (y_par & 1);
+            const double *src = prm.Yt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)uo * 2);
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + y_slot * YSLAB + c * 1024), 16, 0, 0);
+        }
+        y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
+        y_par ^= 1;
+        y_u0 += 8;
+        if (y_u0 == NUp) {
+            y_u0 = 0;
+            y_band += 1;
+            if (y_band == nb) { y_band = 0; y_pi += 1; }
+        }
+    };
+    int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
+    auto issue_x = [&]() {
+        const unsigned spx = pair_at(x_pi);
+        const int64_t p = spx == NOPAIR ? 0 : (int64_t)spx;
+        const int64_t a = split_a(p);
+        const int lamj = x_lam0 < L ? x_lam0 : 0;
+        const int gl0 = x_band * L + lamj;
+        const double *xa = prm.Xr + a * prm.Mrows * FD;
+        const double *ecol = prm.edges + p * EE + (nb * NNp - 2 + MMp - (gl0 + 8) * R);
+        const double *scp = prm.scale ? reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(prm.scale + p) & ~(uintptr_t)15) : prm.Xr;
+        char *dst = lds + X_BASE + x_slot * XSLAB;
+#pragma unroll
+        for (int c = 0; c < (NPIECES + 63) / 64; ++c) {
+            const int idx = c * 64 + lam;
+            if (idx < NPIECES) {
+                const double *src;
+                if (idx < 8 * RC * PPR) {
+                    const int i = idx / PPR;
+                    src = xa + (int64_t)(Mcp - 1 - (gl0 * RC + i)) * FD + (idx % PPR) * 2;    // coarse row (>= Mc: zero padding)
+                } else if (idx < 8 * RC * PPR + NPCOL) {
+                    src = ecol + 2 * (idx - 8 * RC * PPR);
+                } else {
+                    src = scp;
+                }
+                __builtin_amdgcn_global_load_lds(src, (lds_void *)(dst + c * 1024), 16, 0, 0);
+            }
+        }
+        if (lam < CPIECES) {
+            const double *sb = (x_band == 0 ? wsrow + (int64_t)NUp * E : wsrow + (int64_t)x_lam0 * E) + lam * 2;
+            __builtin_amdgcn_global_load_lds(sb, (lds_void *)(lds + BI_BASE + x_slot * CHUNK), 16, 0, 17);
+        }
+        if (lam < NPC) {
+            const int k = NNp - (x_lam0 + LINE_UNITS) * S - 2 + 2 * lam;
+            if (k >= 0)
+                __builtin_amdgcn_global_load_lds(prm.edges + p * EE + (int64_t)x_band * NNp + k, (lds_void *)(lds + EC_BASE + x_slot * ECG), 16, 0, 0);
+        }
+        x_slot ^= 1;
+        x_lam0 += 8;
+        if (x_lam0 == NUp) {
+            x_lam0 = 0;
+            x_band += 1;
+            if (x_band == nb) { x_band = 0; x_pi += 1; }
+        }
+    };
+    int f_pos = 0;
+    auto flush_chunk = [&]() {
+        if (lam < CPIECES) {
+            d2_t v;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + BO_BASE + (unsigned)(lam * 16)) : "memory");
+            amb_store_through(wsrow + (int64_t)f_pos * E + lam * 2, v);
+        }
+        f_pos += 8;
+        if (f_pos == NUp) f_pos = 0;
+    };
+
+    double dxr[RC][FD], tacc[RC][FD];
+#pragma unroll
+    for (int k = 0; k < RC; ++k)
+#pragma unroll
+        for (int j = 0; j < FD; ++j) { dxr[k][j] = 0.0; tacc[k][j] = 0.0; }
+    double leftR[R], botR[S], cornerR = 1.0;
+    double leftF[R], botF[S], cornerF = 1.0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = 1.0; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) { botR[i] = 1.0; botF[i] = 1.0; }
+    double chk_val = 0.0;
+    int64_t chk_pair = -1;
+    double sx = 0.0;
+    int valid = 0;
+    bool row_ok[RC];
+#pragma unroll
+    for (int k = 0; k < RC; ++k) row_ok[k] = false;
+    double *gp_cur = nullptr, *gp_prev = nullptr;
+
+    {
+        const d2_t z = {0.0, 0.0};
+        for (unsigned o = (unsigned)lam * 16u; o < LDS_END; o += WAVE * 16) lds_write_b128(lds0 + o, z);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (lam < CPIECES) amb_store_through(wsrow + (int64_t)NUp * E + lam * 2, d2_t{1.0, 1.0});   // the constant chunk of band 0: ones
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_y();
+    issue_x();
+
+    for (int t0 = 0; t0 < t_end; t0 += 8) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue_y();
+        issue_x();
+        const unsigned slot_w = (unsigned)((t0 >> 3) & 1);
+        const unsigned x_rd = slot_w * XSLAB;
+        const unsigned bi_rd = lds0 + BI_BASE + slot_w * CHUNK;
+        const unsigned ec_rd = lds0 + EC_BASE + slot_w * ECG;
+        const int t_stop = t0 + 8 < t_end ? t0 + 8 : t_end;
+        for (int t = t0; t < t_stop; ++t) {
+        d2_t pend[NPB], bnd[NPB];
+        {
+            const unsigned ba = bi_rd + (unsigned)((t & 7) * (E * 8));
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) amb_begin(pend[i]);
+            amb_read_pend<0>(pend[0], ba);
+            if constexpr (NPB > 1) amb_read_pend<16>(pend[1], ba);
+            if constexpr (NPB > 2) { amb_read_pend<32>(pend[2], ba); amb_read_pend<48>(pend[3], ba); }
+        }
+        double trow_p[S], trow[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+        lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+
+        if (chk_pair >= 0) {
+            atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
+            chk_pair = -1;
+        }
+        const int uo = NUp - 1 - u;
+
+        if (u == 0) {
+            asm volatile("");
+            // the sums of the band being left: complete (a cell's weight is contracted in its own macro-step)
+            if (gp_cur) {
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int j = 0; j < FD; j += 2) *reinterpret_cast<d2_t *>(gp_cur + (int64_t)k * OUTW + j) = d2_t{tacc[k][j], tacc[k][j + 1]};
+            }
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int j = 0; j < FD; ++j) tacc[k][j] = 0.0;
+            const unsigned sp = pair_at(ps);
+            const int64_t pe = (int64_t)sp;
+            const int gl = band * L + lam;
+            valid = sp != NOPAIR ? 1 : 0;
+#pragma unroll
+            for (int k = 0; k < RC; ++k) row_ok[k] = Mcp - 1 - (gl * RC + k) < prm.Mc;
+            const unsigned xa = my_x + x_rd;
+#pragma unroll
+            for (int k = 0; k < RC; ++k) amb_read_xrow<FD>(dxr[k], xa + k * XROW);
+            double col[6];
+            {
+                d2_t c3[3];
+                const unsigned ca_ = my_col + x_rd;
+                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
+                col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+            }
+            cornerR = 1.0;
+            cornerF = col[1 + R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
+            if (gl * R + R == MMp) leftF[R - 1] = 1.0;
+            double sv = 1.0;
+            if (prm.scale && valid) sv = lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u));
+            gp_cur = valid ? prm.Gpart + (pe * (int64_t)Mcp + (int64_t)gl * RC) * OUTW : nullptr;   // flipped coarse row gl RC + k
+            if (sv != sv) valid = 0;      // NaN: taken out of the sweep by the rescue's screen (its sums are stored as zeros)
+            sx = valid ? sv : 0.0;
+        }
+        (void)gp_prev;
+
+        // -- top rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
+        lds_take<S>(trow, trow_p);
+        double topR[S], topF[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            double tf = trow[S - 1 - i];
+            if (i == S - 1 && u == NUp - 1) tf = 1.0;
+            topR[i] = dpp_shr1(botR[i], bnd[i >> 1][i & 1]);
+            topF[i] = dpp_shr1(botF[i], tf);
+        }
+
+        // -- y differences of the unit (original column order inside the unit), increments, coefficients
+        const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
+        const unsigned ya_e = ya + (unsigned)(ypar << 7), ya_o = ya + (unsigned)((ypar ^ 1) << 7);
+        const bool c0_ok = 2 * uo < prm.Nc, c1_ok = 2 * uo + 1 < prm.Nc;
+        double ginc[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) ginc[k][q] = 0.0;
+#pragma unroll
+        for (int h = 0; h < FD / 8; ++h) {
+            d2_t yh[8];
+            amb_read_ydims<8>(yh, ya_e + h * 1024u, ya_o + h * 1024u);
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ginc[k][q] = fma(dxr[k][8 * h + j], yh[j][q], ginc[k][q]);
+        }
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            ginc[k][0] = (row_ok[k] && c0_ok) ? ginc[k][0] : 0.0;
+            ginc[k][1] = (row_ok[k] && c1_ok) ? ginc[k][1] : 0.0;
+        }
+        double ca[RC][CW], cb[RC][CW], ca2[RC][CW], cib[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) {
+                const double g = ginc[k][CW - 1 - q];   // flipped column order inside the unit
+                const double g2 = g * g;
+                ca[k][q] = fma(g2, c_12, fma(g, c_half, 1.0));
+                cb[k][q] = fma(g2, -c_12, 1.0);
+                cib[k][q] = fast_rcp(cb[k][q]);
+                ca2[k][q] = ca[k][q] * cib[k][q];
+            }
+
+        double acc[RC][CW];
+#pragma unroll
+        for (int k = 0; k < RC; ++k)
+#pragma unroll
+            for (int q = 0; q < CW; ++q) acc[k][q] = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < S; ++cc) {
+            double aboveR = topR[cc], diagR = cc == 0 ? cornerR : topR[cc - 1];
+            double aboveF = topF[cc], diagF = cc == 0 ? cornerF : topF[cc - 1];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int k = rr >> DY, q = cc >> DY;
+                const double a = ca[k][q], b = cb[k][q], a2 = ca2[k][q], ib = cib[k][q];
+                const double lR = leftR[rr], lF = leftF[rr];
+                const double vR = fma(aboveR, a, fma(lR, a, -(diagR * b)));
+                const double vF = fma(aboveF, a2, fma(lF, a2, -(diagF * ib)));
+                acc[k][q] = fma(vF, diagR, acc[k][q]);
+                diagR = lR; aboveR = vR; leftR[rr] = vR;
+                diagF = lF; aboveF = vF; leftF[rr] = vF;
+            }
+            botR[cc] = aboveR;
+            botF[cc] = aboveF;
+        }
+        cornerR = topR[S - 1];
+        cornerF = topF[S - 1];
+
+        if (is_bot) {
+            const unsigned ea = lds0 + BO_BASE + (unsigned)((u & 7) * (E * 8));
+#pragma unroll
+            for (int cc = 0; cc < S; cc += 2) lds_write_b128(ea + cc * 8u, d2_t{botR[cc], botR[cc + 1]});
+        }
+
+        // -- W of the RC x 2 coarse cells (with the pair's upstream gradient), contracted with the y differences of their columns
+        {
+            const bool live = valid != 0;
+            const double wsc = sc * sx;
+            double w0[RC], w1[RC];
+#pragma unroll
+            for (int k = 0; k < RC; ++k) {
+                w0[k] = (live && row_ok[k] && c0_ok) ? acc[k][1] * wsc : 0.0;     // original columns 0, 1
+                w1[k] = (live && row_ok[k] && c1_ok) ? acc[k][0] * wsc : 0.0;
+            }
+#pragma unroll
+            for (int h = 0; h < FD / 8; ++h) {
+                d2_t yh[8];
+                amb_read_ydims<8>(yh, ya_e + h * 1024u, ya_o + h * 1024u);
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tacc[k][8 * h + j] = fma(w0[k], yh[j][0], fma(w1[k], yh[j][1], tacc[k][8 * h + j]));
+            }
+        }
+
+        if (u == NUp - 1 && prm.err && valid) {
+            double e = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
+            chk_val = e;
+            chk_pair = (int64_t)pair_at(ps);
+        }
+
+        u += 1;
+        if (((t + 1) & 7) == lam7) {
+            yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
+            ypar ^= 1;
+            if (u == NUp) {
+                u = 0;
+                band += 1;
+                if (band == nb) { band = 0; ps += 1; }
+            }
+        }
+        if (((t + 1) & 7) == 7 && t >= L - 1 + 7) flush_chunk();
+        }
+    }
+    if (chk_pair >= 0)
+        atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 struct AmbPlan {
     int RC, S, NUp, nb, fd;
     size_t lds_bytes;
@@ -691,18 +1075,19 @@ struct AmbPlan {
     bool ok;
 };
 
-AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D, bool y32 = false) {
+AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D, bool y32 = false, int kind = 1) {
     AmbPlan pl{};
     pl.ok = false;
-    if (dyadic < 1 || dyadic > 2 || D < 1 || D > 16) return pl;
-    pl.RC = dyadic == 1 ? 2 : 1;
+    if (dyadic < (kind == 1 ? 1 : 0) || dyadic > 2 || D < 1 || D > 16) return pl;
+    pl.RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
     pl.S = 2 << dyadic;
     pl.fd = D <= 8 ? 8 : 16;
-    const int NU = (Nc + 2) / 2;                             // the forward's units (sk_wave_fused_mb.hip: mb_plan, RBF)
+    const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;  // the forward's units (sk_wave_fused_mb.hip: mb_plan)
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (pl.NUp < AMB_L + 16) return pl;                      // band boundary slack
-    pl.nb = (Mc + 1 + AMB_L * pl.RC - 1) / (AMB_L * pl.RC);  // the node rows must fit the lanes (the first lane-row is padding)
-    const int R = 4, E = pl.S + 4;
+    // rbf: the node rows must fit the lanes (the first lane-row is padding); linear: the coarse rows
+    pl.nb = (Mc + (kind == 1 ? 1 : 0) + AMB_L * pl.RC - 1) / (AMB_L * pl.RC);
+    const int R = 4, E = kind == 1 ? pl.S + 4 : pl.S;
     const size_t xslab = ((size_t)8 * pl.RC * pl.fd * 8 + (4 * R + 1) * 16 + 16 + 63) / 64 * 64;
     pl.lds_bytes = (size_t)(AMB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + AMB_X_SLOTS * xslab + (size_t)3 * 8 * E * 8 + (size_t)2 * (4 * pl.S + 1) * 16;
     pl.ws_stride = (int64_t)(pl.NUp + 8) * E;
@@ -711,9 +1096,12 @@ AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D, bool y32 = false) {
     return pl;
 }
 
-template <int DY, int RC, int FD, bool Y32 = false>
+template <int DY, int RC, int FD, bool Y32 = false, int KIND = 1>
 int launch_amb(AdjMbParams prm, const AmbPlan &pl, void *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_adj_fused_rbf_mb<DY, RC, FD, Y32>;
+    auto kern = [] {
+        if constexpr (KIND == 0) return k_adj_fused_linear_mb<DY, RC, FD>;
+        else return k_adj_fused_rbf_mb<DY, RC, FD, Y32>;
+    }();
     static const int vgprs = [&] {
         hipFuncAttributes attr;
         return hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
@@ -750,12 +1138,12 @@ int launch_amb(AdjMbParams prm, const AmbPlan &pl, void *ws, size_t ws_bytes, hi
 // node rows and doubles per node row of gpart, node columns of n0, edge doubles per pair (what sk_solve_fwd_static_* writes with
 // `edges`), bands, units, workspace bytes.
 bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int *ncols, int64_t *edge_doubles,
-                         int *nb, int *nup, size_t *ws_bytes) {
-    const AmbPlan pl = amb_plan(Mc, Nc, dyadic, D);
+                         int *nb, int *nup, size_t *ws_bytes, int kind) {
+    const AmbPlan pl = amb_plan(Mc, Nc, dyadic, D, false, kind);
     if (!pl.ok || P <= 0) return false;
     if (mrows) *mrows = pl.nb * AMB_L * pl.RC + 8;
-    if (rows) *rows = pl.nb * AMB_L * pl.RC + 1;
-    if (outw) *outw = pl.fd + 2;
+    if (rows) *rows = pl.nb * AMB_L * pl.RC + (kind == 1 ? 1 : 0);
+    if (outw) *outw = kind == 1 ? pl.fd + 2 : pl.fd;
     if (ncols) *ncols = 2 * pl.NUp;
     if (edge_doubles) *edge_doubles = pl.edge_doubles;
     if (nb) *nb = pl.nb;
@@ -806,6 +1194,49 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
     cs.nr = 1; cs.nch = (int)(B > 0 ? B : 1); cs.cpr = cs.nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = 1; cs.off[0] = 0;
     return launch_fused_rescue(1, Xr, Yt64, scale, err, rescue->tol, gpart, nullptr, A, B, Mrows, Ncp, D, g, (int)rows, pl.fd + 2, 0, inv_sigma, cs,
                                g.P, rws, rws_bytes, s, pl.fd, n0, 2 * pl.NUp);
+}
+
+// LinearKernel on long paths: gpart [P][nb 64 RC][fd], FLIPPED coarse rows (row f = rows - 1 - p), per PAIR; summed over the pairs of
+// an x_a and flipped back it is the T of sk_linear_adjoint_* (dL/dx[m] = s^2 (T[m-1] - T[m])).
+int launch_adj_fused_linear_mb(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
+                               const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err, void *ws,
+                               size_t ws_bytes, const FusedRescue *rescue, hipStream_t s) {
+    if (g.naive || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    const AmbPlan pl = amb_plan(g.Mc, g.Nc, g.dyadic, D, false, 0);
+    if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
+    if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < pl.nb * AMB_L * pl.RC) return SK_ERR_UNSUPPORTED;
+    if (g.Nc > 2 * pl.NUp) return SK_ERR_UNSUPPORTED;
+    const int64_t rows = (int64_t)pl.nb * AMB_L * pl.RC;
+    if (gpart_doubles < (size_t)(g.P * rows * pl.fd)) return SK_ERR_WORKSPACE;
+    AdjMbParams prm{};
+    prm.Xr = dXr; prm.Yt = dYt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.N0 = nullptr; prm.err = err;
+    prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb;
+    prm.inv_sigma = 0.0;
+    void *rws = nullptr;
+    size_t rws_bytes = 0;
+    if (rescue && rescue->ws) {
+        const size_t head = sizeof(double) * (size_t)((g.P + 1) / 2 * 2);
+        if (rescue->ws_bytes <= head) return SK_ERR_WORKSPACE;
+        rws = (char *)rescue->ws + head;
+        rws_bytes = rescue->ws_bytes - head;
+        if (rescue->kfinal) {
+            const int rc = launch_fused_screen(rescue->kfinal, scale, g.P, rescue->screen, (double *)rescue->ws, err, s);
+            if (rc != SK_OK) return rc;
+            prm.scale = (const double *)rescue->ws;
+        }
+    }
+    int rc;
+    if (pl.fd == 8)
+        rc = g.dyadic == 0 ? launch_amb<0, 4, 8, false, 0>(prm, pl, ws, ws_bytes, s)
+           : g.dyadic == 1 ? launch_amb<1, 2, 8, false, 0>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 8, false, 0>(prm, pl, ws, ws_bytes, s);
+    else
+        rc = g.dyadic == 0 ? launch_amb<0, 4, 16, false, 0>(prm, pl, ws, ws_bytes, s)
+           : g.dyadic == 1 ? launch_amb<1, 2, 16, false, 0>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16, false, 0>(prm, pl, ws, ws_bytes, s);
+    if (rc != SK_OK || !rws) return rc;
+    ChunkSplit cs{};          // one pair per chunk, slot = pair
+    cs.nr = 1; cs.nch = (int)(B > 0 ? B : 1); cs.cpr = cs.nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = 1; cs.off[0] = 0;
+    return launch_fused_rescue(0, dXr, dYt, scale, err, rescue->tol, gpart, nullptr, A, B, Mrows, Ncp, D, g, (int)rows, pl.fd, 0, 0.0, cs, g.P, rws,
+                               rws_bytes, s, pl.fd, nullptr, 0);
 }
 
 }  // namespace sk

@@ -743,7 +743,7 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bo
     const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (pl.NUp < MB_L + 16) return pl;                      // band boundary slack (see the header)
-    pl.nb = (Mc + (edges ? 1 : 0) + MB_L * pl.RC - 1) / (MB_L * pl.RC);   // edges: the bands of sk_wave_adj_fused_mb.hip (node rows)
+    pl.nb = (Mc + (edges && kind == 1 ? 1 : 0) + MB_L * pl.RC - 1) / (MB_L * pl.RC);   // edges: the bands of sk_wave_adj_fused_mb.hip (rbf: node rows)
     const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
     const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
     pl.lds_bytes = (size_t)(MB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + MB_X_SLOTS * xslab + 3 * chunk + (kind == 1 ? 2 * pl.fd * 8 : 0);
@@ -763,7 +763,12 @@ template <typename TO, int DY, int KIND>
 int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y32, int64_t P, double *ws, size_t ws_bytes,
                  hipStream_t s) {
     if (naive) return SK_ERR_UNSUPPORTED;   // the _naive_solver scheme is not built for this kernel (streaming route instead)
-    if (prm.edges) {   // with the terminal edges: RBF at dyadic 1..2, what sk_rbf_adjoint_fused_mb_f64 sweeps
+    if (prm.edges) {   // with the edges: what sk_rbf_adjoint_fused_mb_f64 (dyadic 1..2) / sk_linear_adjoint_fused_mb_f64 sweep
+        if constexpr (KIND == 0) {
+            if (y32) return SK_ERR_UNSUPPORTED;
+            if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+            return launch_mb_one<TO, DY, false, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+        }
         if constexpr (KIND == 1 && DY >= 1) {
             if (y32) {
                 if constexpr (sizeof(TO) == 4) {
@@ -799,7 +804,7 @@ size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic,
 // rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
 int fused_mb_rows(int kind, int Mc, int dyadic, bool edges) {
     const int RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
-    const int nb = (Mc + (edges ? 1 : 0) + MB_L * RC - 1) / (MB_L * RC);
+    const int nb = (Mc + (edges && kind == 1 ? 1 : 0) + MB_L * RC - 1) / (MB_L * RC);
     return nb * MB_L * RC + 8;
 }
 

@@ -110,6 +110,14 @@ def _fused_rbf_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
             and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF") and not os.environ.get("SK_NO_FUSED_MB"))
 
 
+def _fused_linear_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
+    """Whether sk_linear_adjoint_fused_mb_f64 is worth trying: exactly LinearKernel, default scheme, dyadic <= 2, path dim <= 16, a
+    second path long enough for the band pipeline (the kernel has the last word)."""
+    return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused_mb") and not naive
+            and X.shape[2] <= 16 and dyadic in (0, 1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
+            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_MB"))
+
+
 def _upcast_tile(X, dyadic):
     return X.dtype == torch.float32 and dyadic == 2
 
@@ -155,8 +163,11 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
     A, M = Xd.shape[0], Xd.shape[1]
     linear = type(static_kernel) is LinearKernel
     param = _fused_static(static_kernel, gram)[1]
-    mb = not linear and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
+    mb = (not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram) if linear
+          else not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram))
     if mb:
+        kind = 0 if linear else 1
+        adj_mb = be.linear_adjoint_fused_mb if linear else be.rbf_adjoint_fused_mb
         # long / wide paths: sk_solve_fwd_static_* (edges) + sk_rbf_adjoint_fused_mb_f64; per pair 8 (MM + NN) bytes of edges and
         # (M + 128) (fd + 2) doubles of partial sums
         per_row = (Yd.shape[0] if gram else 1) * (8 * ((M + Yd.shape[1]) << dyadic) + 8 * 18 * (M + 128) + 4096)
@@ -166,13 +177,13 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
             Yt = Yd if gram else Yd[a0:a1].contiguous()
             got = go if go is None else go[a0:a1].reshape(-1).contiguous()
             Kt = None if Kvals is None else Kvals[a0:a1]
-            res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=Kt) if edges is not None else None
+            res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=Kt) if edges is not None else None
             if res is None:    # no edges kept, or kept by another kernel in its own layout
-                fw = be.solve_fwd_fused_static(1, param, Xt, Yt, dyadic, naive, gram, keep_edges=True)
+                fw = be.solve_fwd_fused_static(kind, param, Xt, Yt, dyadic, naive, gram, keep_edges=True)
                 edges = fw[1] if fw is not None else None
                 if edges is None:
                     return None
-                res = be.rbf_adjoint_fused_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=fw[0])
+                res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=fw[0])
                 if res is None:
                     return None
             grad[a0:a1] = res[0]
@@ -206,7 +217,8 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
     budget = _budget(Xd.device, workspace_bytes)
     if (_fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
             or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
-            or _fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
+            or _fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
+            or _fused_linear_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
         g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals)
         if g is not None:
             return g
@@ -467,8 +479,9 @@ class _SigKernelGram(torch.autograd.Function):
             # its mirror image, through the second-argument contraction of the same W) -- fused static kernels only
             # (the fused linear adjoint is faster on all pairs than the unfused one on the triangle: 14 vs 20 ms at the C3 shape)
             # (long / wide RBF paths: the multi-band fused adjoint on ALL pairs beats the unfused triangle -- C5's shape 0.29 s against 0.46 s)
-            mb_only = (_fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
-                       and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
+            mb_only = ((_fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
+                        and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
+                       or _fused_linear_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
             if (X.requires_grad and Y.requires_grad and _fused_static(static_kernel, True) is not None and not mb_only
                     and not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
                     and hasattr(be, "static_adjoint2") and X.shape[2] <= (8 if type(static_kernel) is LinearKernel else 32)):

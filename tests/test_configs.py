@@ -625,6 +625,32 @@ def test_multiband_fused_rbf_adjoint_vs_oracle(d, A, B, M, N, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,A,B,M,N,D", [(1, 3, 4, 300, 170, 3), (0, 2, 3, 300, 200, 10), (2, 3, 2, 150, 180, 5), (1, 2, 2, 129, 161, 16),
+                                         (0, 2, 2, 257, 300, 12), (2, 5, 7, 64, 165, 4), (1, 2, 3, 140, 161, 8), (0, 3, 2, 513, 160, 2)])
+def test_multiband_fused_linear_adjoint_vs_oracle(d, A, B, M, N, D, monkeypatch):
+    """LinearKernel on long / wide paths: edges from sk_solve_fwd_static_* (kind 0) + sk_linear_adjoint_fused_mb_f64 against the oracle's
+    closed form, row by row (1..3 bands, band boundaries, dims up to 16, dyadic 0..2, LinearKernel(scale)); through the API no
+    increments and no W are formed (sk_static_increments / sk_solve_adj never called)."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(M * 5 + N)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    k = sigkernel_amd.LinearKernel()
+    for name in ("static_increments", "solve_adj", "static_adjoint"):
+        monkeypatch.setattr(type(be), name, (lambda nm: (lambda self, *a, **kw: (_ for _ in ()).throw(AssertionError(nm + " called"))))(name))
+    Xg = Xc.to(DEV).requires_grad_(True)
+    K = sigkernel_amd.SigKernel(k, d).compute_Gram(Xg, Yc.to(DEV))
+    assert rel_err(K.detach().cpu().numpy(), O.gram_forward(Xc, Yc, k, d, nthreads=NT)) <= 1e-11
+    (K * w.to(DEV)).sum().backward()
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, d, nthreads=NT)
+    got = Xg.grad.cpu().numpy()
+    scale = np.abs(want).max()
+    for r in range(M):
+        assert np.abs(got[:, r] - want[:, r]).max() <= 1e-10 * scale, (r, np.abs(got[:, r] - want[:, r]).max() / scale)
+    assert float(be.last_fused_err.max()) <= _lib.HipBackend.ADJ_RESIDUAL_TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("screen", [1e3, 1e300])
 def test_multiband_fused_adjoint_rescues_an_exploding_pair_on_the_device(screen, monkeypatch):
     """Failure injection on long paths: x_2 and y_5 are the same straight line, k(x_2, y_5) ~ 1e6 and more.  With the screen the
