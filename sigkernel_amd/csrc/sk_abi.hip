@@ -184,7 +184,7 @@ int device_cu_count() {
 
 extern "C" {
 
-int sk_version(void) { return 300; }
+int sk_version(void) { return 310; }   // 310: edges argument of sk_solve_fwd_static_*, the multi-band adjoints, the fused derivative solver
 
 /* Development hook: parse the SK_* environment variables again (tools that sweep a knob inside one process).  Not
  * thread-safe against concurrent launches; product code never calls it. */

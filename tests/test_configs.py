@@ -651,6 +651,29 @@ def test_multiband_fused_linear_adjoint_vs_oracle(d, A, B, M, N, D, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_paired_batches_of_long_paths_take_the_multiband_adjoints(kind, monkeypatch):
+    """compute_kernel(X, Y).backward() on long paths (paired batch, B == 0 in the C ABI) through the multi-band forward with edges and
+    the multi-band fused adjoint, fp64 and fp32 inputs, against the oracle pair by pair."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(29)
+    A, M, N, D, d = 5, 150, 170, 6, 1
+    Xc, Yc = walk(gen, A, M, D), walk(gen, A, N, D)
+    w = torch.randn(A, generator=gen, dtype=torch.float64)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.9)
+    for name in ("static_increments", "solve_adj", "static_adjoint"):
+        monkeypatch.setattr(type(be), name, (lambda nm: (lambda self, *a, **kw: (_ for _ in ()).throw(AssertionError(nm + " called"))))(name))
+    want = np.stack([O.gram_grad_weighted(Xc[i:i + 1], Yc[i:i + 1], w[i:i + 1, None].numpy(), k, d)[0] for i in range(A)])
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 5e-6)):
+        Xg = Xc.to(dt).to(DEV).requires_grad_(True)
+        kv = sigkernel_amd.SigKernel(k, d).compute_kernel(Xg, Yc.to(dt).to(DEV))
+        (kv * w.to(dt).to(DEV)).sum().backward()
+        wantd = want if dt == torch.float64 else np.stack([O.gram_grad_weighted(Xc[i:i + 1].float().double(), Yc[i:i + 1].float().double(),
+                                                                                  w[i:i + 1, None].float().double().numpy(), k, d)[0] for i in range(A)])
+        assert rel_err(Xg.grad.double().cpu().numpy(), wantd) <= tol, (dt, rel_err(Xg.grad.double().cpu().numpy(), wantd))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("screen", [1e3, 1e300])
 def test_multiband_fused_adjoint_rescues_an_exploding_pair_on_the_device(screen, monkeypatch):
     """Failure injection on long paths: x_2 and y_5 are the same straight line, k(x_2, y_5) ~ 1e6 and more.  With the screen the
