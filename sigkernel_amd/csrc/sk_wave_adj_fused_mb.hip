@@ -43,10 +43,14 @@ struct AdjMbParams {
     double *ws;            // per wave: [NUp + 8][E] band-boundary row + the constant chunk of band 0
     int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired
     int Mrows, Ncp, Mc, Nc, NUp, nb;
-    int per;               // pairs per wave
+    int per;               // pairs per wave (the equal share)
     double inv_sigma;
     int64_t ws_stride;     // doubles per wave
     WaveGroup wg;
+    // the wave's stream of pairs (sk_wave_fused_mb.hip): C0 pairs fixed per wave, then one pair at a time drawn from `queue`
+    unsigned long long *queue;   // the launch's counter (zeroed by the launcher; behind the boundary rows), nullptr: equal static shares
+    int64_t q_first;
+    int C0;
 };
 
 __device__ __forceinline__ void amb_store_through(double *p, d2_t v) {
@@ -156,14 +160,38 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     // ---- the wave's pairs: positions 0 .. per-1 are pairs wave_id per + i ----------------------------------------------------------
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
-    const int per = prm.per;
-    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * per));
+    const int C0 = prm.C0;
+    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * C0));
+    unsigned cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR, cb0 = NOPAIR;   // drawn pair of position C0 + j in cb[j & 3]
+    int have = 0;                     // drawn positions known so far
+    int t_end = 0x7fffffff;           // macro-steps this wave runs: known once a draw comes back empty
     auto pair_at = [&](int i) __attribute__((always_inline)) -> unsigned {
-        if (i < 0 || i >= per) return NOPAIR;
-        const unsigned p = base0 + (unsigned)i;
-        return p < P32 ? p : NOPAIR;
+        if (i < 0) return NOPAIR;
+        if (i < C0) { const unsigned p = base0 + (unsigned)i; return p < P32 ? p : NOPAIR; }
+        const int kk = (i - C0) & 3;
+        return (cb0 & -(unsigned)(kk == 0)) | (cb1 & -(unsigned)(kk == 1)) | (cb2 & -(unsigned)(kk == 2)) | (cb3 & -(unsigned)(kk == 3));
     };
-    const int t_end = per * nb * NUp + (L - 1) + 1;   // + 1: node column 0 of the last band completes one step later
+    auto ensure = [&](int f) __attribute__((always_inline)) {
+        while (C0 + have <= f) {
+            unsigned b = NOPAIR;
+            if (prm.queue && t_end == 0x7fffffff) {
+                unsigned long long v = 0;
+                if (lam == 0) v = atomicAdd(prm.queue, 1ULL);
+                const unsigned long long q = (unsigned long long)prm.q_first +
+                                             (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+                b = q < (unsigned long long)P32 ? (unsigned)q : NOPAIR;
+            }
+            if (b == NOPAIR && t_end == 0x7fffffff) t_end = (C0 + have) * prm.nb * prm.NUp + (AMB_L - 1) + 1;
+            const int kk = have & 3;
+            const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
+            cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));
+            cb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb1 & ~m1) | (b & m1)));
+            cb2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb2 & ~m2) | (b & m2)));
+            cb3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb3 & ~m3) | (b & m3)));
+            have += 1;
+        }
+    };
 
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     // its pair's y)
     int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
+        ensure(y_pi);
         const unsigned spy = pair_at(y_pi);
         const int64_t b = split_b(spy == NOPAIR ? 0 : (int64_t)spy);
         const int uo = NUp - 1 - (y_u0 + (lam & 7));
@@ -215,6 +244,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     // x_lam0 .. x_lam0+7, which start that band during the window; lane 0's boundary chunk; in band 0 its terminal-row chunk
     int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
     auto issue_x = [&]() {
+        ensure(x_pi);
         const unsigned spx = pair_at(x_pi);
         const int64_t p = spx == NOPAIR ? 0 : (int64_t)spx;
         const int64_t a = split_a(p);
@@ -736,14 +766,38 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     }
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
-    const int per = prm.per;
-    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * per));
+    const int C0 = prm.C0;
+    const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * C0));
+    unsigned cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR, cb0 = NOPAIR;   // drawn pair of position C0 + j in cb[j & 3]
+    int have = 0;                     // drawn positions known so far
+    int t_end = 0x7fffffff;           // macro-steps this wave runs: known once a draw comes back empty
     auto pair_at = [&](int i) __attribute__((always_inline)) -> unsigned {
-        if (i < 0 || i >= per) return NOPAIR;
-        const unsigned p = base0 + (unsigned)i;
-        return p < P32 ? p : NOPAIR;
+        if (i < 0) return NOPAIR;
+        if (i < C0) { const unsigned p = base0 + (unsigned)i; return p < P32 ? p : NOPAIR; }
+        const int kk = (i - C0) & 3;
+        return (cb0 & -(unsigned)(kk == 0)) | (cb1 & -(unsigned)(kk == 1)) | (cb2 & -(unsigned)(kk == 2)) | (cb3 & -(unsigned)(kk == 3));
     };
-    const int t_end = per * nb * NUp + (L - 1) + 1;   // + 1: the last band's sums go out at the first macro-step after it
+    auto ensure = [&](int f) __attribute__((always_inline)) {
+        while (C0 + have <= f) {
+            unsigned b = NOPAIR;
+            if (prm.queue && t_end == 0x7fffffff) {
+                unsigned long long v = 0;
+                if (lam == 0) v = atomicAdd(prm.queue, 1ULL);
+                const unsigned long long q = (unsigned long long)prm.q_first +
+                                             (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+                b = q < (unsigned long long)P32 ? (unsigned)q : NOPAIR;
+            }
+            if (b == NOPAIR && t_end == 0x7fffffff) t_end = (C0 + have) * prm.nb * prm.NUp + (AMB_L - 1) + 1;
+            const int kk = have & 3;
+            const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
+            cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));
+            cb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb1 & ~m1) | (b & m1)));
+            cb2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb2 & ~m2) | (b & m2)));
+            cb3 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb3 & ~m3) | (b & m3)));
+            have += 1;
+        }
+    };
 
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
@@ -761,6 +815,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
 
     int y_pi = 0, y_band = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
+        ensure(y_pi);
         const unsigned spy = pair_at(y_pi);
         const int64_t b = split_b(spy == NOPAIR ? 0 : (int64_t)spy);
         const int uo = NUp - 1 - (y_u0 + (lam & 7));
@@ -781,6 +836,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     };
     int x_pi = 0, x_band = 0, x_lam0 = 0, x_slot = 0;
     auto issue_x = [&]() {
+        ensure(x_pi);
         const unsigned spx = pair_at(x_pi);
         const int64_t p = spx == NOPAIR ? 0 : (int64_t)spx;
         const int64_t a = split_a(p);
@@ -1118,9 +1174,21 @@ int launch_amb(AdjMbParams prm, const AmbPlan &pl, void *ws, size_t ws_bytes, hi
     const int64_t max_waves = (int64_t)device_cu_count() * wpc;
     int64_t waves = prm.P < max_waves ? prm.P : max_waves;
     const int64_t per = (prm.P + waves - 1) / waves;
-    waves = (prm.P + per - 1) / per;
     if (prm.P >= 0x7ff00000LL || per > 0x1fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < (size_t)waves * (size_t)pl.ws_stride * sizeof(double)) return SK_ERR_WORKSPACE;
+    if (!ws || ws_bytes < (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64) return SK_ERR_WORKSPACE;
+    const int pct = knobs().adjmb_q_static > 0 ? (knobs().adjmb_q_static > 100 ? 100 : knobs().adjmb_q_static) : 50;
+    if (waves == max_waves && per >= 8 && pct < 100) {
+        // the launch fills the chip: `pct` per cent of the equal share is dealt out up front, the rest is drawn pair by pair
+        prm.C0 = (int)(per * pct / 100);
+        prm.queue = reinterpret_cast<unsigned long long *>(static_cast<double *>(ws) + (size_t)waves * (size_t)pl.ws_stride);
+        prm.q_first = waves * (int64_t)prm.C0;
+        if (hipMemsetAsync(prm.queue, 0, sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
+    } else {
+        waves = (prm.P + per - 1) / per;
+        prm.C0 = (int)per;
+        prm.queue = nullptr;
+        prm.q_first = prm.P;
+    }
     prm.per = (int)per;
     prm.ws = static_cast<double *>(ws);
     prm.ws_stride = pl.ws_stride;
@@ -1149,7 +1217,7 @@ bool adj_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrow
     if (nb) *nb = pl.nb;
     if (nup) *nup = pl.NUp;
     const int64_t max_waves = (int64_t)device_cu_count() * 8;
-    if (ws_bytes) *ws_bytes = (size_t)(P < max_waves ? P : max_waves) * (size_t)pl.ws_stride * sizeof(double);
+    if (ws_bytes) *ws_bytes = (size_t)(P < max_waves ? P : max_waves) * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the work counter
     return true;
 }
 
