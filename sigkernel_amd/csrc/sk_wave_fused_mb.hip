@@ -395,6 +395,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
     ExpCoef expc;   // the polynomial's coefficients in VGPRs: as SGPR pairs they spill the scalar state (v_readlane in the loop)
     if (RBF) expc.init();
+    double *e_base = nullptr;   // EDGES: edge block of the pair the lane's sweep is in
 
     // ones for the windows whose sweep is in band 0 (see issue_x); visible to the LDS-DMA after the vmcnt(0) below
     if (lam < CHUNK / 16) store_through(wsrow + (int64_t)NUp * E + lam * 2, d2_t{1.0, 1.0});
@@ -423,6 +424,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             corner = 1.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) left[i] = 1.0;
+            if constexpr (EDGES) {
+                if (bandk == 0) {   // the sweep enters a pair: its edge block (1 / nb of the band starts)
+                    asm volatile("");
+                    const unsigned pair_e = stream_pair(psk);
+                    e_base = pair_e != NOPAIR ? prm.edges + (int64_t)pair_e * ((int64_t)nb * NUp * S + (int64_t)nb * L * R) : nullptr;
+                }
+            }
         }
         // -- start of a row unit for the path reads: this lane's x rows (differences / points)
         if (u == 0) {
@@ -604,23 +612,16 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if constexpr (EDGES) {
             // the bottom fine row of every band (row nb-1-band of the pair's block: the LAST band's is the terminal row), from the
             // bottom lane; the terminal column: every lane's rows after the last unit
-            if (is_bot || uk == NUp - 1) {
-                int pv = psk;
-                asm volatile("" : "+v"(pv));
-                const unsigned pair_e = stream_pair(pv);
-                if (pair_e != NOPAIR && uk >= 0) {
-                    double *e = prm.edges + (int64_t)pair_e * ((int64_t)nb * NUp * S + (int64_t)nb * L * R);
-                    if (is_bot) {
-                        double *er = e + ((int64_t)(nb - 1 - bandk) * NUp + uk) * S;
+            // (e_base: the edge block of the pair this lane's sweep is in, looked up once per pair -- see the top of the step)
+            if (is_bot && e_base) {
+                double *er = e_base + ((nb - 1 - bandk) * NUp + uk) * S;
 #pragma unroll
-                        for (int cc = 0; cc < S; cc += 2) *reinterpret_cast<d2_t *>(er + cc) = d2_t{bot[cc], bot[cc + 1]};
-                    }
-                    if (uk == NUp - 1) {
-                        double *ec = e + (int64_t)nb * NUp * S + (int64_t)(bandk * L + lam) * R;
+                for (int cc = 0; cc < S; cc += 2) *reinterpret_cast<d2_t *>(er + cc) = d2_t{bot[cc], bot[cc + 1]};
+            }
+            if (uk == NUp - 1 && e_base) {
+                double *ec = e_base + (nb * NUp * S + (bandk * L + lam) * R);
 #pragma unroll
-                        for (int rr = 0; rr < R; rr += 2) *reinterpret_cast<d2_t *>(ec + rr) = d2_t{left[rr], left[rr + 1]};
-                    }
-                }
+                for (int rr = 0; rr < R; rr += 2) *reinterpret_cast<d2_t *>(ec + rr) = d2_t{left[rr], left[rr + 1]};
             }
         }
 
