@@ -349,6 +349,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     for (int k = 0; k < RC; ++k) row_ok[k] = false;
     double *gp_cur = nullptr, *gp_prev = nullptr;     // Gpart row r_0 of this lane in the band being swept / the band before (null: none)
     double *n0_cur = nullptr, *n0_prev = nullptr;     // bottom lane in the last band: it also owns node row 0 -- N0 row of the pair
+    double *gp_pair = nullptr;                        // Gpart block of the pair the lane is in (looked up once per pair)
+    unsigned sp_cur = NOPAIR;                         // ... and its index
+    const unsigned sc_par = (unsigned)((reinterpret_cast<uintptr_t>(prm.scale) >> 3) & 1u);
 
     {   // lanes ahead of their first band read slabs no DMA has written yet: make those finite
         const d2_t z = {0.0, 0.0};
@@ -404,8 +407,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         // -- start of a band: boundaries, terminal column, upstream gradient, this lane's x points, where its sums go
         if (u == 0) {
             asm volatile("");
-            const unsigned sp = pair_at(ps);
-            const int64_t pe = (int64_t)sp;
+            if (band == 0) {   // the lane enters a pair (1 / nb of the band starts): its index and the base of its partial sums
+                asm volatile("");
+                sp_cur = pair_at(ps);
+                gp_pair = sp_cur != NOPAIR ? prm.Gpart + (int64_t)sp_cur * (int64_t)(Mcp + 1) * OUTW : nullptr;
+            }
+            const unsigned sp = sp_cur;
             const int gl = band * L + lam;
             valid = sp != NOPAIR ? 1 : 0;
 #pragma unroll
@@ -437,11 +444,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
             if (gl * R + R == MMp) leftF[R - 1] = 1.0;
             double sv = 1.0;
-            if (prm.scale && valid) sv = lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u));
+            if (prm.scale && valid) sv = lds_read_f64(my_sc + x_rd + ((sc_par ^ (sp & 1u)) << 3));   // which half of the aligned 16 bytes holds scale[pair]
             gp_prev = gp_cur;
             n0_prev = n0_cur;
-            gp_cur = valid ? prm.Gpart + (pe * (int64_t)(Mcp + 1) + (Mcp - gl * RC)) * OUTW : nullptr;
-            n0_cur = (valid && is_bot && band == nb - 1) ? prm.N0 + pe * (int64_t)(2 * NUp) : nullptr;
+            gp_cur = gp_pair ? gp_pair + (Mcp - gl * RC) * OUTW : nullptr;
+            n0_cur = nullptr;
+            if (is_bot && band == nb - 1 && valid) n0_cur = prm.N0 + (int64_t)sp * (int64_t)(2 * NUp);
             if (sv != sv) valid = 0;      // NaN: a pair the rescue's screen took out of the sweep (its sums are stored as zeros)
             sx = valid ? sv : 0.0;
         }
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
             chk_val = e;
-            chk_pair = (int64_t)pair_at(ps);
+            chk_pair = (int64_t)sp_cur;
         }
 
         // -- close the step
