@@ -916,7 +916,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     bool row_ok[RC];
 #pragma unroll
     for (int k = 0; k < RC; ++k) row_ok[k] = false;
-    double *gp_cur = nullptr, *gp_prev = nullptr;
+    double *gp_cur = nullptr, *gp_pair = nullptr;   // Gpart rows of this lane in the band being swept; the pair's block
+    unsigned sp_cur = NOPAIR;
+    const unsigned sc_par = (unsigned)((reinterpret_cast<uintptr_t>(prm.scale) >> 3) & 1u);
 
     {
         const d2_t z = {0.0, 0.0};
@@ -971,8 +973,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
             for (int k = 0; k < RC; ++k)
 #pragma unroll
                 for (int j = 0; j < FD; ++j) tacc[k][j] = 0.0;
-            const unsigned sp = pair_at(ps);
-            const int64_t pe = (int64_t)sp;
+            if (band == 0) {   // the lane enters a pair (1 / nb of the band starts): its index and the base of its partial sums
+                asm volatile("");
+                sp_cur = pair_at(ps);
+                gp_pair = sp_cur != NOPAIR ? prm.Gpart + (int64_t)sp_cur * (int64_t)Mcp * OUTW : nullptr;
+            }
+            const unsigned sp = sp_cur;
             const int gl = band * L + lam;
             valid = sp != NOPAIR ? 1 : 0;
 #pragma unroll
@@ -994,12 +1000,11 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
             if (gl * R + R == MMp) leftF[R - 1] = 1.0;
             double sv = 1.0;
-            if (prm.scale && valid) sv = lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u));
-            gp_cur = valid ? prm.Gpart + (pe * (int64_t)Mcp + (int64_t)gl * RC) * OUTW : nullptr;   // flipped coarse row gl RC + k
+            if (prm.scale && valid) sv = lds_read_f64(my_sc + x_rd + ((sc_par ^ (sp & 1u)) << 3));
+            gp_cur = gp_pair ? gp_pair + gl * RC * OUTW : nullptr;   // flipped coarse row gl RC + k
             if (sv != sv) valid = 0;      // NaN: taken out of the sweep by the rescue's screen (its sums are stored as zeros)
             sx = valid ? sv : 0.0;
         }
-        (void)gp_prev;
 
         // -- top rows
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1111,7 +1116,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
             chk_val = e;
-            chk_pair = (int64_t)pair_at(ps);
+            chk_pair = (int64_t)sp_cur;
         }
 
         u += 1;
