@@ -20,7 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sigkernel_amd", "csrc")
 DEFAULT = ["sk_wave_adj.hip", "sk_wave_deriv.hip", "sk_wave_fused.hip", "sk_wave_adj_fused.hip", "sk_wave_fused_mb.hip",
-           "sk_wave_adj_fused_rbf.hip"]
+           "sk_wave_adj_fused_rbf.hip", "sk_wave_adj_fused_mb.hip", "sk_wave_deriv_fused.hip"]
 
 
 def regs(tok):
