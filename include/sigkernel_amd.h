@@ -250,6 +250,12 @@ int sk_prep_paths_f64(const double *X, int64_t A, int M, int D, int diff, int di
                       void *stream);
 int sk_prep_paths_f32(const float *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int fd,
                       void *stream);
+/* Both arrays of a call in ONE launch: out_x [A][rows_x][fd] (dim_major = 0) from X scaled by scale_x and out_y [B][fd][rows_y]
+ * (dim_major = 1) from Y scaled by scale_y; small calls are launch-bound. */
+int sk_prep_pair_f64(const double *X, int64_t A, int M, const double *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y,
+                     double *out_x, int rows_x, double *out_y, int rows_y, int fd, void *stream);
+int sk_prep_pair_f32(const float *X, int64_t A, int M, const float *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y,
+                     double *out_x, int rows_x, double *out_y, int rows_y, int fd, void *stream);
 
 /* ---- forward solve ------------------------------------------------------------------------
  * Solves the Goursat PDE for every pair and returns K[MM][NN].

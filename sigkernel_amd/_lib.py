@@ -53,6 +53,8 @@ SIGNATURES = {
     "sk_solve_fwd_linear_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_f32": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_prep_pair_f64": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _int, _vp, _int, _int, _vp]),
+    "sk_prep_pair_f32": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _int, _vp, _int, _int, _vp]),
     "sk_solve_fwd_static_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
     "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
     "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
@@ -176,18 +178,47 @@ def _row_stride(t, name):
     return t, Nc
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """The raw handle of torch's current stream on t's device (the fast C entry point where torch has it: a C1-sized call spent a
+    third of its host time constructing Stream objects)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device(dev):
+    """`with _device(dev):` -- torch.cuda.device(dev), or nothing at all when dev is the current device already (the usual case: the
+    guard's two device switches are a measurable part of a small call)."""
+    idx = dev.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _queue(dev):
+def _queue(dev, pairs=1 << 30):
     """64 bytes of device scratch for one launch's work counter (the library zeroes it on the launch stream); the caching
-    allocator keeps it alive for the work queued on this stream and hands it out again afterwards."""
-    return torch.empty(8, dtype=torch.int64, device=dev)
+    allocator keeps it alive for the work queued on this stream and hands it out again afterwards.  None for launches too small to
+    fill the chip (the library then deals out equal static shares, as it would anyway)."""
+    return torch.empty(8, dtype=torch.int64, device=dev) if pairs >= 16384 else None
 
 
 def _prep_paths(X, diff, dim_major, scale, rows, fd=8):
@@ -202,6 +233,20 @@ def _prep_paths(X, diff, dim_major, scale, rows, fd=8):
     return out
 
 
+def _prep_pair(X, Y, diff, scale_x, rows_x, rows_y, fd=8):
+    """Both staged arrays of a call from ONE allocation and ONE launch (sk_prep_pair_*): ([A][rows_x][fd] from X scaled by scale_x,
+    [B][fd][rows_y] from Y)."""
+    A, M, D = X.shape
+    B, N = Y.shape[0], Y.shape[1]
+    nx = A * rows_x * fd
+    buf = torch.empty(nx + B * fd * rows_y, dtype=torch.float64, device=X.device)
+    out_x, out_y = buf[:nx].view(A, rows_x, fd), buf[nx:].view(B, fd, rows_y)
+    fn = getattr(load(), "sk_prep_pair_" + _suffix(X))
+    _check(fn(_ptr(X), A, M, _ptr(Y), B, N, D, int(bool(diff)), float(scale_x), 1.0, _ptr(out_x), int(rows_x), _ptr(out_y), int(rows_y), int(fd),
+              _stream(X)), "sk_prep_pair")
+    return out_x, out_y
+
+
 class HipBackend:
     """The product back-end: every method enqueues HIP kernels on the current stream."""
 
@@ -214,7 +259,7 @@ class HipBackend:
         P = G.numel() // (M * N)
         ld = _padded_ld(N - 1, G.element_size())
         out = torch.empty(G.shape[:-2] + (M - 1, ld), dtype=G.dtype, device=G.device)
-        with torch.cuda.device(G.device):
+        with _device(G.device):
             fn = getattr(load(), "sk_increments_" + _suffix(G))
             _check(fn(_ptr(G), P, M, N, _ptr(out), ld, _stream(G)), "sk_increments")
         return out[..., : N - 1]      # rows stay 16-byte aligned underneath (stride(-2) == ld)
@@ -235,7 +280,7 @@ class HipBackend:
         ld = _padded_ld(N - 1, X.element_size())
         shape = (A, B, M - 1, ld) if gram else (A, M - 1, ld)
         out = torch.empty(shape, dtype=X.dtype, device=X.device)
-        with torch.cuda.device(X.device):
+        with _device(X.device):
             fn = getattr(load(), "sk_static_increments_" + _suffix(X))
             _check(fn(int(kind), float(param), _ptr(X), _ptr(Y), A, B if gram else 0, M, N, D, _ptr(out), ld, _stream(X)),
                    "sk_static_increments")
@@ -259,23 +304,23 @@ class HipBackend:
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
-        with torch.cuda.device(dev):
+        with _device(dev):
             kappa = float(lib.sk_linear_prescale(int(dyadic)))             # 4^-d / sqrt(12): see sk_solve_fwd_linear_*
-            dXr = _prep_paths(X, True, False, kappa * float(scale) ** 2, Mrows)   # kappa s^2 (x[p+1] - x[p]), [A][256][8]
-            dYt = _prep_paths(Y, True, True, 1.0, Ncp)                      # y[q+1] - y[q], dimension-major [B][8][Ncp]
+            # kappa s^2 (x[p+1] - x[p]), [A][256][8];  y[q+1] - y[q], dimension-major [B][8][Ncp]
+            dXr, dYt = _prep_pair(X, Y, True, kappa * float(scale) ** 2, Mrows, Ncp)
             if keep_edges and X.dtype == torch.float64 and 0 <= dyadic <= 2:
                 P = A * B if gram else A
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_linear_edges_f64(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D,
-                                                           int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(_queue(dev)), _stream(X))
+                                                           int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(_queue(dev, A * B if gram else A)), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_linear_edges")
             fn = getattr(lib, "sk_solve_fwd_linear_" + _suffix(X))
-            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, _ptr(out), _ptr(_queue(dev)), _stream(X))
+            rc = fn(_ptr(dXr), _ptr(dYt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, _ptr(out), _ptr(_queue(dev, A * B if gram else A)), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_linear")
@@ -297,23 +342,22 @@ class HipBackend:
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
-        with torch.cuda.device(dev):
-            Xr = _prep_paths(X, False, False, 1.0, Mrows)     # the path points, [A][256][8]
-            Yt = _prep_paths(Y, False, True, 1.0, Ncp)        # dimension-major [B][8][Ncp]
+        with _device(dev):
+            Xr, Yt = _prep_pair(X, Y, False, 1.0, Mrows, Ncp)     # the path points, [A][256][8]; dimension-major [B][8][Ncp]
             if keep_edges and X.dtype == torch.float64:
                 P = A * B if gram else A
                 nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic),
-                                                        scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _ptr(_queue(dev)), _stream(X))
+                                                        scheme, 1.0 / float(sigma), _ptr(out), _ptr(edges), _ptr(_queue(dev, A * B if gram else A)), _stream(X))
                     if rc == SK_OK:
                         return out, edges
                     if rc != 2:
                         _check(rc, "sk_solve_fwd_rbf_edges")
             fn = getattr(lib, "sk_solve_fwd_rbf_" + _suffix(X))
             rc = fn(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic), scheme, 1.0 / float(sigma),
-                    _ptr(out), _ptr(_queue(dev)), _stream(X))
+                    _ptr(out), _ptr(_queue(dev, A * B if gram else A)), _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_rbf")
@@ -333,7 +377,7 @@ class HipBackend:
         out = torch.empty(A, A, dtype=X.dtype, device=X.device)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
-        with torch.cuda.device(X.device):
+        with _device(X.device):
             if kind == 0:
                 kappa = float(lib.sk_linear_prescale(int(dyadic)))
                 Xr, Xt = _prep_paths(X, True, False, kappa * float(param) ** 2, Mrows), _prep_paths(X, True, True, 1.0, Ncp)
@@ -400,7 +444,7 @@ class HipBackend:
         Ncp = 2 * NUp
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
-        with torch.cuda.device(dev):
+        with _device(dev):
             y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
             if kind == 0:
                 Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
@@ -447,7 +491,7 @@ class HipBackend:
         dev = X.device
         if scale is not None:
             scale = scale.double().contiguous()
-        with torch.cuda.device(dev):
+        with _device(dev):
             dXr = _prep_paths(X, True, False, float(param) ** 2, mrows, fd)
             dYt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
             tpart = torch.empty(P, rows, fd, dtype=torch.float64, device=dev)
@@ -491,7 +535,7 @@ class HipBackend:
         dev = X.device
         if scale is not None:
             scale = scale.double().contiguous()
-        with torch.cuda.device(dev):
+        with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
             y32 = fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
             if y32:      # fp32 points, two dimensions per 16-byte unit + a row of fp64 norms: half the LDS ring (as the forward)
@@ -547,7 +591,7 @@ class HipBackend:
         lib = load()
         P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
-        with torch.cuda.device(dev):
+        with _device(dev):
             # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
             dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
             dYt = _prep_paths(Y, True, True, 1.0, Ncp)
@@ -605,7 +649,7 @@ class HipBackend:
         lib = load()
         P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows, outw, ycols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-        with torch.cuda.device(dev):
+        with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, Mrows)
             Yt = _prep_paths(Y, False, True, 1.0, Ncp)
             args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_DEFAULT, float(sigma), _ptr(edges), _ptr(scale))
@@ -676,7 +720,7 @@ class HipBackend:
             _dev(scale, "scale")
             if scale.dtype != W.dtype:
                 raise ValueError("scale must have W's dtype")
-        with torch.cuda.device(X.device):
+        with _device(X.device):
             fn = getattr(load(), "sk_static_adjoint_" + _suffix(X))
             if kind == 0:
                 T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
@@ -713,7 +757,7 @@ class HipBackend:
             if scale.dtype != W.dtype or scale.numel() != A * B:
                 raise ValueError("scale must be (A, B) with W's dtype")
         dev = X.device
-        with torch.cuda.device(dev):
+        with _device(dev):
             fn = getattr(load(), "sk_static_adjoint2_" + _suffix(X))
             if kind == 0:
                 dXr = _prep_paths(X, True, False, float(param) ** 2, M - 1)
@@ -739,7 +783,7 @@ class HipBackend:
             if scale.dtype != W.dtype or scale.numel() != P:
                 raise ValueError("scale must have one entry per pair and W's dtype")
         out = torch.empty(W.shape[:-2] + (Mc + 1, Nc + 1), dtype=W.dtype, device=W.device)
-        with torch.cuda.device(W.device):
+        with _device(W.device):
             fn = getattr(load(), "sk_increments_adjoint_" + _suffix(W))
             _check(fn(_ptr(W), ldw, _ptr(scale), P, Mc + 1, Nc + 1, _ptr(out), _stream(W)), "sk_increments_adjoint")
         return out
@@ -754,7 +798,7 @@ class HipBackend:
         out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
         grid = torch.empty(batch + (MM + 1, NN + 1), dtype=inc_c.dtype, device=inc_c.device) if want_grid else None
         edges = torch.empty(batch + (MM + NN + 2,), dtype=torch.float64, device=inc_c.device) if want_edges else None
-        with torch.cuda.device(inc_c.device):
+        with _device(inc_c.device):
             fn = getattr(load(), "sk_solve_fwd_" + _suffix(inc_c))
             _check(fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, int(flags),
                       _ptr(out), _ptr(grid), _ptr(edges), _stream(inc_c)), "sk_solve_fwd")
@@ -775,7 +819,7 @@ class HipBackend:
         if nbytes and (ld * inc_c.element_size()) % 128 == 0:
             out = torch.empty(batch, dtype=inc_c.dtype, device=inc_c.device)
             edges = torch.empty(nbytes // 8, dtype=torch.float64, device=inc_c.device)
-            with torch.cuda.device(inc_c.device):
+            with _device(inc_c.device):
                 fn = getattr(lib, "sk_solve_fwd_edges_" + _suffix(inc_c))
                 rc = fn(_ptr(inc_c), ld, P, Mc, Nc, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(out), _ptr(edges),
                         _stream(inc_c))
@@ -815,7 +859,7 @@ class HipBackend:
         lib = load()
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         es = inc_c.element_size()
-        with torch.cuda.device(dev):
+        with _device(dev):
             fn = getattr(lib, "sk_solve_adj_" + _suffix(inc_c))
             fast = False
             if edges is not None:
@@ -896,7 +940,7 @@ class HipBackend:
         P = G0.numel() // (M * N)
         ld = _padded_ld(N - 1, G0.element_size())
         out = torch.empty((3,) + G0.shape[:-2] + (M - 1, ld), dtype=G0.dtype, device=G0.device)
-        with torch.cuda.device(G0.device):
+        with _device(G0.device):
             fn = getattr(load(), "sk_deriv_increments_" + _suffix(G0))
             _check(fn(_ptr(G0), _ptr(G1), _ptr(G2), float(eps), P, M, N, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), ld,
                       _stream(G0)), "sk_deriv_increments")
@@ -913,7 +957,7 @@ class HipBackend:
             return None
         ld = _padded_ld(N - 1, X0.element_size())
         out = torch.empty(3, A, B, M - 1, ld, dtype=X0.dtype, device=X0.device)
-        with torch.cuda.device(X0.device):
+        with _device(X0.device):
             fn = getattr(load(), "sk_static_deriv_increments_" + _suffix(X0))
             _check(fn(int(kind), float(param), _ptr(X0), _ptr(X1), _ptr(X2), _ptr(Y), A, B, M, N, D, float(eps), _ptr(out[0]),
                       _ptr(out[1]), _ptr(out[2]), ld, _stream(X0)), "sk_static_deriv_increments")
@@ -942,7 +986,7 @@ class HipBackend:
         Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
         dev = X0.device
         out = torch.empty(3, A, B, dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _device(dev):
             Xr = [_prep_paths(x.contiguous(), False, False, 1.0, mrows.value, fd) for x in (X0, X1, X2)]
             Yt = _prep_paths(Y.contiguous(), False, True, 1.0, Ncp, fd)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -980,7 +1024,7 @@ class HipBackend:
         batch = inc3.shape[1:-2]
         P = inc3[0].numel() // (Mc * Nc)
         out = torch.empty((3,) + batch, dtype=inc3.dtype, device=inc3.device)
-        with torch.cuda.device(inc3.device):
+        with _device(inc3.device):
             fn = getattr(load(), "sk_solve_deriv_" + _suffix(inc3))
             _check(fn(_ptr(inc3[0]), _ptr(inc3[1]), _ptr(inc3[2]), ld, P, Mc, Nc, int(dyadic), int(flags), _ptr(out[0]),
                       _ptr(out[1]), _ptr(out[2]), _stream(inc3)), "sk_solve_deriv")

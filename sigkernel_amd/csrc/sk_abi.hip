@@ -567,6 +567,21 @@ int sk_prep_paths_f32(const float *X, int64_t A, int M, int D, int diff, int dim
     return launch_prep_paths<float>(X, A, M, D, diff != 0, dim_major, scale, out, rows, fd, (hipStream_t)stream);
 }
 
+int sk_prep_pair_f64(const double *X, int64_t A, int M, const double *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y,
+                     double *out_x, int rows_x, double *out_y, int rows_y, int fd, void *stream) {
+    if (!X || !Y || !out_x || !out_y || A < 0 || B < 0 || M < 1 || N < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
+    if (rows_x < (diff ? M - 1 : M) || rows_y < (diff ? N - 1 : N) || (diff && (M < 2 || N < 2))) return SK_ERR_BAD_ARG;
+    if (A == 0 && B == 0) return SK_OK;
+    return launch_prep_pair<double>(X, A, M, Y, B, N, D, diff != 0, scale_x, scale_y, out_x, rows_x, out_y, rows_y, fd, (hipStream_t)stream);
+}
+int sk_prep_pair_f32(const float *X, int64_t A, int M, const float *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y,
+                     double *out_x, int rows_x, double *out_y, int rows_y, int fd, void *stream) {
+    if (!X || !Y || !out_x || !out_y || A < 0 || B < 0 || M < 1 || N < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
+    if (rows_x < (diff ? M - 1 : M) || rows_y < (diff ? N - 1 : N) || (diff && (M < 2 || N < 2))) return SK_ERR_BAD_ARG;
+    if (A == 0 && B == 0) return SK_OK;
+    return launch_prep_pair<float>(X, A, M, Y, B, N, D, diff != 0, scale_x, scale_y, out_x, rows_x, out_y, rows_y, fd, (hipStream_t)stream);
+}
+
 size_t sk_strip_edges_bytes(int64_t P, int Mc, int Nc, int dyadic, int elem_size) {
     if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > (elem_size == 8 ? 2 : 1) || (elem_size != 4 && elem_size != 8)) return 0;
     const Geom g = make_geom(P, Mc, Nc, dyadic, SK_SCHEME_DEFAULT);

@@ -168,6 +168,9 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
 
 // ---- sk_prep.hip: fp64, zero-padded, row-major / dimension-major staging of the paths for the fused kernels ----
 template <typename T>
+int launch_prep_pair(const T *X, int64_t A, int M, const T *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y, double *out_x,
+                     int rows_x, double *out_y, int rows_y, int FDp, hipStream_t s);
+template <typename T>
 int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int FDp,
                       hipStream_t s);
 

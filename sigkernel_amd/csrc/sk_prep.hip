@@ -78,7 +78,56 @@ __global__ __launch_bounds__(256) void k_prep_paths_packed32(const T *__restrict
     }
 }
 
+// both staged arrays of a call in ONE launch: rows [A][rows_x][FDp] from X and cols [B][FDp][rows_y] from Y (small calls are
+// launch-bound: a C1-sized compute_Gram was 2 staging launches + 1 solve)
+template <typename T, bool DIFF>
+__global__ __launch_bounds__(256) void k_prep_pair(const T *__restrict__ X, int64_t A, int M, const T *__restrict__ Y, int64_t B, int N, int D,
+                                                   double scale_x, double scale_y, double *__restrict__ out_x, int rows_x,
+                                                   double *__restrict__ out_y, int rows_y, int FDp) {
+    const int64_t nx = A * (int64_t)rows_x * FDp, ny = B * (int64_t)rows_y * FDp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx + ny; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nx) {          // [a][p][j]
+            const int64_t a = i / ((int64_t)rows_x * FDp);
+            const int rem = (int)(i - a * (int64_t)rows_x * FDp);
+            const int p = rem / FDp, j = rem - p * FDp;
+            double v = 0.0;
+            if (p < (DIFF ? M - 1 : M) && j < D) {
+                const T *x = X + (a * M + p) * (int64_t)D + j;
+                v = DIFF ? ((double)x[D] - (double)x[0]) * scale_x : (double)x[0] * scale_x;
+            }
+            out_x[i] = v;
+        } else {               // [b][j][q], q < rows_y
+            const int64_t k = i - nx;
+            const int64_t b = k / ((int64_t)rows_y * FDp);
+            const int rem = (int)(k - b * (int64_t)rows_y * FDp);
+            const int j = rem / rows_y, q = rem - j * rows_y;
+            double v = 0.0;
+            if (q < (DIFF ? N - 1 : N) && j < D) {
+                const T *y = Y + (b * N + q) * (int64_t)D + j;
+                v = DIFF ? ((double)y[D] - (double)y[0]) * scale_y : (double)y[0] * scale_y;
+            }
+            out_y[k] = v;
+        }
+    }
+}
+
 }  // namespace
+
+template <typename T>
+int launch_prep_pair(const T *X, int64_t A, int M, const T *Y, int64_t B, int N, int D, int diff, double scale_x, double scale_y, double *out_x,
+                     int rows_x, double *out_y, int rows_y, int FDp, hipStream_t s) {
+    const int64_t n = (A * (int64_t)rows_x + B * (int64_t)rows_y) * FDp;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    if (diff) hipLaunchKernelGGL((k_prep_pair<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
+    else hipLaunchKernelGGL((k_prep_pair<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
+    return check_launch();
+}
+template int launch_prep_pair<double>(const double *, int64_t, int, const double *, int64_t, int, int, int, double, double, double *, int, double *, int,
+                                      int, hipStream_t);
+template int launch_prep_pair<float>(const float *, int64_t, int, const float *, int64_t, int, int, int, double, double, double *, int, double *, int,
+                                     int, hipStream_t);
 
 template <typename T>
 int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_major, double scale, double *out, int rows, int FDp,

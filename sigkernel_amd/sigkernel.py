@@ -581,6 +581,19 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
     return out[0], out[1], out[2]
 
 
+class _NoGradCtx:
+    """What the autograd Functions' forward needs of a context when no gradient can be asked for: the call skips
+    torch.autograd.Function.apply (a quarter of the host time of a C1-sized call) and returns the same values."""
+    needs_input_grad = (False,) * 8
+
+    def save_for_backward(self, *tensors):
+        pass
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
 class SigKernel:
     """Signature kernel k_sig(x, y) = <S(f(x)), S(f(y))> for a static kernel k(x, y) = <f(x), f(y)>.
 
@@ -603,6 +616,8 @@ class SigKernel:
         """X (batch, len_x, dim), Y (batch, len_y, dim) -> (batch,) vector k(X^i_T, Y^i_T).
 
         ``max_batch`` is kept for signature compatibility (sigkernel.py:23); tiling is by HBM budget."""
+        if not _wants_grad(X, Y):
+            return _SigKernel.forward(_NoGradCtx(), X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)
         return _SigKernel.apply(X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)
 
     def compute_kernel_and_derivatives_Gram(self, X, Y, gamma, max_batch=100):
@@ -618,6 +633,9 @@ class SigKernel:
         if self.process_group is not None:
             from .distributed import sharded_gram
             return sharded_gram(self, X, Y, sym, self.process_group)
+        if not _wants_grad(X, Y):
+            return _SigKernelGram.forward(_NoGradCtx(), X, Y, self.static_kernel, self.dyadic_order, sym, self._naive_solver,
+                                          self.workspace_bytes)
         return _SigKernelGram.apply(X, Y, self.static_kernel, self.dyadic_order, sym, self._naive_solver,
                                     self.workspace_bytes)
 
