@@ -292,6 +292,17 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     double sx = 0.0, sx_d = 0.0;
     int valid = 0;
     double *yp_cur = nullptr, *yp_prev = nullptr;   // YSIDE: the Ypart blocks of this lane's pair and of the one before (null: none)
+    // per-lane constants of the pair-start block below (some lane starts a pair in EVERY macro-step, so the wave pays for that block
+    // every step: 32-bit compares and one multiply-add instead of 64-bit pair arithmetic): how many of the group's pairs exist,
+    // which half of its aligned 16 bytes holds scale[pair0], the Ypart block of pair0
+    int ps_end;
+    {
+        const int64_t rem = prm.P - pair0;
+        ps_end = rem <= 0 ? 0 : (rem < (int64_t)PPG ? (int)rem : PPG);
+    }
+    const unsigned sc_par0 = (unsigned)(((reinterpret_cast<uintptr_t>(prm.scale) >> 3) ^ (uintptr_t)pair0) & 1u);
+    double *const yp_base = YSIDE ? prm.Ypart + pair0 * (int64_t)(2 * NUp * YW) : nullptr;
+    asm volatile("" : "+v"(ps_end));
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite
         const int total = (int)(G * y_bytes + G * RX_SLOTS * JMAX * XSLAB + 2 * G * ECG + (YSIDE ? 5 * YC_PIECE : 0));
@@ -328,15 +339,14 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // -- start of a (flipped) pair: boundaries, terminal column, upstream gradient, this lane's x points
         if (u == 0) {
             asm volatile("");
-            const int64_t pe = pair0 + ps;
-            valid = (ps >= 0 && ps < PPG && pe < prm.P) ? 1 : 0;
+            valid = (unsigned)ps < (unsigned)ps_end ? 1 : 0;
             const unsigned xa = my_x + x_rd;
 #pragma unroll
             for (int k = 0; k < RC; ++k) lds_read_xpt<ND>(xr[k], xa + k * 64u);
             if constexpr (YSIDE) {
                 lds_read_xpt<ND>(xup, my_xup + x_rd);
                 yp_prev = yp_cur;
-                yp_cur = valid ? prm.Ypart + pe * (int64_t)(2 * NUp * YW) : nullptr;
+                yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YW) : nullptr;
             }
             double col[6];
             {
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
             if (lam * R + R == MMp) leftF[R - 1] = 1.0;
-            const double sv = prm.scale ? lds_read_f64(my_sc + x_rd + (unsigned)(reinterpret_cast<uintptr_t>(prm.scale + pe) & 8u)) : 1.0;
+            const double sv = prm.scale ? lds_read_f64(my_sc + x_rd + (((sc_par0 ^ (unsigned)ps) & 1u) << 3)) : 1.0;
             if (sv != sv) valid = 0;      // NaN: a pair the rescue's screen took out of the sweep (sk_adj_fused_rescue.hip)
             sx = valid ? sv : 0.0;
             if constexpr (YSIDE) { if (!valid) yp_cur = nullptr; }
