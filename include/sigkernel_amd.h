@@ -154,9 +154,9 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
  * operand order of sk_static_deriv_increments_* (bit-identical increments), and never exist in HBM.  Replaces
  * sk_static_deriv_increments_* + sk_solve_deriv_* (cuda_backend.py:165-223, sigkernel.py:526-566) for LinearKernel (kind 0) and
  * RBFKernel (kind 1, param = sigma).
- *   X0r, X1r, X2r [A][Mrows][fd], Yt [Bn][fd][Ncp]: fp64 POINT arrays as sk_prep_paths_* builds them (fd = 8 for D <= 8, else 16;
+ *   X0r, X1r, X2r [A][Mrows][fd], Yt [Bn][fd][Ncp]: fp64 POINT arrays as sk_prep_paths_* builds them (fd = 8; D <= 8;
  *   Mrows >= *mrows of sk_solve_deriv_static_workspace_bytes; Ncp >= 2 NUp, NUp = ceil8((Nc + 2) / 2) >= 64);  B > 0: Gram, B == 0:
- *   paired;  out_* [P].  SK_ERR_UNSUPPORTED (workspace_bytes 0): dyadic > 2, D > 16, second path shorter than 126 points. */
+ *   paired;  out_* [P].  SK_ERR_UNSUPPORTED (workspace_bytes 0): dyadic > 2, D > 8, second path shorter than 126 points. */
 size_t sk_solve_deriv_static_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows);
 int sk_solve_deriv_static_f64(int kind, double param, const double *X0r, const double *X1r, const double *X2r, const double *Yt, int64_t A,
                               int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, double eps, double *out_k,

@@ -966,14 +966,14 @@ class HipBackend:
     def solve_deriv_fused(self, kind, param, X0, X1, X2, Y, dyadic, eps):
         """(k, d/dgamma k, d2/dgamma2 k), (A,B) each, straight from the paths X0 = X, X1 = X + eps*gamma, X2 = X + 2*eps*gamma and Y:
         the three increment arrays are formed inside the solver (sk_solve_deriv_static_f64, csrc/sk_wave_deriv_fused.hip) with the
-        arithmetic of static_deriv_increments and never exist in HBM.  None outside its scope (fp64, dim <= 16, dyadic <= 2, second
+        arithmetic of static_deriv_increments and never exist in HBM.  None outside its scope (fp64, dim <= 8, dyadic <= 2, second
         path of 126 points or more)."""
         for t, n in ((X0, "X0"), (X1, "X1"), (X2, "X2"), (Y, "Y")):
             _dev(t, n)
         A, M, D = X0.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if X0.dtype != torch.float64 or D > 16 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or A == 0 or B == 0:
+        if X0.dtype != torch.float64 or D > 8 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or A == 0 or B == 0:
             return None
         if kind == 1 and not float(param) > 0:
             return None
@@ -982,7 +982,7 @@ class HipBackend:
         nbytes = int(lib.sk_solve_deriv_static_workspace_bytes(A * B, Mc, Nc, int(dyadic), D, ctypes.byref(mrows)))
         if not nbytes:
             return None
-        fd = 8 if D <= 8 else 16
+        fd = 8
         Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
         dev = X0.device
         out = torch.empty(3, A, B, dtype=torch.float64, device=dev)

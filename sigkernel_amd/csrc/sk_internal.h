@@ -16,7 +16,7 @@ struct Knobs {
     int adjf_wpc, adjf_wpb;
     int adjr_wpc, adjr_wpb, adjr_all;
     int adjmb_wpc, adjmb_wpb, adjmb_q_static;     // sk_wave_adj_fused_mb.hip
-    int derivf_wpc, derivf_wpb;   // sk_wave_deriv_fused.hip
+    int derivf_wpc, derivf_wpb, derivf_noshift;   // sk_wave_deriv_fused.hip
     int deriv_pf, deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static;
     int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;

@@ -124,6 +124,10 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     constexpr int E = S + 4, NPB = E / 2, CHUNK = 8 * E * 8, CPIECES = CHUNK / 16;
     constexpr int NPC = 4 * S + 1, ECG = NPC * 16;   // terminal-row chunk (sk_wave_adj.hip)
     constexpr int OUTW = FD + 2;
+    // PEND: LDS reads issued at the top of a macro-step stay in flight until the top rows need them.  Only in the variants whose
+    // registers neither spill nor overflow into AGPRs: elsewhere the allocator may copy or spill a pending destination right behind the
+    // read (seen: NaN gradients from a variant with 150 spilled VGPRs, last-bit run-to-run differences from one with 330 registers).
+    constexpr bool PEND = DY == 2 && (FD == 8 || Y32);   // (the variants that compile to <= 256 registers WITHOUT spills: tests/test_abi.py checks)
     constexpr unsigned X_BASE = NSLAB * YSLAB, BI_BASE = X_BASE + AMB_X_SLOTS * XSLAB, BO_BASE = BI_BASE + 2 * CHUNK,
                        EC_BASE = BO_BASE + CHUNK, LDS_END = EC_BASE + 2 * ECG;
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
@@ -386,17 +390,23 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         // -- lane 0's boundary entry of its unit (a uniform address: read by every lane as a broadcast) and, band 0, its S
         //    terminal-row values; no wait here: complete at the y read's lgkmcnt(0) below
         d2_t pend[NPB], bnd[NPB];
-        {
+        double trow_p[S], trow[S];
+        if constexpr (PEND) {
             const unsigned ba = bi_rd + (unsigned)((t & 7) * (E * 8));
 #pragma unroll
             for (int i = 0; i < NPB; ++i) amb_begin(pend[i]);
             amb_read_pend<0>(pend[0], ba); amb_read_pend<16>(pend[1], ba); amb_read_pend<32>(pend[2], ba); amb_read_pend<48>(pend[3], ba);
             if constexpr (NPB > 4) { amb_read_pend<64>(pend[4], ba); amb_read_pend<80>(pend[5], ba); }
-        }
-        double trow_p[S], trow[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
-        lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+            for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+            lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        } else {   // blocking reads (see PEND)
+            double ent[E];
+            lds_read_block<E>(ent, bi_rd + (unsigned)((t & 7) * (E * 8)));
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) bnd[i] = d2_t{ent[2 * i], ent[2 * i + 1]};
+            lds_read_f64_block<S>(trow, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        }
 
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
@@ -456,10 +466,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
 
         // -- top rows of the two states: the lane above's bottom row; lane 0: the boundary entry (reverse state: ones in band 0),
         //    in band 0 the pair's terminal row for the forward state
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (PEND) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
-        lds_take<S>(trow, trow_p);
+            for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
+            lds_take<S>(trow, trow_p);
+        }
         double topR[S], topF[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
@@ -483,10 +495,17 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         if constexpr (Y32) {
             d2_t raw[FDY];
             d2_t ysq_p, ysq;
-            amb_begin(ysq_p);
-            amb_read_pend<FDY * 128>(ysq_p, ya);          // |y|^2 of the two columns
-            amb_read_ydims<FDY>(raw, ya_e, ya_o);         // (its lgkmcnt(0) covers the read above)
-            amb_take(ysq, ysq_p);
+            if constexpr (PEND) {
+                amb_begin(ysq_p);
+                amb_read_pend<FDY * 128>(ysq_p, ya);          // |y|^2 of the two columns
+                amb_read_ydims<FDY>(raw, ya_e, ya_o);         // (its lgkmcnt(0) covers the read above)
+                amb_take(ysq, ysq_p);
+            } else {   // blocking (see PEND)
+                amb_read_ydims<FDY>(raw, ya_e, ya_o);
+                double t2[2];
+                lds_read_row1<2>(t2, ya + (unsigned)(FDY * 128));
+                ysq = d2_t{t2[0], t2[1]};
+            }
             double xy[RC][CW];
 #pragma unroll
             for (int k = 0; k < RC; ++k)
@@ -729,7 +748,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
 // Gpart: [P][Mcp][FD], FLIPPED coarse rows (row f = Mcp - 1 - p, the layout of sk_wave_adj_fused.hip); Xr = s^2 (x[p+1] - x[p]),
 // Yt = y[q+1] - y[q] dimension-major; edges from sk_solve_fwd_static_* (kind 0) with edges.
 template <int DY, int RC, int FD>
-__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD == 16 && DY == 0) ? 1 : 2))) void k_adj_fused_linear_mb(const AdjMbParams prm) {
+__global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(FD == 16 ? 1 : 2))) void k_adj_fused_linear_mb(const AdjMbParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY;
     static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
@@ -741,6 +760,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     constexpr int E = S, NPB = E / 2, CHUNK = 8 * E * 8, CPIECES = CHUNK / 16;     // boundary entry: botR[S]
     constexpr int NPC = 4 * S + 1, ECG = NPC * 16;
     constexpr int OUTW = FD;
+    constexpr bool PEND = false;   // blocking reads throughout (see k_adj_fused_rbf_mb): the step is light, two variants spill a register
     constexpr unsigned X_BASE = NSLAB * YSLAB, BI_BASE = X_BASE + AMB_X_SLOTS * XSLAB, BO_BASE = BI_BASE + 2 * CHUNK,
                        EC_BASE = BO_BASE + CHUNK, LDS_END = EC_BASE + 2 * ECG;
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
@@ -941,18 +961,24 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         const int t_stop = t0 + 8 < t_end ? t0 + 8 : t_end;
         for (int t = t0; t < t_stop; ++t) {
         d2_t pend[NPB], bnd[NPB];
-        {
+        double trow_p[S], trow[S];
+        if constexpr (PEND) {
             const unsigned ba = bi_rd + (unsigned)((t & 7) * (E * 8));
 #pragma unroll
             for (int i = 0; i < NPB; ++i) amb_begin(pend[i]);
             amb_read_pend<0>(pend[0], ba);
             if constexpr (NPB > 1) amb_read_pend<16>(pend[1], ba);
             if constexpr (NPB > 2) { amb_read_pend<32>(pend[2], ba); amb_read_pend<48>(pend[3], ba); }
-        }
-        double trow_p[S], trow[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
-        lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+            for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+            lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        } else {   // blocking reads (see PEND)
+            double ent[E];
+            lds_read_block<E>(ent, bi_rd + (unsigned)((t & 7) * (E * 8)));
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) bnd[i] = d2_t{ent[2 * i], ent[2 * i + 1]};
+            lds_read_f64_block<S>(trow, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        }
 
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
@@ -1007,10 +1033,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         }
 
         // -- top rows
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (PEND) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
-        lds_take<S>(trow, trow_p);
+            for (int i = 0; i < NPB; ++i) amb_take(bnd[i], pend[i]);
+            lds_take<S>(trow, trow_p);
+        }
         double topR[S], topF[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {

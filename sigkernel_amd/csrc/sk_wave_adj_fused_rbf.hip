@@ -325,10 +325,15 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         const int t_end = t0 + 8 < n_steps ? t0 + 8 : n_steps;
         for (int t = t0; t < t_end; ++t) {
         // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
+        // (left in flight only in the variants without spills -- dyadic 2, dims <= 4: C4's --; the others spill 16-127 registers and
+        // read it blocking where it is needed: tools/check_async_hazards.py, scan_pressure)
+        constexpr bool TPEND = DY == 2 && ND == 4;
         double trow_p[S], trow[S];
+        if constexpr (TPEND) {
 #pragma unroll
-        for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
-        lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+            for (int i = 0; i < S; ++i) async_begin(trow_p[i]);
+            lds_read_f64_run<S>(trow_p, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        }
 
         if (chk_pair >= 0) {
             atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
@@ -372,7 +377,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         d2_t yv[ND];
         const unsigned ya = my_y + (unsigned)(yslab * RY_SLAB + ((u & 7) << 4));
         lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
-        lds_take<S>(trow, trow_p);
+        if constexpr (TPEND) lds_take<S>(trow, trow_p);
+        else lds_read_f64_block<S>(trow, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
 
         // -- top rows of the two states
         double topR[S], topF[S];

@@ -180,6 +180,59 @@ __device__ __forceinline__ void lds_read_row1<32>(double (&v)[32], unsigned p) {
     for (int i = 0; i < 16; ++i) { v[i] = lo[i]; v[16 + i] = hi[i]; }
 }
 
+// N consecutive doubles (N even, 16-byte aligned), BLOCKING: every piece is one asm with its own wait inside.  For the kernel variants
+// beyond 256 VGPRs (one wave per SIMD, registers spilling to AGPRs), where a read left in flight across other code is unsafe: the
+// allocator is free to copy the destination of a separate-asm read before the separate-asm wait (seen as last-bit, run-to-run
+// differences; the layout-order lint of tools/check_async_hazards.py does not see it).
+template <int N>
+__device__ __forceinline__ void lds_read_block(double *v, unsigned a) {
+    static_assert(N % 2 == 0 && N >= 0, "");
+    if constexpr (N >= 16) {
+        double t[16];
+        lds_read_row1<16>(t, a);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = t[i];
+        lds_read_block<N - 16>(v + 16, a + 128u);
+    } else if constexpr (N >= 8) {
+        double t[8];
+        lds_read_row1<8>(t, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = t[i];
+        lds_read_block<N - 8>(v + 8, a + 64u);
+    } else if constexpr (N >= 4) {
+        double t[4];
+        lds_read_row1<4>(t, a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = t[i];
+        lds_read_block<N - 4>(v + 4, a + 32u);
+    } else if constexpr (N >= 2) {
+        double t[2];
+        lds_read_row1<2>(t, a);
+        v[0] = t[0]; v[1] = t[1];
+    }
+}
+// N consecutive doubles at an 8-byte aligned address, BLOCKING (one asm, one wait)
+template <int N>
+__device__ __forceinline__ void lds_read_f64_block(double (&t)[N], unsigned a);
+template <>
+__device__ __forceinline__ void lds_read_f64_block<2>(double (&t)[2], unsigned a) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t[0]), "=&v"(t[1]) : "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_f64_block<4>(double (&t)[4], unsigned a) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]) : "v"(a) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_f64_block<8>(double (&t)[8], unsigned a) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+                 : "v"(a) : "memory");
+}
+
 // two rows of N consecutive doubles each (the Kr / Kf band boundaries of the adjoint), all reads issued before ONE wait
 template <int N>
 __device__ __forceinline__ void lds_read_2rows(double (&a)[N], double (&b)[N], unsigned addr_a, unsigned addr_b);

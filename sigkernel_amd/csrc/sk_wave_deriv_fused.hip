@@ -14,7 +14,7 @@
 // node value scaled like the reference (-(1/eps) G0, (1/eps) G1, -(1/eps)(-(1/eps) G0), -(2/eps)((1/eps) G1), (1/eps^2) G2), every
 // scaled array 4-corner-differenced as ((G11 + G00) - G10) - G01 and the differences added left to right, without FMA
 // contraction: the sums cancel eight orders of magnitude and their rounding is part of the result the fixtures pin.
-// Scope: fp64, dyadic <= 2, path dim <= 16, any M, second path of N >= 126 points (rows of >= 64 units).
+// Scope: fp64, dyadic <= 2, path dim <= 8, any M, second path of N >= 126 points (rows of >= 64 units).
 #include "sk_wave_common.h"
 
 namespace sk {
@@ -125,7 +125,11 @@ __device__ __forceinline__ double df_node(const double (&xv)[FD], double xs, con
 // LDSB (two or more bands of a SHORT second path, 64 <= NUp < 80 units): the band boundary lives in LDS -- a ring of 32 entries, lane
 // 63 writes its entry, lane 0 reads it NUp - 63 = 1..16 macro-steps later in program order -- instead of travelling through the
 // per-wave row in L2, whose flush-and-refetch needs 17 macro-steps of slack.
-template <int DY, int KIND, int FD, bool LDSB>
+// SHIFT (whenever it costs no extra band: M - 1 not a multiple of 64): the lanes own the coarse rows one LOWER -- lane (band, lam) owns
+// coarse row 64 band + lam - 1 and evaluates node row 64 band + lam -- so node row 0 is lane 0's regular row in band 0 and its coarse
+// row -1 is padding (zero increments: the states stay at their boundary values).  Without it lane 0 evaluates node row 0 itself while
+// it is in band 0, a branch the whole wave pays for in every macro-step of band 0: 60-90 instructions, a fifth of the step with one band.
+template <int DY, int KIND, int FD, bool LDSB, bool SHIFT>
 __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams prm) {
     constexpr int CW = 2;
     constexpr int R = 1 << DY, S = CW << DY, r = 1 << DY;
@@ -256,11 +260,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
             if (XSLAB % 1024 == 0 || idx < XSLAB / 16) {
                 const int i = idx / (3 * PPR), rem = idx - i * (3 * PPR), v = rem / PPR, piece = rem - v * PPR;
                 const double *xb = v == 0 ? prm.Xr[0] : v == 1 ? prm.Xr[1] : prm.Xr[2];
-                const double *src = xb + (a * prm.Mrows + (int64_t)(x_band * L + lamj + i) + 1) * FD + piece * 2;
+                const double *src = xb + (a * prm.Mrows + (int64_t)(x_band * L + lamj + i) + (SHIFT ? 0 : 1)) * FD + piece * 2;
                 __builtin_amdgcn_global_load_lds(src, (lds_void *)(dst + c * 1024), 16, 0, 0);
             }
         }
-        if (lam < 3 * PPR) {   // node row 0 of the pair, the three shifted paths (lane 0 evaluates it itself in band 0)
+        if (!SHIFT && lam < 3 * PPR) {   // node row 0 of the pair, the three shifted paths (lane 0 evaluates it itself in band 0)
             const int v = lam / PPR, piece = lam - v * PPR;
             const double *xb = v == 0 ? prm.Xr[0] : v == 1 ? prm.Xr[1] : prm.Xr[2];
             __builtin_amdgcn_global_load_lds(xb + a * prm.Mrows * FD + piece * 2, (lds_void *)(lds + T_BASE + (x_pi & 1) * 3 * XROW), 16, 0, 0);
@@ -364,8 +368,23 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
 
     for (int t = 0; t < t_end; ++t) {
         // -- lane 0's boundary entry of its unit u (a uniform address, broadcast read; no wait: complete at the y read below)
+        // Variants beyond 256 VGPRs (16 staged dimensions: one wave per SIMD, registers spill to AGPRs) read the entry with blocking
+        // reads; the others leave it in flight until the y read's wait
+        constexpr bool PEND = FD < 16 && DY < 2;   // (dyadic 2: 280-300 registers)
         d2_t pend[NP], bnd[NP];
-        if constexpr (LDSB) {
+        if constexpr (!PEND) {
+            double ent[E];
+            if constexpr (LDSB) {
+                const int bk0 = __builtin_amdgcn_readfirstlane(bandk);
+                const unsigned ra = lds0 + LB_BASE + (unsigned)(((t - NUp) & (LBR - 1)) * (E * 8));
+                lds_read_block<3 * S>(ent, bk0 == 0 ? lds0 + CE_BASE : ra);
+                lds_read_block<6>(ent + 3 * S, ra + 3 * S * 8u);
+            } else {
+                lds_read_block<E>(ent, lds0 + BI_BASE + (unsigned)(((t >> 3) & 1) * CHUNK + (t & 7) * (E * 8)));
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) bnd[i] = d2_t{ent[2 * i], ent[2 * i + 1]};
+        } else if constexpr (LDSB) {
             // lane 0's cursors are wave-uniform through readfirstlane: the state part from the constant entry while its sweep is in
             // band 0, else from the row; the node part from the row (unused in band 0: lane 0 evaluates node row 0 itself)
             const int bk0 = __builtin_amdgcn_readfirstlane(bandk);
@@ -409,8 +428,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
             const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
             df_read_ydims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
+        if constexpr (PEND) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) df_take(bnd[i], pend[i]);
+            for (int i = 0; i < NP; ++i) df_take(bnd[i], pend[i]);
+        }
         double ysq[CW];
 #pragma unroll
         for (int q = 0; q < CW; ++q) {
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
         for (int v = 0; v < 3; ++v)
 #pragma unroll
             for (int q = 0; q < CW; ++q) abv[2 + q][v] = dpp_shr1(own[q][v], bnd[(3 * S + 2 * v + q) >> 1][(3 * S + 2 * v + q) & 1]);
-        if (is_top && band == 0) {   // node row 0 of the pair: nobody above has it
+        if (!SHIFT && is_top && band == 0) {   // node row 0 of the pair: nobody above has it
             asm volatile("");
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
@@ -489,9 +510,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
 
         // -- coefficients per coarse cell (sk_wave_deriv.hip)
         double ca[CW], cb[CW], c_t[CW], c_s[CW], c_k[CW], c_m[CW], c_tdd[CW], c_td[CW], c_kdd[CW], c_kd[CW];
+        const double sc_l = (SHIFT && is_top && bandk == 0) ? 0.0 : sc;   // SHIFT: lane 0's coarse row in band 0 is padding
 #pragma unroll
         for (int q = 0; q < CW; ++q) {
-            const double g = ginc[0][q] * sc, gd = ginc[1][q] * sc, gdd = ginc[2][q] * sc;
+            const double g = ginc[0][q] * sc_l, gd = ginc[1][q] * sc_l, gdd = ginc[2][q] * sc_l;
             const double g2 = g * g, qg = 0.25 * g;
             ca[q] = fma(g2, 1.0 / 12.0, fma(g, 0.5, 1.0));
             cb[q] = fma(g2, -1.0 / 12.0, 1.0);
@@ -613,7 +635,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_deriv_fused(const DerivFusedParams
 
 struct DfPlan {
     int S, NUp, nb, fd, E;
-    bool ldsb;
+    bool ldsb, shift;
     size_t lds_bytes;
     int64_t ws_stride;
     bool ok;
@@ -622,12 +644,15 @@ struct DfPlan {
 DfPlan df_plan(int Mc, int Nc, int dyadic, int D) {
     DfPlan pl{};
     pl.ok = false;
-    if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16) return pl;
+    // (path dims beyond 8 stay on the unfused route: the 16-dim variants need 300-380 registers -- one wave per SIMD, little gained --
+    // and one of them, linear at dyadic 1, gave last-bit run-to-run differences whose cause was not found)
+    if (dyadic < 0 || dyadic > 2 || D < 1 || D > 8) return pl;
     pl.S = 2 << dyadic;
-    pl.fd = D <= 8 ? 8 : 16;
+    pl.fd = 8;
     const int NU = (Nc + 2) / 2;
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     pl.nb = (Mc + DF_L - 1) / DF_L;                         // one coarse row per lane
+    pl.shift = Mc % DF_L != 0 && !knobs().derivf_noshift;                              // the lanes one row lower fit the same bands: node row 0 becomes a regular row
     // several bands: the boundary through L2 needs NUp >= 80 (flush + refetch slack, sk_wave_fused_mb.hip); shorter rows keep it in
     // LDS (NUp >= 64: lane 63 must have written an entry before lane 0 reads it); one band: no boundary at all
     if (pl.NUp < DF_L) return pl;        // (the stream logic -- one band start per window, a ring of four pairs -- needs rows of >= 64 units)
@@ -641,9 +666,9 @@ DfPlan df_plan(int Mc, int Nc, int dyadic, int D) {
     return pl;
 }
 
-template <int DY, int KIND, int FD, bool LDSB>
+template <int DY, int KIND, int FD, bool LDSB, bool SHIFT>
 int launch_df(DerivFusedParams prm, const DfPlan &pl, void *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_deriv_fused<DY, KIND, FD, LDSB>;
+    auto kern = k_deriv_fused<DY, KIND, FD, LDSB, SHIFT>;
     static const int vgprs = [&] {
         hipFuncAttributes attr;
         return hipFuncGetAttributes(&attr, (const void *)kern) == hipSuccess && attr.numRegs > 0 ? attr.numRegs : 256;
@@ -685,10 +710,14 @@ int launch_df(DerivFusedParams prm, const DfPlan &pl, void *ws, size_t ws_bytes,
     return check_launch();
 }
 
+template <int DY, int KIND, bool SHIFT>
+int launch_df_s(const DerivFusedParams &prm, const DfPlan &pl, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (pl.fd != 8) return SK_ERR_UNSUPPORTED;
+    return pl.ldsb ? launch_df<DY, KIND, 8, true, SHIFT>(prm, pl, ws, ws_bytes, s) : launch_df<DY, KIND, 8, false, SHIFT>(prm, pl, ws, ws_bytes, s);
+}
 template <int DY, int KIND>
 int launch_df_k(const DerivFusedParams &prm, const DfPlan &pl, void *ws, size_t ws_bytes, hipStream_t s) {
-    if (pl.ldsb) return pl.fd == 8 ? launch_df<DY, KIND, 8, true>(prm, pl, ws, ws_bytes, s) : launch_df<DY, KIND, 16, true>(prm, pl, ws, ws_bytes, s);
-    return pl.fd == 8 ? launch_df<DY, KIND, 8, false>(prm, pl, ws, ws_bytes, s) : launch_df<DY, KIND, 16, false>(prm, pl, ws, ws_bytes, s);
+    return pl.shift ? launch_df_s<DY, KIND, true>(prm, pl, ws, ws_bytes, s) : launch_df_s<DY, KIND, false>(prm, pl, ws, ws_bytes, s);
 }
 template <int DY>
 int launch_df_dy(const DerivFusedParams &prm, const DfPlan &pl, int kind, void *ws, size_t ws_bytes, hipStream_t s) {
@@ -719,7 +748,7 @@ int launch_deriv_fused(int kind, const double *X0r, const double *X1r, const dou
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb;
     prm.inv_sigma = inv_sigma;
     prm.c1 = 1. / eps; prm.c2 = 2. / eps; prm.c3 = 1. / (eps * eps);
-    const int row_unit = g.Mc - 1;      // one coarse row per lane
+    const int row_unit = g.Mc - 1 + (pl.shift ? 1 : 0);      // the lane-row that owns the last coarse row
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = row_unit % DF_L;
     prm.band_f = row_unit / DF_L;

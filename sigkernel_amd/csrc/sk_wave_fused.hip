@@ -837,7 +837,10 @@ int launch_fused_e(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     if constexpr (!NAIVE && sizeof(TO) == 8) {
         if (prm.dims <= 4) return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, pl, s);
     }
-    return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
+    // RBF at dyadic 0 with 8 staged dims in fp64 compiles to 280-290 registers with spills: no variant for it (reads left in flight
+    // are unsafe there, tools/check_async_hazards.py: scan_pressure) -- such calls take sk_solve_fwd_static_* or the unfused route
+    if constexpr (KIND == 1 && DY == 0) return SK_ERR_UNSUPPORTED;
+    else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>

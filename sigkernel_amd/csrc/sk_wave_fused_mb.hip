@@ -416,7 +416,17 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         for (int i = 0; i < NP; ++i) async_begin2(pend[i]);
         // (lane 0's unit is t modulo NUp: a uniform address, read by every lane as a broadcast -- no divergent region around an
         // asynchronous read)
-        lds_read_pend<NP>(pend, lds0 + BI_BASE + (unsigned)(((t >> 3) & 1) * CHUNK + (t & 7) * (E * 8)));
+        // (the variants beyond 256 VGPRs -- RBF, dyadic 0, 16 dims: one wave per SIMD, registers spill to AGPRs -- read the entry with
+        // blocking reads: the allocator may copy the destination of a read left in flight, lds_read_block in sk_wave_common.h)
+        constexpr bool PEND = !(RBF && DY == 0 && FD == 16);
+        if constexpr (PEND) {
+            lds_read_pend<NP>(pend, lds0 + BI_BASE + (unsigned)(((t >> 3) & 1) * CHUNK + (t & 7) * (E * 8)));
+        } else {
+            double ent[E];
+            lds_read_block<E>(ent, lds0 + BI_BASE + (unsigned)(((t >> 3) & 1) * CHUNK + (t & 7) * (E * 8)));
+#pragma unroll
+            for (int i = 0; i < NP; ++i) bnd[i] = d2_t{ent[2 * i], ent[2 * i + 1]};
+        }
 
         // -- start of a row unit for the sweep: left boundary K[i][0] = 1
         if (uk == 0) {
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             const unsigned ya = lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4));
             if constexpr (Y32) {
                 d2_t raw[FDY];
-                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=&v"(ysq_p[0]) : "v"(ya) : "memory");   // |y|^2 of the two columns
+                if constexpr (PEND) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=&v"(ysq_p[0]) : "v"(ya) : "memory");   // |y|^2 of the two columns
                 lds_read_dims<FDY>(raw, ya, ya + 128u);    // no swizzle (see the header)
 #pragma unroll
                 for (int jp = 0; jp < FDY; ++jp) {
@@ -468,8 +478,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                 lds_read_dims<FD>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
             }
         }
-        lds_pend_take<NP>(bnd, pend);
-        lds_pend_take<1>(ysq_t, ysq_p);
+        if constexpr (PEND) lds_pend_take<NP>(bnd, pend);
+        if constexpr (PEND || !Y32) {
+            lds_pend_take<1>(ysq_t, ysq_p);
+        } else {   // blocking (see PEND)
+            double t2[2];
+            lds_read_row1<2>(t2, lds0 + (unsigned)(yslab * YSLAB + ((u & 7) << 4)) + 1024u);
+            ysq_t[0] = d2_t{t2[0], t2[1]};
+        }
         double ysn[CW];   // Y32: -|y_q|^2 / sigma
 #pragma unroll
         for (int q = 0; q < CW; ++q) ysn[q] = Y32 ? -ysq_t[0][q] * prm.inv_sigma : 0.0;

@@ -392,7 +392,9 @@ def test_fuzz_fused_forwards_against_the_streaming_route(be):
             res = be.solve_fwd_fused_linear(X, Y, 1.0, d, naive, gram=True, keep_edges=True)
         else:
             res = be.solve_fwd_fused_rbf(X, Y, param, d, naive, gram=True, keep_edges=True)
-        assert res is not None, (it, kind, A, B, M, N, D, d)
+        if res is None:      # round 3: no RBF variant at dyadic 0 for the naive scheme / dims > 4 (see test_fused_rbf_forward_matches_oracle)
+            assert kind == 1 and d == 0 and (naive or D > 4), (it, kind, A, B, M, N, D, d)
+            continue
         K, edges = res
         n_fused += 1
         assert rel_err(K.cpu().numpy(), want.cpu().numpy()) <= 1e-12, (it, kind, A, B, M, N, D, d, naive)
@@ -402,7 +404,7 @@ def test_fuzz_fused_forwards_against_the_streaming_route(be):
             _, W1, r1 = be.solve_adj(inc, d, naive, flags=_lib.FLAG_FAST_ONLY, return_residual=True, edges=edges)
             tol = max(ADJ_TOL, 10 * float(r0.max()))
             assert rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= tol, (it, kind, A, B, M, N, D, d, naive)
-    assert n_fused == 150 and n_edges >= 60
+    assert n_fused >= 120 and n_edges >= 50
 
 
 def test_increments_and_transpose_bit_identical(be):
@@ -542,14 +544,26 @@ def test_fused_rbf_forward_matches_oracle(be, A, B, M, N, D, d, naive):
     Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
     X, Y = Xc.to(DEV), Yc.to(DEV)
     sigma = 0.7
-    K = be.solve_fwd_fused_rbf(X, Y, sigma, d, naive, gram=True)
-    assert K is not None, "shape is inside the fused kernel's scope"
     want = O.gram_forward(Xc, Yc, sigkernel_amd.RBFKernel(sigma), d, naive=naive, nthreads=8)
+    # round 3: at dyadic 0 only the 4-dim fp64 default-scheme variant is built (the 8-dim ones need 280-290 registers and spill:
+    # reads left in flight are unsafe there, tools/check_async_hazards.py); the other calls say `unsupported` and the API falls back
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(sigma), d, _naive_solver=naive)
+    K = be.solve_fwd_fused_rbf(X, Y, sigma, d, naive, gram=True)
+    if d == 0 and (naive or D > 4):
+        assert K is None
+        K = sk.compute_Gram(X, Y)
+    assert K is not None, "shape is inside the fused kernel's scope"
     assert rel_err(K.cpu().numpy(), want) <= 1e-12
     n = min(A, B)
     Kp = be.solve_fwd_fused_rbf(X[:n].contiguous(), Y[:n].contiguous(), sigma, d, naive, gram=False)
+    if Kp is None:
+        assert d == 0
+        Kp = sk.compute_kernel(X[:n].contiguous(), Y[:n].contiguous())
     assert rel_err(Kp.cpu().numpy(), np.diag(want)[:n]) <= 1e-12
     K32 = be.solve_fwd_fused_rbf(X.float(), Y.float(), sigma, d, naive, gram=True)
+    if K32 is None:
+        assert d == 0
+        K32 = sk.compute_Gram(X.float(), Y.float())
     np.testing.assert_allclose(K32.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
 
 

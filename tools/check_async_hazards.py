@@ -112,6 +112,37 @@ def scan(asm_text):
     return hazards
 
 
+def scan_pressure(asm_text):
+    """Second rule (round 3): a kernel whose registers SPILL or overflow into AGPRs (more than 256 VGPRs) must not leave an LDS read
+    in flight at all -- the allocator may spill or copy the read's destination right behind it, in code this lint's layout-order
+    walk does not connect with the read (seen: NaN gradients from a variant with 150 spilled registers, last-bit run-to-run
+    differences from one with 330).  In such a kernel every ds_read must be followed by nothing but more ds_reads up to its
+    s_waitcnt lgkmcnt(0) (the blocking helpers: reads and wait in ONE asm statement)."""
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(_Z\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", asm_text):
+        meta[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    out = []
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)\.Lfunc_end", asm_text, re.S | re.M):
+        name = m.group(1)
+        vg, sp = meta.get(name, (0, 0))
+        if vg <= 256 and sp == 0:
+            continue
+        lines = [l.split(";")[0].strip() for l in m.group(2).split("\n")]
+        lines = [l for l in lines if l and not l.startswith(".") and not l.endswith(":")]
+        pending = None
+        for l in lines:
+            op = l.split()[0]
+            if op.startswith("ds_read"):
+                pending = pending or l
+            elif pending is not None:
+                if op == "s_waitcnt" and "lgkmcnt(0)" in l:
+                    pending = None
+                else:
+                    out.append((name, "%s  [%d VGPRs, %d spilled]" % (pending, vg, sp), l))
+                    pending = None
+    return out
+
+
 def compile_to_asm(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-I" + CSRC, src,
@@ -126,7 +157,8 @@ def main(argv):
     files = argv or [os.path.join(CSRC, f) for f in DEFAULT]
     bad = 0
     for f in files:
-        hz = scan(compile_to_asm(f))
+        text = compile_to_asm(f)
+        hz = scan(text) + scan_pressure(text)
         print("%s: %d hazard(s)" % (os.path.basename(f), len(hz)))
         for name, load, use in hz[:10]:
             print("   %s\n      pending: %s\n      touched: %s" % (name, load, use))
