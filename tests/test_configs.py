@@ -678,6 +678,15 @@ def test_multiband_routes_are_deterministic_and_finite_in_every_variant(kind, d,
 
 
 @pytest.mark.gpu
+def test_every_route_is_deterministic_run_to_run():
+    """tools/r03_det_sweep.py: 444 combinations of static kernel x dyadic order x path dim x lengths x precision x scheme, each through
+    compute_Gram + backward, compute_mmd + backward and the derivative Gram, four runs compared bit for bit (no NaN either)."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r03_det_sweep.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "444 combinations, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["linear", "rbf"])
 def test_paired_batches_of_long_paths_take_the_multiband_adjoints(kind, monkeypatch):
     """compute_kernel(X, Y).backward() on long paths (paired batch, B == 0 in the C ABI) through the multi-band forward with edges and
