@@ -56,6 +56,7 @@ struct FusedParams {
     unsigned long long *queue;
     int64_t q_first;     // first pair handed out by the counter (= waves G C0)
     int C0, logC;
+    int n_big;           // queue == nullptr: waves [0, n_big) take C0 + 1 pairs per lane group (wave w starts at G (w C0 + min(w, n_big)))
 };
 
 template <int N>
@@ -243,8 +244,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // live in VGPRs and every producer call computes its addresses with vector instructions.)
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
-    const int C0 = prm.C0, logC = prm.logC, CQ = 1 << logC;
-    unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * G * C0)), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
+    // (launches without a queue deal the pairs out as evenly as whole pairs allow: the first n_big waves take one pair more
+    // per lane group than the others -- everything below, t_end included, follows from this wave's own C0)
+    const int w32 = (int)wave_id;
+    const int C0 = __builtin_amdgcn_readfirstlane(prm.C0 + (w32 < prm.n_big ? 1 : 0)), logC = prm.logC, CQ = 1 << logC;
+    unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane(G * (w32 * prm.C0 + (w32 < prm.n_big ? w32 : prm.n_big))), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
     int have = 1;                     // chunks known so far
     int t_end = 0x7fffffff;           // macro-steps this wave runs: known once a draw comes back empty
     // (masks, not a chain of selects: hipcc turns `k == 0 ? cb0 : k == 1 ? cb1 : ...` into an indexed array in scratch memory)
@@ -811,13 +815,19 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     if (prm.queue && waves == max_waves && per >= (8 << logC) && pct < 100) {
         // the launch fills the chip: `pct` per cent of the equal share is dealt out up front, the rest is drawn from the counter
         prm.C0 = (int)(per * pct / 100);
+        prm.n_big = 0;
         prm.logC = logC;
         prm.q_first = waves * pl.G * (int64_t)prm.C0;
         if (hipMemsetAsync(prm.queue, 0, sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
     } else {
-        waves = (pl.P + per * pl.G - 1) / (per * pl.G);            // no more waves than the pairs need
+        // as even as whole pairs allow: every lane group takes floor(P / groups) pairs and the first n_big waves one more
+        // (128 x 128 symmetric pairs: 8256 = 4096 groups x 2 + 64 -- an equal share of 3 would run a third fewer waves
+        // for a third more macro-steps each)
+        const int64_t base = pl.P / (waves * pl.G), rem = pl.P - base * waves * pl.G;
         prm.queue = nullptr;
-        prm.C0 = (int)per;
+        prm.C0 = (int)base;
+        prm.n_big = (int)((rem + pl.G - 1) / pl.G);
+        if (base == 0) waves = prm.n_big;                          // no more waves than the pairs need
         prm.logC = logC;      // (the chunks after the first are all empty here, but the ring must not wrap onto the first)
         prm.q_first = pl.P;
     }
