@@ -26,12 +26,14 @@
 // a pair's last unit borrows from the next pair are padding: M <= 64*RC and N <= 2*NUp.
 // All waves are independent (no barrier, private LDS slice) and launched four per workgroup (sk_wave_common.h).
 #include "sk_wave_common.h"
+#include <algorithm>
 
 namespace sk {
 namespace {
 
 constexpr int FD = 8;              // dims carried (inputs are zero-padded to 8)
-constexpr int Y_SLAB_PITCH = FD * 128;   // 8 dimension rows of 8 units; no padding (parity swizzle, see above)
+constexpr int y_slab_pitch(int nd) { return nd * 128; }   // ND dimension rows of 8 units (the four-dimension variants stage and keep
+                                                          // dims 0..3 only); no padding (parity swizzle, see above)
 constexpr int X_SLOTS = 2;   // the window being consumed + the one in flight
 
 struct FusedParams {
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
     constexpr int XSLAB = RC * 512;   // 8 lanes x RC rows x 64 B
+    constexpr int Y_SLAB_PITCH = y_slab_pitch(ND);
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
     const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);   // independent waves, see sk_wave_common.h
@@ -245,8 +248,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
     // (launches without a queue deal the pairs out as evenly as whole pairs allow: the first n_big waves take one pair more
-    // per lane group than the others -- everything below, t_end included, follows from this wave's own C0)
-    const int w32 = (int)wave_id;
+    // per lane group than the others -- everything below, t_end included, follows from this wave's own C0.  Spreading those
+    // waves evenly over the wave numbers instead was measured slower: 0.215 vs 0.197 ms on 128 x 128 symmetric pairs.)
+    const int w32 = __builtin_amdgcn_readfirstlane((int)wave_id);
     const int C0 = __builtin_amdgcn_readfirstlane(prm.C0 + (w32 < prm.n_big ? 1 : 0)), logC = prm.logC, CQ = 1 << logC;
     unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane(G * (w32 * prm.C0 + (w32 < prm.n_big ? w32 : prm.n_big))), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
     int have = 1;                     // chunks known so far
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             const int64_t b = split_b(p);
             const int krow = (lane >> 3) ^ ((y_par + g) & 1);   // odd slabs (per group): dimension rows swapped in pairs
             const double *src = prm.dYt + ((b * FD + krow) * (int64_t)prm.Ncp + (int64_t)(y_u0 + (lane & 7)) * 2);
-            __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + y_slot * Y_SLAB_PITCH), 16, 0, 0);
+            if (ND == 8 || lane < 32)   // (ND = 4: dimension rows 0..3 = the lower half of the wave; LDS-DMA writes lane l's 16 bytes at base + 16 l)
+                __builtin_amdgcn_global_load_lds(src, (lds_void *)(lds + g * y_bytes + y_slot * Y_SLAB_PITCH), 16, 0, 0);
         }
         y_slot = y_slot + 1 == NSLAB ? 0 : y_slot + 1;
         y_par ^= 1;
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             const bool turn = ((t + 1) & 7) == 0;   // the next step opens a y slab (for lane 0) and an x window: their DMA
             if (turn) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // was issued 8 steps ago
             a_e += 16;
-            if (((t + 1) & 7) == lam7) {   // next slab: the other parity, 1024 - 128 bytes on, wrapping at the end of the ring
+            if (((t + 1) & 7) == lam7) {   // next slab: the other parity, one slab less one row on, wrapping at the end of the ring
                 asm volatile("");          // (a real branch: if-converted, the update costs two more VALU instructions per step)
                 const unsigned e = (a_e + (unsigned)(Y_SLAB_PITCH - 128)) ^ 128u;
                 a_e = e - (e >= y_lim ? ring_bytes : 0u);
@@ -797,10 +802,39 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     const int by_regs = 4 * (512 / ((vgprs + 7) & ~7));
     if (waves_per_cu > by_regs) waves_per_cu = by_regs;
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
+    int64_t max_waves = (int64_t)device_cu_count() * waves_per_cu;
     int64_t waves = (pl.P + pl.G - 1) / pl.G;
     if (waves > max_waves) waves = max_waves;
     int64_t per = (pl.P + waves * pl.G - 1) / (waves * pl.G);      // the equal share, pairs per lane group
+    if (per < 8 && waves_per_cu >= 8) {
+        // A launch of a few pairs per lane group (no queue, see below): whole pairs do not divide evenly, every wave pays the
+        // skew's fill (L - 1 + lag macro-steps) once, and fewer resident waves run faster each.  Take the resident waves per
+        // SIMD q that minimise (macro-steps of the busiest SIMD) x (time per macro-step with q waves on it): 1.00 / 0.735 /
+        // 0.65 for q = 1 / 2 / 3, from per-wave timestamps of the 128 x 128 symmetric RBF launch (1.13 / 0.83 / 0.73 us,
+        // tools/experiments/r03_c2_wave_times.py) -- there 8256 pairs are 4096 lane groups x 2 + 64, and q = 2 (0.193 ms)
+        // beats q = 3 (6144 lane groups, a third of them with two pairs: 0.220 ms).
+        static const double rate[4] = {1.0, 1.0, 0.735, 0.65};
+        const int64_t nsimd = (int64_t)device_cu_count() * 4;
+        const int fill = pl.L - 1 + pl.lag;
+        double best = 0;
+        int best_q = 0;
+        for (int q = 1; q <= waves_per_cu / 4 && q <= 3; ++q) {
+            int64_t W = (pl.P + pl.G - 1) / pl.G;
+            if (W > nsimd * q) W = nsimd * q;
+            const int64_t base = pl.P / (W * pl.G), rem = pl.P - base * W * pl.G, nbig = (rem + pl.G - 1) / pl.G;
+            if (base == 0) W = nbig;
+            const int64_t on_simd = (W + nsimd - 1) / nsimd, big_on_simd = std::min(on_simd, (nbig + nsimd - 1) / nsimd);
+            const double cost = (double)(big_on_simd * ((base + 1) * pl.NUp + fill) + (on_simd - big_on_simd) * (base * pl.NUp + fill)) * rate[on_simd];
+            if (best_q == 0 || cost < best * 0.98) { best = cost; best_q = q; }
+        }
+        if (best_q && knobs().fused_wpc <= 0) {
+            waves_per_cu = 4 * best_q;
+            max_waves = (int64_t)device_cu_count() * waves_per_cu;
+            waves = (pl.P + pl.G - 1) / pl.G;
+            if (waves > max_waves) waves = max_waves;
+            per = (pl.P + waves * pl.G - 1) / (waves * pl.G);
+        }
+    }
     if (per > 0x1fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
     // drawn chunks: small, but never so small that more than three of them are in flight between the producers' frontier and
     // the last lane of the sweep (the kernel keeps a ring of four chunk bases)
@@ -893,7 +927,8 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int G = WAVE / L;
     const int JMAX = (L + NUp - 1) / NUp;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512);   // (a multiple of 256: the y reads rely on 256-byte aligned slices)
+    const int nd = (!g.naive && sizeof(TO) == 8 && D <= 4) ? 4 : 8;   // the variant launch_fused_e picks
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * y_slab_pitch(nd) + X_SLOTS * JMAX * RC * 512);   // (a multiple of 256: the y reads rely on 256-byte aligned slices)
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);

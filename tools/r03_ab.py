@@ -15,6 +15,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         X, Y = walk(512, 128, 8), walk(512, 128, 8); sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c2":
         X = walk(128, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1); fn = lambda: sk.compute_Gram(X, X, sym=True)
+    elif cfg == "c2big":
+        X, Y = walk(512, 64, 3), walk(512, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c5":
         X, Y = walk(256, 512, 16, torch.float32), walk(256, 512, 16, torch.float32); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c4fwd":
@@ -23,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
         def fn():
             Xg = X.detach().requires_grad_(True); sk.compute_mmd(Xg, Y).backward(); return Xg.grad
-    n = 30 if cfg in ("c3", "c2") else 6
+    n = 30 if cfg in ("c3", "c2", "c2big") else 6
     for _ in range(max(3, n // 3)): out = fn()
     torch.cuda.synchronize()
     ts = []
