@@ -299,7 +299,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 b = q < (unsigned long long)P32 ? (unsigned)q : NOPAIR;
             }
             if (b == NOPAIR && t_end == 0x7fffffff)
-                t_end = (C0 + (have - 1) * CQ) * NUp + (L - 1) + LAG;   // the stream ends where chunk `have` would begin
+                // the stream ends where chunk `have` would begin; without edges to keep, a wave is done with the step in which
+                // the lane of the last row stores the last pair's K[MM][NN] (its unit u_f, not the padded NUp - 1)
+                t_end = EDGES ? (C0 + (have - 1) * CQ) * NUp + (L - 1) + LAG
+                              : (C0 + (have - 1) * CQ - 1) * NUp + prm.u_f + prm.lam_f + LAG + 1;
             const int kk = have & 3;
             const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
             cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));

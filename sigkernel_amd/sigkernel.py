@@ -297,8 +297,9 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     pair, 8(MM+NN) bytes per pair, which lets backward skip its forward sweep.  The reference keeps the whole solution
     grid for the same purpose (sigkernel.py:248, :397-399)."""
     A, B, M, N = Xd.shape[0], Yd.shape[0], Xd.shape[1], Yd.shape[1]
-    budget = _budget(Xd.device, workspace_bytes)
+    budget = None   # (asked of the device only where it is needed: a small fused call does not pay for hipMemGetInfo)
     if keep is not None and hasattr(be, "solve_fwd_keep_edges"):
+        budget = _budget(Xd.device, workspace_bytes)
         edge_bytes = 8.0 * A * B * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
         if edge_bytes > _KEEP_EDGES_FRACTION * budget:
             keep = None
@@ -317,6 +318,8 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
             return K
     K = torch.empty(A, B, dtype=Xd.dtype, device=Xd.device)
     fused = _fused_static(static_kernel, True) is not None
+    if budget is None:
+        budget = _budget(Xd.device, workspace_bytes)
     # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
     per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
     for a0, a1 in _tiles(A, per_row, budget):
