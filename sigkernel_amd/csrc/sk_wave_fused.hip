@@ -940,7 +940,9 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     // waves on every SIMD: 8 waves/CU 5.66 ms, 12: 5.30, 13: 6.65 (single-wave workgroups, whose placement is uneven:
     // 8: 7.58, 10: 6.31, 12: 6.77).  d = 0 (four coarse rows per lane): 4: 4.60 ms, 8: 3.33, 12: 3.32; d = 2: 8: 3.31,
     // 12: 3.07 on 512 x 512 pairs of length 64.  SK_FUSED_WPC overrides.
-    const int cap = wpc_env > 0 ? 16 : (DY == 0 ? 8 : 12);
+    // (d = 2 with four-dimension slabs: the RBF variant that keeps edges has 112 VGPRs and room for a fourth wave per SIMD --
+    // C4's training step 359.6 -> 357.2 ms; the variants above 128 VGPRs stay at three through by_regs)
+    const int cap = wpc_env > 0 ? 16 : (DY == 0 ? 8 : (DY == 2 && nd == 4) ? 16 : 12);
     if (waves_per_cu > cap) waves_per_cu = cap;
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups
