@@ -953,3 +953,40 @@ def test_shares_by_wave_age_rank_do_not_change_any_result(monkeypatch):
         for K, g, Kn in out[1:]:
             assert torch.equal(K, out[0][0]) and torch.equal(Kn, out[0][2])
             assert float((g - out[0][1]).abs().max()) <= 1e-12 * float(out[0][1].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,A,B,M,N,D,d,sym", [
+    ("rbf", 128, 128, 64, 64, 3, 1, True),     # C2 itself: 8256 pairs = 4096 lane groups x 2 + 64 (two lane groups per wave)
+    ("rbf", 100, 103, 14, 23, 2, 1, False),    # eight lane groups per wave, a last wave that is partly empty, 23 columns in 16 padded units
+    ("linear", 97, 101, 30, 41, 5, 0, False),  # dim > 4: the eight-dimension slabs
+    ("linear", 90, 131, 33, 20, 4, 2, False),  # four lane groups, d = 2
+])
+def test_small_launches_with_uneven_shares_against_the_oracle(kind, A, B, M, N, D, d, sym):
+    """Launches of a few pairs per lane group take no work queue: every lane group gets floor(P / groups) pairs, the first n_big
+    waves one more, and a wave ends with its last output store (sk_wave_fused.hip, launch_fused_nd).  Every entry against the
+    oracle at 1e-12 (fp64); the entries of the waves with the longer and with the shorter share are both in there."""
+    gen = torch.Generator().manual_seed(1000 + A + M)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    k = sigkernel_amd.RBFKernel(0.8) if kind == "rbf" else sigkernel_amd.LinearKernel()
+    sk = sigkernel_amd.SigKernel(k, dyadic_order=d)
+    calls = []
+    be = _lib.get_backend()
+    for name in ("solve_fwd_fused_rbf", "solve_fwd_fused_linear", "solve_fwd_fused_sym"):
+        orig = getattr(be, name)
+        setattr(be, name, (lambda o, n: (lambda *a, **kw: (calls.append(n), o(*a, **kw))[1]))(orig, name))
+    try:
+        if sym:
+            X = Xc.to(DEV)
+            K = sk.compute_Gram(X, X, sym=True)
+            want = O.gram_forward(Xc, Xc, k, d, nthreads=NT)
+        else:
+            K = sk.compute_Gram(Xc.to(DEV), Yc.to(DEV))
+            want = O.gram_forward(Xc, Yc, k, d, nthreads=NT)
+    finally:
+        for name in ("solve_fwd_fused_rbf", "solve_fwd_fused_linear", "solve_fwd_fused_sym"):
+            delattr(be, name)
+    assert calls, "the single-band fused kernel did not run"
+    got = K.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) <= 1e-12
