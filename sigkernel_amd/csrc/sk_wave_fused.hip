@@ -183,7 +183,7 @@ __device__ __forceinline__ void lds_load_row<2>(d2_t (&r)[2], unsigned a) {
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
-    constexpr bool AHEAD = !(RBF && EDGES);   // y units read one macro-step ahead: 2 * ND more VGPRs, which the RBF kernel
+    constexpr bool AHEAD = !(RBF && EDGES && ND == 8);   // y units read one macro-step ahead: 2 * ND more VGPRs, which the RBF kernel
                                               // that also keeps edges does not have below the 3-waves-per-SIMD line (168)
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
