@@ -602,6 +602,7 @@ class HipBackend:
                 return None
             _check(rc, "sk_linear_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
+            self.last_fused_ppg = ppg.value      # (pairs per lane-group chunk of the last fused adjoint: what the tests look at)
             tpart = torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
             err = torch.zeros(P, dtype=torch.float64, device=dev)
             kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev)
@@ -660,6 +661,7 @@ class HipBackend:
                 return None
             _check(rc, "sk_rbf_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
+            self.last_fused_ppg = ppg.value
             gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
             err = torch.zeros(P, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read

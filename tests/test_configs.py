@@ -990,3 +990,36 @@ def test_small_launches_with_uneven_shares_against_the_oracle(kind, A, B, M, N, 
     got = K.cpu().numpy()
     assert np.isfinite(got).all()
     assert rel_err(got, want) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+@pytest.mark.parametrize("screen", [1e3, 1e300])
+def test_fused_rescue_finds_the_flagged_pair_among_short_chunks(kind, screen, monkeypatch):
+    """140 x 64 pairs of 32 points: more pairs than the fused adjoint has lane groups, so every lane group sweeps a chunk of a few
+    pairs -- the case in which k_fused_rescue scans 64 chunks at a time, one per lane (sk_adj_fused_rescue.hip).  One pair explodes;
+    marked by the screen or failing its self-check after the fact, its share (or its whole chunk) is re-solved exactly on the device."""
+    be = _lib.get_backend()
+    monkeypatch.setattr(type(be), "FUSED_SCREEN", screen)
+    gen = torch.Generator().manual_seed(43)
+    A, B, d = 140, 64, 1
+    Xc, Yc = _one_wild_pair(gen, A, B, 32, 4)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(1.0)
+    wc = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    Kc = O.gram_forward(Xc, Yc, k, d, nthreads=NT)
+    wild = np.abs(Kc) > 1e3
+    assert np.abs(Kc[2, 5]) > 1e5 and 1 <= wild.sum() <= 40
+    be.last_fused_err = None
+    Xg = Xc.to(DEV).requires_grad_(True)
+    (sigkernel_amd.SigKernel(k, d).compute_Gram(Xg, Yc.to(DEV)) * wc.to(DEV)).sum().backward()
+    assert be.last_fused_err is not None, "the fused adjoint declined the case"
+    assert 1 < be.last_fused_ppg < 32, be.last_fused_ppg      # chunks of a few pairs: the lane-per-chunk scan
+    err = be.last_fused_err.cpu().numpy().reshape(A, B)
+    if screen < 1e100:
+        assert np.array_equal(err < 0, wild)
+    else:
+        assert err[2, 5] > be.ADJ_RESIDUAL_TOL or np.isnan(err[2, 5])
+    want = O.gram_grad_weighted(Xc, Yc, wc.numpy(), k, d, nthreads=NT)
+    got = Xg.grad.cpu().numpy()
+    for a in range(A):
+        assert rel_err(got[a], want[a]) <= 2 * be.ADJ_RESIDUAL_TOL, (a, rel_err(got[a], want[a]))
