@@ -8,6 +8,8 @@ import os
 
 import torch
 
+from ._routes import routes
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsigkernel_amd.so")
 
@@ -445,7 +447,7 @@ class HipBackend:
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         with _device(dev):
-            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
+            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not routes.no_y32
             if kind == 0:
                 Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
                 Yt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
@@ -537,7 +539,7 @@ class HipBackend:
             scale = scale.double().contiguous()
         with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
-            y32 = fd == 16 and X.dtype == torch.float32 and not os.environ.get("SK_FUSEDMB_NO_Y32")
+            y32 = fd == 16 and X.dtype == torch.float32 and not routes.no_y32
             if y32:      # fp32 points, two dimensions per 16-byte unit + a row of fp64 norms: half the LDS ring (as the forward)
                 Yt = torch.empty(B, fd // 2 + 1, Ncp, 2, dtype=torch.float32, device=dev)
                 _check(load().sk_prep_paths_f32(_ptr(Y), B, N, D, 0, 2, 1.0, _ptr(Yt), Ncp, fd, _stream(X)), "sk_prep_paths (packed fp32)")

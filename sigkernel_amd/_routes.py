@@ -1,0 +1,35 @@
+"""Route switches of the host layer: which fused HIP kernels a call may take.  They exist for A/B measurements and for the
+tests that compare a fused route with the unfused one; every combination gives the same results to the stated tolerances.
+
+Read from the environment ONCE, when the package is imported -- no `os.environ` look-up on any call path (the C library does
+the same with its SK_* knobs, sk_abi.hip):
+
+    SK_NO_FUSED_RBF      RBFKernel: no fused forward / adjoint (static kernel in its own pass, increments in HBM)
+    SK_NO_FUSED_MB       no multi-band fused forward (long or wide paths stream precomputed increments)
+    SK_NO_FUSED_ADJOINT  gradients by the unfused adjoint (W = dk/dinc in HBM, then the static-kernel chain rule)
+    SK_NO_FUSED_DERIV    compute_kernel_and_derivatives_Gram through three precomputed increment arrays
+    SK_FUSEDMB_NO_Y32    the multi-band kernels stage fp32 inputs as fp64
+
+A running process flips them through the attributes of `sigkernel_amd.routes` (tests: monkeypatch.setattr), or calls
+`routes.reload()` after changing the environment."""
+import os
+
+_ENV = {"no_fused_rbf": "SK_NO_FUSED_RBF", "no_fused_mb": "SK_NO_FUSED_MB", "no_fused_adjoint": "SK_NO_FUSED_ADJOINT",
+        "no_fused_deriv": "SK_NO_FUSED_DERIV", "no_y32": "SK_FUSEDMB_NO_Y32"}
+
+
+class Routes:
+    __slots__ = tuple(_ENV)
+
+    def __init__(self):
+        self.reload()
+
+    def reload(self):
+        for attr, name in _ENV.items():
+            setattr(self, attr, bool(os.environ.get(name)))
+
+    def __repr__(self):
+        return "Routes(" + ", ".join("%s=%s" % (a, getattr(self, a)) for a in _ENV) + ")"
+
+
+routes = Routes()

@@ -11,11 +11,10 @@ Goursat PDE solve and the adjoint PDE run in the HIP kernels of libsigkernel_amd
 * big batches are tiled by an HBM budget (``SigKernel.workspace_bytes``), not by ``max_batch``:
   results never depended on ``max_batch`` (sigkernel.py:31-39, :102-127) and still do not.
 """
-import os
-
 import torch
 
 from . import _lib
+from ._routes import routes
 from .static_kernels import LinearKernel, RBFKernel
 
 __all__ = ["SigKernel", "_SigKernel", "_SigKernelGram", "k_kgrad"]
@@ -60,10 +59,10 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
         kind, param = 0, (1.0 if gram else float(static_kernel.scale))
         res = be.solve_fwd_fused_linear(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
     elif (type(static_kernel) is RBFKernel and hasattr(be, "solve_fwd_fused_rbf") and float(static_kernel.sigma) > 0
-            and not os.environ.get("SK_NO_FUSED_RBF")):
+            and not routes.no_fused_rbf):
         kind, param = 1, float(static_kernel.sigma)
         res = be.solve_fwd_fused_rbf(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
-    if res is None and kind is not None and hasattr(be, "solve_fwd_fused_static") and not os.environ.get("SK_NO_FUSED_MB"):
+    if res is None and kind is not None and hasattr(be, "solve_fwd_fused_static") and not routes.no_fused_mb:
         # several bands per pair / wide paths: the multi-band fused kernel.  It keeps no edges: with a gradient pending the values
         # still come from it (nothing of size pairs x M x N in HBM) and the adjoint sweeps forward by itself later
         # (with a gradient pending: RBF at dyadic 1..2 keeps the edges sk_rbf_adjoint_fused_mb_f64 reads; otherwise none, and the
@@ -90,7 +89,7 @@ def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
     `unsupported` otherwise)."""
     return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused") and not naive
             and X.shape[2] <= 8 and dyadic in (0, 1, 2)
-            and X.shape[1] - 1 <= (64 if dyadic == 2 else 128) and Y.shape[1] >= 2 and not os.environ.get("SK_NO_FUSED_ADJOINT"))
+            and X.shape[1] - 1 <= (64 if dyadic == 2 else 128) and Y.shape[1] >= 2 and not routes.no_fused_adjoint)
 
 
 def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
@@ -99,7 +98,7 @@ def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
     for the shapes whose node rows / columns do not fit its lanes and units)."""
     return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused") and not naive and float(static_kernel.sigma) > 0
             and X.shape[2] <= 4 and dyadic in (1, 2) and X.shape[1] <= 64 * (4 >> dyadic) and Y.shape[1] >= 2
-            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF"))
+            and not routes.no_fused_adjoint and not routes.no_fused_rbf)
 
 
 def _fused_rbf_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
@@ -107,7 +106,7 @@ def _fused_rbf_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
     path long enough for the band pipeline (the kernel has the last word)."""
     return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused_mb") and not naive and float(static_kernel.sigma) > 0
             and X.shape[2] <= 16 and dyadic in (1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
-            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_RBF") and not os.environ.get("SK_NO_FUSED_MB"))
+            and not routes.no_fused_adjoint and not routes.no_fused_rbf and not routes.no_fused_mb)
 
 
 def _fused_linear_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
@@ -115,7 +114,7 @@ def _fused_linear_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
     second path long enough for the band pipeline (the kernel has the last word)."""
     return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused_mb") and not naive
             and X.shape[2] <= 16 and dyadic in (0, 1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
-            and not os.environ.get("SK_NO_FUSED_ADJOINT") and not os.environ.get("SK_NO_FUSED_MB"))
+            and not routes.no_fused_adjoint and not routes.no_fused_mb)
 
 
 def _upcast_tile(X, dyadic):
@@ -342,7 +341,7 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
         # exactly LinearKernel / RBFKernel within the single-band fused kernels' scope: the triangle in ONE launch, every value
         # written to both halves (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*)
         kind = 0 if type(static_kernel) is LinearKernel else 1 if (type(static_kernel) is RBFKernel
-                                                                    and not os.environ.get("SK_NO_FUSED_RBF")) else None
+                                                                    and not routes.no_fused_rbf) else None
         if kind is not None:
             param = 1.0 if kind == 0 else float(static_kernel.sigma)
             K = be.solve_fwd_fused_sym(kind, param, Xd, dyadic_order, naive) if (kind == 0 or param > 0) else None
@@ -564,7 +563,7 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
     for a0, a1 in _tiles(A, per_row, _budget(X.device, workspace_bytes)):
         Xt, gt = Xd[a0:a1], gd[a0:a1]
         X1, X2 = Xt + eps * gt, Xt + 2. * eps * gt                                   # sigkernel.py:530, :537
-        if fused is not None and hasattr(be, "solve_deriv_fused") and not os.environ.get("SK_NO_FUSED_DERIV"):
+        if fused is not None and hasattr(be, "solve_deriv_fused") and not routes.no_fused_deriv:
             # static kernel, finite differences, increments AND the three-state sweep in one kernel (sk_solve_deriv_static_f64)
             res = be.solve_deriv_fused(fused[0], fused[1], Xt.contiguous(), X1, X2, Yd.contiguous(), dyadic_order, eps)
             if res is not None:

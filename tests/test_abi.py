@@ -199,3 +199,21 @@ def test_launch_paths_read_no_environment_and_assume_no_cu_count():
         assert "256LL" not in code, name
         for m in re.finditer(r"\bstatic\s+(?!const\b|constexpr\b|inline\b|_assert)(\w+)", code):
             assert False, "%s: mutable static `%s`" % (name, m.group(0))
+
+
+def test_host_layer_reads_its_route_switches_once(monkeypatch):
+    """The Python layer's route switches (SK_NO_FUSED_*): parsed from the environment when the package is imported, flipped through
+    `sigkernel_amd.routes` afterwards -- no call path looks at os.environ (the round-2 review counted five look-ups per call)."""
+    import sigkernel_amd
+    from sigkernel_amd import _routes
+    for mod in ("sigkernel.py", "distributed.py", "stats.py", "static_kernels.py", "transforms.py"):
+        assert "os.environ" not in open(os.path.join(ROOT, "sigkernel_amd", mod)).read(), mod
+    lib_src = open(os.path.join(ROOT, "sigkernel_amd", "_lib.py")).read()
+    assert "os.environ.get(\"SK_" not in lib_src
+    r = _routes.Routes()
+    assert not any(getattr(r, a) for a in _routes._ENV)            # (the test environment sets none of them)
+    monkeypatch.setenv("SK_NO_FUSED_RBF", "1")
+    assert not sigkernel_amd.routes.no_fused_rbf                   # the environment is not consulted again ...
+    r.reload()
+    assert r.no_fused_rbf and not r.no_fused_mb                    # ... until asked
+    assert set(_routes._ENV) == set(_routes.Routes.__slots__)

@@ -495,7 +495,7 @@ def test_nan_coordinates_give_nan_on_every_route(kernel, monkeypatch):
     sk = sigkernel_amd.SigKernel(k, 1)
     for env in ("", "1"):
         if env:
-            monkeypatch.setenv("SK_NO_FUSED_RBF", env)
+            monkeypatch.setattr(sigkernel_amd.routes, "no_fused_rbf", True)
         K = sk.compute_Gram(X, Y)
         assert torch.isnan(K[1]).all(), (kernel, env, K)
         assert torch.isfinite(K[0]).all() and torch.isfinite(K[3]).all()
@@ -570,9 +570,9 @@ def test_fused_multiband_scope_and_c5_route(monkeypatch):
     gen = torch.Generator().manual_seed(8)
     X, Y = walk(gen, 3, 512, 16, torch.float32).to(DEV), walk(gen, 5, 512, 16, torch.float32).to(DEV)
     sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
-    monkeypatch.setenv("SK_NO_FUSED_MB", "1")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_mb", True)
     K_stream = sk.compute_Gram(X, Y)
-    monkeypatch.delenv("SK_NO_FUSED_MB")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_mb", False)
     monkeypatch.setattr(type(be), "static_increments", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("increments materialised")))
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
@@ -875,14 +875,14 @@ def test_fused_rbf_adjoint_is_what_the_api_runs(monkeypatch):
     assert rel_err(X1.grad.cpu().numpy(), want) <= 1e-10
     Xp = X[:9].clone().requires_grad_(True)
     sk.compute_kernel(Xp, Y).sum().backward()
-    monkeypatch.setenv("SK_NO_FUSED_ADJOINT", "1")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", True)
     X2 = X.clone().requires_grad_(True)
     (sk.compute_Gram(X2, Y) * w.to(DEV)).sum().backward()
     Xq = X[:9].clone().requires_grad_(True)
     sk.compute_kernel(Xq, Y).sum().backward()
     assert rel_err(X1.grad.cpu().numpy(), X2.grad.cpu().numpy()) <= 1e-10
     assert rel_err(Xp.grad.cpu().numpy(), Xq.grad.cpu().numpy()) <= 1e-10
-    monkeypatch.delenv("SK_NO_FUSED_ADJOINT")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", False)
     c = golden("gram_c4mini_rbf_d2")
     Xf, Yf = torch.from_numpy(c["X"]).to(DEV), torch.from_numpy(c["Y"]).to(DEV)
     n0 = len(calls)

@@ -359,9 +359,9 @@ def test_gpu_fused_derivative_solver_is_bit_identical_to_the_unfused_route(kind,
         X, Y = walk(gen, A, M, D).cuda(), walk(gen, B, N, D).cuda()
         g = torch.randn(A, M, D, generator=gen, dtype=torch.float64).cuda()
         sk = sigkernel_amd.SigKernel(kern, d)
-        monkeypatch.setenv("SK_NO_FUSED_DERIV", "1")
+        monkeypatch.setattr(sigkernel_amd.routes, "no_fused_deriv", True)
         want = sk.compute_kernel_and_derivatives_Gram(X, Y, g)
-        monkeypatch.delenv("SK_NO_FUSED_DERIV")
+        monkeypatch.setattr(sigkernel_amd.routes, "no_fused_deriv", False)
         with monkeypatch.context() as m:
             if D <= 8:      # (the fused solver's scope; wider paths keep the unfused route)
                 m.setattr(type(be), "static_deriv_increments", lambda self, *a, **k: (_ for _ in ()).throw(AssertionError("increments materialised")))

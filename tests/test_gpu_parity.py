@@ -320,7 +320,7 @@ def test_fused_linear_adjoint_against_the_unfused_route(be, monkeypatch):
 
 @pytest.mark.parametrize("A,M,N,D,d,par", [(7, 40, 33, 5, 1, 1.0), (70, 64, 64, 8, 2, 0.8), (3, 128, 17, 2, 1, 1.4), (1, 2, 2, 1, 2, 1.0),
                                               (9, 129, 50, 8, 0, 1.0), (5, 30, 130, 3, 0, 0.9)])
-def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par):
+def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par, monkeypatch):
     """Paired batches (compute_kernel gradients) and fp32 inputs (swept in fp64) through the fused adjoint."""
     gen = torch.Generator().manual_seed(A + M + N)
     X, Y = (walk(gen, A, M, D) * 2).to(DEV), (walk(gen, A, N, D) * 2).to(DEV)
@@ -342,14 +342,11 @@ def test_fused_linear_adjoint_paired_and_fp32(be, A, M, N, D, d, par):
     for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
         res = []
         for env in ("", "1"):
-            if env:
-                os.environ["SK_NO_FUSED_ADJOINT"] = env
-            else:
-                os.environ.pop("SK_NO_FUSED_ADJOINT", None)
+            monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", bool(env))
             Xg = X.to(dt).clone().requires_grad_(True)
             (sk.compute_kernel(Xg, Y.to(dt)) * go.to(dt)).sum().backward()
             res.append(Xg.grad.double().cpu().numpy())
-        os.environ.pop("SK_NO_FUSED_ADJOINT", None)
+        monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", False)
         assert rel_err(res[0], res[1]) <= tol, (dt, rel_err(res[0], res[1]))
 
 
@@ -364,7 +361,7 @@ def test_fused_linear_adjoint_is_what_the_api_runs(be, monkeypatch):
     X1 = X.clone().requires_grad_(True)
     sk.compute_mmd(X1, Y).backward()
     assert calls, "LinearKernel backward did not use the fused adjoint"
-    monkeypatch.setenv("SK_NO_FUSED_ADJOINT", "1")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", True)
     X2 = X.clone().requires_grad_(True)
     sk.compute_mmd(X2, Y).backward()
     assert rel_err(X1.grad.cpu().numpy(), X2.grad.cpu().numpy()) <= 1e-10
@@ -617,7 +614,7 @@ def test_fused_rbf_forward_scope_and_route(be, monkeypatch):
     monkeypatch.setattr(type(be), "solve_fwd_fused_rbf", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
     K1 = sk.compute_Gram(Xw, Yw)
     assert calls, "RBFKernel forward without gradient did not use the fused kernel"
-    monkeypatch.setenv("SK_NO_FUSED_RBF", "1")
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_rbf", True)
     K2 = sk.compute_Gram(Xw, Yw)
     assert rel_err(K1.cpu().numpy(), K2.cpu().numpy()) <= 1e-12
 

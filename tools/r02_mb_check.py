@@ -65,16 +65,16 @@ for wpc in os.environ.get("WPCS", "0").split(","):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
     print("C5 compute_Gram wpc=%s: %.1f ms  -> %.3e cells/s" % (wpc, ms, 65536 * 2044.0 * 2044 / (ms * 1e-3)))
-os.environ["SK_NO_FUSED_MB"] = "1"
+os.environ["SK_NO_FUSED_MB"] = "1"; sigkernel_amd.routes.reload()
 K2 = sk.compute_Gram(X, Y)
 print("C5 fused-mb vs streaming route: rel diff %.3e" % float((K - K2).abs().max() / K2.abs().max()))
 # linear long paths, fp64
 Xl, Yl = walk(gen, 128, 300, 8).to(dev), walk(gen, 128, 300, 8).to(dev)
 skl = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1)
-os.environ.pop("SK_NO_FUSED_MB")
+os.environ.pop("SK_NO_FUSED_MB"); sigkernel_amd.routes.reload()
 for env in ("", "1"):
     if env:
-        os.environ["SK_NO_FUSED_MB"] = "1"
+        os.environ["SK_NO_FUSED_MB"] = "1"; sigkernel_amd.routes.reload()
     for _ in range(2):
         K = skl.compute_Gram(Xl, Yl)
     torch.cuda.synchronize()

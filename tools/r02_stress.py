@@ -20,12 +20,12 @@ def check(name, err, tol):
 X, Y = walk(gen, 2, 700, 3).to(dev), walk(gen, 3, 5000, 3).to(dev)
 for kern in (sigkernel_amd.RBFKernel(1.0), sigkernel_amd.LinearKernel()):
     sk = sigkernel_amd.SigKernel(kern, 1)
-    K = sk.compute_Gram(X, Y); os.environ["SK_NO_FUSED_MB"] = "1"; K2 = sk.compute_Gram(X, Y); os.environ.pop("SK_NO_FUSED_MB")
+    K = sk.compute_Gram(X, Y); os.environ["SK_NO_FUSED_MB"] = "1"; sigkernel_amd.routes.reload(); K2 = sk.compute_Gram(X, Y); os.environ.pop("SK_NO_FUSED_MB"); sigkernel_amd.routes.reload()
     check("MB len 700 x 5000 d=1 %s" % type(kern).__name__, rel(K, K2), 1e-10)
 # 2. paired, many pairs, long paths
 X, Y = walk(gen, 3000, 300, 5).to(dev), walk(gen, 3000, 260, 5).to(dev)
 sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.7), 2)
-K = sk.compute_kernel(X, Y); os.environ["SK_NO_FUSED_MB"] = "1"; K2 = sk.compute_kernel(X, Y); os.environ.pop("SK_NO_FUSED_MB")
+K = sk.compute_kernel(X, Y); os.environ["SK_NO_FUSED_MB"] = "1"; sigkernel_amd.routes.reload(); K2 = sk.compute_kernel(X, Y); os.environ.pop("SK_NO_FUSED_MB"); sigkernel_amd.routes.reload()
 check("MB paired 3000 pairs len 300/260 d=2", rel(K, K2), 1e-10)
 # 3. triangular launch, large batch (pair index beyond 2^22) and tiny ones
 for A in (1, 2, 3, 3001):
@@ -41,10 +41,10 @@ for (A, B, M, N, D, d) in ((1, 1, 64, 64, 4, 2), (5000, 1, 30, 40, 2, 1), (1, 30
     sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.9), d)
     g = []
     for env in ("", "1"):
-        if env: os.environ["SK_NO_FUSED_ADJOINT"] = "1"
+        if env: os.environ["SK_NO_FUSED_ADJOINT"] = "1"; sigkernel_amd.routes.reload()
         Xg = X.clone().requires_grad_(True)
         (sk.compute_Gram(Xg, Y) * w).sum().backward()
         g.append(Xg.grad)
-        os.environ.pop("SK_NO_FUSED_ADJOINT", None)
+        os.environ.pop("SK_NO_FUSED_ADJOINT", None); sigkernel_amd.routes.reload()
     check("fused RBF adjoint A=%d B=%d len %d/%d dim %d d=%d" % (A, B, M, N, D, d), rel(g[0], g[1]), 1e-9)
 print("ALL OK" if ok else "FAILURES")

@@ -9,6 +9,7 @@ def walk(g, A, M, D): return torch.cumsum(torch.randn(A, M, D, generator=g, dtyp
 def run(kern, d, X, Y, gm, fused):
     if fused: os.environ.pop("SK_NO_FUSED_DERIV", None)
     else: os.environ["SK_NO_FUSED_DERIV"] = "1"
+    sigkernel_amd.routes.reload()
     return sigkernel_amd.SigKernel(kern, d).compute_kernel_and_derivatives_Gram(X, Y, gm)
 cases = [(1, 3, 2, 130, 128, 5), (0, 2, 3, 100, 140, 8), (2, 2, 2, 70, 127, 3), (1, 2, 3, 128, 158, 16), (1, 4, 3, 50, 127, 4), (0, 3, 2, 64, 126, 7), (1, 3, 4, 40, 170, 3), (0, 2, 3, 70, 200, 8), (1, 3, 2, 130, 180, 5), (2, 2, 2, 20, 161, 2), (1, 2, 2, 65, 300, 12), (0, 5, 7, 129, 165, 4), (2, 2, 3, 70, 170, 9)]
 for kern in (sigkernel_amd.LinearKernel(), sigkernel_amd.RBFKernel(0.8)):

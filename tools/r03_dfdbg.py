@@ -11,6 +11,7 @@ def run(kern, d, X, Y, gm, mode):
     os.environ.pop("SK_NO_FUSED_DERIV", None); os.environ.pop("SK_DERIVF_NOSHIFT", None)
     if mode == "unfused": os.environ["SK_NO_FUSED_DERIV"] = "1"
     if mode == "noshift": os.environ["SK_DERIVF_NOSHIFT"] = "1"
+    sigkernel_amd.routes.reload()
     _lib.load().sk_reload_knobs()
     return sigkernel_amd.SigKernel(kern, d).compute_kernel_and_derivatives_Gram(X, Y, gm)
 kname = sys.argv[1] if len(sys.argv) > 1 else "linear"
