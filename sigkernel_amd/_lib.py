@@ -249,6 +249,22 @@ def _prep_pair(X, Y, diff, scale_x, rows_x, rows_y, fd=8):
     return out_x, out_y
 
 
+class _WorstResidual:
+    """The worst self-check residual of a fused-adjoint launch (NaN-propagating, as torch.max is), reduced only when somebody asks
+    for it -- `float(r)` or `r.tensor()`: it is a diagnostic, and a backward pass should not pay a reduction kernel for it.  The
+    per-pair residuals themselves are in `HipBackend.last_fused_err` (entries of -1: pairs the rescue took out of the sweep)."""
+    __slots__ = ("err",)
+
+    def __init__(self, err):
+        self.err = err
+
+    def tensor(self):
+        return self.err.max()
+
+    def __float__(self):
+        return float(self.err.max())
+
+
 class HipBackend:
     """The product back-end: every method enqueues HIP kernels on the current stream."""
 
@@ -474,7 +490,7 @@ class HipBackend:
     FUSED_RESCUE_BLOCKS_MB = 8   # (a stored pair of 2044 x 2044 grids is 67 MB)
 
     def linear_adjoint_fused_mb(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
-        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel on LONG or WIDE paths
+        """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel on LONG or WIDE paths
         straight from the paths and the edges solve_fwd_fused_static(0, ..., keep_edges=True) kept (sk_linear_adjoint_fused_mb_f64; fp64
         sweep; dim <= 16, dyadic 0..2, any M, N >= ~160).  None outside that scope."""
         _dev(X, "X")
@@ -513,10 +529,10 @@ class HipBackend:
         g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
         if float(param) != 1.0:
             g = g * (float(param) ** 2)
-        return g.to(X.dtype), err.max()
+        return g.to(X.dtype), _WorstResidual(err)
 
     def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True, kfinal=None):
-        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel on LONG or WIDE paths
+        """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel on LONG or WIDE paths
         straight from the paths and the terminal edges solve_fwd_fused_static(keep_edges=True) kept: adjoint PDE, node evaluation and
         chain rule in one multi-band kernel (sk_rbf_adjoint_fused_mb_f64; fp64 sweep whatever the dtype of X; dim <= 16, dyadic
         1..2, any M, N >= ~160).  None outside that scope."""
@@ -569,10 +585,10 @@ class HipBackend:
         # (one small product per y_b, then the sum over b: the flat (A x BN) (BN x D) product runs at 75 GFLOP/s in rocBLAS)
         accd[:, 0] += torch.bmm(n0v.transpose(0, 1), Yd).sum(0) if gram else torch.einsum("ac,acd->ad", n0v[:, 0], Yd)
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
-        return g.to(X.dtype), err.max()
+        return g.to(X.dtype), _WorstResidual(err)
 
     def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
-        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the LINEAR static kernel straight from the paths
+        """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
         gradient is only valid when the residual is <= ADJ_RESIDUAL_TOL (not NaN) -- unless `kfinal` (the forward values, one
@@ -616,7 +632,7 @@ class HipBackend:
             _check(rc, "sk_linear_adjoint_fused")
         # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device (diagnostics; with
         # `kfinal` the rescue has already dealt with exploding pairs: entries of -1 are pairs it took out of the sweep)
-        res = err.max()
+        res = _WorstResidual(err)
         self.last_fused_err = err
         T = tpart.sum(1).flip(1)[:, :Mc, :D]     # chunks of an a added in a fixed order; flipped rows back to p
         g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
@@ -628,7 +644,7 @@ class HipBackend:
         return g, res
 
     def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None):
-        """(dL/dX (A,M,D), worst self-check residual as a 0-d device tensor) for the RBF static kernel straight from the paths and
+        """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
         linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL, unless `kfinal` (forward values per
@@ -675,7 +691,7 @@ class HipBackend:
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused")
-        res = err.max()
+        res = _WorstResidual(err)
         self.last_fused_err = err
         T = gpart.sum(1)[:, :M]                                   # chunks of an a added in a fixed order
         cs, accd = T[..., 0:1], T[..., 2:2 + D]

@@ -204,6 +204,8 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
         res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram, kfinal=Kt)
         if res is None:
             return None
+        if a0 == 0 and a1 == A and res[0].shape == Xd.shape and res[0].dtype == Xd.dtype:
+            return res[0]                # one tile: the kernel's own output, no copy
         grad[a0:a1] = res[0]
     return grad
 
@@ -273,11 +275,12 @@ class _SigKernel(torch.autograd.Function):
         sk, d, naive = ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver
         be = _lib.get_backend()
         A, M, N = X.shape[0], X.shape[1], Y.shape[1]
-        grad_X = torch.zeros_like(X)
         if M >= 2 and N >= 2 and A > 0:
             go = grad_output.to(X.dtype).contiguous()
             grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, False, None,
                                     ctx.workspace_bytes, getattr(ctx, "K", None))
+        else:
+            grad_X = torch.zeros_like(X)     # single points / an empty batch: k = 1 whatever X is
         return grad_X, None, None, None, None, None
 
 
@@ -509,7 +512,7 @@ class _SigKernelGram(torch.autograd.Function):
         sk, d, naive = ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver
         be = _lib.get_backend()
         A, B, M, N = X.shape[0], Y.shape[0], X.shape[1], Y.shape[1]
-        grad_X = torch.zeros_like(X)
+        grad_X = None
         if M >= 2 and N >= 2 and getattr(ctx, "sym_blocks", None):
             # compute_Gram(X, X, sym=True): per row block r0:r1 the pairs (a, b >= r0) were solved.  Their first-argument
             # contraction gives rows r0:r1; the second-argument contraction of the SAME W, weighted by the transposed
@@ -532,7 +535,9 @@ class _SigKernelGram(torch.autograd.Function):
                                     ctx.workspace_bytes, getattr(ctx, "K", None))
         # the reference doubles the gradient when Y requires grad (written for compute_Gram(X, X) with a
         # symmetric grad_output, sigkernel.py:410-412) and never returns a gradient for Y
-        if ctx.needs_input_grad[1]:
+        if grad_X is None:
+            grad_X = torch.zeros_like(X)     # single points / an empty batch: k = 1 whatever X is
+        elif ctx.needs_input_grad[1]:
             grad_X = 2 * grad_X
         return grad_X, None, None, None, None, None, None
 
