@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Either launch works: started as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) with N > 1, the script
+re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 and a free port, one rank per GPU (LOCAL_RANK ->
+device), and rank 0's JSON line comes out of the same stdout.
+
 A "step" is one pass of the hot path over one batch of synthetic paths already resident in HBM:
   * gram configs (c2, c3, c4mini, c5): one SigKernel.compute_Gram call (static kernel -> increments -> PDE solve);
   * c4 (BASELINE configs[3]): one compute_mmd(X, Y).backward() -- three Gram matrices and two adjoint-PDE Grams.
@@ -42,7 +46,9 @@ import sigkernel_amd  # noqa: E402
 from sigkernel_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-FP64_VECTOR_PEAK_TF = 78.6   # MI355X fp64 vector peak (FMA = 2 flop), same guide
+# MI355X fp64 VECTOR peak (FMA = 2 flop): SURVEY 8(d)'s figure = half of the part's 157.3 TFLOP/s fp64 matrix peak
+# (256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz); the microarch guide carries no fp64-vector row
+FP64_VECTOR_PEAK_TF = 78.6
 
 CONFIGS = {
     # name: rows of X (per GPU under weak scaling), B, M, N, D, static kernel, dyadic, dtype, mode, description
@@ -56,6 +62,11 @@ CONFIGS = {
                     "compute_mmd(X, Y).backward() (3 Gram matrices + 2 adjoint-PDE Grams), Gram rows sharded over the GPUs"),
     "c4mini": dict(A=512, B=512, M=64, N=64, D=4, kernel="rbf", dyadic=2, dtype=torch.float64, mode="gram",
                    desc="BASELINE configs[3] reduced to 512x512 pairs: len 64, dim 4, RBFKernel(1.0), dyadic 2, fp64, compute_Gram"),
+    "mmd64": dict(A=64, B=64, M=64, N=64, D=3, kernel="rbf", dyadic=1, dtype=torch.float64, mode="mmd",
+                  desc="a training-sized step: compute_mmd(X, Y).backward(), 64 x 64 paths of BASELINE configs[1]'s shape (len 64, dim 3, "
+                       "RBFKernel(1.0), dyadic 1, fp64)"),
+    "mmd32": dict(A=32, B=32, M=64, N=64, D=3, kernel="rbf", dyadic=1, dtype=torch.float64, mode="mmd",
+                  desc="a training-sized step: compute_mmd(X, Y).backward(), 32 x 32 paths of BASELINE configs[1]'s shape"),
     "c5": dict(A=256, B=256, M=512, N=512, D=16, kernel="rbf", dyadic=2, dtype=torch.float32, mode="gram",
                desc="BASELINE configs[4]: batch 256x256, len 512, dim 16, RBFKernel(1.0), dyadic 2, fp32, compute_Gram "
                     "(grid 2044x2044 per pair)"),
@@ -194,6 +205,109 @@ def traffic_source(key):
         return None
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(gpus):
+    """`python bench.py --gpus N` started without a launcher: re-execute under torch.distributed.run, N ranks on this node,
+    rendezvous on 127.0.0.1 and a free port.  The ranks inherit stdout, so rank 0's JSON line is this process's output."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, SK_BENCH_LAUNCH="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world, rank, local_rank):
+    """--launch-check: only the rendezvous (RCCL on GPUs, gloo where there is none): every rank adds rank + 1, rank 0 prints what
+    it saw.  What the non-GPU test of the self-launch runs."""
+    import torch.distributed as dist
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl" if on_gpu else "gloo", **({"device_id": torch.device("cuda", local_rank)} if on_gpu else {}))
+    t = torch.tensor([rank + 1.0], device="cuda" if on_gpu else "cpu")
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "world_size_seen": dist.get_world_size(),
+                          "backend": dist.get_backend(), "rank_sum": float(t.item()),
+                          "launch": os.environ.get("SK_BENCH_LAUNCH", "torchrun")}))
+        sys.stdout.flush()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class Workload:
+    """One BASELINE config on this rank: synthetic paths resident in HBM, the SigKernel that runs it, one `step`."""
+
+    def __init__(self, name, world, scaling, dev, group):
+        cfg = CONFIGS[name]
+        self.name, self.cfg, self.world = name, cfg, world
+        A, self.B, self.M, self.N, self.D = cfg["A"], cfg["B"], cfg["M"], cfg["N"], cfg["D"]
+        self.kname, self.dyadic, self.dtype, self.mode = cfg["kernel"], cfg["dyadic"], cfg["dtype"], cfg["mode"]
+        self.scaling = scaling or ("strong" if self.mode == "mmd" else "weak")
+        if self.mode == "mmd" and self.scaling == "weak":
+            raise SystemExit("%s is a fixed-size job: use --scaling strong" % name)
+        self.A_total = A * world if self.scaling == "weak" else A
+        self.sym = bool(cfg.get("sym"))
+        # every rank holds the (small) inputs in full, exactly as SigKernel(process_group=...) expects; each solves its own rows
+        self.Xc = make_paths(self.A_total, self.M, self.D, seed=1000, dtype=self.dtype)
+        self.Yc = self.Xc if self.sym else make_paths(self.B, self.N, self.D, seed=7, dtype=self.dtype)
+        if self.sym:
+            self.B = self.A_total
+        self.X = self.Xc.to(dev)
+        self.Y = self.X if self.sym else self.Yc.to(dev)
+        self.sk = sigkernel_amd.SigKernel(static_kernel(self.kname), self.dyadic, process_group=group)
+        self.sk1 = sigkernel_amd.SigKernel(static_kernel(self.kname), self.dyadic)   # single-GPU instance for the rank-0 extras
+        At, B = self.A_total, self.B
+        self.entries_per_step = At * B if self.mode == "gram" else (At * At + B * B + At * B)
+        self.cells_per_entry = ((self.M - 1) << self.dyadic) * ((self.N - 1) << self.dyadic)
+
+    def step(self):
+        if self.mode == "gram":
+            return self.sk.compute_Gram(self.X, self.Y, sym=self.sym)   # N > 1: rows sharded, one all-gather (sigkernel_amd.distributed)
+        Xg = self.X.detach().requires_grad_(True)
+        loss = self.sk.compute_mmd(Xg, self.Y)
+        loss.backward()
+        return loss.detach(), Xg.grad
+
+    def config(self):
+        return {"workload": self.cfg["desc"], "name": self.name,
+                "step": "compute_Gram" if self.mode == "gram" else "compute_mmd + backward (entries = the three Gram matrices of one step)",
+                "batch_x": self.A_total, "rows_per_gpu": -(-self.A_total // self.world), "batch_y": self.B, "len_x": self.M,
+                "len_y": self.N, "dim": self.D, "static_kernel": self.kname, "dyadic_order": self.dyadic,
+                "parallelism": "SigKernel(process_group): gram rows sharded over %d GPU(s), 1 all-gather per Gram" % self.world}
+
+
+def timed(step, steps, warmup, dist, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; the MAX over ranks.  (seconds, last output)"""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,21 +317,28 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / adjoint / parity / cpu_baseline legs")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs timed after the headline (N = 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only (no kernels): checks the launch path")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # plain `python bench.py --gpus N`: spawn the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.launch_check:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
+        return launch_check(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -225,64 +346,20 @@ def main():
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:              # --force-dist without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    group = dist.group.WORLD if use_dist else None
 
-    cfg = CONFIGS[args.config]
-    A, B, M, N, D = cfg["A"], cfg["B"], cfg["M"], cfg["N"], cfg["D"]
-    kname, dyadic, dtype, mode = cfg["kernel"], cfg["dyadic"], cfg["dtype"], cfg["mode"]
-    scaling = args.scaling or ("strong" if mode == "mmd" else "weak")
-    if mode == "mmd" and scaling == "weak":
-        raise SystemExit("c4 is a fixed-size job (BASELINE configs[3]): use --scaling strong")
-    A_total = A * world if scaling == "weak" else A
-    # every rank holds the (small) inputs in full, exactly as SigKernel(process_group=...) expects; each solves its own rows
-    sym = bool(cfg.get("sym"))
-    Xc = make_paths(A_total, M, D, seed=1000, dtype=dtype)
-    Yc = Xc if sym else make_paths(B, N, D, seed=7, dtype=dtype)
-    if sym:
-        B = A_total
-    X = Xc.to(dev)
-    Y = X if sym else Yc.to(dev)
-    sk = sigkernel_amd.SigKernel(static_kernel(kname), dyadic, process_group=dist.group.WORLD if use_dist else None)
-    sk1 = sigkernel_amd.SigKernel(static_kernel(kname), dyadic)       # single-GPU instance for the rank-0 extras
+    wl = Workload(args.config, world, args.scaling, dev, group)
     be = _lib.get_backend()
     assert isinstance(be, _lib.HipBackend), "bench must run on the HIP back-end"
 
-    if mode == "gram":
-        def step():
-            return sk.compute_Gram(X, Y, sym=sym)         # N > 1: rows sharded, one all-gather (sigkernel_amd.distributed)
-    else:
-        def step():
-            Xg = X.detach().requires_grad_(True)
-            loss = sk.compute_mmd(Xg, Y)
-            loss.backward()
-            return loss.detach(), Xg.grad
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    entries_per_step = A_total * B if mode == "gram" else (A_total * A_total + B * B + A_total * B)
-    cells_per_entry = ((M - 1) << dyadic) * ((N - 1) << dyadic)
-    value = entries_per_step * args.steps / elapsed
-    dname = "f64" if dtype == torch.float64 else "f32"
+    elapsed, out = timed(wl.step, args.steps, args.warmup, dist, dev)
+    value = wl.entries_per_step * args.steps / elapsed
+    dname = "f64" if wl.dtype == torch.float64 else "f32"
 
     result = {
-        "metric": "Gram entries/sec (%s)" % ("fp64" if dtype == torch.float64 else "fp32 I/O, fp64 PDE state"),
+        "metric": "Gram entries/sec (%s)" % ("fp64" if wl.dtype == torch.float64 else "fp32 I/O, fp64 PDE state"),
         "value": value,
         "unit": "entries/s",
         "n_gpus": world,
@@ -290,20 +367,32 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": scaling,
+        "scaling": wl.scaling,
         "vs_baseline": None,
         "dtype": dname,
         "data": "synthetic",
-        "config": {"workload": cfg["desc"], "name": args.config, "step": "compute_Gram" if mode == "gram" else
-                   "compute_mmd + backward (entries = the three Gram matrices of one step)",
-                   "batch_x": A_total, "rows_per_gpu": -(-A_total // world), "batch_y": B, "len_x": M, "len_y": N, "dim": D,
-                   "static_kernel": kname, "dyadic_order": dyadic,
-                   "parallelism": "SigKernel(process_group): gram rows sharded over %d GPU(s), 1 all-gather per Gram" % world},
-        "grid_cells_per_s": value * cells_per_entry,
+        "config": wl.config(),
+        "grid_cells_per_s": value * wl.cells_per_entry,
+        "launch": os.environ.get("SK_BENCH_LAUNCH", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
+        "world_size_seen": dist.get_world_size() if use_dist else 1,
     }
 
+    if use_dist and wl.mode == "gram" and args.scaling is None:
+        # the other scaling of the same config in the same line: BASELINE's ">= 6x at 8 GPUs" reads on the FIXED batch (strong:
+        # the batch divided over the ranks); `value` above is the weak figure (the batch per GPU fixed).  At N = 1 they coincide.
+        other = Workload(args.config, world, "strong" if wl.scaling == "weak" else "weak", dev, group)
+        el2, _ = timed(other.step, args.steps, args.warmup, dist, dev)
+        result[other.scaling + "_scaling"] = {
+            "value": other.entries_per_step * args.steps / el2, "unit": "entries/s", "ms_per_step": 1e3 * el2 / args.steps,
+            "batch_x": other.A_total, "rows_per_gpu": -(-other.A_total // world), "batch_y": other.B,
+            "note": "same config, same steps / warmup / barriers, timed right after the headline region"}
+        del other
+
     if rank == 0 and not args.no_extras:
-        extras(result, args, cfg, sk1, be, X, Y, Xc, Yc, out, A_total, world, value)
+        extras(result, args, wl.cfg, wl.sk1, be, wl.X, wl.Y, wl.Xc, wl.Yc, out, wl.A_total, world, value)
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_configs and args.config == "c3":
+        del out
+        result["configs"] = other_configs(dev, args)
     if rank == 0:
         print(json.dumps(result))
         sys.stdout.flush()
@@ -311,6 +400,76 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def mmd_parity(wl, loss, grad, rows):
+    """The timed compute_mmd(X, Y).backward() against the oracle: gradient rows `rows` in full (every pair of K_XX and K_XY that
+    row takes part in, with the reference's 2x rule on K_XX, sigkernel.py:190-197, :410-412) and, for small batches, the scalar."""
+    from oracle import oracle as O
+    skern = static_kernel(wl.kname)
+    A, B = wl.A_total, wl.B
+    nt = os.cpu_count() or 1
+    Xr = wl.Xc[rows]
+    wxx = np.full((len(rows), A), 1.0 / (A * (A - 1.0)))
+    wxx[np.arange(len(rows)), rows] = 0.0
+    wxy = np.full((len(rows), B), -2.0 / (A * B))
+    want = 2.0 * O.gram_grad_weighted(Xr, wl.Xc, wxx, skern, wl.dyadic, nthreads=nt) + \
+        O.gram_grad_weighted(Xr, wl.Yc, wxy, skern, wl.dyadic, nthreads=nt)
+    got = grad[rows].double().cpu().numpy()
+    gerr = float(np.max(np.abs(got - want)) / np.max(np.abs(want)))
+    par = {"grad_rows_checked": [int(r) for r in rows], "grad_max_rel_err_vs_oracle": gerr, "grad_tolerance": 1e-6,
+           "grad_ok": bool(gerr <= 1e-6), "mmd": float(loss)}
+    if A * A + B * B + A * B <= 3 * 128 * 128:
+        Kxx, Kyy = O.gram_forward(wl.Xc, wl.Xc, skern, wl.dyadic, nthreads=nt), O.gram_forward(wl.Yc, wl.Yc, skern, wl.dyadic, nthreads=nt)
+        Kxy = O.gram_forward(wl.Xc, wl.Yc, skern, wl.dyadic, nthreads=nt)
+        ref = (Kxx.sum() - np.trace(Kxx)) / (A * (A - 1.0)) + (Kyy.sum() - np.trace(Kyy)) / (B * (B - 1.0)) - 2.0 * Kxy.mean()
+        # the MMD is a difference of O(1) means: judged against the means it is formed from
+        par.update(mmd_oracle=float(ref), mmd_abs_err=abs(float(loss) - float(ref)), mmd_tolerance=1e-6 * float(abs(Kxy.mean())),
+                   mmd_ok=bool(abs(float(loss) - float(ref)) <= 1e-6 * abs(Kxy.mean())))
+    return par
+
+
+def gram_parity(wl, K, n_chk):
+    """n_chk random entries of the timed Gram matrix re-solved by the oracle."""
+    from oracle import oracle as O
+    skern = static_kernel(wl.kname)
+    Kc = K.double().cpu().numpy()
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for p in rng.integers(0, wl.A_total * wl.B, size=n_chk):
+        a, b = divmod(int(p), wl.B)
+        want = O.gram_forward(wl.Xc[a:a + 1], wl.Yc[b:b + 1], skern, wl.dyadic)[0, 0]
+        worst = max(worst, abs(float(Kc[a, b]) - want) / abs(want))
+    tol = 1e-6 if wl.dtype == torch.float64 else 1e-4       # fp32 I/O: the reference's own fp32 bar (test_mps.py:32)
+    par = {"pairs_checked": int(n_chk), "max_rel_err_vs_oracle": worst, "tolerance": tol, "ok": bool(worst <= tol)}
+    if wl.sym:
+        par["exactly_symmetric"] = bool(np.array_equal(Kc, Kc.T))
+    return par
+
+
+def other_configs(dev, args):
+    """The other BASELINE configs (and two training-sized MMD steps) on this GPU, after the headline's timed region: 1 warm-up
+    + 2 timed steps each between synchronisations, with a parity block per config -- so that the driver's default run carries a
+    number for every config, not only the headline."""
+    res = {}
+    for name, steps, warmup in (("c2", 20, 3), ("mmd32", 10, 2), ("mmd64", 10, 2), ("c5", 2, 1), ("c4", 2, 1)):
+        try:
+            wl = Workload(name, 1, None, dev, None)
+            elapsed, out = timed(wl.step, steps, warmup, None, dev)
+            ent = {"workload": wl.cfg["desc"], "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+                   "value": wl.entries_per_step * steps / elapsed, "unit": "entries/s", "dtype": "f64" if wl.dtype == torch.float64 else "f32",
+                   "grid_cells_per_s": wl.entries_per_step * steps / elapsed * wl.cells_per_entry}
+            if wl.mode == "gram":
+                ent["parity"] = gram_parity(wl, out, 64 if wl.cells_per_entry < 1e6 else 8)
+            else:
+                rows = np.array([0, wl.A_total - 1]) if wl.A_total > 128 else np.arange(wl.A_total)
+                ent["parity"] = mmd_parity(wl, out[0], out[1], rows)
+            res[name] = ent
+            del wl, out
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001 -- a failing secondary config must not cost the headline its line
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):

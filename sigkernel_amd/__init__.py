@@ -8,8 +8,8 @@ from ._routes import routes
 from .static_kernels import LinearKernel, RBFKernel
 from .sigkernel import SigKernel, _SigKernel, _SigKernelGram, k_kgrad
 from .stats import SigCHSIC, c_alpha, hypothesis_test
-from .transforms import add_time, lead_lag, transform
+from .transforms import AddTime, LeadLag, add_time, lead_lag, transform
 
 __all__ = ["SigKernel", "LinearKernel", "RBFKernel", "_SigKernel", "_SigKernelGram", "hypothesis_test", "SigCHSIC",
-           "c_alpha", "transform", "add_time", "lead_lag", "k_kgrad", "routes"]
+           "c_alpha", "transform", "add_time", "lead_lag", "AddTime", "LeadLag", "k_kgrad", "routes"]
 __version__ = "0.1.0"

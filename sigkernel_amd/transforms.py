@@ -1,11 +1,25 @@
 """Path transforms applied before the kernel in every example of the reference (transformers.py:12-80), as batched
 tensor ops that run on the device the paths live on (the reference maps numpy lists one path at a time on the CPU).
 
-All take and return tensors of shape (batch, length, dim).
+The functions take and return tensors of shape (batch, length, dim).  `AddTime` / `LeadLag` are the reference's sklearn-style
+transformer classes (transformers.py:30-44, :57-80) over the same code: `fit` / `transform` / `fit_transform` / `transform_instance`,
+constructor arguments as there; they accept what the reference's accept (a list of per-path arrays, ragged lengths included, or one
+array) and, additionally, a (batch, length, dim) tensor, which stays a tensor on its device.
 """
+import numpy as np
 import torch
 
-__all__ = ["add_time", "lead_lag", "transform"]
+__all__ = ["add_time", "lead_lag", "transform", "AddTime", "LeadLag"]
+
+try:    # the reference's classes are sklearn estimators (pipelines, get_params); without sklearn they are plain objects
+    from sklearn.base import BaseEstimator, TransformerMixin
+except Exception:      # noqa: BLE001
+    class BaseEstimator:
+        pass
+
+    class TransformerMixin:
+        def fit_transform(self, X, y=None, **fit_params):
+            return self.fit(X, y, **fit_params).transform(X)
 
 
 def add_time(paths, init_time=0.):
@@ -33,3 +47,47 @@ def transform(paths, at=False, ll=False, scale=1.):
     if at:
         paths = add_time(paths)
     return paths
+
+
+class _PathTransformer(BaseEstimator, TransformerMixin):
+    """A (batch, length, dim) tensor goes through the batched op in one piece; anything else is the reference's interface: an
+    iterable of per-path arrays (length, dim) -- possibly of different lengths -- mapped one by one to a list of numpy arrays."""
+
+    def fit(self, X, y=None):
+        return self
+
+    def _op(self, paths):
+        raise NotImplementedError
+
+    def transform_instance(self, X):
+        x = torch.as_tensor(np.asarray(X, dtype=np.float64))
+        if x.dim() == 1:
+            x = x[:, None]
+        return self._op(x[None])[0].numpy()
+
+    def transform(self, X, y=None):
+        if isinstance(X, torch.Tensor) and X.dim() == 3:
+            return self._op(X)
+        return [self.transform_instance(x) for x in X]
+
+
+class AddTime(_PathTransformer):
+    """The reference's ``AddTime`` (transformers.py:30-44): a leading time channel over [init_time, init_time + 1]
+    (``total_time`` is stored and, as in the reference, not used)."""
+
+    def __init__(self, init_time=0., total_time=1.):
+        self.init_time = init_time
+        self.total_time = total_time
+
+    def _op(self, paths):
+        return add_time(paths, self.init_time)
+
+
+class LeadLag(_PathTransformer):
+    """The reference's ``LeadLag`` (transformers.py:57-80): length 2L-1, channels [lag, lead]."""
+
+    def __init__(self):
+        pass
+
+    def _op(self, paths):
+        return lead_lag(paths)

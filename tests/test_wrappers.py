@@ -21,6 +21,28 @@ def test_transforms_match_the_reference():
     assert sigkernel_amd.lead_lag(P).shape == (4, 17, 4) and sigkernel_amd.add_time(P).shape == (4, 9, 3)
 
 
+def test_transformer_classes_match_the_reference_interface():
+    """AddTime / LeadLag as classes (transformers.py:30-44, :57-80): fit / transform / fit_transform / transform_instance on lists
+    of per-path arrays (ragged lengths included) and on one batched tensor; values pinned by the `transform` fixtures."""
+    c = golden("wrappers")
+    P = c["paths"]
+    ll = sigkernel_amd.LeadLag().fit_transform(list(0.5 * P))
+    assert isinstance(ll, list) and np.array_equal(np.array(ll), c["transform_at0_ll1"])
+    at = sigkernel_amd.AddTime().fit_transform(ll)
+    assert np.array_equal(np.array(at), c["transform_at1_ll1"])
+    assert np.array_equal(np.array(sigkernel_amd.AddTime().fit(None).transform(list(0.5 * P))), c["transform_at1_ll0"])
+    # tensors stay tensors, in one batched op
+    T = sigkernel_amd.AddTime().transform(sigkernel_amd.LeadLag().transform(torch.from_numpy(0.5 * P)))
+    assert isinstance(T, torch.Tensor) and np.array_equal(T.numpy(), c["transform_at1_ll1"])
+    # ragged input, 1-d paths, constructor arguments
+    rag = [np.arange(5.0), np.arange(3.0) * 2]
+    out = sigkernel_amd.AddTime(init_time=2.0, total_time=9.0).transform(rag)
+    assert out[0].shape == (5, 2) and out[1].shape == (3, 2) and np.array_equal(out[1][:, 0], np.linspace(2.0, 3.0, 3))
+    assert sigkernel_amd.AddTime(init_time=2.0).get_params()["init_time"] == 2.0
+    lead = sigkernel_amd.LeadLag().transform_instance(np.array([[1.0], [2.0], [4.0]]))
+    assert np.array_equal(lead, np.array([[1, 1], [1, 2], [2, 2], [2, 4], [4, 4]], dtype=float))
+
+
 def _check_stats(dev):
     c = golden("wrappers")
     X, Y, Z = (torch.from_numpy(c[k]).to(dev) for k in ("X", "Y", "Z"))
