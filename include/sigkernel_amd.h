@@ -60,6 +60,32 @@ typedef enum sk_status {
                                cover the shape/layout (used by tests and benchmarks)            */
 
 int sk_version(void);
+/* "sigkernel_amd gfx950; sources <hash>; <hipcc --version>; ISA hazard lint passed at build": the sources and the toolchain this
+ * binary was built from (static string).  The hand-scheduled kernels are linted at build time against the register allocator of
+ * THAT compiler (csrc/Makefile); a deployment that rebuilds with another one gets a different string -- and a fresh lint. */
+const char *sk_build_info(void);
+
+/* ---- routing (host only: no device work) --------------------------------------------------------------------------------------
+ * Which kernel family serves a call -- the ONE statement of the fused kernels' scope: the host layer asks it instead of keeping
+ * its own predicates, and every launcher honours it (csrc/sk_route.hip holds the rules; tests pin them against a table).
+ *   op     SK_OP_FORWARD: k_sig values (sigkernel.py:216-234, :362-382);  SK_OP_ADJOINT: the gradient (sigkernel.py:257-343, :404-502)
+ *          -- the forward of a call with a gradient pending keeps the edges of the family the ADJOINT query names
+ *   kind   0 = LinearKernel, 1 = RBFKernel (sigma > 0); anything else streams
+ *   D, M, N, dyadic, scheme (SK_SCHEME_*), elem_size (8 / 4: the dtype of the caller's paths)
+ * Returns
+ *   SK_ROUTE_STREAM         static kernel -> increments in HBM (pairs x M x N) -> sk_solve_fwd_* / sk_solve_adj_*
+ *   SK_ROUTE_FUSED          one band per pair: sk_solve_fwd_linear_* / _rbf_* (+ _edges_f64), sk_linear_adjoint_fused_f64,
+ *                           sk_rbf_adjoint_fused_f64 -- nothing of size pairs x M x N exists
+ *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
+ *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
+ * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer is never SK_ROUTE_STREAM. */
+#define SK_OP_FORWARD 0
+#define SK_OP_ADJOINT 1
+#define SK_ROUTE_STREAM 0
+#define SK_ROUTE_FUSED 1
+#define SK_ROUTE_FUSED_MB 2
+#define SK_ROUTE_FUSED_MB_SWAP 3
+int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size);
 
 /* Development hook: the SK_* tuning knobs are parsed from the environment ONCE, when the library is loaded; tools that sweep a
  * knob inside one process call this after changing it.  Not for product code (not thread-safe against concurrent launches). */
@@ -116,12 +142,15 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
  * from the path differences, recomputes K from the terminal edges a forward with edges kept (sk_solve_fwd_linear_edges_f64),
  * and contracts W = d k / d inc with the y differences on the spot -- neither the increments nor W exist in HBM.  Replaces
  * sigkernel.py:438-500 for LinearKernel, i.e. sk_static_increments + sk_solve_adj(EDGES_GIVEN) + sk_linear_adjoint.
- *   dXr, dYt, Mrows, Ncp: the arrays sk_solve_fwd_linear_* takes;  edges: sk_strip_edges_bytes layout;  scale [A*B] nullable.
+ *   dXr [A][Mrows][8] = s^2 (x[p+1]-x[p]) -- the LAYOUT of sk_solve_fwd_linear_*'s array but WITHOUT its kappa = sk_linear_prescale(dyadic)
+ *   factor (this kernel forms inc = <dXr, dYt> itself, and so does its rescue: a forward's pre-scaled staging would give gradients
+ *   wrong by kappa);  dYt [Bn][8][Ncp] = y[q+1]-y[q], Mrows, Ncp: as sk_solve_fwd_linear_* takes them;
+ *   edges: sk_strip_edges_bytes layout;  scale [A*B] nullable;  either scheme.
  *   tpart [tpart_doubles] receives partial sums over b: viewed as [A][B / *ppg_out][*rows_out][8], sum over the chunk axis,
  *   then T[a][p][:] = that[a][*rows_out - 1 - p][:] for p < Mc is what sk_linear_adjoint_* returns.  tpart == NULL: only
  *   *ppg_out and *rows_out are set (size query: A * (B / ppg) * rows * 8 doubles).  err [P] zero-initialised: per-pair
- *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic <= 2, default scheme, Mc <= 128 (64 at dyadic 2),
- *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED. */
+ *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic <= 2, Mc <= 128 (64 at dyadic 2),
+ *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED (sk_route_query(SK_OP_ADJOINT, 0, ...) == SK_ROUTE_FUSED says when it applies). */
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
                                 size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, const double *kfinal, double screen,
@@ -136,8 +165,9 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  *   scale [P] nullable (upstream gradient per pair).  gpart [gpart_doubles] receives partial sums over b, viewed as
  *   [A][B / *ppg_out][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
  *   dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == NULL: size query only.  err [P] zero-initialised: self-check residual
- *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2, default scheme, path dim <= 8, one band per pair with
- *   M <= lanes x rows per lane and N - 1 <= 2 NUp - 1; otherwise SK_ERR_UNSUPPORTED.
+ *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2, either scheme, path dim <= 8, one band per pair with
+ *   M <= lanes x rows per lane and N - 1 <= 2 NUp - 1 (N - 1 not a multiple of 16); otherwise SK_ERR_UNSUPPORTED
+ *   (sk_route_query(SK_OP_ADJOINT, 1, ...) == SK_ROUTE_FUSED says when the host layer takes it: path dim <= 4).
  *   ypart (nullable; Gram, path dim <= 4): the SECOND-argument sums of the same sweep, for compute_Gram(X, X, sym=True) with a
  *   gradient (compute_mmd's K_XX, sigkernel.py:190), where only the pairs on and above the diagonal are solved and a pair (a, b)
  *   also owes d1 k(x_b, x_a) = d2 k(x_a, x_b) to row b.  Viewed as [A*B][*ycols_out][6], node column c < N of pair (a, b) holds
@@ -168,7 +198,8 @@ int sk_solve_deriv_static_f64(int kind, double param, const double *X0r, const d
  * sk_static_adjoint.
  *   sk_rbf_adjoint_fused_mb_layout: *mrows = rows of Xr per path, gpart = [P][*rows][*outw] doubles, n0 = [P][*ncols] doubles,
  *   *edge_doubles per pair, *workspace_bytes (one band-boundary row per resident wave); SK_ERR_UNSUPPORTED outside the scope
- *   (dyadic 1..2, D <= 16, second path of >= ~160 points).
+ *   (dyadic 0..2, D <= 16; any M, N: second paths shorter than ~160 points are swept with masked padding units, *ncols = 2 NUp = Ncp;
+ *   at dyadic 0 the kernel gives a lane two coarse rows -- bands of 128 rows -- and sk_solve_fwd_static_* keeps its edges likewise).
  *   Xr [A][Mrows][fd] / Yt [Bn][fd][Ncp]: the fp64 POINT arrays of sk_solve_fwd_static_* (kind 1), fd = 8 or 16; yt_f32 = 1 (fd = 16,
  *   fp32 inputs): Yt is the packed fp32 array sk_solve_fwd_static_f32 takes -- half the LDS ring, two waves per SIMD at 16 dimensions;
  *   edges: what sk_solve_fwd_static_* kept;  scale [P] nullable.  gpart receives, per PAIR and node row 1 <= r < M, cs = [..][0]
@@ -188,8 +219,8 @@ int sk_rbf_adjoint_fused_mb_f64(const double *Xr, const void *Yt, int yt_f32, in
 /* The same for LinearKernel on long / wide paths (csrc/sk_wave_adj_fused_mb.hip: k_adj_fused_linear_mb): increments from the path
  * differences, W contracted with the y differences on the spot.  Replaces sigkernel.py:419-502 + :404-416 there, i.e.
  * sk_static_increments + sk_solve_fwd + sk_solve_adj + sk_linear_adjoint.
- *   dXr [A][Mrows][fd] = s^2 (x[p+1]-x[p]), dYt [Bn][fd][Ncp] = y[q+1]-y[q] (sk_solve_fwd_static_*'s kind-0 arrays; Ncp >= 2 NUp,
- *   NUp = ceil8((Nc + 1) / 2) >= 80);  edges: what sk_solve_fwd_static_* (kind 0, edges, Mrows = *mrows) kept, *edge_doubles per pair;
+ *   dXr [A][Mrows][fd] = s^2 (x[p+1]-x[p]), dYt [Bn][fd][Ncp] = y[q+1]-y[q] (sk_solve_fwd_static_*'s kind-0 arrays; Ncp >=
+ *   sk_solve_fwd_static_cols(0, Nc) = 2 NUp, NUp = max(80, ceil8((Nc + 1) / 2)));  edges: what sk_solve_fwd_static_* (kind 0, edges, Mrows = *mrows) kept, *edge_doubles per pair;
  *   gpart [P][*rows][*outw = fd]: per PAIR and FLIPPED coarse row (row *rows - 1 - p holds coarse row p); summed over the pairs of an
  *   x_a and flipped back it is the T of sk_linear_adjoint_*: dL/dx[m] = s^2 (T[m-1] - T[m]).  Rescue arguments as above.  dyadic 0..2. */
 int sk_linear_adjoint_fused_mb_layout(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows, int *rows, int *outw, int64_t *edge_doubles,
@@ -215,8 +246,8 @@ size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int 
  * compute_Gram(X, X, sym=True) with a gradient: only the blocks on and above the diagonal are solved, and a pair (a, b)
  * above the diagonal also stands for (b, a), whose first-argument gradient is this pair's second-argument one.
  *   W [A*B, M-1, ldw], scale [A*B] nullable (the caller passes the TRANSPOSED upstream gradient block).
- *   kind 0 (linear, D <= 8): dXr [A][Mrows][8] fp64 = param^2 (x[p+1]-x[p]) zero-padded (the array sk_solve_fwd_linear_* takes),
- *                    X, Y unused; out = T2 [B-b0, N-1, D], the caller forms dL/dy[b][n] = T2[b][n-1] - T2[b][n].
+ *   kind 0 (linear, D <= 8): dXr [A][Mrows][8] fp64 = param^2 (x[p+1]-x[p]) zero-padded (the layout of sk_solve_fwd_linear_*'s array,
+ *                    WITHOUT its kappa = sk_linear_prescale(dyadic) factor), X, Y unused; out = T2 [B-b0, N-1, D], the caller forms dL/dy[b][n] = T2[b][n-1] - T2[b][n].
  *   kind 1 (rbf):    dXr unused; out = dL/dY [B-b0, N, D]. */
 int sk_static_adjoint2_f64(int kind, double param, const double *X, const double *Y, const double *dXr, int Mrows,
                            const double *W, int64_t ldw, const double *scale, int64_t A, int64_t B, int b0, int M, int N, int D,
@@ -331,13 +362,16 @@ int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int 
  *   kind 0 (linear, param unused): Xr [A][Mrows][fd] = s^2 (x[p+1]-x[p]), Yt [Bn][fd][Ncp] = y[q+1]-y[q];
  *   kind 1 (rbf, param = sigma):   Xr = the points x[p], Yt = the points y[q];  both fp64, zero-padded, as sk_prep_paths_* builds
  *   them;  fd = 8 for D <= 8, 16 for D <= 16;  Mrows >= sk_solve_fwd_static_rows(kind, Mc, dyadic);
- *   Ncp >= 2 NUp with NUp = ceil8((Nc + 1 + kind) / 2), NUp >= 72;  B > 0: Gram, B == 0: paired;  out_final [P];
+ *   Ncp >= sk_solve_fwd_static_cols(kind, Nc) = 2 NUp, NUp = max(80, ceil8((Nc + 1 + kind) / 2)) (second paths shorter than ~160 points
+ *   are swept with padding units behind them: wasted steps, same result -- swap the arguments when the first path is the longer
+ *   one, the kernel is symmetric);  B > 0: Gram, B == 0: paired;  out_final [P];  either scheme;
  *   workspace: sk_solve_fwd_static_workspace_bytes(...) bytes (one band-boundary row per resident wave; 0 = unsupported).
- * SK_ERR_UNSUPPORTED: dyadic > 2, D > 16, or a second path too short for the band pipeline (N < ~130: use the kernels above,
- * sk_static_increments_* + sk_solve_fwd_*, or swap the arguments -- the kernel is symmetric). */
+ * SK_ERR_UNSUPPORTED: dyadic > 2, D > 16. */
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
-/* edges (nullable; kind 1 at dyadic 1..2, kind 0 at dyadic 0..2): also keep, of the grid PADDED to the bands and units of sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64 (padding
+/* Ncp = 2 NUp: columns per dimension row of Yt (zero-padded), the same for sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64. */
+int sk_solve_fwd_static_cols(int kind, int Nc);
+/* edges (nullable; dyadic 0..2, either kind): also keep, of the grid PADDED to the bands and units of sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64 (padding
  * carries no increments), the bottom row of every band of 64 lanes (the last one is the pair's terminal row) and the terminal column
  * -- *edge_doubles (sk_rbf_adjoint_fused_mb_layout) doubles per pair: what that adjoint recomputes K from, band by band.  Mrows must
  * then be the layout's *mrows. */

@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsigkernel_amd.so")
 
 SK_OK = 0
+# sk_route_query: operations and answers (include/sigkernel_amd.h)
+OP_FORWARD, OP_ADJOINT = 0, 1
+ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP = 0, 1, 2, 3
 SCHEME_DEFAULT = 0
 SCHEME_NAIVE = 1
 FLAG_EXACT = 1
@@ -31,6 +34,9 @@ _sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/sigkernel_amd.h one to one
 SIGNATURES = {
     "sk_version": (_int, []),
+    "sk_build_info": (ctypes.c_char_p, []),
+    "sk_route_query": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
+    "sk_solve_fwd_static_cols": (_int, [_int, _int]),
     "sk_reload_knobs": (None, []),
     "sk_linear_prescale": (ctypes.c_double, [_int]),
     "sk_status_string": (ctypes.c_char_p, [_int]),
@@ -270,6 +276,12 @@ class HipBackend:
 
     name = "hip"
 
+    @staticmethod
+    def route(op, kind, D, M, N, dyadic, naive, elem_size):
+        """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP."""
+        return int(load().sk_route_query(int(op), int(kind), int(D), int(M), int(N), int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT,
+                                         int(elem_size)))
+
     def increments(self, G):
         """G [..., M, N] -> inc_c [..., M-1, N-1] (sigkernel.py:217, :363)."""
         _dev(G, "G")
@@ -426,44 +438,43 @@ class HipBackend:
             return None
         return mrows.value, rows.value, outw.value, int(ed.value), int(wsb.value), ncols.value
 
-    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, _swapped=False, keep_edges=False):
+    def solve_fwd_fused_static(self, kind, param, X, Y, dyadic, naive, gram, swap=False, keep_edges=False):
         """K[MM][NN] with the static kernel (kind 0 linear / param = scale, 1 rbf / param = sigma) formed inside the solver, for
         pairs that need several bands of a wavefront and for path dims up to 16 (sk_solve_fwd_static_*, csrc/sk_wave_fused_mb.hip):
-        nothing of size pairs x M x N in HBM.  None outside the kernel's scope (dyadic > 2, dim > 16, naive scheme, second path
-        shorter than ~130 points)."""
+        nothing of size pairs x M x N in HBM; either scheme, any M and N.  None outside the kernel's scope (dyadic > 2, dim > 16).
+        swap: solved as K(y, x) -- the kernel is symmetric in its arguments (both static kernels and the stencil are); what
+        sk_route_query asks for when the second path is the short one.  keep_edges: (K, edges or None)."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if naive or D > 16 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or (kind == 1 and not float(param) > 0):
+        if D > 16 or not 0 <= dyadic <= 2 or Mc < 1 or Nc < 1 or (kind == 1 and not float(param) > 0):
             return None
+        if swap:
+            Kt = self.solve_fwd_fused_static(kind, param, Y, X, dyadic, naive, gram)
+            Kt = None if Kt is None else (Kt.t().contiguous() if gram else Kt)
+            return (Kt, None) if (keep_edges and Kt is not None) else Kt
         lib = load()
         P = A * B if gram else A
         nbytes = int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), D))
         if not nbytes:
-            # the band pipeline needs a second path of ~160 points or more; the kernel is symmetric in its arguments (both static
-            # kernels and the stencil are), so a long first path against a short second one is solved as K(y, x)
-            if _swapped or not int(lib.sk_solve_fwd_static_workspace_bytes(int(kind), P, Nc, Mc, int(dyadic), D)):
-                return None
-            Kt = self.solve_fwd_fused_static(kind, param, Y, X, dyadic, naive, gram, _swapped=True)
-            Kt = None if Kt is None else (Kt.t().contiguous() if gram else Kt)
-            return (Kt, None) if (keep_edges and Kt is not None) else Kt
+            return None
         fd = 8 if D <= 8 else 16
         Mrows = int(lib.sk_solve_fwd_static_rows(int(kind), Mc, int(dyadic)))
         # keep_edges (RBF at dyadic 1..2, Linear): every band's bottom row and the terminal column of every pair, in the layout
         # sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64 read
-        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D, int(kind)) if (keep_edges and not _swapped) else None
+        lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D, int(kind)) if keep_edges else None
         edges = None
         if lay is not None:
             Mrows = lay[0]
             edges = torch.empty(P * lay[3], dtype=torch.float64, device=X.device)
-        NUp = ((Nc + 1 + int(kind)) // 2 + 7) // 8 * 8
-        Ncp = 2 * NUp
+        Ncp = int(lib.sk_solve_fwd_static_cols(int(kind), Nc))      # 2 NUp: short second paths are padded to the band pipeline's minimum
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         with _device(dev):
-            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not routes.no_y32
+            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not routes.no_y32 and dyadic >= 1
             if kind == 0:
                 Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
                 Yt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
@@ -477,11 +488,11 @@ class HipBackend:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             if X.dtype == torch.float32:
                 rc = lib.sk_solve_fwd_static_f32(int(kind), float(param), _ptr(Xr), _ptr(Yt), int(y32), A, B if gram else 0, Mrows, Mc,
-                                                 Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(edges), _ptr(ws), nbytes,
+                                                 Nc, Ncp, D, fd, int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(ws), nbytes,
                                                  _stream(X))
             else:
                 rc = lib.sk_solve_fwd_static_f64(int(kind), float(param), _ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp,
-                                                 D, fd, int(dyadic), SCHEME_DEFAULT, _ptr(out), _ptr(edges), _ptr(ws), nbytes, _stream(X))
+                                                 D, fd, int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(ws), nbytes, _stream(X))
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_static")
@@ -489,7 +500,7 @@ class HipBackend:
 
     FUSED_RESCUE_BLOCKS_MB = 8   # (a stored pair of 2044 x 2044 grids is 67 MB)
 
-    def linear_adjoint_fused_mb(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
+    def linear_adjoint_fused_mb(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel on LONG or WIDE paths
         straight from the paths and the edges solve_fwd_fused_static(0, ..., keep_edges=True) kept (sk_linear_adjoint_fused_mb_f64; fp64
         sweep; dim <= 16, dyadic 0..2, any M, N >= ~160).  None outside that scope."""
@@ -505,7 +516,7 @@ class HipBackend:
         if lay is None or edges.numel() != P * lay[3]:
             return None
         mrows, rows, fd, _, nbytes, _ = lay
-        Ncp = 2 * (((Nc + 1) // 2 + 7) // 8 * 8)
+        Ncp = int(load().sk_solve_fwd_static_cols(0, Nc))
         dev = X.device
         if scale is not None:
             scale = scale.double().contiguous()
@@ -516,7 +527,8 @@ class HipBackend:
             err = torch.zeros(P, dtype=torch.float64, device=dev)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev, self.FUSED_RESCUE_BLOCKS_MB)
-            rc = load().sk_linear_adjoint_fused_mb_f64(_ptr(dXr), _ptr(dYt), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
+            rc = load().sk_linear_adjoint_fused_mb_f64(_ptr(dXr), _ptr(dYt), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic),
+                                                       SCHEME_NAIVE if naive else SCHEME_DEFAULT,
                                                        _ptr(edges), _ptr(scale), _ptr(tpart), tpart.numel(), _ptr(err), _ptr(ws), nbytes, _ptr(kf),
                                                        float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
             if rc == 2:
@@ -531,7 +543,7 @@ class HipBackend:
             g = g * (float(param) ** 2)
         return g.to(X.dtype), _WorstResidual(err)
 
-    def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True, kfinal=None):
+    def rbf_adjoint_fused_mb(self, X, Y, sigma, dyadic, edges, scale, gram=True, kfinal=None, naive=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel on LONG or WIDE paths
         straight from the paths and the terminal edges solve_fwd_fused_static(keep_edges=True) kept: adjoint PDE, node evaluation and
         chain rule in one multi-band kernel (sk_rbf_adjoint_fused_mb_f64; fp64 sweep whatever the dtype of X; dim <= 16, dyadic
@@ -541,7 +553,7 @@ class HipBackend:
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if D > 16 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0 or edges is None:
+        if D > 16 or dyadic not in (0, 1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0 or edges is None:
             return None
         P, Bk = (A * B, B) if gram else (A, 0)
         lay = self._adjoint_mb_layout(P, Mc, Nc, dyadic, D)
@@ -549,13 +561,13 @@ class HipBackend:
             return None
         mrows, rows, outw, _, nbytes, ncols = lay
         fd = outw - 2
-        Ncp = 2 * (((Nc + 2) // 2 + 7) // 8 * 8)
+        Ncp = ncols
         dev = X.device
         if scale is not None:
             scale = scale.double().contiguous()
         with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
-            y32 = fd == 16 and X.dtype == torch.float32 and not routes.no_y32
+            y32 = fd == 16 and X.dtype == torch.float32 and not routes.no_y32 and dyadic >= 1
             if y32:      # fp32 points, two dimensions per 16-byte unit + a row of fp64 norms: half the LDS ring (as the forward)
                 Yt = torch.empty(B, fd // 2 + 1, Ncp, 2, dtype=torch.float32, device=dev)
                 _check(load().sk_prep_paths_f32(_ptr(Y), B, N, D, 0, 2, 1.0, _ptr(Yt), Ncp, fd, _stream(X)), "sk_prep_paths (packed fp32)")
@@ -568,7 +580,8 @@ class HipBackend:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev, self.FUSED_RESCUE_BLOCKS_MB)
             Yt64 = None if rws is None else (_prep_paths(Y, False, True, 1.0, Ncp, fd) if y32 else Yt)
-            rc = load().sk_rbf_adjoint_fused_mb_f64(_ptr(Xr), _ptr(Yt), int(y32), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic), SCHEME_DEFAULT,
+            rc = load().sk_rbf_adjoint_fused_mb_f64(_ptr(Xr), _ptr(Yt), int(y32), A, Bk, mrows, Mc, Nc, Ncp, D, fd, int(dyadic),
+                                                    SCHEME_NAIVE if naive else SCHEME_DEFAULT,
                                                     float(sigma), _ptr(edges), _ptr(scale), _ptr(gpart), gpart.numel(), _ptr(n0), n0.numel(),
                                                     _ptr(err), _ptr(ws), nbytes, _ptr(Yt64), _ptr(kf), float(self.FUSED_SCREEN),
                                                     float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
@@ -587,7 +600,7 @@ class HipBackend:
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), _WorstResidual(err)
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
@@ -613,7 +626,8 @@ class HipBackend:
             # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
             dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
             dYt = _prep_paths(Y, True, True, 1.0, Ncp)
-            args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_DEFAULT, _ptr(edges), _ptr(scale))
+            args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(edges),
+                    _ptr(scale))
             rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), None, 0.0, 0.0, None, 0,
                                                  _stream(X))
             if rc == 2:
@@ -643,7 +657,7 @@ class HipBackend:
         g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
@@ -671,7 +685,8 @@ class HipBackend:
         with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, Mrows)
             Yt = _prep_paths(Y, False, True, 1.0, Ncp)
-            args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_DEFAULT, float(sigma), _ptr(edges), _ptr(scale))
+            args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, float(sigma),
+                    _ptr(edges), _ptr(scale))
             head = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None)
             tail = head + (None, 0.0, 0.0, None, 0, _stream(X))
             rc = lib.sk_rbf_adjoint_fused_f64(*args, None, 0, None, None, 0, *tail)
@@ -720,7 +735,14 @@ class HipBackend:
         (None, None, 0) without forward values or for grids the stored-grid kernel cannot hold."""
         if kfinal is None:
             return None, None, 0
-        nbytes = int(load().sk_fused_rescue_workspace_bytes(int(kind), P, Mc, Nc, int(dyadic), blocks or self.FUSED_RESCUE_BLOCKS))
+        blocks = int(blocks or self.FUSED_RESCUE_BLOCKS)
+        q = load().sk_fused_rescue_workspace_bytes
+        nbytes = int(q(int(kind), P, Mc, Nc, int(dyadic), blocks))
+        # the workspace holds `blocks` pairs of stored fine grids: bounded like the unfused route's scratch (a long second path
+        # would otherwise ask for tens of GB per backward call); fewer blocks only make the -- rare -- rescue less concurrent
+        while nbytes > self.GRID_SCRATCH_BYTES and blocks > 1:
+            blocks = max(1, blocks // 2)
+            nbytes = int(q(int(kind), P, Mc, Nc, int(dyadic), blocks))
         if not nbytes:
             return None, None, 0
         kf = kfinal.detach().reshape(-1).double().contiguous()

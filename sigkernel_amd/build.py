@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, "libsigkernel_amd.so")
 
 
 def build(force=False, verbose=False):
-    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode:
         print(res.stdout)

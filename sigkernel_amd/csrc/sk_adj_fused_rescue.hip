@@ -41,6 +41,7 @@ struct FusedRescueParams {
     double *Ypart;             // rbf, nullable: [P][ycols][6]
     int64_t A, B, P, n_groups;
     int Mrows, Ncp, Mc, Nc, D, dyadic, rows, outw, ycols;
+    int naive;                 // _naive_solver stencil (cython_backend.pyx:114)
     int fd;                    // dims carried by Xs / Ys (8; 8 or 16 for sk_wave_adj_fused_mb.hip)
     double *N0;                // sk_wave_adj_fused_mb.hip, nullable: [P][n0cols] node row 0 weights of the sweep, cleared for a failed pair
     int n0cols;
@@ -85,7 +86,7 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
         }
     }
     __syncthreads();
-    adj_pair<double>(inc, Nc, Mc, Nc, d, 0, lds, Kf, Kr, nullptr, W, Nc);
+    adj_pair<double>(inc, Nc, Mc, Nc, d, prm.naive, lds, Kf, Kr, nullptr, W, Nc);
     if (prm.kind == 0) {
         // T[a][pp][k] += s sum_q W[pp][q] dy[q][k], kept at flipped row rows - 1 - pp (sk_wave_adj_fused.hip)
         for (int c = lane; c < Mc * fd; c += WAVE) {
@@ -259,6 +260,7 @@ int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const doub
     FusedRescueParams prm;
     prm.kind = kind; prm.Xs = Xs; prm.Ys = Ys; prm.scale = scale; prm.err = err; prm.tol = tol; prm.part = part; prm.Ypart = ypart;
     prm.A = A; prm.B = B; prm.P = g.P; prm.n_groups = n_groups; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.D = D;
+    prm.naive = g.naive;
     prm.dyadic = g.dyadic; prm.rows = rows; prm.outw = outw; prm.ycols = ycols; prm.inv_sigma = inv_sigma; prm.cs = cs;
     prm.ws = (double *)ws; prm.ws_block = (int64_t)(per_block / sizeof(double));
     prm.fd = fd; prm.N0 = n0; prm.n0cols = n0cols;

@@ -1,0 +1,63 @@
+// sk_route.hip -- ONE place that says which kernel family serves a call (host code only; no device work, no HIP call).
+//
+// The host layer (sigkernel_amd/sigkernel.py), the launchers in this library and DESIGN.md used to carry three copies of the
+// scope rules; sk_route_query is now the only one the host layer consults, tests/test_abi.py pins it against a table, and a GPU
+// test (tests/test_routes.py) checks that every launcher honours what it says: a FUSED / FUSED_MB answer means the launch
+// succeeds and nothing of size pairs x M x N is ever allocated.
+//
+// The rules (kind 0 = exactly LinearKernel, 1 = exactly RBFKernel with sigma > 0; M, N = points of the two paths; D = path
+// dimension; d = dyadic order; either stencil -- the _naive_solver one is a launch-time constant of every fused kernel):
+//
+//   forward (SK_OP_FORWARD: sigkernel.py:216-234, :362-382)
+//     FUSED      one band per pair, path dim <= 8 (csrc/sk_wave_fused.hip):  rows <= 64 RC (RC = 4 / 2 / 1 coarse rows per lane at
+//                d = 0 / 1 / 2; rows = M - 1 linear, M rbf);  rbf at d = 0: only dim <= 4, default stencil, fp64 (the 8-dim variants
+//                spill registers)
+//     FUSED_MB   any number of bands, path dim <= 16, any M, N (csrc/sk_wave_fused_mb.hip); _SWAP: solved as k(y, x) -- the kernel
+//                and both static kernels are symmetric -- when that orientation sweeps at most 80 % of the macro-steps
+//     STREAM     everything else (dim > 16, d > 2, other static kernels): static kernel -> increments in HBM -> sk_solve_fwd_*
+//
+//   adjoint (SK_OP_ADJOINT: sigkernel.py:257-343, :404-502; the forward of a call with a gradient pending keeps the edges of the
+//   SAME family: sk_solve_fwd_{linear,rbf}_edges_f64 for FUSED, sk_solve_fwd_static_* with edges for FUSED_MB)
+//     FUSED      linear: dim <= 8, M - 1 <= 128 (64 at d = 2) (csrc/sk_wave_adj_fused.hip);
+//                rbf: dim <= 4, d = 1..2, M <= 128 / 64, N - 1 not a multiple of 16 (csrc/sk_wave_adj_fused_rbf.hip; its 8-dim
+//                variants spill and lose)
+//     FUSED_MB   dim <= 16, d = 0..2, any M, N (csrc/sk_wave_adj_fused_mb.hip); never swapped (the gradient is the first argument's)
+//     STREAM     everything else: sk_static_increments -> sk_solve_adj -> sk_static_adjoint (or the generic vector-Jacobian route)
+#include "sk_internal.h"
+
+namespace sk {
+
+namespace {
+constexpr int MB_MIN_UNITS = 80;   // units per band of the multi-band kernels (sk_wave_fused_mb.hip: MB_L + 16)
+
+inline int rc_of(int d) { return d == 0 ? 4 : d == 1 ? 2 : 1; }
+// macro-steps per pair of the multi-band forward: bands x units per band
+inline long mb_steps(int kind, int Mc, int Nc, int d) {
+    const int nb = (Mc + 64 * rc_of(d) - 1) / (64 * rc_of(d));
+    int nup = ((kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2) + 7) / 8 * 8;
+    if (nup < MB_MIN_UNITS) nup = MB_MIN_UNITS;
+    return (long)nb * nup;
+}
+}  // namespace
+
+int route_query(int op, int kind, int D, int M, int N, int d, int naive, int elem_size) {
+    if ((kind != 0 && kind != 1) || D < 1 || D > 16 || M < 2 || N < 2 || d < 0 || d > 2) return SK_ROUTE_STREAM;
+    if (elem_size != 8 && elem_size != 4) return SK_ROUTE_STREAM;
+    const int Mc = M - 1, Nc = N - 1;
+    if (op == SK_OP_FORWARD) {
+        const int rows = kind == 1 ? M : Mc;
+        bool one_band = D <= 8 && rows <= 64 * rc_of(d);
+        if (kind == 1 && d == 0 && (D > 4 || naive || elem_size != 8)) one_band = false;
+        if (one_band) return SK_ROUTE_FUSED;
+        return 5 * mb_steps(kind, Nc, Mc, d) <= 4 * mb_steps(kind, Mc, Nc, d) ? SK_ROUTE_FUSED_MB_SWAP : SK_ROUTE_FUSED_MB;
+    }
+    if (op == SK_OP_ADJOINT) {
+        if (kind == 0 && D <= 8 && Mc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED;
+        // (rbf: node column 2 NUp of the strip layout must be padding -- N - 1 a multiple of 16 has none)
+        if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d) && Nc % 16 != 0) return SK_ROUTE_FUSED;
+        return SK_ROUTE_FUSED_MB;
+    }
+    return SK_ROUTE_STREAM;
+}
+
+}  // namespace sk

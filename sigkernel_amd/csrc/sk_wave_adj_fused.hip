@@ -34,6 +34,7 @@ struct AdjFusedParams {
     ChunkSplit cs;         // chunk sizes by wave age rank; PPG / n_steps are the equal split's
     int E;                 // doubles per pair in `edges`
     WaveGroup wg;
+    int naive;             // _naive_solver stencil: c_12 = 0 (a = 1 + g/2, b = 1 exactly; see sk_wave_fused_mb.hip)
 };
 
 __device__ __forceinline__ void lds_read_dims8(d2_t (&v)[8], unsigned a_even, unsigned a_odd) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     const unsigned y_bytes = (unsigned)(NSLAB * Y_SLAB_PITCH);
     const unsigned x_base0 = (unsigned)G * y_bytes;
     const double sc = 1.0 / (double)(1 << (2 * DY));
-    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double c_half = 0.5 * sc, c_12 = prm.naive ? 0.0 : sc * sc / 12.0;
 
     // ---- consumer state (flipped coordinates; one band per pair) ---------------------------------------------------------
     int u, ps;
@@ -446,7 +447,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
                                  int *ppg_out, int *rows_out, int64_t *rows_per_launch, int64_t *epair, int64_t force_nch,
                                  const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes, hipStream_t s) {
     const int DY = g.dyadic;
-    if (DY > 2 || B < 0 || g.naive || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    if (DY > 2 || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
     // dyadic 0: the strip kernels give a lane four coarse rows; with the two 4 x 8 register arrays of this kernel that is
@@ -497,6 +498,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.PPG = (int)PPG;
     prm.E = st.NNp + st.MMp;
+    prm.naive = g.naive;
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.wg = wave_group(lds_bytes, waves, knobs().adjf_wpb);
     prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), knobs().adjf_rank_w);

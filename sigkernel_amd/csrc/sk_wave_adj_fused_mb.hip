@@ -20,7 +20,8 @@
 //     completed during the first macro-step of the next one (sk_wave_adj_fused_rbf.hip), and that part still belongs to the
 //     rows being left.  The caller adds the pairs of an x_a.
 //
-// Scope: fp64 sweep, dyadic 1..2, path dim <= 16, N - 1 <= 2 NUp - 1 with NUp >= 80 units, any M (M + 1 <= 64 RC nb).
+// Scope: fp64 sweep, dyadic 0..2 (at 0 two coarse rows per lane, bands of 128 rows: k_fwd_fused_mb keeps its edges in that layout),
+// path dim <= 16, either stencil, any M and N (second paths shorter than ~160 points are swept with masked padding units: NUp >= 80).
 // Replaces, for RBFKernel on long or wide paths, sk_static_increments + sk_solve_fwd(EDGES) + sk_solve_adj + sk_static_adjoint,
 // i.e. sigkernel.py:419-502 (prep_backward) + :404-416.
 #include "sk_wave_common.h"
@@ -51,6 +52,7 @@ struct AdjMbParams {
     unsigned long long *queue;   // the launch's counter (zeroed by the launcher; behind the boundary rows), nullptr: equal static shares
     int64_t q_first;
     int C0;
+    int naive;             // _naive_solver stencil: c_12 = 0 (a = 1 + g/2, b = 1 exactly; see sk_wave_fused_mb.hip)
 };
 
 __device__ __forceinline__ void amb_store_through(double *p, d2_t v) {
@@ -109,7 +111,7 @@ template <int DY, int RC, int FD, bool Y32>
 __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD == 16 && (DY == 1 || !Y32)) ? 1 : 2))) void k_adj_fused_rbf_mb(const AdjMbParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY;
-    static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
+    static_assert(R == 4 || R == 2, "the column-edge reads below take R + 1 doubles out of R / 2 + 1 aligned 16-byte pieces");
     constexpr int L = AMB_L;
     constexpr int XROW = FD * 8, PPR = FD / 2;     // bytes / 16-byte pieces of one x row
     // one x window slab: [the x points of the node rows of the 8 lanes that start a band during the window]
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
     const int MMp = Mcp << DY, NNp = (NUp * CW) << DY;
     const int EE = nb * NNp + MMp;   // edge doubles per pair
     const double sc = 1.0 / (double)(1 << (2 * DY));
-    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double c_half = 0.5 * sc, c_12 = prm.naive ? 0.0 : sc * sc / 12.0;
     const double two_inv_sigma = 2.0 * prm.inv_sigma;
     const bool is_bot = lam == L - 1;
     const int lam7 = lam & 7;
@@ -439,13 +441,20 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
                     xsn[k] = -q2 * prm.inv_sigma;
                 }
             }
-            double col[6];
+            double col[R + 2];
             {
-                d2_t c3[3];
                 const unsigned ca_ = my_col + x_rd;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
-                col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+                if constexpr (R == 4) {
+                    d2_t c3[3];
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
+                    col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+                } else {
+                    d2_t c2[2];
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c2[0]), "=&v"(c2[1]) : "v"(ca_) : "memory");
+                    col[0] = c2[0][0]; col[1] = c2[0][1]; col[2] = c2[1][0]; col[3] = c2[1][1];
+                }
             }
             // col[1 + m] = K[MMp - gl R - R + m][NN], m = 0..R: the lane's fine rows bottom to top; K[0][NN] = 1 is not stored
             cornerR = 1.0;
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(FD == 
     const int MMp = Mcp << DY, NNp = (NUp * CW) << DY;
     const int EE = nb * NNp + MMp;
     const double sc = 1.0 / (double)(1 << (2 * DY));
-    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double c_half = 0.5 * sc, c_12 = prm.naive ? 0.0 : sc * sc / 12.0;
     const bool is_bot = lam == L - 1;
     const int lam7 = lam & 7;
 
@@ -1175,16 +1184,16 @@ struct AmbPlan {
 AmbPlan amb_plan(int Mc, int Nc, int dyadic, int D, bool y32 = false, int kind = 1) {
     AmbPlan pl{};
     pl.ok = false;
-    if (dyadic < (kind == 1 ? 1 : 0) || dyadic > 2 || D < 1 || D > 16) return pl;
-    pl.RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
+    if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16) return pl;
+    pl.RC = dyadic == 0 ? (kind == 1 ? 2 : 4) : dyadic == 1 ? 2 : 1;   // (rbf at dyadic 0: two rows per lane -- four would need > 256 registers)
     pl.S = 2 << dyadic;
     pl.fd = D <= 8 ? 8 : 16;
     const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;  // the forward's units (sk_wave_fused_mb.hip: mb_plan)
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
-    if (pl.NUp < AMB_L + 16) return pl;                      // band boundary slack
+    if (pl.NUp < AMB_L + 16) pl.NUp = AMB_L + 16;            // band boundary slack: shorter second paths are swept with (masked) padding units
     // rbf: the node rows must fit the lanes (the first lane-row is padding); linear: the coarse rows
     pl.nb = (Mc + (kind == 1 ? 1 : 0) + AMB_L * pl.RC - 1) / (AMB_L * pl.RC);
-    const int R = 4, E = kind == 1 ? pl.S + 4 : pl.S;
+    const int R = pl.RC << dyadic, E = kind == 1 ? pl.S + 4 : pl.S;
     const size_t xslab = ((size_t)8 * pl.RC * pl.fd * 8 + (4 * R + 1) * 16 + 16 + 63) / 64 * 64;
     pl.lds_bytes = (size_t)(AMB_L / 8 + 2) * ((y32 ? pl.fd / 2 + 1 : pl.fd) * 128) + AMB_X_SLOTS * xslab + (size_t)3 * 8 * E * 8 + (size_t)2 * (4 * pl.S + 1) * 16;
     pl.ws_stride = (int64_t)(pl.NUp + 8) * E;
@@ -1266,7 +1275,7 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
                             double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *n0,
                             size_t n0_doubles, double *err, void *ws, size_t ws_bytes, const FusedRescue *rescue, const double *Yt64,
                             hipStream_t s) {
-    if (g.naive || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    if (B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const double *Yt = static_cast<const double *>(Yt_any);
     const bool y32 = yt_f32 != 0;
     const AmbPlan pl = amb_plan(g.Mc, g.Nc, g.dyadic, D, y32);
@@ -1279,6 +1288,7 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
     prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.N0 = n0; prm.err = err;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb;
     prm.inv_sigma = inv_sigma;
+    prm.naive = g.naive;
     // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN: the
     // sweep stores zeros for them), and their exact, stored-grid share is added to gpart afterwards -- one pair per chunk here
     void *rws = nullptr;
@@ -1295,7 +1305,9 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
         }
     }
     int rc;
+    if (y32 && g.dyadic == 0) return SK_ERR_UNSUPPORTED;
     if (y32) rc = g.dyadic == 1 ? launch_amb<1, 2, 16, true>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16, true>(prm, pl, ws, ws_bytes, s);
+    else if (g.dyadic == 0) rc = pl.fd == 8 ? launch_amb<0, 2, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<0, 2, 16>(prm, pl, ws, ws_bytes, s);
     else if (g.dyadic == 1) rc = pl.fd == 8 ? launch_amb<1, 2, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<1, 2, 16>(prm, pl, ws, ws_bytes, s);
     else rc = pl.fd == 8 ? launch_amb<2, 1, 8>(prm, pl, ws, ws_bytes, s) : launch_amb<2, 1, 16>(prm, pl, ws, ws_bytes, s);
     if (rc != SK_OK || !rws) return rc;
@@ -1310,7 +1322,7 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
 int launch_adj_fused_linear_mb(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, int fd, const Geom &g,
                                const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err, void *ws,
                                size_t ws_bytes, const FusedRescue *rescue, hipStream_t s) {
-    if (g.naive || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    if (B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const AmbPlan pl = amb_plan(g.Mc, g.Nc, g.dyadic, D, false, 0);
     if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
     if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < pl.nb * AMB_L * pl.RC) return SK_ERR_UNSUPPORTED;
@@ -1321,6 +1333,7 @@ int launch_adj_fused_linear_mb(const double *dXr, const double *dYt, int64_t A, 
     prm.Xr = dXr; prm.Yt = dYt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.N0 = nullptr; prm.err = err;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb;
     prm.inv_sigma = 0.0;
+    prm.naive = g.naive;
     void *rws = nullptr;
     size_t rws_bytes = 0;
     if (rescue && rescue->ws) {

@@ -62,6 +62,7 @@ struct AdjRbfParams {
     ChunkSplit cs;         // chunk sizes by wave age rank; PPG / n_steps are the equal split's
     double inv_sigma;
     WaveGroup wg;
+    int naive;             // _naive_solver stencil: c_12 = 0 (a = 1 + g/2, b = 1 exactly; see sk_wave_fused_mb.hip)
 };
 
 template <int ND>
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     const unsigned y_bytes = (unsigned)(NSLAB * RY_SLAB);
     const unsigned x_base0 = (unsigned)G * y_bytes;
     const double sc = 1.0 / (double)(1 << (2 * DY));
-    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double c_half = 0.5 * sc, c_12 = prm.naive ? 0.0 : sc * sc / 12.0;
 
     // ---- consumer state (flipped coordinates; one band per pair) ---------------------------------------------------------
     int u, ps;
@@ -627,7 +628,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
                               int64_t force_nch, const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes,
                               hipStream_t s) {
     const int DY = g.dyadic;
-    if (DY < 1 || DY > 2 || B < 0 || g.naive || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    if (DY < 1 || DY > 2 || B < 0 || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges; the sweep uses the same lanes and units
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
     const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
@@ -681,6 +682,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     AdjRbfParams prm;
     prm.Xr = Xr; prm.Yt = Yt; prm.edges = edges; prm.scale = scale; prm.Gpart = gpart; prm.err = err; prm.Ypart = ypart;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
+    prm.naive = g.naive;
     prm.PPG = (int)PPG;
     prm.inv_sigma = inv_sigma;
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + 1;    // + 1: node column 0 of the last pair completes one step later

@@ -25,8 +25,10 @@
 //     row 0 of the pair -- evaluates it itself: a divergent branch that the wave pays for 1 / nb of the time.
 //   * FD = 16 dimensions (zero-padded), two LDS-DMA instructions per y slab.
 //
-// Scope: dyadic <= 2, path dim <= 16, N <= 2 NUp with NUp >= 80 units (a chunk must be flushed and acknowledged before the
-// window that consumes it is fetched: NUp - 63 >= 17 macro-steps), any M.  Shorter second paths with long first paths: the caller swaps the arguments (the kernel is symmetric).
+// Scope: dyadic <= 2, path dim <= 16, either stencil, any M and N.  A pair's stream has NUp >= 80 units per band (a chunk must be
+// flushed and acknowledged before the window that consumes it is fetched: NUp - 63 >= 17 macro-steps; and at most one row unit may
+// start per window): second paths shorter than ~160 points are swept with padding units behind them (wasted steps, same result --
+// the caller may swap the arguments when the first path is the longer one: the kernel is symmetric).
 // Replaces, for LinearKernel / RBFKernel on long or wide paths, static_kernels.py:26-33 / :58-73 + sigkernel.py:362-382.
 #include "sk_wave_common.h"
 
@@ -55,6 +57,7 @@ struct FusedMbParams {
     unsigned long long *queue;   // the launch's counter (zeroed by the launcher; inside the workspace), nullptr: equal static shares
     int64_t q_first;
     int C0;
+    int naive;          // _naive_solver stencil (cython_backend.pyx:114): the g^2 / 12 terms drop out of both coefficients
 };
 
 // 16-byte asynchronous global load past the L1 (sc0 sc1: the line was written by another lane of this wave a few
@@ -174,14 +177,18 @@ __device__ __forceinline__ void lds_pend_take(d2_t (&o)[NP], d2_t (&t)[NP]) { as
 // products are exact in fp64 and the cancellation costs nothing the inputs could resolve; the fp64-ring variants keep the
 // direct sum over (x - y)^2.  The slab pitch (9 x 128 bytes) is an odd multiple of 128, so lanes 8 apart (same unit of
 // neighbouring slabs) hit different halves of the bank row without the parity swizzle of the fp64 ring.
-template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES>
+// RCX: coarse rows per lane; the strip kernels' Tile<DY>::RC, except for the RBF edges at dyadic 0, which are kept for
+// k_adj_fused_rbf_mb<0, 2, ..> (two rows per lane there: four would need > 256 registers) in ITS bands of 128 rows
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES, int RCX = Tile<DY>::RC>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams prm) {
-    constexpr bool NAIVE = false;   // the _naive_solver scheme is not built for this kernel
+    // The _naive_solver stencil (k10 + k01)(1 + g/2) - k00 is the default one with c_12 = 0: a = 1 + g/2 + 0 g^2 and b = 1 - 0 g^2 = 1
+    // exactly (finite g), so diag * b = diag -- a launch-time constant instead of a second set of kernel variants
+    constexpr bool NAIVE = false;
     constexpr int FDY = Y32 ? FD / 2 : FD;   // rows of a y slab
     constexpr bool RBF = KIND == 1;
     constexpr int LAG = RBF ? 1 : 0;   // macro-steps by which the block sweep trails the node evaluation
     constexpr int CW = 2;
-    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int RC = RCX, R = RCX << DY, S = CW << DY, r = 1 << DY;
     constexpr int L = MB_L;
     constexpr int XROW = FD * 8;              // bytes of one x row
     constexpr int XSLAB = 8 * RC * XROW;      // the rows of 8 lanes
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     const int lam = threadIdx.x & (WAVE - 1);
     const int NUp = prm.NUp, nb = prm.nb;
     const double sc = 1.0 / (double)(1 << (2 * DY));
-    const double c_half = 0.5 * sc, c_12 = sc * sc / 12.0;
+    const double c_half = 0.5 * sc, c_12 = prm.naive ? 0.0 : sc * sc / 12.0;
     const double two_inv_sigma = 2.0 * prm.inv_sigma;
     const bool is_top = lam == 0, is_bot = lam == L - 1;
 
@@ -701,9 +708,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false>
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false, int RCX = Tile<DY>::RC>
 int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD, EDGES>;
+    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD, EDGES, RCX>;
     // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
     // thread-safely, at the variant's first launch -- not mutable library state)
     static const int vgprs = [&] {
@@ -754,12 +761,14 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bo
     MbPlan pl{};
     pl.ok = false;
     if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16 || (kind != 0 && kind != 1)) return pl;
-    pl.RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
+    pl.RC = dyadic == 0 ? (kind == 1 && edges ? 2 : 4) : dyadic == 1 ? 2 : 1;   // (rbf edges at dyadic 0: the adjoint's two rows per lane)
     pl.S = 2 << dyadic;
     pl.fd = D <= 8 ? 8 : 16;
     const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
     pl.NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
-    if (pl.NUp < MB_L + 16) return pl;                      // band boundary slack (see the header)
+    // band boundary slack, and at most one row unit starting per window (see the header): a shorter second path is swept with
+    // padding units behind it -- causality keeps K[MM][NN] what it is, the EDGES variant masks the padding's increments
+    if (pl.NUp < MB_L + 16) pl.NUp = MB_L + 16;
     pl.nb = (Mc + (edges && kind == 1 ? 1 : 0) + MB_L * pl.RC - 1) / (MB_L * pl.RC);   // edges: the bands of sk_wave_adj_fused_mb.hip (rbf: node rows)
     const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
     const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
@@ -779,12 +788,17 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bo
 template <typename TO, int DY, int KIND>
 int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y32, int64_t P, double *ws, size_t ws_bytes,
                  hipStream_t s) {
-    if (naive) return SK_ERR_UNSUPPORTED;   // the _naive_solver scheme is not built for this kernel (streaming route instead)
+    (void)naive;   // (a launch-time constant of the kernel: FusedMbParams::naive)
     if (prm.edges) {   // with the edges: what sk_rbf_adjoint_fused_mb_f64 (dyadic 1..2) / sk_linear_adjoint_fused_mb_f64 sweep
         if constexpr (KIND == 0) {
             if (y32) return SK_ERR_UNSUPPORTED;
             if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
             return launch_mb_one<TO, DY, false, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+        }
+        if constexpr (KIND == 1 && DY == 0) {
+            if (y32) return SK_ERR_UNSUPPORTED;
+            if (pl.fd == 8) return launch_mb_one<TO, 0, false, KIND, 8, true, 2>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+            return launch_mb_one<TO, 0, false, KIND, 16, true, 2>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
         }
         if constexpr (KIND == 1 && DY >= 1) {
             if (y32) {
@@ -818,9 +832,16 @@ size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic,
     const int64_t waves = P < max_waves ? P : max_waves;
     return (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the launch's work counter
 }
+// columns (Ncp = 2 NUp) the caller must provide per dimension row of Yt: the units of a band incl. the padding of short second paths
+int fused_mb_cols(int kind, int Nc) {
+    const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
+    int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
+    if (NUp < MB_L + 16) NUp = MB_L + 16;
+    return 2 * NUp;
+}
 // rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
 int fused_mb_rows(int kind, int Mc, int dyadic, bool edges) {
-    const int RC = dyadic == 0 ? 4 : dyadic == 1 ? 2 : 1;
+    const int RC = dyadic == 0 ? (kind == 1 && edges ? 2 : 4) : dyadic == 1 ? 2 : 1;
     const int nb = (Mc + (edges && kind == 1 ? 1 : 0) + MB_L * RC - 1) / (MB_L * RC);
     return nb * MB_L * RC + 8;
 }
@@ -838,6 +859,7 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f
     FusedMbParams prm{};
     prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.edges = edges; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb; prm.inv_sigma = inv_sigma; prm.ws_stride = pl.ws_stride;
+    prm.naive = g.naive;
     const int row_unit = (g.Mc - 1) / pl.RC;      // lane-row that holds the last coarse row
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = row_unit % MB_L;

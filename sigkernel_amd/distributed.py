@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .sigkernel import (_SigKernelGram, _budget, _fused_linear_adjoint_ok, _fused_static, _gram_block, _sym_fused_gradient,
+from .sigkernel import (_SigKernelGram, _budget, _fused_static, _gram_block, _sym_fused_gradient, _sym_triangle_ok,
                         _sym_unfused_gradient, k_kgrad)
 
 __all__ = ["row_range", "sharded_gram", "ShardedGram", "ShardedSymGram", "sharded_kgrad"]
@@ -207,9 +207,7 @@ def sharded_gram(sigkernel, X, Y, sym=False, group=None):
     be = _lib.get_backend()
     sk = sigkernel.static_kernel
     if (sym and same and X.requires_grad and dist.get_world_size(group) > 1 and X.shape[0] >= 2 and X.shape[1] >= 2
-            and _fused_static(sk, True) is not None and hasattr(be, "static_adjoint2")
-            and not _fused_linear_adjoint_ok(be, sk, X, Y, sigkernel.dyadic_order, sigkernel._naive_solver, True)
-            and X.shape[2] <= 32):
+            and _sym_triangle_ok(be, sk, X.detach(), sigkernel.dyadic_order, sigkernel._naive_solver)):
         # the triangle WITH a gradient: folded row blocks, second-argument sums, one all-reduce of the gradient
         return ShardedSymGram.apply(X, sk, sigkernel.dyadic_order, sigkernel._naive_solver, sigkernel.workspace_bytes, group)
     return ShardedGram.apply(X, Y, sk, sigkernel.dyadic_order, sym, sigkernel._naive_solver,

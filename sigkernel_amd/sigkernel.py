@@ -48,27 +48,54 @@ def _fused_static(static_kernel, gram):
     return None
 
 
+STREAM, FUSED, FUSED_MB, FUSED_MB_SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
+OP_FORWARD, OP_ADJOINT = _lib.OP_FORWARD, _lib.OP_ADJOINT
+
+
+def _route(be, op, static_kernel, Xd, Yd, dyadic, naive, gram):
+    """Which kernel family serves the call: the library's own answer (sk_route_query, csrc/sk_route.hip -- the one statement of the
+    fused kernels' scope) for exactly LinearKernel / exactly RBFKernel, STREAM for every other static kernel; then the route
+    switches (`sigkernel_amd.routes`: A/B measurements and the tests that compare a fused route with the streaming one)."""
+    fused = _fused_static(static_kernel, gram)
+    if fused is None or not hasattr(be, "route"):
+        return STREAM
+    if (fused[0] == 1 and routes.no_fused_rbf) or (op == OP_ADJOINT and routes.no_fused_adjoint):
+        return STREAM
+    r = be.route(op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, naive, Xd.element_size())
+    if r in (FUSED_MB, FUSED_MB_SWAP) and routes.no_fused_mb:
+        return STREAM
+    return r
+
+
 def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=False):
-    """Whole forward in one kernel when the static kernel is exactly LinearKernel or exactly RBFKernel and the shape fits:
-    the increments are formed inside the solver.  Single-band pairs of path dim <= 8: sk_solve_fwd_linear_* /
-    sk_solve_fwd_rbf_*; several bands per pair or dims up to 16 (no edges): sk_solve_fwd_static_*.  None otherwise.
-    keep_edges: (K, edges)."""
+    """Whole forward in one kernel when sk_route_query says so (exactly LinearKernel / RBFKernel, dim <= 16, dyadic <= 2): the
+    increments are formed inside the solver.  FUSED: sk_solve_fwd_linear_* / sk_solve_fwd_rbf_*; FUSED_MB (several bands per pair,
+    wide paths): sk_solve_fwd_static_*.  None otherwise.  keep_edges (a gradient is pending): (K, edges) -- the edges of the family
+    the ADJOINT route names, None when that adjoint forms its own (fp32 paths) or streams."""
+    fused = _fused_static(static_kernel, gram)
+    if fused is None or not hasattr(be, "route"):      # (the tests' oracle-backed back-end has no fused kernels: it streams)
+        return None
+    kind, param = fused
     Xd, Yd = Xd.contiguous(), Yd.contiguous()
-    res, kind = None, None
-    if type(static_kernel) is LinearKernel and hasattr(be, "solve_fwd_fused_linear"):
-        kind, param = 0, (1.0 if gram else float(static_kernel.scale))
-        res = be.solve_fwd_fused_linear(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
-    elif (type(static_kernel) is RBFKernel and hasattr(be, "solve_fwd_fused_rbf") and float(static_kernel.sigma) > 0
-            and not routes.no_fused_rbf):
-        kind, param = 1, float(static_kernel.sigma)
-        res = be.solve_fwd_fused_rbf(Xd, Yd, param, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
-    if res is None and kind is not None and hasattr(be, "solve_fwd_fused_static") and not routes.no_fused_mb:
-        # several bands per pair / wide paths: the multi-band fused kernel.  It keeps no edges: with a gradient pending the values
-        # still come from it (nothing of size pairs x M x N in HBM) and the adjoint sweeps forward by itself later
-        # (with a gradient pending: RBF at dyadic 1..2 keeps the edges sk_rbf_adjoint_fused_mb_f64 reads; otherwise none, and the
-        # adjoint sweeps forward by itself later)
-        res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, **({"keep_edges": True} if keep_edges else {}))
-    return res
+    one_band = be.solve_fwd_fused_linear if kind == 0 else be.solve_fwd_fused_rbf
+    if keep_edges:
+        ra = _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic, naive, gram)
+        res = None
+        if ra == FUSED:
+            res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
+        elif ra == FUSED_MB:
+            res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, keep_edges=True)
+        if res is not None:
+            return res
+    rf = _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, gram)
+    res = None
+    if rf == FUSED:
+        res = one_band(Xd, Yd, param, dyadic, naive, gram)
+    elif rf in (FUSED_MB, FUSED_MB_SWAP):
+        res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, swap=rf == FUSED_MB_SWAP)
+    if res is None:
+        return None
+    return (res, None) if keep_edges else res
 
 
 def _increments(be, static_kernel, Xd, Yd, gram):
@@ -83,38 +110,14 @@ def _increments(be, static_kernel, Xd, Yd, gram):
     return be.increments(G)
 
 
-def _fused_linear_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_linear_adjoint_fused_f64 covers the case: exactly LinearKernel, default scheme, dyadic <= 2, path dim <= 8,
-    at most 128 increments per path (64 at dyadic 2); Gram or paired; fp32 inputs are swept in fp64 (the kernel itself has the last word: it returns
-    `unsupported` otherwise)."""
-    return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused") and not naive
-            and X.shape[2] <= 8 and dyadic in (0, 1, 2)
-            and X.shape[1] - 1 <= (64 if dyadic == 2 else 128) and Y.shape[1] >= 2 and not routes.no_fused_adjoint)
-
-
-def _fused_rbf_adjoint_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_rbf_adjoint_fused_f64 is worth trying: exactly RBFKernel, default scheme, dyadic 1..2, path dim <= 4 (the 8-dim
-    variants spill registers and lose to the unfused route), one band per pair (the kernel has the last word: `unsupported`
-    for the shapes whose node rows / columns do not fit its lanes and units)."""
-    return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused") and not naive and float(static_kernel.sigma) > 0
-            and X.shape[2] <= 4 and dyadic in (1, 2) and X.shape[1] <= 64 * (4 >> dyadic) and Y.shape[1] >= 2
-            and not routes.no_fused_adjoint and not routes.no_fused_rbf)
-
-
-def _fused_rbf_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_rbf_adjoint_fused_mb_f64 is worth trying: exactly RBFKernel, default scheme, dyadic 1..2, path dim <= 16, a second
-    path long enough for the band pipeline (the kernel has the last word)."""
-    return (type(static_kernel) is RBFKernel and hasattr(be, "rbf_adjoint_fused_mb") and not naive and float(static_kernel.sigma) > 0
-            and X.shape[2] <= 16 and dyadic in (1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
-            and not routes.no_fused_adjoint and not routes.no_fused_rbf and not routes.no_fused_mb)
-
-
-def _fused_linear_adjoint_mb_ok(be, static_kernel, X, Y, dyadic, naive, gram):
-    """Whether sk_linear_adjoint_fused_mb_f64 is worth trying: exactly LinearKernel, default scheme, dyadic <= 2, path dim <= 16, a
-    second path long enough for the band pipeline (the kernel has the last word)."""
-    return (type(static_kernel) is LinearKernel and hasattr(be, "linear_adjoint_fused_mb") and not naive
-            and X.shape[2] <= 16 and dyadic in (0, 1, 2) and Y.shape[1] >= 160 and X.shape[1] >= 2
-            and not routes.no_fused_adjoint and not routes.no_fused_mb)
+def _mb_pair_bytes(be, kind, Xd, Yd, dyadic):
+    """Bytes per pair of what the multi-band fused routes hold in HBM: the edges sk_solve_fwd_static_* keeps (every band's bottom
+    row and the terminal column), the adjoint's partial sums and its node-row-0 weights."""
+    lay = be._adjoint_mb_layout(1, Xd.shape[1] - 1, Yd.shape[1] - 1, dyadic, Xd.shape[2], kind)
+    if lay is None:
+        return None
+    _, rows, outw, edge_doubles, _, ncols = lay
+    return 8 * (edge_doubles + rows * outw + ncols) + 64
 
 
 def _upcast_tile(X, dyadic):
@@ -152,37 +155,38 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
     return g
 
 
-def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals=None):
-    """dL/dX for all rows through the fused adjoints -- sk_linear_adjoint_fused_f64 / sk_rbf_adjoint_fused_f64: adjoint PDE and
-    the static kernel's chain rule in one kernel, from the paths and the forward's terminal edges; no matrix of size pairs x M x N
-    -- one launch per row tile.  None when the kernel does not cover the case (the caller then takes the unfused route, tiled by
-    ITS transient memory).  Exploding kernels are the library's business: with the forward values (Kvals, or what the forward
-    re-run here returns) the launch takes such pairs out of the sweep and adds their exact, stored-grid share on the device
-    (csrc/sk_adj_fused_rescue.hip) -- nothing is read back, a backward pass has no host synchronisation."""
+def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals=None, route=FUSED):
+    """dL/dX for all rows through the fused adjoints -- sk_linear_adjoint_fused_f64 / sk_rbf_adjoint_fused_f64 (route FUSED) or their
+    multi-band forms (FUSED_MB): adjoint PDE and the static kernel's chain rule in one kernel, from the paths and the forward's
+    edges; no matrix of size pairs x M x N -- one launch per row tile.  None when the kernel does not cover the case after all (the
+    caller then takes the streaming route, tiled by ITS transient memory).  Exploding kernels are the library's business: with the
+    forward values (Kvals, or what the forward re-run here returns) the launch takes such pairs out of the sweep and adds their
+    exact, stored-grid share on the device (csrc/sk_adj_fused_rescue.hip) -- nothing is read back, a backward pass has no host
+    synchronisation."""
     A, M = Xd.shape[0], Xd.shape[1]
-    linear = type(static_kernel) is LinearKernel
-    param = _fused_static(static_kernel, gram)[1]
-    mb = (not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram) if linear
-          else not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram))
-    if mb:
-        kind = 0 if linear else 1
+    kind, param = _fused_static(static_kernel, gram)
+    linear = kind == 0
+    if route == FUSED_MB:
         adj_mb = be.linear_adjoint_fused_mb if linear else be.rbf_adjoint_fused_mb
-        # long / wide paths: sk_solve_fwd_static_* (edges) + sk_rbf_adjoint_fused_mb_f64; per pair 8 (MM + NN) bytes of edges and
-        # (M + 128) (fd + 2) doubles of partial sums
-        per_row = (Yd.shape[0] if gram else 1) * (8 * ((M + Yd.shape[1]) << dyadic) + 8 * 18 * (M + 128) + 4096)
+        # long / wide paths: sk_solve_fwd_static_* (edges) + the multi-band adjoint; per pair the edges, the partial sums and node row 0
+        pair_bytes = _mb_pair_bytes(be, kind, Xd, Yd, dyadic)
+        if pair_bytes is None:
+            return None
+        per_row = (Yd.shape[0] if gram else 1) * pair_bytes
         grad = torch.empty_like(Xd)
         for a0, a1, edges in _edge_tiles(kept, A, per_row, budget, strict=True):
             Xt = Xd[a0:a1].contiguous()
             Yt = Yd if gram else Yd[a0:a1].contiguous()
             got = go if go is None else go[a0:a1].reshape(-1).contiguous()
             Kt = None if Kvals is None else Kvals[a0:a1]
-            res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=Kt) if edges is not None else None
+            res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=Kt, naive=naive) if edges is not None else None
             if res is None:    # no edges kept, or kept by another kernel in its own layout
                 fw = be.solve_fwd_fused_static(kind, param, Xt, Yt, dyadic, naive, gram, keep_edges=True)
                 edges = fw[1] if fw is not None else None
                 if edges is None:
                     return None
-                res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=fw[0])
+                res = adj_mb(Xt, Yt, param, dyadic, edges, got, gram=gram, kfinal=fw[0], naive=naive)
+                del edges
                 if res is None:
                     return None
             grad[a0:a1] = res[0]
@@ -201,7 +205,7 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
         if edges is None:
             return None
         adj = be.linear_adjoint_fused if linear else be.rbf_adjoint_fused
-        res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram, kfinal=Kt)
+        res = adj(Xt, Yt, param, dyadic, edges, None if go is None else go[a0:a1].reshape(-1).contiguous(), gram=gram, kfinal=Kt, naive=naive)
         if res is None:
             return None
         if a0 == 0 and a1 == A and res[0].shape == Xd.shape and res[0].dtype == Xd.dtype:
@@ -216,11 +220,9 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
     size of the tile's increments).  kept: what forward left for the tiles ([(a0, a1, edges)] or None)."""
     A, M, N = Xd.shape[0], Xd.shape[1], Yd.shape[1]
     budget = _budget(Xd.device, workspace_bytes)
-    if (_fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
-            or _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
-            or _fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)
-            or _fused_linear_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic, naive, gram)):
-        g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals)
+    route = _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic, naive, gram)
+    if route in (FUSED, FUSED_MB):
+        g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals, route)
         if g is not None:
             return g
     fused = _fused_static(static_kernel, gram) is not None
@@ -303,6 +305,10 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     if keep is not None and hasattr(be, "solve_fwd_keep_edges"):
         budget = _budget(Xd.device, workspace_bytes)
         edge_bytes = 8.0 * A * B * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
+        if _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic_order, naive, True) == FUSED_MB:
+            # the multi-band forward keeps every band's bottom row: nb / 2 times the terminal row and column alone
+            pair_bytes = _mb_pair_bytes(be, _fused_static(static_kernel, True)[0], Xd, Yd, dyadic_order)
+            edge_bytes = float(A) * B * (pair_bytes or 0)
         if edge_bytes > _KEEP_EDGES_FRACTION * budget:
             keep = None
     else:
@@ -343,11 +349,9 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     if keep_blocks is None and hasattr(be, "solve_fwd_fused_sym"):
         # exactly LinearKernel / RBFKernel within the single-band fused kernels' scope: the triangle in ONE launch, every value
         # written to both halves (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*)
-        kind = 0 if type(static_kernel) is LinearKernel else 1 if (type(static_kernel) is RBFKernel
-                                                                    and not routes.no_fused_rbf) else None
-        if kind is not None:
-            param = 1.0 if kind == 0 else float(static_kernel.sigma)
-            K = be.solve_fwd_fused_sym(kind, param, Xd, dyadic_order, naive) if (kind == 0 or param > 0) else None
+        if _route(be, OP_FORWARD, static_kernel, Xd, Xd, dyadic_order, naive, True) == FUSED:
+            kind, param = _fused_static(static_kernel, True)
+            K = be.solve_fwd_fused_sym(kind, param, Xd, dyadic_order, naive)
             if K is not None:
                 return K
     K = torch.empty(A, A, dtype=Xd.dtype, device=Xd.device)
@@ -394,6 +398,25 @@ def _edge_tiles(kept, n_rows, per_row, budget, strict=False):
     return tiles
 
 
+def _sym_triangle_ok(be, static_kernel, Xd, dyadic, naive):
+    """Whether compute_Gram(X, X, sym=True) WITH a gradient solves the triangle only (a pair above the diagonal also stands for its
+    mirror image, through the second-argument contraction of the same adjoint sweep), by the ADJOINT route of the shape:
+      FUSED, RBFKernel, fp64   yes -- sk_rbf_adjoint_fused_f64 with the second-argument sums (_sym_fused_gradient; dim <= 4 by the route)
+      FUSED, LinearKernel      no  -- the fused adjoint on ALL pairs is faster than any triangle route (14 vs 20 ms at the C3 shape)
+      FUSED_MB                 no  -- likewise (C5's shape: 0.29 s on all pairs against 0.46 s on the streamed triangle)
+      STREAM (fused static kernels beyond dim 16 / dyadic 2, or a route switch): yes where sk_static_adjoint2 exists (linear: dim <= 8)
+    One predicate for the single-GPU Function and the sharded one (sigkernel_amd.distributed)."""
+    fused = _fused_static(static_kernel, True)
+    if fused is None or not hasattr(be, "static_adjoint2"):
+        return False
+    route = _route(be, OP_ADJOINT, static_kernel, Xd, Xd, dyadic, naive, True)
+    if route == FUSED:
+        return fused[0] == 1 and Xd.dtype == torch.float64 and hasattr(be, "second_argument_gradient")
+    if route == STREAM:
+        return Xd.shape[2] <= (8 if fused[0] == 0 else 32)
+    return False
+
+
 def _same_storage(Xd, Yd):
     return Xd.shape == Yd.shape and Xd.data_ptr() == Yd.data_ptr() and Xd.stride() == Yd.stride()
 
@@ -405,8 +428,8 @@ def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, bu
     (b, a), b >= r1, owe to rows r1: is folded from (d1 K(x_b, x_a) = d2 K(x_a, x_b): the scheme is symmetric).  Neither the
     increments nor W exist in HBM, and exploding pairs are rescued on the device (Kvals: the forward's (A, A) values).  None when
     the kernel does not cover the case or the forward kept no edges; the caller then takes the unfused triangular route."""
-    if not (_fused_rbf_adjoint_ok(be, static_kernel, Xd, Xd, dyadic, naive, True) and Xd.dtype == torch.float64
-            and hasattr(be, "second_argument_gradient")):
+    if not (type(static_kernel) is RBFKernel and _route(be, OP_ADJOINT, static_kernel, Xd, Xd, dyadic, naive, True) == FUSED
+            and Xd.dtype == torch.float64 and hasattr(be, "second_argument_gradient")):
         return None
     A, M = Xd.shape[0], Xd.shape[1]
     sigma = float(static_kernel.sigma)
@@ -424,7 +447,7 @@ def _sym_fused_gradient(be, static_kernel, Xd, go, dyadic, naive, sym_blocks, bu
             Xt = Xd[r0 + a0:r0 + a1].contiguous()
             Kt = None if Kvals is None else Kvals[r0 + a0:r0 + a1, r0:]
             res = be.rbf_adjoint_fused(Xt, Xc, sigma, dyadic, edges[a0 * per:a1 * per], go[r0 + a0:r0 + a1, r0:].reshape(-1).contiguous(),
-                                       gram=True, yside=r1 < A, kfinal=Kt)
+                                       gram=True, yside=r1 < A, kfinal=Kt, naive=naive)
             if res is None:
                 return None
             grad[r0 + a0:r0 + a1] += res[0]
@@ -454,7 +477,10 @@ def _sym_unfused_gradient(be, kind, param, Xd, go, dyadic, naive, sym_blocks, bu
             del inc
             grad_X[r0 + a0:r0 + a1] += be.static_adjoint(kind, param, Xt, Xc, W, go_blk[a0:a1].contiguous(), True)
             if r1 < A:
-                grad_X[r1:] += be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
+                g2 = be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)
+                if g2 is None:      # (_sym_triangle_ok keeps such shapes off the triangle: a caller that bypassed it)
+                    raise RuntimeError("sigkernel_amd: the triangular adjoint has no second-argument kernel for path dim %d" % Xd.shape[2])
+                grad_X[r1:] += g2
             del W
     return grad_X
 
@@ -484,12 +510,7 @@ class _SigKernelGram(torch.autograd.Function):
             # its mirror image, through the second-argument contraction of the same W) -- fused static kernels only
             # (the fused linear adjoint is faster on all pairs than the unfused one on the triangle: 14 vs 20 ms at the C3 shape)
             # (long / wide RBF paths: the multi-band fused adjoint on ALL pairs beats the unfused triangle -- C5's shape 0.29 s against 0.46 s)
-            mb_only = ((_fused_rbf_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
-                        and not _fused_rbf_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
-                       or _fused_linear_adjoint_mb_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True))
-            if (X.requires_grad and Y.requires_grad and _fused_static(static_kernel, True) is not None and not mb_only
-                    and not _fused_linear_adjoint_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, True)
-                    and hasattr(be, "static_adjoint2") and X.shape[2] <= (8 if type(static_kernel) is LinearKernel else 32)):
+            if X.requires_grad and Y.requires_grad and _sym_triangle_ok(be, static_kernel, Xd, dyadic_order, _naive_solver):
                 ctx.sym_blocks = []
                 K = _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes,
                                     ctx.sym_blocks)

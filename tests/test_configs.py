@@ -553,20 +553,23 @@ def test_fused_multiband_scope_and_c5_route(monkeypatch):
     what compute_Gram runs: nothing of size pairs x M x N is materialised (sk_static_increments is never called)."""
     be = _lib.get_backend()
     Z = lambda A, M, D, dt=torch.float64: torch.zeros(A, M, D, dtype=dt, device=DEV)
-    assert be.solve_fwd_fused_static(1, 1.0, Z(2, 100, 3), Z(2, 100, 3), 1, False, True) is None      # both paths too short
-    # a long first path against a short second one is solved with the arguments swapped (the kernel is symmetric)
+    # (round 4: short second paths are swept with padding units -- no shape of dim <= 16, dyadic <= 2 is outside the scope)
+    assert torch.equal(be.solve_fwd_fused_static(1, 1.0, Z(2, 100, 3), Z(2, 100, 3), 1, False, True), torch.ones(2, 2, dtype=torch.float64, device=DEV))
+    # a long first path against a short second one: either orientation (the kernel is symmetric; sk_route_query picks the cheaper)
     gen0 = torch.Generator().manual_seed(4)
     Xs, Ys = walk(gen0, 3, 400, 5).to(DEV), walk(gen0, 4, 90, 5).to(DEV)
     for kind, kern in ((0, sigkernel_amd.LinearKernel()), (1, sigkernel_amd.RBFKernel(0.9))):
-        Ksw = be.solve_fwd_fused_static(kind, 1.0 if kind == 0 else 0.9, Xs, Ys, 1, False, True)
-        assert Ksw is not None and Ksw.shape == (3, 4)
-        assert rel_err(Ksw.cpu().numpy(), O.gram_forward(Xs.cpu(), Ys.cpu(), kern, 1, nthreads=NT)) <= 1e-11
+        for swap in (False, True):
+            Ksw = be.solve_fwd_fused_static(kind, 1.0 if kind == 0 else 0.9, Xs, Ys, 1, False, True, swap=swap)
+            assert Ksw is not None and Ksw.shape == (3, 4)
+            assert rel_err(Ksw.cpu().numpy(), O.gram_forward(Xs.cpu(), Ys.cpu(), kern, 1, nthreads=NT)) <= 1e-11
     Kp = be.solve_fwd_fused_static(0, 0.8, Xs, Ys[:3].contiguous(), 1, False, False)
     Gp = sigkernel_amd.LinearKernel(0.8).batch_kernel(Xs.cpu(), Ys[:3].cpu()).numpy()
     assert rel_err(Kp.cpu().numpy(), O.solve_coarse(O.increments(Gp), 1)) <= 1e-11
     assert be.solve_fwd_fused_static(1, 1.0, Z(2, 300, 17), Z(2, 300, 17), 1, False, True) is None     # dim 17
     assert be.solve_fwd_fused_static(1, 1.0, Z(2, 300, 3), Z(2, 300, 3), 3, False, True) is None       # dyadic 3
-    assert be.solve_fwd_fused_static(0, 1.0, Z(2, 300, 3), Z(2, 300, 3), 1, True, True) is None        # naive scheme
+    Kn = be.solve_fwd_fused_static(0, 1.0, Xs, Ys, 1, True, True)                                        # naive scheme: a launch-time constant
+    assert rel_err(Kn.cpu().numpy(), O.gram_forward(Xs.cpu(), Ys.cpu(), sigkernel_amd.LinearKernel(), 1, naive=True, nthreads=NT)) <= 1e-11
     gen = torch.Generator().manual_seed(8)
     X, Y = walk(gen, 3, 512, 16, torch.float32).to(DEV), walk(gen, 5, 512, 16, torch.float32).to(DEV)
     sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
@@ -860,7 +863,7 @@ def test_fused_rbf_adjoint_is_what_the_api_runs(monkeypatch):
     unfused route and with the oracle's closed form; compute_mmd (triangular K_XX + fused K_XY) agrees with the reference fixture."""
     be = _lib.get_backend()
     gen = torch.Generator().manual_seed(31)
-    Xc, Yc = walk(gen, 12, 40, 4), walk(gen, 9, 33, 4)
+    Xc, Yc = walk(gen, 12, 40, 4), walk(gen, 9, 34, 4)      # (N - 1 = 32 would have no padding node column: multi-band adjoint)
     X, Y = Xc.to(DEV), Yc.to(DEV)
     w = torch.randn(12, 9, generator=gen, dtype=torch.float64)
     k = sigkernel_amd.RBFKernel(0.8)

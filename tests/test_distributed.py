@@ -157,6 +157,12 @@ def test_sharded_symmetric_gram_is_folded_over_the_ranks(tmp_path, world):
     assert max(solved) <= 0.75 * (11 * 11 / world) + 11 and sum(solved) < 0.75 * 11 * 11, solved
 
 
+def _wide_paths():
+    gen = torch.Generator().manual_seed(12)
+    mk = lambda A: torch.cumsum(torch.randn(A, 20, 20, generator=gen, dtype=torch.float64), dim=1) * 0.05
+    return mk(7), mk(5)
+
+
 def _hip_gloo_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -178,6 +184,15 @@ def _hip_gloo_worker(rank, world, port, out_dir):
             mmd = sk.compute_mmd(Xg, Y)
             mmd.backward()
             res[name + ".mmd"], res[name + ".grad_mmd"] = mmd.detach().cpu().numpy(), Xg.grad.cpu().numpy()
+        # LinearKernel with path dim 9..32 and a gradient under a process group -- compute_mmd's K_XX is
+        # compute_Gram(X, X, sym=True); the triangle has no second-argument kernel for such paths and must not be chosen
+        X12, Y12 = _wide_paths()
+        for D in (12, 20):
+            sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1, process_group=dist.group.WORLD)
+            Xg = X12[:, :, :D].contiguous().cuda().requires_grad_(True)
+            mmd = sk.compute_mmd(Xg, Y12[:, :, :D].contiguous().cuda())
+            mmd.backward()
+            res["lin%d.mmd" % D], res["lin%d.grad_mmd" % D] = mmd.detach().cpu().numpy(), Xg.grad.cpu().numpy()
         np.savez(os.path.join(out_dir, "hipgloo%d.npz" % rank), **res)
     finally:
         dist.destroy_process_group()
@@ -198,3 +213,14 @@ def test_sharded_gram_two_ranks_sharing_one_gpu(tmp_path):
             assert rel_err(got[name + ".grad_w"], c["grad_w"]) <= grad_tol(name, "grad_w")
             assert abs(float(got[name + ".mmd"]) - float(c["mmd"])) <= 1e-11
             assert rel_err(got[name + ".grad_mmd"], c["grad_mmd"]) <= grad_tol(name, "grad_mmd")
+        import sigkernel_amd
+        from oracle import oracle as O
+        X12, Y12 = _wide_paths()
+        for D in (12, 20):
+            X, Y, k = X12[:, :, :D].contiguous(), Y12[:, :, :D].contiguous(), sigkernel_amd.LinearKernel()
+            A, B = X.shape[0], Y.shape[0]
+            Kxx, Kyy, Kxy = O.gram_forward(X, X, k, 1), O.gram_forward(Y, Y, k, 1), O.gram_forward(X, Y, k, 1)
+            mmd = (Kxx.sum() - np.trace(Kxx)) / (A * (A - 1.0)) + (Kyy.sum() - np.trace(Kyy)) / (B * (B - 1.0)) - 2.0 * Kxy.mean()
+            gw = 2.0 * O.gram_grad_weighted(X, X, (1.0 - np.eye(A)) / (A * (A - 1.0)), k, 1) + \
+                O.gram_grad_weighted(X, Y, np.full((A, B), -2.0 / (A * B)), k, 1)
+            assert abs(float(got["lin%d.mmd" % D]) - mmd) <= 1e-11 and rel_err(got["lin%d.grad_mmd" % D], gw) <= 1e-9, D

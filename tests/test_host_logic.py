@@ -174,6 +174,11 @@ def test_input_validation(oracle_backend):
         sk.compute_Gram(torch.rand(2, 3), torch.rand(2, 3, 3))
 
 
+def _lib_route(*args):
+    from sigkernel_amd import _lib
+    return _lib.HipBackend.route(*args)
+
+
 class _FusedFake:
     """The oracle-backed fake with a fused linear adjoint that declines the case (returns None, as the HIP one does outside its
     scope): exercises the re-tiled fallback of sigkernel._rows_gradient on CPU.  (Exploding kernels are no longer a reason to
@@ -189,7 +194,9 @@ class _FusedFake:
     def solve_fwd_fused_linear(self, X, Y, scale, dyadic, naive, gram, keep_edges=False):
         return None          # forward takes the tiled route; the fused adjoint asks for edges itself
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None):
+    route = staticmethod(_lib_route)     # the library's own answer (sk_route_query is host code: no GPU needed)
+
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False):
         self.fused_calls += 1
         self.got_kfinal = kfinal is not None
         return None

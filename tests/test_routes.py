@@ -1,0 +1,187 @@
+"""sk_route_query (csrc/sk_route.hip) is the one statement of the fused kernels' scope.
+
+CPU: the answers against a table written out by hand, and the promise in the header -- exactly LinearKernel / RBFKernel, path
+dim <= 16, dyadic <= 2, either stencil NEVER stream (nothing of size pairs x M x N in HBM).
+GPU: every launcher honours the answer.  For kind x dim 1..16 x dyadic 0..2 x stencil x {values, gradient} the call must not
+touch sk_static_increments (the only producer of a pairs x M x N tensor for these static kernels) and must agree with the oracle
+(O.gram_forward: _SigKernelGram.forward, sigkernel.py:350-401; O.gram_grad_weighted: prep_backward + backward, :404-502)."""
+import numpy as np
+import pytest
+import torch
+
+import sigkernel_amd
+from sigkernel_amd import _lib
+from conftest import rel_err
+
+STREAM, FUSED, MB, SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
+FWD, ADJ = _lib.OP_FORWARD, _lib.OP_ADJOINT
+
+# (op, kind, D, M, N, dyadic, naive, elem_size) -> route
+TABLE = [
+    # the five BASELINE configs
+    ((FWD, 1, 2, 10, 20, 1, False, 8), FUSED), ((ADJ, 1, 2, 10, 20, 1, False, 8), FUSED),            # C1
+    ((FWD, 1, 3, 64, 64, 1, False, 8), FUSED), ((ADJ, 1, 3, 64, 64, 1, False, 8), FUSED),            # C2
+    ((FWD, 0, 8, 128, 128, 1, False, 8), FUSED), ((ADJ, 0, 8, 128, 128, 1, False, 8), FUSED),        # C3
+    ((FWD, 1, 4, 64, 64, 2, False, 8), FUSED), ((ADJ, 1, 4, 64, 64, 2, False, 8), FUSED),            # C4
+    ((FWD, 1, 16, 512, 512, 2, False, 4), MB), ((ADJ, 1, 16, 512, 512, 2, False, 4), MB),            # C5
+    # one band per pair: rows <= 64 RC (256 / 128 / 64 at dyadic 0 / 1 / 2; rbf counts node rows)
+    ((FWD, 0, 8, 257, 40, 0, False, 8), FUSED), ((FWD, 0, 8, 258, 260, 0, False, 8), MB),
+    ((FWD, 1, 4, 256, 40, 0, False, 8), FUSED), ((FWD, 1, 4, 257, 257, 0, False, 8), MB),
+    ((FWD, 0, 8, 65, 40, 2, False, 8), FUSED), ((FWD, 0, 8, 66, 400, 2, False, 8), MB),
+    ((FWD, 0, 8, 129, 129, 1, True, 4), FUSED),
+    # rbf at dyadic 0: the one-band kernel exists for dim <= 4, default stencil, fp64 only (the reference's example workload --
+    # RBF, dyadic 0, lead-lag + time paths, examples/time_series_classification.py:186-197 -- goes multi-band otherwise)
+    ((FWD, 1, 5, 100, 100, 0, False, 8), MB), ((FWD, 1, 4, 100, 100, 0, True, 8), MB), ((FWD, 1, 4, 100, 100, 0, False, 4), MB),
+    # wide paths
+    ((FWD, 0, 9, 30, 30, 1, False, 8), MB), ((FWD, 1, 16, 30, 30, 0, True, 8), MB),
+    # multi-band forward, orientation by swept macro-steps (bands x max(80, units))
+    ((FWD, 0, 12, 20, 700, 1, False, 8), MB), ((FWD, 0, 12, 700, 20, 1, False, 8), SWAP), ((FWD, 1, 12, 300, 290, 1, False, 8), MB),
+    # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
+    ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED),
+    ((ADJ, 0, 8, 66, 30, 2, False, 8), MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), MB),
+    # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64, N - 1 not a multiple of 16
+    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED), ((ADJ, 1, 4, 129, 100, 1, False, 8), MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), MB),
+    ((ADJ, 1, 4, 40, 40, 0, False, 8), MB), ((ADJ, 1, 4, 40, 33, 1, False, 8), MB), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED),
+    # never swapped: the gradient is the first argument's
+    ((ADJ, 0, 12, 700, 20, 1, False, 8), MB),
+    # outside: other kernels, dim > 16, dyadic > 2, single points
+    ((FWD, 2, 3, 30, 30, 1, False, 8), STREAM), ((FWD, 0, 17, 30, 30, 1, False, 8), STREAM), ((ADJ, 1, 17, 30, 30, 1, False, 8), STREAM),
+    ((FWD, 0, 3, 30, 30, 3, False, 8), STREAM), ((ADJ, 1, 3, 30, 30, 3, False, 8), STREAM), ((FWD, 0, 3, 1, 30, 1, False, 8), STREAM),
+    ((FWD, 0, 3, 30, 30, 1, False, 2), STREAM),
+]
+
+
+def test_route_query_against_the_table():
+    be = _lib.HipBackend()
+    for args, want in TABLE:
+        assert be.route(*args) == want, (args, be.route(*args), want)
+
+
+def test_linear_and_rbf_up_to_16_dims_never_stream():
+    be = _lib.HipBackend()
+    rng = np.random.default_rng(0)
+    for _ in range(4000):
+        op, kind, D = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 17))
+        M, N = int(rng.integers(2, 3000)), int(rng.integers(2, 3000))
+        d, naive, es = int(rng.integers(0, 3)), bool(rng.integers(0, 2)), int(rng.choice([4, 8]))
+        r = be.route(op, kind, D, M, N, d, naive, es)
+        assert r != STREAM, (op, kind, D, M, N, d, naive, es)
+        assert op == FWD or r != SWAP
+
+
+def test_host_layer_has_no_scope_rules_of_its_own():
+    """The eight `_fused_*_ok` predicates of round 3 are gone: sigkernel.py and distributed.py ask sk_route_query."""
+    import inspect
+    from sigkernel_amd import distributed, sigkernel
+    for mod in (sigkernel, distributed):
+        src = inspect.getsource(mod)
+        assert "_adjoint_ok" not in src and "_adjoint_mb_ok" not in src
+    assert "be.route(" in inspect.getsource(sigkernel._route)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+DEV = "cuda"
+
+
+def _walk(gen, A, M, D, dtype=torch.float64):
+    return (torch.cumsum(torch.randn(A, M, D, generator=gen, dtype=torch.float64), dim=1) * (0.6 / np.sqrt(M * D))).to(dtype)
+
+
+def _no_increments(monkeypatch):
+    be = _lib.get_backend()
+
+    def boom(self, *a, **k):
+        raise AssertionError("sk_static_increments called: a pairs x M x N tensor was materialised")
+    monkeypatch.setattr(type(be), "static_increments", boom)
+    monkeypatch.setattr(type(be), "increments", boom)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+@pytest.mark.parametrize("dyadic", [0, 1, 2])
+@pytest.mark.parametrize("naive", [False, True])
+def test_no_call_up_to_16_dims_materialises_increments(kind, dyadic, naive, monkeypatch):
+    from oracle import oracle as O
+    _no_increments(monkeypatch)
+    gen = torch.Generator().manual_seed(100 * dyadic + 10 * naive + (kind == "rbf"))
+    mk = (lambda: sigkernel_amd.LinearKernel()) if kind == "linear" else (lambda: sigkernel_amd.RBFKernel(0.8))
+    for D in range(1, 17):
+        # two shapes per dimension: short ragged paths, and one with N - 1 a multiple of 16 / a longer first path
+        for (A, B, M, N) in ((3, 4, 9 + D, 14 + (D % 5)), (2, 3, 40 + 3 * D, 33)):
+            X, Y = _walk(gen, A, M, D), _walk(gen, B, N, D)
+            w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+            sk = sigkernel_amd.SigKernel(mk(), dyadic, _naive_solver=naive)
+            K = sk.compute_Gram(X.to(DEV), Y.to(DEV))
+            want = O.gram_forward(X, Y, mk(), dyadic, naive=naive)
+            assert rel_err(K.cpu().numpy(), want) <= 1e-11, ("forward", kind, D, dyadic, naive, M, N)
+            Xg = X.to(DEV).requires_grad_(True)
+            Kg = sk.compute_Gram(Xg, Y.to(DEV))
+            (Kg * w.to(DEV)).sum().backward()
+            assert rel_err(Kg.detach().cpu().numpy(), want) <= 1e-11, ("forward with a gradient pending", kind, D, dyadic, naive, M, N)
+            gwant = O.gram_grad_weighted(X, Y, w.numpy(), mk(), dyadic, naive=naive)
+            assert rel_err(Xg.grad.cpu().numpy(), gwant) <= 1e-9, ("gradient", kind, D, dyadic, naive, M, N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,dyadic,naive,M,N", [
+    ("rbf", 6, 0, False, 41, 37),      # the reference's example workload: RBF, dyadic 0, lead-lag + time (dim 5..8)
+    ("rbf", 7, 1, False, 64, 64),      # rbf adjoint with dim 5..8 on one-band paths
+    ("rbf", 3, 0, False, 300, 45),     # rbf adjoint at dyadic 0, several bands of 128 rows
+    ("rbf", 12, 0, True, 150, 170),    # ... 16 staged dims, naive stencil
+    ("linear", 12, 1, True, 30, 25),   # short wide paths
+    ("linear", 5, 2, True, 140, 20),   # multi-band with a short second path
+    ("rbf", 4, 2, True, 64, 64),       # C4's shape with the naive stencil: one-band kernels
+    ("linear", 8, 1, True, 128, 128),  # C3's shape with the naive stencil
+])
+def test_paired_sym_and_mmd_on_the_closed_holes(kind, D, dyadic, naive, M, N, monkeypatch):
+    """compute_kernel (paired), compute_Gram(X, X, sym=True) and compute_mmd().backward() on the shapes round 3 streamed."""
+    from oracle import oracle as O
+    _no_increments(monkeypatch)
+    gen = torch.Generator().manual_seed(7)
+    mk = (lambda: sigkernel_amd.LinearKernel(0.9)) if kind == "linear" else (lambda: sigkernel_amd.RBFKernel(1.1))
+    sk = sigkernel_amd.SigKernel(mk(), dyadic, _naive_solver=naive)
+    X, Y = _walk(gen, 5, M, D), _walk(gen, 5, N, D)
+    # paired
+    Xg = X.to(DEV).requires_grad_(True)
+    k = sk.compute_kernel(Xg, Y.to(DEV))
+    G = mk().batch_kernel(X, Y).numpy()
+    kw = O.solve_coarse(O.increments(G), dyadic, naive)
+    assert rel_err(k.detach().cpu().numpy(), kw) <= 1e-11
+    v = torch.randn(5, generator=gen, dtype=torch.float64)
+    (k * v.to(DEV)).sum().backward()
+    gp = np.stack([O.gram_grad_weighted(X[i:i + 1], Y[i:i + 1], np.array([[float(v[i])]]), _paired_kernel(mk()), dyadic, naive=naive)[0]
+                   for i in range(5)])
+    assert rel_err(Xg.grad.cpu().numpy(), gp) <= 1e-9
+    # symmetric Gram, then the MMD with its gradient (triangle or all pairs: the route's choice)
+    Xd = X.to(DEV)
+    Ks = sk.compute_Gram(Xd, Xd, sym=True)
+    want = O.gram_forward(X, X, _gram_kernel(mk()), dyadic, naive=naive)
+    assert rel_err(Ks.cpu().numpy(), want) <= 1e-11 and torch.equal(Ks, Ks.t())
+    if N == M:
+        Xg = X.to(DEV).requires_grad_(True)
+        sk.compute_mmd(Xg, Y.to(DEV)).backward()
+        A = 5
+        wxx = (1.0 - np.eye(A)) / (A * (A - 1.0))
+        wxy = np.full((A, A), -2.0 / (A * A))
+        gk = _gram_kernel(mk())
+        gw = 2.0 * O.gram_grad_weighted(X, X, wxx, gk, dyadic, naive=naive) + O.gram_grad_weighted(X, Y, wxy, gk, dyadic, naive=naive)
+        assert rel_err(Xg.grad.cpu().numpy(), gw) <= 1e-9
+
+
+def _gram_kernel(k):
+    return k
+
+
+class _Paired:
+    """LinearKernel.Gram_matrix ignores `scale`, batch_kernel applies it (static_kernels.py:24,33): the oracle's Gram route on ONE
+    pair reproduces batch_kernel when its Gram_matrix does the scaling."""
+
+    def __init__(self, k):
+        self.k = k
+
+    def Gram_matrix(self, X, Y):
+        return self.k.batch_kernel(X, Y)[:, None] if X.shape[0] == 1 else None
+
+
+def _paired_kernel(k):
+    return _Paired(k)

@@ -4,6 +4,7 @@ wait is a separate inline-asm s_waitcnt) for the one thing the compiler cannot k
 or writes a destination register while the load is still in flight.
 
     python tools/check_async_hazards.py [file.hip ...]      exit status 1 if any hazard is found
+    python tools/check_async_hazards.py --asm file.s ...    the same on ISA already emitted (csrc/Makefile: the BUILD GATE)
 
 Model: a walk over each function in layout order, restarted with nothing pending after every unconditional branch.  A VMEM
 load makes its destination VGPRs pending until an s_waitcnt whose vmcnt(N) leaves at most N loads outstanding (loads return
@@ -154,10 +155,16 @@ def compile_to_asm(src):
 
 
 def main(argv):
+    asm = bool(argv) and argv[0] == "--asm"      # the build gate (csrc/Makefile): the .s files -save-temps left next to the objects
+    if asm:
+        argv = argv[1:]
+        if not argv:
+            print("--asm needs the ISA files")
+            return 2
     files = argv or [os.path.join(CSRC, f) for f in DEFAULT]
     bad = 0
     for f in files:
-        text = compile_to_asm(f)
+        text = open(f).read() if asm else compile_to_asm(f if os.path.isabs(f) or os.path.exists(f) else os.path.join(CSRC, f))
         hz = scan(text) + scan_pressure(text)
         print("%s: %d hazard(s)" % (os.path.basename(f), len(hz)))
         for name, load, use in hz[:10]:

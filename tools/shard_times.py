@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""(GPU box, ONE GPU) Per-rank compute time of strong-scaled BASELINE configs[3] -- compute_mmd(X, Y).backward(), 2048 x 2048
-paths of length 64, dim 4, RBF, dyadic 2 -- for R = 1, 2, 4, 8 ranks: every rank's share is run through the PRODUCT code
+"""(GPU box, ONE GPU) Per-rank compute time of a strong-scaled BASELINE config for R = 1, 2, 4, 8 ranks -- c4 (default): configs[3],
+compute_mmd(X, Y).backward(), 2048 x 2048 paths of length 64, dim 4, RBF, dyadic 2;  c3: configs[2], the headline,
+compute_Gram of 512 x 512 paths of length 128, dim 8, LinearKernel, dyadic 1 (64 rows per rank at R = 8) --: every rank's share is run through the PRODUCT code
 (sigkernel_amd.distributed: row shard of K_XY, folded triangular blocks of K_XX with the all-reduced gradient, folded K_YY)
 one after the other on this GPU, with the collectives replaced by local copies of the same size.  No scaling curve can be
 measured on a 1-GPU lease; what this gives is max_r t_r(R), i.e. the speed-up the kernels and the host layer allow before
 communication (three all-gathers of <= 4 MB + one all-reduce of 4 MB per step, timed separately at world 1 over RCCL).
 
-    python tools/r03_shard_times.py [out.json]
+    python tools/shard_times.py [c4|c3] [out.json]
 """
 import json, os, sys, time, types
 import numpy as np, torch
@@ -14,7 +15,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sigkernel_amd
 from sigkernel_amd import distributed as D
 
-A, M, Dm, d = 2048, 64, 4, 2
+CFG = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("c3", "c4") else "c4"
+OUT = [a for a in sys.argv[1:] if a not in ("c3", "c4")]
+A, M, Dm, d = (2048, 64, 4, 2) if CFG == "c4" else (512, 128, 8, 1)
+kern = (lambda: sigkernel_amd.RBFKernel(1.0)) if CFG == "c4" else (lambda: sigkernel_amd.LinearKernel())
 g = torch.Generator().manual_seed(0)
 mk = lambda: (torch.cumsum(torch.randn(A, M, Dm, generator=g, dtype=torch.float64), 1) / np.sqrt(M * Dm)).cuda()
 X, Y = mk(), mk()
@@ -35,13 +39,16 @@ def fake_gather(out, inp, group):          # every rank's slot receives THIS ran
 D.dist = shim
 D._gather = fake_gather
 D._all_reduce_sum = lambda t, group: t
-sk_dist = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), d, process_group="shim")
-sk_one = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), d)       # R = 1: what bench.py --gpus 1 runs (no process group)
+sk_dist = sigkernel_amd.SigKernel(kern(), d, process_group="shim")
+sk_one = sigkernel_amd.SigKernel(kern(), d)       # R = 1: what bench.py --gpus 1 runs (no process group)
 
 
 def step():
+    sk = sk_one if state["world"] == 1 else sk_dist
+    if CFG == "c3":
+        return sk.compute_Gram(X, Y)
     Xg = X.detach().requires_grad_(True)
-    (sk_one if state["world"] == 1 else sk_dist).compute_mmd(Xg, Y).backward()
+    sk.compute_mmd(Xg, Y).backward()
     return Xg.grad
 
 
@@ -51,18 +58,20 @@ for R in (1, 2, 4, 8):
     times = []
     for r in range(R):
         state["rank"] = r
-        for _ in range(2):
+        nrep = 3 if CFG == "c4" else 30
+        for _ in range(2 if CFG == "c4" else 5):
             step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(nrep):
             step()
         torch.cuda.synchronize()
-        times.append((time.perf_counter() - t0) / 3 * 1e3)
+        times.append((time.perf_counter() - t0) / nrep * 1e3)
     res[R] = times
     print("R=%d: per-rank ms %s  max %.1f" % (R, ["%.1f" % t for t in times], max(times)), flush=True)
 t1 = max(res[1])
-out = {"workload": "BASELINE configs[3], strong scaling: compute_mmd(X, Y).backward(), 2048 x 2048 paths, len 64, dim 4, RBF, dyadic 2, fp64",
-       "method": "each rank's share through sigkernel_amd.distributed on ONE MI355X, collectives replaced by local copies (tools/r03_shard_times.py); "
+out = {"workload": ("BASELINE configs[3], strong scaling: compute_mmd(X, Y).backward(), 2048 x 2048 paths, len 64, dim 4, RBF, dyadic 2, fp64" if CFG == "c4"
+                    else "BASELINE configs[2] (headline), strong scaling: compute_Gram, 512 x 512 paths, len 128, dim 8, LinearKernel, dyadic 1, fp64"),
+       "method": "each rank's share through sigkernel_amd.distributed on ONE MI355X, collectives replaced by local copies (tools/shard_times.py); "
                  "NOT a measured scaling curve",
        "per_rank_ms": {str(R): res[R] for R in res},
        "predicted_speedup_before_communication": {str(R): t1 / max(res[R]) for R in res}}
@@ -71,19 +80,21 @@ try:
     D.dist = real_dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
     real_dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
-    blk = torch.zeros(256, 2048, dtype=torch.float64, device="cuda"); full = torch.zeros(256, 2048, dtype=torch.float64, device="cuda")
-    gr = torch.zeros(2048, 64, 4, dtype=torch.float64, device="cuda")
+    blk = torch.zeros(A // 8, A, dtype=torch.float64, device="cuda"); full = torch.zeros(A // 8, A, dtype=torch.float64, device="cuda")
+    gr = torch.zeros(A, M, Dm, dtype=torch.float64, device="cuda")
     for _ in range(3):
         real_dist.all_gather_into_tensor(full, blk); real_dist.all_reduce(gr)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20):
-        real_dist.all_gather_into_tensor(full, blk); real_dist.all_gather_into_tensor(full, blk); real_dist.all_gather_into_tensor(full, blk)
-        real_dist.all_reduce(gr)
+        real_dist.all_gather_into_tensor(full, blk)
+        if CFG == "c4":
+            real_dist.all_gather_into_tensor(full, blk); real_dist.all_gather_into_tensor(full, blk)
+            real_dist.all_reduce(gr)
     torch.cuda.synchronize()
     out["collectives_ms_world1_rccl"] = (time.perf_counter() - t0) / 20 * 1e3
     real_dist.destroy_process_group()
 except Exception as e:      # noqa: BLE001
     out["collectives_ms_world1_rccl"] = "failed: %s" % e
 print(json.dumps(out))
-if len(sys.argv) > 1:
-    json.dump(out, open(sys.argv[1], "w"), indent=1)
+if OUT:
+    json.dump(out, open(OUT[0], "w"), indent=1)
