@@ -1,5 +1,5 @@
 """The reference's gradient FORMULA evaluated without its round-off noise (test infrastructure; imports neither the product
-package nor the reference).
+package, nor the oracle, nor the reference: numpy only -- the yardstick is independent of everything it judges).
 
 The reference differentiates the static kernel by a forward difference with h = 1e-9 in double precision
 (sigkernel.py:313-341 paired, :472-500 Gram): G_h - G_static cancels ~9 of 16 digits, so every gradient it returns -- and
@@ -12,8 +12,6 @@ only the O(h) truncation error (~1e-9) is left.  That value is the yardstick for
        may rest on (tests/golden/grad_errors.json, written by tests/golden/measure_grad_noise.py).
 """
 import numpy as np
-
-from oracle import oracle as O
 
 LD = np.longdouble
 H = LD(1e-9)      # sigkernel.py:313, :472
@@ -38,14 +36,42 @@ def _corner(G):
     return G[..., 1:, 1:] + G[..., :-1, :-1] - G[..., 1:, :-1] - G[..., :-1, 1:]
 
 
+def _solve_fine_ld(inc, naive):
+    """The reference's solver (cython_backend.pyx:101-117) on FINE increments [..., MM, NN] in long double, all pairs at once:
+    the full grids [..., MM+1, NN+1]."""
+    MM, NN = inc.shape[-2:]
+    K = np.ones(inc.shape[:-2] + (MM + 1, NN + 1), dtype=LD)
+    one, half, twelfth = LD(1), LD(0.5), LD(1) / LD(12)
+    for i in range(MM):
+        for j in range(NN):
+            g = inc[..., i, j]
+            if naive:                                       # cython_backend.pyx:114
+                K[..., i + 1, j + 1] = (K[..., i + 1, j] + K[..., i, j + 1]) * (one + half * g) - K[..., i, j]
+            else:                                           # cython_backend.pyx:116
+                K[..., i + 1, j + 1] = (K[..., i + 1, j] + K[..., i, j + 1]) * (one + half * g + twelfth * g * g) - \
+                    K[..., i, j] * (one - twelfth * g * g)
+    return K
+
+
+def adjoint_weights_ld(inc_c, dyadic, naive):
+    """W[..., p, q] = 4^-d sum over the fine cells (i, j) of coarse cell (p, q) of K[i][j] K~[i+1][j+1] (sigkernel.py:438-470 +
+    :489-495: the solution on the refined increments, the solution on the doubly flipped ones flipped back, their product
+    folded over the r x r fine cells) in long double, by a plain double loop -- nothing borrowed from the oracle."""
+    r = 1 << dyadic
+    inc = np.repeat(np.repeat(inc_c.astype(LD), r, axis=-2), r, axis=-1) / LD(r * r)        # tile(): sigkernel.py:218, :364
+    K = _solve_fine_ld(inc, naive)
+    Kr = _solve_fine_ld(inc[..., ::-1, ::-1], naive)[..., ::-1, ::-1]                        # :438-469
+    KK = K[..., :-1, :-1] * Kr[..., 1:, 1:]                                                   # :470
+    Mc, Nc = inc_c.shape[-2:]
+    return KK.reshape(KK.shape[:-2] + (Mc, r, Nc, r)).sum(axis=(-3, -1)) / LD(r * r)
+
+
 def grad_points_ld(kernel, param, X, Y, dyadic, naive, gram=True):
     """grad_points of prep_backward (sigkernel.py:419-502; gram=False: _SigKernel.backward, :255-343) with the static
-    kernel in long double: (A,B,M,D) for a Gram, (A,M,D) paired.  The PDE weights W = 4^-d sum_cell K K~ come from the CPU
-    oracle in double (they carry 1e-16 relative error; the noise under study is the finite difference's)."""
+    kernel AND the PDE weights W = 4^-d sum_cell K K~ in long double: (A,B,M,D) for a Gram, (A,M,D) paired."""
     M, D = X.shape[1], X.shape[2]
     G0 = _static_ld(kernel, param, X, Y, gram)
-    _, W = O.adjoint_coarse(_corner(G0).astype(np.float64), dyadic, bool(naive))
-    W = W.astype(LD)
+    W = adjoint_weights_ld(_corner(G0), dyadic, bool(naive))
     out = np.zeros(G0.shape[:-2] + (M, D), dtype=LD)
     for k in range(D):
         Xh = X.astype(LD).copy()

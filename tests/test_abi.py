@@ -90,12 +90,39 @@ def test_product_package_never_imports_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src and "libsk_oracle" not in src, f
 
 
+def test_build_info_names_the_toolchain_and_the_sources():
+    """sk_build_info(): the hipcc / clang versions and the hash of the sources this binary was built from -- the hand-scheduled kernels
+    are linted against THAT compiler's register allocation at build time (csrc/Makefile), so a library must say what built it."""
+    import hashlib
+    import re
+    from sigkernel_amd import _lib
+    info = _lib.load().sk_build_info().decode()
+    assert "gfx950" in info and "HIP version" in info and "clang version" in info and "hazard lint passed" in info
+    m = re.search(r"sources ([0-9a-f]{16});", info)
+    assert m, info
+    csrc = os.path.join(ROOT, "sigkernel_amd", "csrc")
+    files = sorted([os.path.join("..", "..", "include", "sigkernel_amd.h"), "Makefile"] +
+                   [f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    assert m.group(1) == h.hexdigest()[:16], "libsigkernel_amd.so is stale: rebuild (python -m sigkernel_amd.build)"
+    # the gate itself: the build refuses to link when the lint finds a hazard
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "lint.ok" in mk and "check_async_hazards.py" in mk and "$(OUT): $(OBJS) $(OBJDIR)/sk_build_info.o $(OBJDIR)/lint.ok" in mk
+
+
 def test_no_instruction_touches_an_in_flight_asynchronous_load():
     """sk_wave_adj.hip and sk_wave_deriv.hip issue loads whose wait is a separate inline-asm s_waitcnt; the compiler does not
     know the destination is still in flight, so the generated ISA is linted for any access in between."""
+    import glob
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_hazards.py")], capture_output=True, text=True)
+    # the ISA the library was assembled from lies next to its objects (csrc/Makefile compiles with -save-temps and runs this lint as
+    # a build gate); without it (a library built elsewhere) the lint compiles the units itself
+    isa = sorted(glob.glob(os.path.join(ROOT, "sigkernel_amd", "csrc", "obj", "sk_wave*-hip-amdgcn-amd-amdhsa-gfx950.s")))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "check_async_hazards.py")] + (["--asm"] + isa if len(isa) >= 8 else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
 
 

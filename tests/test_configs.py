@@ -682,11 +682,20 @@ def test_multiband_routes_are_deterministic_and_finite_in_every_variant(kind, d,
 
 @pytest.mark.gpu
 def test_every_route_is_deterministic_run_to_run():
-    """tools/r03_det_sweep.py: 444 combinations of static kernel x dyadic order x path dim x lengths x precision x scheme, each through
+    """tools/det_sweep.py: 600 combinations of static kernel x dyadic order x path dim x lengths x precision x stencil, each through
     compute_Gram + backward, compute_mmd + backward and the derivative Gram, four runs compared bit for bit (no NaN either)."""
     import subprocess, sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r03_det_sweep.py")], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "444 combinations, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_sweep.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "600 combinations x 4 runs, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_every_inline_asm_kernel_family_a_hundred_times():
+    """tools/det_sweep.py --families: one shape per hand-scheduled kernel family, 100 runs each, bit for bit -- the stress behind the
+    build-time hazard lint (csrc/Makefile): what the lint cannot prove, a race would have to survive 100 times."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_sweep.py"), "--families"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "14 combinations x 100 runs, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -131,6 +131,22 @@ def _oracle_gradient(c, key, kernel):
     return wp[:, None, None] * gp[np.arange(n), np.arange(n)]
 
 
+def test_the_gradient_yardstick_is_independent_of_what_it_judges():
+    """tests/ld_reference.py (static kernel, PDE solutions K and K~, the weights 4^-d sum_cell K K~ -- all in long double by plain
+    numpy loops) and tests/golden/measure_grad_noise.py import neither the oracle, nor the product, nor the reference; and its PDE
+    weights agree with the oracle's to double precision, which pins the ORACLE's adjoint against an independent evaluation."""
+    import ld_reference
+    for path in (ld_reference.__file__, os.path.join(os.path.dirname(ld_reference.__file__), "golden", "measure_grad_noise.py")):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src and "import sigkernel" not in src and "from sigkernel" not in src
+    rng = np.random.default_rng(5)
+    for d, naive in ((0, False), (1, False), (2, False), (1, True)):
+        inc = rng.normal(size=(3, 5, 7)) * 0.3
+        W_ld = ld_reference.adjoint_weights_ld(inc, d, naive)
+        _, W = O.adjoint_coarse(inc, d, naive)
+        assert float(np.max(np.abs(W - W_ld.astype(np.float64))) / np.max(np.abs(W))) <= 1e-13
+
+
 @pytest.mark.parametrize("name,key", _fixture_gradient_keys())
 def test_every_gradient_fixture_vs_noise_free_reference_formula(name, key):
     """prep_backward's formula (sigkernel.py:469-500; paired :313-341) with its h = 1e-9 forward difference evaluated in long
