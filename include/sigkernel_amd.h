@@ -72,20 +72,25 @@ const char *sk_build_info(void);
  *          -- the forward of a call with a gradient pending keeps the edges of the family the ADJOINT query names
  *   kind   0 = LinearKernel, 1 = RBFKernel (sigma > 0); anything else streams
  *   D, M, N, dyadic, scheme (SK_SCHEME_*), elem_size (8 / 4: the dtype of the caller's paths)
+ *   flags  SK_ROUTE_NO_STREAM: never answer STREAM where a fused kernel exists (memory first).  Without it the multi-band kernels
+ *          are only chosen where they are not mostly sweeping padding (short paths: the streaming route, whose transient memory the
+ *          caller bounds by tiling over rows, is several times faster there -- csrc/sk_route.hip has the rule and the measurements)
  * Returns
  *   SK_ROUTE_STREAM         static kernel -> increments in HBM (pairs x M x N) -> sk_solve_fwd_* / sk_solve_adj_*
  *   SK_ROUTE_FUSED          one band per pair: sk_solve_fwd_linear_* / _rbf_* (+ _edges_f64), sk_linear_adjoint_fused_f64,
  *                           sk_rbf_adjoint_fused_f64 -- nothing of size pairs x M x N exists
  *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
  *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
- * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer is never SK_ROUTE_STREAM. */
+ * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never
+ * SK_ROUTE_STREAM: every such call CAN run with nothing of size pairs x M x N in HBM. */
+#define SK_ROUTE_NO_STREAM 1
 #define SK_OP_FORWARD 0
 #define SK_OP_ADJOINT 1
 #define SK_ROUTE_STREAM 0
 #define SK_ROUTE_FUSED 1
 #define SK_ROUTE_FUSED_MB 2
 #define SK_ROUTE_FUSED_MB_SWAP 3
-int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size);
+int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size, int flags);
 
 /* Development hook: the SK_* tuning knobs are parsed from the environment ONCE, when the library is loaded; tools that sweep a
  * knob inside one process call this after changing it.  Not for product code (not thread-safe against concurrent launches). */

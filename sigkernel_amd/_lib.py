@@ -17,6 +17,7 @@ SK_OK = 0
 # sk_route_query: operations and answers (include/sigkernel_amd.h)
 OP_FORWARD, OP_ADJOINT = 0, 1
 ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP = 0, 1, 2, 3
+ROUTE_NO_STREAM = 1
 SCHEME_DEFAULT = 0
 SCHEME_NAIVE = 1
 FLAG_EXACT = 1
@@ -35,7 +36,7 @@ _sz = ctypes.c_size_t
 SIGNATURES = {
     "sk_version": (_int, []),
     "sk_build_info": (ctypes.c_char_p, []),
-    "sk_route_query": (_int, [_int, _int, _int, _int, _int, _int, _int, _int]),
+    "sk_route_query": (_int, [_int, _int, _int, _int, _int, _int, _int, _int, _int]),
     "sk_solve_fwd_static_cols": (_int, [_int, _int]),
     "sk_reload_knobs": (None, []),
     "sk_linear_prescale": (ctypes.c_double, [_int]),
@@ -277,10 +278,12 @@ class HipBackend:
     name = "hip"
 
     @staticmethod
-    def route(op, kind, D, M, N, dyadic, naive, elem_size):
-        """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP."""
+    def route(op, kind, D, M, N, dyadic, naive, elem_size, no_stream=False):
+        """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP.
+        no_stream: never STREAM where a fused kernel exists (by default short paths, on which the multi-band kernels would mostly
+        sweep padding, take the faster streaming route)."""
         return int(load().sk_route_query(int(op), int(kind), int(D), int(M), int(N), int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT,
-                                         int(elem_size)))
+                                         int(elem_size), ROUTE_NO_STREAM if no_stream else 0))
 
     def increments(self, G):
         """G [..., M, N] -> inc_c [..., M-1, N-1] (sigkernel.py:217, :363)."""

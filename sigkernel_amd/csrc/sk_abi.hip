@@ -370,8 +370,8 @@ int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
     if (Mc < 1 || dyadic < 0 || dyadic > 2) return 0;
     return fused_mb_rows(kind, Mc, dyadic);
 }
-int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size) {
-    return route_query(op, kind, D, M, N, dyadic, scheme == SK_SCHEME_NAIVE, elem_size);
+int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size, int flags) {
+    return route_query(op, kind, D, M, N, dyadic, scheme == SK_SCHEME_NAIVE, elem_size, flags);
 }
 int sk_solve_fwd_static_cols(int kind, int Nc) {
     if (Nc < 1 || (kind != 0 && kind != 1)) return 0;

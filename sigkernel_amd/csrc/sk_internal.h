@@ -146,7 +146,7 @@ int fused_mb_rows(int kind, int Mc, int dyadic, bool edges = false);
 int fused_mb_cols(int kind, int Nc);
 
 // ---- sk_route.hip: which kernel family serves a call (host only) ----
-int route_query(int op, int kind, int D, int M, int N, int dyadic, int naive, int elem_size);
+int route_query(int op, int kind, int D, int M, int N, int dyadic, int naive, int elem_size, int flags);
 
 // ---- sk_wave_deriv_fused.hip: k, d/dgamma, d2/dgamma2 with the static kernel fused in (no increment arrays in HBM) ----
 size_t deriv_fused_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int D, int *mrows);

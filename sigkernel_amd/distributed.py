@@ -42,10 +42,13 @@ def _gather(out, inp, group):
 def _all_gather_rows(block, n_rows, chunk, group):
     """block: this rank's rows, shape (rows_r, ...) with rows_r <= chunk -> (n_rows, ...) on every rank."""
     world = dist.get_world_size(group)
-    pad = torch.zeros((chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    pad[: block.shape[0]] = block
+    if block.shape[0] == chunk:          # the rows divide evenly (the usual case): the block goes out as it is -- at 64 rows per rank
+        pad = block.contiguous()         # the zero-fill and the copy were two launches of a 0.6 ms step
+    else:
+        pad = torch.zeros((chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+        pad[: block.shape[0]] = block
     out = torch.empty((world * chunk,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    _gather(out, pad.contiguous(), group)
+    _gather(out, pad, group)
     return out[:n_rows]
 
 

@@ -61,7 +61,7 @@ def _route(be, op, static_kernel, Xd, Yd, dyadic, naive, gram):
         return STREAM
     if (fused[0] == 1 and routes.no_fused_rbf) or (op == OP_ADJOINT and routes.no_fused_adjoint):
         return STREAM
-    r = be.route(op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, naive, Xd.element_size())
+    r = be.route(op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, naive, Xd.element_size(), routes.no_stream)
     if r in (FUSED_MB, FUSED_MB_SWAP) and routes.no_fused_mb:
         return STREAM
     return r
@@ -89,6 +89,12 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
             return res
     rf = _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, gram)
     res = None
+    if rf == FUSED and keep_edges:
+        # a streaming adjoint ahead: the one-band forward's strip edges are the layout sk_solve_adj_* reads (SK_FLAG_EDGES_GIVEN),
+        # so that adjoint skips its own forward sweep
+        res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
+        if res is not None:
+            return res
     if rf == FUSED:
         res = one_band(Xd, Yd, param, dyadic, naive, gram)
     elif rf in (FUSED_MB, FUSED_MB_SWAP):

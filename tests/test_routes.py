@@ -1,10 +1,12 @@
-"""sk_route_query (csrc/sk_route.hip) is the one statement of the fused kernels' scope.
+"""sk_route_query (csrc/sk_route.hip) is the one statement of the fused kernels' scope and of the default choice among them.
 
 CPU: the answers against a table written out by hand, and the promise in the header -- exactly LinearKernel / RBFKernel, path
-dim <= 16, dyadic <= 2, either stencil NEVER stream (nothing of size pairs x M x N in HBM).
-GPU: every launcher honours the answer.  For kind x dim 1..16 x dyadic 0..2 x stencil x {values, gradient} the call must not
-touch sk_static_increments (the only producer of a pairs x M x N tensor for these static kernels) and must agree with the oracle
-(O.gram_forward: _SigKernelGram.forward, sigkernel.py:350-401; O.gram_grad_weighted: prep_backward + backward, :404-502)."""
+dim <= 16, dyadic <= 2, either stencil CAN always run fused: with SK_ROUTE_NO_STREAM the answer is never STREAM (nothing of size
+pairs x M x N in HBM); without it short paths, on which the multi-band kernels would mostly sweep padding, stream (measured faster).
+GPU: every launcher honours the answers.  For kind x dim 1..16 x dyadic 0..2 x stencil x {values, gradient}, in memory-first mode
+the call must not touch sk_static_increments (the only producer of a pairs x M x N tensor for these static kernels), and in BOTH
+modes it must agree with the oracle (O.gram_forward: _SigKernelGram.forward, sigkernel.py:350-401; O.gram_grad_weighted:
+prep_backward + backward, :404-502)."""
 import numpy as np
 import pytest
 import torch
@@ -16,57 +18,69 @@ from conftest import rel_err
 STREAM, FUSED, MB, SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
 FWD, ADJ = _lib.OP_FORWARD, _lib.OP_ADJOINT
 
-# (op, kind, D, M, N, dyadic, naive, elem_size) -> route
+# (op, kind, D, M, N, dyadic, naive, elem_size) -> (default route, route with SK_ROUTE_NO_STREAM)
 TABLE = [
     # the five BASELINE configs
-    ((FWD, 1, 2, 10, 20, 1, False, 8), FUSED), ((ADJ, 1, 2, 10, 20, 1, False, 8), FUSED),            # C1
-    ((FWD, 1, 3, 64, 64, 1, False, 8), FUSED), ((ADJ, 1, 3, 64, 64, 1, False, 8), FUSED),            # C2
-    ((FWD, 0, 8, 128, 128, 1, False, 8), FUSED), ((ADJ, 0, 8, 128, 128, 1, False, 8), FUSED),        # C3
-    ((FWD, 1, 4, 64, 64, 2, False, 8), FUSED), ((ADJ, 1, 4, 64, 64, 2, False, 8), FUSED),            # C4
-    ((FWD, 1, 16, 512, 512, 2, False, 4), MB), ((ADJ, 1, 16, 512, 512, 2, False, 4), MB),            # C5
+    ((FWD, 1, 2, 10, 20, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 2, 10, 20, 1, False, 8), FUSED, FUSED),            # C1
+    ((FWD, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED),            # C2
+    ((FWD, 0, 8, 128, 128, 1, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 128, 128, 1, False, 8), FUSED, FUSED),        # C3
+    ((FWD, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED),            # C4
+    ((FWD, 1, 16, 512, 512, 2, False, 4), MB, MB), ((ADJ, 1, 16, 512, 512, 2, False, 4), MB, MB),                  # C5
     # one band per pair: rows <= 64 RC (256 / 128 / 64 at dyadic 0 / 1 / 2; rbf counts node rows)
-    ((FWD, 0, 8, 257, 40, 0, False, 8), FUSED), ((FWD, 0, 8, 258, 260, 0, False, 8), MB),
-    ((FWD, 1, 4, 256, 40, 0, False, 8), FUSED), ((FWD, 1, 4, 257, 257, 0, False, 8), MB),
-    ((FWD, 0, 8, 65, 40, 2, False, 8), FUSED), ((FWD, 0, 8, 66, 400, 2, False, 8), MB),
-    ((FWD, 0, 8, 129, 129, 1, True, 4), FUSED),
-    # rbf at dyadic 0: the one-band kernel exists for dim <= 4, default stencil, fp64 only (the reference's example workload --
-    # RBF, dyadic 0, lead-lag + time paths, examples/time_series_classification.py:186-197 -- goes multi-band otherwise)
-    ((FWD, 1, 5, 100, 100, 0, False, 8), MB), ((FWD, 1, 4, 100, 100, 0, True, 8), MB), ((FWD, 1, 4, 100, 100, 0, False, 4), MB),
-    # wide paths
-    ((FWD, 0, 9, 30, 30, 1, False, 8), MB), ((FWD, 1, 16, 30, 30, 0, True, 8), MB),
+    ((FWD, 0, 8, 257, 40, 0, False, 8), FUSED, FUSED), ((FWD, 0, 8, 258, 260, 0, False, 8), MB, MB),
+    ((FWD, 1, 4, 256, 40, 0, False, 8), FUSED, FUSED), ((FWD, 1, 4, 500, 500, 0, False, 8), MB, MB),
+    ((FWD, 0, 8, 65, 40, 2, False, 8), FUSED, FUSED), ((FWD, 0, 8, 129, 129, 1, True, 4), FUSED, FUSED),
+    # rbf at dyadic 0: the one-band kernel exists for dim <= 4, default stencil, fp64 only.  The reference's example workload -- RBF,
+    # dyadic 0, lead-lag + time paths (dim 5..8) of a few hundred points, examples/time_series_classification.py:186-197 -- is
+    # multi-band; short such paths stream by default
+    ((FWD, 1, 7, 297, 297, 0, False, 8), MB, MB), ((FWD, 1, 7, 199, 199, 0, False, 8), MB, MB),
+    ((FWD, 1, 5, 100, 100, 0, False, 8), STREAM, MB), ((FWD, 1, 4, 100, 100, 0, True, 8), STREAM, MB), ((FWD, 1, 4, 100, 100, 0, False, 4), STREAM, MB),
+    # wide paths: multi-band where the sweep is not mostly padding (efficiency rows / (bands 64 RC) x units / max(80, units) >= 0.45;
+    # rbf forward 0.5) -- measured crossovers, profiles/r04_ab_routes.txt
+    ((FWD, 0, 12, 128, 128, 1, False, 8), MB, MB), ((FWD, 0, 12, 40, 40, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 30, 30, 0, True, 8), STREAM, MB),
+    ((FWD, 1, 12, 128, 128, 1, False, 8), MB, MB), ((FWD, 1, 7, 128, 128, 0, False, 8), STREAM, MB),
     # multi-band forward, orientation by swept macro-steps (bands x max(80, units))
-    ((FWD, 0, 12, 20, 700, 1, False, 8), MB), ((FWD, 0, 12, 700, 20, 1, False, 8), SWAP), ((FWD, 1, 12, 300, 290, 1, False, 8), MB),
+    ((FWD, 0, 12, 20, 700, 1, False, 8), STREAM, MB), ((FWD, 0, 12, 700, 100, 1, False, 8), SWAP, SWAP), ((FWD, 1, 12, 300, 290, 1, False, 8), MB, MB),
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
-    ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED),
-    ((ADJ, 0, 8, 66, 30, 2, False, 8), MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), MB),
+    ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
+    ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
     # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64, N - 1 not a multiple of 16
-    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED), ((ADJ, 1, 4, 129, 100, 1, False, 8), MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), MB),
-    ((ADJ, 1, 4, 40, 40, 0, False, 8), MB), ((ADJ, 1, 4, 40, 33, 1, False, 8), MB), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED),
+    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), STREAM, MB),
+    ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), STREAM, MB), ((ADJ, 1, 3, 128, 128, 0, False, 8), MB, MB),
+    ((ADJ, 1, 4, 40, 33, 1, False, 8), STREAM, MB), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
     # never swapped: the gradient is the first argument's
-    ((ADJ, 0, 12, 700, 20, 1, False, 8), MB),
+    ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
     # outside: other kernels, dim > 16, dyadic > 2, single points
-    ((FWD, 2, 3, 30, 30, 1, False, 8), STREAM), ((FWD, 0, 17, 30, 30, 1, False, 8), STREAM), ((ADJ, 1, 17, 30, 30, 1, False, 8), STREAM),
-    ((FWD, 0, 3, 30, 30, 3, False, 8), STREAM), ((ADJ, 1, 3, 30, 30, 3, False, 8), STREAM), ((FWD, 0, 3, 1, 30, 1, False, 8), STREAM),
-    ((FWD, 0, 3, 30, 30, 1, False, 2), STREAM),
+    ((FWD, 2, 3, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 17, 30, 30, 1, False, 8), STREAM, STREAM),
+    ((ADJ, 1, 17, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 3, 30, 30, 3, False, 8), STREAM, STREAM),
+    ((ADJ, 1, 3, 30, 30, 3, False, 8), STREAM, STREAM), ((FWD, 0, 3, 1, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 3, 30, 30, 1, False, 2), STREAM, STREAM),
 ]
 
 
 def test_route_query_against_the_table():
     be = _lib.HipBackend()
-    for args, want in TABLE:
+    for args, want, want_ns in TABLE:
         assert be.route(*args) == want, (args, be.route(*args), want)
+        assert be.route(*args, no_stream=True) == want_ns, (args, be.route(*args, no_stream=True), want_ns)
 
 
-def test_linear_and_rbf_up_to_16_dims_never_stream():
+def test_linear_and_rbf_up_to_16_dims_can_always_run_fused():
     be = _lib.HipBackend()
     rng = np.random.default_rng(0)
+    streamed = 0
     for _ in range(4000):
         op, kind, D = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 17))
         M, N = int(rng.integers(2, 3000)), int(rng.integers(2, 3000))
         d, naive, es = int(rng.integers(0, 3)), bool(rng.integers(0, 2)), int(rng.choice([4, 8]))
-        r = be.route(op, kind, D, M, N, d, naive, es)
+        r = be.route(op, kind, D, M, N, d, naive, es, no_stream=True)
         assert r != STREAM, (op, kind, D, M, N, d, naive, es)
         assert op == FWD or r != SWAP
+        r0 = be.route(op, kind, D, M, N, d, naive, es)
+        assert r0 in (STREAM, r)                              # the default only ever falls back to streaming
+        if r0 == STREAM:
+            assert r in (MB, SWAP) and min(M, N) < 400         # ... and only from the multi-band kernels on short paths
+            streamed += 1
+    assert 0 < streamed < 800
 
 
 def test_host_layer_has_no_scope_rules_of_its_own():
@@ -100,9 +114,14 @@ def _no_increments(monkeypatch):
 @pytest.mark.parametrize("kind", ["linear", "rbf"])
 @pytest.mark.parametrize("dyadic", [0, 1, 2])
 @pytest.mark.parametrize("naive", [False, True])
-def test_no_call_up_to_16_dims_materialises_increments(kind, dyadic, naive, monkeypatch):
+@pytest.mark.parametrize("memory_first", [True, False])
+def test_no_call_up_to_16_dims_materialises_increments(kind, dyadic, naive, memory_first, monkeypatch):
+    """memory_first (routes.no_stream): sk_static_increments is never called.  Default: the same shapes, whatever route the cost rule
+    picks (these short paths mostly stream), the same answers."""
     from oracle import oracle as O
-    _no_increments(monkeypatch)
+    monkeypatch.setattr(sigkernel_amd.routes, "no_stream", memory_first)
+    if memory_first:
+        _no_increments(monkeypatch)
     gen = torch.Generator().manual_seed(100 * dyadic + 10 * naive + (kind == "rbf"))
     mk = (lambda: sigkernel_amd.LinearKernel()) if kind == "linear" else (lambda: sigkernel_amd.RBFKernel(0.8))
     for D in range(1, 17):
@@ -134,8 +153,10 @@ def test_no_call_up_to_16_dims_materialises_increments(kind, dyadic, naive, monk
     ("linear", 8, 1, True, 128, 128),  # C3's shape with the naive stencil
 ])
 def test_paired_sym_and_mmd_on_the_closed_holes(kind, D, dyadic, naive, M, N, monkeypatch):
-    """compute_kernel (paired), compute_Gram(X, X, sym=True) and compute_mmd().backward() on the shapes round 3 streamed."""
+    """compute_kernel (paired), compute_Gram(X, X, sym=True) and compute_mmd().backward() on the shapes round 3 streamed, in
+    memory-first mode (routes.no_stream): none of them holds increments."""
     from oracle import oracle as O
+    monkeypatch.setattr(sigkernel_amd.routes, "no_stream", True)
     _no_increments(monkeypatch)
     gen = torch.Generator().manual_seed(7)
     mk = (lambda: sigkernel_amd.LinearKernel(0.9)) if kind == "linear" else (lambda: sigkernel_amd.RBFKernel(1.1))

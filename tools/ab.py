@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Same-box A/B of the round-2 build (build_ab/r02: package + library of commit 7529476, made by hand in the build container)
-against the working tree: box-to-box variance is +-3 %, so only timings from ONE call compare.
-usage: r03_ab.py [c3|c4fwd|c4|c5|c2 ...]   (each build runs in its own process, alternating, three rounds)"""
+"""Same-box A/B of an older build against the working tree: box-to-box variance is +-5 %, so only timings from ONE gpurun call
+compare.  The base is a copy of the package (its .py files + libsigkernel_amd.so built from that commit) under ab_base/<name>/
+(git-ignored; it travels to the GPU box): `git worktree add /tmp/base <commit> && make -C /tmp/base/sigkernel_amd/csrc`, then copy
+sigkernel_amd/*.py and the .so.
+usage: SK_AB_BASE=<name> ab.py [c3|c4fwd|c4|c5|c2|c2big ...]   (each build runs in its own process, alternating, three rounds)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     which, cfg = sys.argv[2], sys.argv[3]
-    sys.path.insert(0, os.path.join(ROOT, "build_ab", which) if which != "new" else ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "ab_base", which) if which != "new" else ROOT)
     import numpy as np, torch
     import sigkernel_amd
     gen = torch.Generator().manual_seed(0)
@@ -19,6 +21,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         X, Y = walk(512, 64, 3), walk(512, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c5":
         X, Y = walk(256, 512, 16, torch.float32), walk(256, 512, 16, torch.float32); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
+    elif cfg.startswith("g:") or cfg.startswith("f:"):
+        # g:kind:A:M:N:D:d[:naive]  compute_Gram(X, Y) with a weighted-sum backward (f: forward only) on a free shape -- what the
+        # round-4 route changes are checked with (shapes that streamed increments before)
+        _, kind, A, M, N, D, d = cfg.split(":")[:7]
+        naive = cfg.endswith(":naive")
+        A, M, N, D, d = int(A), int(M), int(N), int(D), int(d)
+        X, Y = walk(A, M, D), walk(A, N, D)
+        w = torch.randn(A, A, generator=gen, dtype=torch.float64).cuda()
+        k = sigkernel_amd.RBFKernel(1.0) if kind == "rbf" else sigkernel_amd.LinearKernel()
+        sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
+        if cfg.startswith("f:"):
+            fn = lambda: sk.compute_Gram(X, Y)
+        else:
+            def fn():
+                Xg = X.detach().requires_grad_(True); (sk.compute_Gram(Xg, Y) * w).sum().backward(); return Xg.grad
     elif cfg == "c4fwd":
         X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
     else:
@@ -26,6 +43,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         def fn():
             Xg = X.detach().requires_grad_(True); sk.compute_mmd(Xg, Y).backward(); return Xg.grad
     n = 30 if cfg in ("c3", "c2", "c2big") else 6
+    if ":" in cfg: n = 10
     for _ in range(max(3, n // 3)): out = fn()
     torch.cuda.synchronize()
     ts = []
@@ -36,5 +54,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.exit(0)
 for cfg in sys.argv[1:] or ["c3"]:
     for rnd in range(3):
-        for which in (os.environ.get("SK_AB_BASE", "r02"), "new"):
+        for which in (os.environ.get("SK_AB_BASE", "base"), "new"):
             subprocess.run([sys.executable, __file__, "--one", which, cfg])
