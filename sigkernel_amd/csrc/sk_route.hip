@@ -31,8 +31,9 @@
 // profiles/r04_ab_routes.txt: linear dim 12, 40 x 40 points: 0.88 ms streamed against 3.9 ms multi-band; rbf dim 7, 64 x 64, d = 1
 // with a gradient: 4.0 against 12.2 ms; at 128 x 128 points the multi-band route wins: 12.2 against 14.0 ms).  So FUSED_MB is only
 // answered when the sweep's efficiency  rows / (bands 64 RC) x units / max(80, units)  reaches 0.45 (forward with the rbf kernel:
-// 0.5 -- at 0.4 its multi-band forward still loses 5.4 to 3.8 ms, dim 7, d = 0, 128 points); below that the answer is STREAM.
-// The crossover sits at efficiency ~0.5 for every adjoint measured.  A deployment that must not hold increments at all (memory
+// 0.5; rbf with 9..16 dims of fp64 paths, whose 16 staged fp64 dimensions leave one wave per SIMD: never for the forward, 0.9 for
+// the adjoint -- mb_min_eff has the numbers); below that the answer is STREAM.  The crossover sits at efficiency ~0.5 for every
+// other adjoint measured.  A deployment that must not hold increments at all (memory
 // first) passes SK_ROUTE_NO_STREAM (host layer: sigkernel_amd.routes.no_stream / SK_NO_STREAM=1).
 #include "sk_internal.h"
 
@@ -58,7 +59,13 @@ inline double mb_efficiency(int kind, int Mc, int Nc, int d, int rc) {
     if (nup < MB_MIN_UNITS) nup = MB_MIN_UNITS;
     return (double)rows / (double)(nb * 64 * rc) * (double)nu / (double)nup;
 }
-constexpr double MB_MIN_EFF = 0.45, MB_MIN_EFF_RBF_FWD = 0.5;
+// least sweep efficiency at which the multi-band kernels are the default (measured crossovers, profiles/r04_ab_routes.txt)
+inline double mb_min_eff(int op, int kind, int D, int elem_size) {
+    if (kind == 1 && D > 8 && elem_size == 8)   // 16 staged fp64 dims: one wave per SIMD (the fp32 ring of fp32 inputs holds two) --
+        return op == SK_OP_FORWARD ? 1.01 : 0.9;   // forward 7.4 against 5.1 ms streamed at 0.8; with a gradient 35.7 against 27.5 at 0.8
+    if (kind == 1 && op == SK_OP_FORWARD) return 0.5;   // at 0.4: 5.4 against 3.8 ms (dim 7, d = 0, 128 points)
+    return 0.45;
+}
 }  // namespace
 
 int route_query(int op, int kind, int D, int M, int N, int d, int naive, int elem_size, int flags) {
@@ -73,14 +80,14 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         if (one_band) return SK_ROUTE_FUSED;
         const bool swap = 5 * mb_steps(kind, Nc, Mc, d) <= 4 * mb_steps(kind, Mc, Nc, d);
         const double eff = swap ? mb_efficiency(kind, Nc, Mc, d, rc_of(d)) : mb_efficiency(kind, Mc, Nc, d, rc_of(d));
-        if (may_stream && eff < (kind == 1 ? MB_MIN_EFF_RBF_FWD : MB_MIN_EFF)) return SK_ROUTE_STREAM;
+        if (may_stream && eff < mb_min_eff(op, kind, D, elem_size)) return SK_ROUTE_STREAM;
         return swap ? SK_ROUTE_FUSED_MB_SWAP : SK_ROUTE_FUSED_MB;
     }
     if (op == SK_OP_ADJOINT) {
         if (kind == 0 && D <= 8 && Mc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED;
         // (rbf: node column 2 NUp of the strip layout must be padding -- N - 1 a multiple of 16 has none)
         if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d) && Nc % 16 != 0) return SK_ROUTE_FUSED;
-        if (may_stream && mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)) < MB_MIN_EFF) return SK_ROUTE_STREAM;
+        if (may_stream && mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)) < mb_min_eff(op, kind, D, elem_size)) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }
     return SK_ROUTE_STREAM;

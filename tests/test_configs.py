@@ -582,7 +582,9 @@ def test_fused_multiband_scope_and_c5_route(monkeypatch):
     K = sk.compute_Gram(X, Y)
     assert torch.cuda.max_memory_allocated() - base < 600 << 20      # workspace rows only (the increments would be 16 MB per pair)
     assert rel_err(K.cpu().numpy(), K_stream.cpu().numpy()) <= 2e-6
-    # fp64 tensors of the same shape: the fp64 ring
+    # fp64 tensors of the same shape: the fp64 ring (16 staged fp64 dims: by default such calls stream -- measured faster --, the
+    # memory-first switch keeps them fused)
+    monkeypatch.setattr(sigkernel_amd.routes, "no_stream", True)
     K64 = sk.compute_Gram(X.double(), Y.double())
     assert rel_err(K64.cpu().numpy(), O.gram_forward(X.double().cpu(), Y.double().cpu(), sigkernel_amd.RBFKernel(1.0), 2, nthreads=NT)) <= 1e-11
     # LinearKernel on long paths (two bands at dyadic 1) goes the same way
@@ -765,6 +767,9 @@ def test_c5_route_with_a_gradient_materialises_nothing(monkeypatch):
     from exact values at every band of rows, not along a row), and its rounding error grows with that width -- 1e-12 at C4's 252
     columns, 1e-11 at 660, 2e-10 here; north_star asks for 1e-6.  compute_mmd (the symmetric Grams included) goes the same way."""
     be = _lib.get_backend()
+    # (fp32 paths -- the config -- take these kernels by default; fp64 tensors of this shape stage 16 fp64 dims, one wave per SIMD,
+    # and by default stream where that is faster: the memory-first switch keeps them on the fused route for this test)
+    monkeypatch.setattr(sigkernel_amd.routes, "no_stream", True)
     gen = torch.Generator().manual_seed(18)
     X, Y = walk(gen, 3, 512, 16, torch.float32), walk(gen, 4, 512, 16, torch.float32)
     w = torch.randn(3, 4, generator=gen, dtype=torch.float64)
