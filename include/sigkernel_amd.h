@@ -241,7 +241,8 @@ int sk_linear_adjoint_fused_mb_f64(const double *dXr, const double *dYt, int64_t
  *   rescue_ws (sk_fused_rescue_workspace_bytes; NULL: no rescue -- the residuals in err are then the caller's to act on), with
  *   kfinal [P] = the forward values K[MM][NN] (nullable): pairs with |kfinal| > screen are taken out of the sweep (their err entry
  *   becomes -1) and their EXACT contribution (stored-grid adjoint + static-kernel chain rule) is added to the partial sums after it;
- *   a chunk in which a pair that was not screened still ends with a residual above `tol` is recomputed exactly, all its pairs.
+ *   a chunk in which a pair that was not screened still ends with a residual above `tol` -- or with a NaN residual while its
+ *   forward value is finite (an overflow of the recompute, not poisoned inputs) -- is recomputed exactly, all its pairs.
  *   With kfinal the library initialises err itself.  When nothing is screened or fails (the normal case) the rescue reads P
  *   doubles and returns.  `blocks` flagged chunks are processed concurrently (1..1024; the workspace grows with it). */
 size_t sk_fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int blocks);
@@ -424,8 +425,9 @@ size_t sk_adj_workspace_bytes(int64_t P, int Mc, int Nc, int dyadic, int flags, 
  *   SK_FLAG_EXACT calls or shapes the fast kernels do not cover. */
 
 /* Device-side rescue of the fast adjoint: re-solves with stored grids exactly the pairs whose self-check residual
- * err[p] (as written by sk_solve_adj_*) exceeds `tol`, overwriting their W (and out_final when non-NULL); a NaN residual
- * (NaN / inf coordinates) is left alone -- the re-solve could only reproduce the NaN.
+ * err[p] (as written by sk_solve_adj_*) exceeds `tol`, overwriting their W (and out_final when non-NULL); a NaN residual is
+ * left alone when the pair's increments are themselves not finite (NaN / inf coordinates: the re-solve could only reproduce the
+ * NaN) and re-solved when they are finite (the backward recompute overflowed).
  * Enqueue it unconditionally right after sk_solve_adj_*: when no pair is flagged it reads P doubles and returns, so the
  * caller never has to read the residuals back (the reference has no such step: it stores both grids for every pair,
  * sigkernel.py:438-470).  workspace: k >= 1 slots of sk_adj_rescue_slot_bytes(Mc, Nc, dyadic) bytes; k slots re-solve k

@@ -42,6 +42,9 @@ struct FusedRescueParams {
     int64_t A, B, P, n_groups;
     int Mrows, Ncp, Mc, Nc, D, dyadic, rows, outw, ycols;
     int naive;                 // _naive_solver stencil (cython_backend.pyx:114)
+    const double *kfinal;      // forward values [P], nullable: tells a NaN residual of poisoned inputs (K not finite either: left alone,
+                               // the re-solve could only reproduce the NaN) from one of a recompute that overflowed on finite inputs
+                               // (K finite: the chunk is recomputed exactly like any other failed self-check)
     int fd;                    // dims carried by Xs / Ys (8; 8 or 16 for sk_wave_adj_fused_mb.hip)
     double *N0;                // sk_wave_adj_fused_mb.hip, nullable: [P][n0cols] node row 0 weights of the sweep, cleared for a failed pair
     int n0cols;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
             chunk_share(prm.cs, gi, A, prm.B, prm.P, first, slot_i, ppg);
             for (int i = 0; i < ppg && first + i < prm.P; ++i) {
                 const double e = prm.err[first + i];
-                failed |= e > prm.tol;          // (NaN: poisoned inputs, left alone)
+                failed |= e > prm.tol || (e != e && prm.kfinal && isfinite(prm.kfinal[first + i]));   // (NaN with K not finite: poisoned inputs, left alone)
                 marked |= e < 0.0;
             }
         }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
         for (int i = threadIdx.x; i < ppg; i += WAVE) {
             if (first + i >= prm.P) break;
             const double e = prm.err[first + i];
-            failed |= e > prm.tol;          // (NaN: poisoned inputs, left alone)
+            failed |= e > prm.tol || (e != e && prm.kfinal && isfinite(prm.kfinal[first + i]));   // (NaN with K not finite: poisoned inputs, left alone)
             marked |= e < 0.0;
         }
         failed = __any(failed);
@@ -249,7 +252,7 @@ int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, do
 int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const double *scale, const double *err, double tol, double *part,
                         double *ypart, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g, int rows, int outw, int ycols,
                         double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s, int fd, double *n0,
-                        int n0cols) {
+                        int n0cols, const double *kfinal) {
     const size_t lds = simple_lds_bytes(g);
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     const size_t per_block = sizeof(double) * fused_rescue_block_doubles(kind, g.Mc, g.Nc, g.dyadic);
@@ -261,6 +264,7 @@ int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const doub
     prm.kind = kind; prm.Xs = Xs; prm.Ys = Ys; prm.scale = scale; prm.err = err; prm.tol = tol; prm.part = part; prm.Ypart = ypart;
     prm.A = A; prm.B = B; prm.P = g.P; prm.n_groups = n_groups; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.D = D;
     prm.naive = g.naive;
+    prm.kfinal = kfinal;
     prm.dyadic = g.dyadic; prm.rows = rows; prm.outw = outw; prm.ycols = ycols; prm.inv_sigma = inv_sigma; prm.cs = cs;
     prm.ws = (double *)ws; prm.ws_block = (int64_t)(per_block / sizeof(double));
     prm.fd = fd; prm.N0 = n0; prm.n0cols = n0cols;

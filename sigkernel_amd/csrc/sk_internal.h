@@ -190,7 +190,7 @@ int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, do
 int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const double *scale, const double *err, double tol, double *part,
                         double *ypart, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g, int rows, int outw, int ycols,
                         double inv_sigma, const ChunkSplit &cs, int64_t n_groups, void *ws, size_t ws_bytes, hipStream_t s, int fd = 8, double *n0 = nullptr,
-                        int n0cols = 0);
+                        int n0cols = 0, const double *kfinal = nullptr);
 
 // ---- sk_increments.hip ------------------------------------------------------------------
 template <typename T>

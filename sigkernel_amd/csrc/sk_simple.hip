@@ -48,7 +48,8 @@ __global__ __launch_bounds__(WAVE) void k_adj_simple(const T *__restrict__ inc_c
 }
 
 // Device-side rescue of the fast adjoint: every block scans 64 self-check residuals at a time and re-solves, with both
-// grids stored, exactly the pairs whose residual exceeds `tol` (a NaN residual -- poisoned inputs -- is left alone).  Launched unconditionally after the fast
+// grids stored, exactly the pairs whose residual exceeds `tol` (a NaN residual is left alone when the pair's increments are poisoned
+// themselves, and re-solved when they are finite: an overflow of the recompute).  Launched unconditionally after the fast
 // kernel: when nothing is flagged (the normal case) it reads P doubles and exits, so the host never has to look at the
 // residuals -- no device-to-host synchronisation in a backward pass.
 template <typename T>
@@ -62,11 +63,21 @@ __global__ __launch_bounds__(WAVE) void k_adj_rescue(const T *__restrict__ inc_c
     double *Kr = Kf + gs;
     for (int64_t p0 = (int64_t)blockIdx.x * WAVE; p0 < P; p0 += (int64_t)gridDim.x * WAVE) {
         const int64_t p = p0 + threadIdx.x;
-        // a NaN residual means the inputs of the pair are already poisoned (NaN / inf coordinates): a stored-grid re-solve would
-        // spend milliseconds to produce NaN again -- leave the fast kernel's NaN in W and move on
+        // a NaN residual usually means the inputs of the pair are already poisoned (NaN / inf coordinates): a stored-grid re-solve
+        // would spend milliseconds to produce NaN again -- such a pair keeps the fast kernel's NaN in W.  But a recompute that
+        // overflowed on FINITE increments (inf - inf) also ends in NaN: those pairs are told apart by one pass over the pair's
+        // increments and re-solved like any other failed self-check
         const double e = p < P ? err[p] : 0.0;
         const bool bad = p < P && e > tol;
-        unsigned long long m = __ballot(bad);
+        unsigned long long m = __ballot(bad), mn = __ballot(p < P && e != e);
+        while (mn) {
+            const int b = __ffsll((long long)mn) - 1;
+            mn &= mn - 1;
+            const T *iq = inc_c + (p0 + b) * (int64_t)Mc * ld;
+            bool fin = true;
+            for (int c = threadIdx.x; c < Mc * Nc; c += WAVE) fin &= isfinite((double)iq[(int64_t)(c / Nc) * ld + c % Nc]);
+            if (__all(fin)) m |= 1ull << b;
+        }
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;

@@ -512,7 +512,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
     return launch_fused_rescue(0, dXr, dYt, scale_orig, err, rescue->tol, tpart, nullptr, A, B, Mrows, Ncp, 8, g, L * RC, FD, 0, 0.0, prm.cs,
-                               groups, rescue_ws, rescue_ws_bytes, s);
+                               groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
 }
 }  // namespace
 

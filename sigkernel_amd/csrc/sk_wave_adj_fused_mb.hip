@@ -1314,7 +1314,7 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt_any, int yt_f32, in
     ChunkSplit cs{};          // one pair per chunk, slot = pair
     cs.nr = 1; cs.nch = (int)(B > 0 ? B : 1); cs.cpr = cs.nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = 1; cs.off[0] = 0;
     return launch_fused_rescue(1, Xr, Yt64, scale, err, rescue->tol, gpart, nullptr, A, B, Mrows, Ncp, D, g, (int)rows, pl.fd + 2, 0, inv_sigma, cs,
-                               g.P, rws, rws_bytes, s, pl.fd, n0, 2 * pl.NUp);
+                               g.P, rws, rws_bytes, s, pl.fd, n0, 2 * pl.NUp, rescue->kfinal);
 }
 
 // LinearKernel on long paths: gpart [P][nb 64 RC][fd], FLIPPED coarse rows (row f = rows - 1 - p), per PAIR; summed over the pairs of
@@ -1358,7 +1358,7 @@ int launch_adj_fused_linear_mb(const double *dXr, const double *dYt, int64_t A, 
     ChunkSplit cs{};          // one pair per chunk, slot = pair
     cs.nr = 1; cs.nch = (int)(B > 0 ? B : 1); cs.cpr = cs.nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = 1; cs.off[0] = 0;
     return launch_fused_rescue(0, dXr, dYt, scale, err, rescue->tol, gpart, nullptr, A, B, Mrows, Ncp, D, g, (int)rows, pl.fd, 0, 0.0, cs, g.P, rws,
-                               rws_bytes, s, pl.fd, nullptr, 0);
+                               rws_bytes, s, pl.fd, nullptr, 0, rescue->kfinal);
 }
 
 }  // namespace sk

@@ -703,7 +703,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
     return launch_fused_rescue(1, Xr, Yt, scale_orig, err, rescue->tol, gpart, ypart, A, B, Mrows, Ncp, D, g, L * RC + 1, OUTW, 2 * NUp, inv_sigma,
-                               prm.cs, groups, rescue_ws, rescue_ws_bytes, s);
+                               prm.cs, groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
 }
 }  // namespace
 
