@@ -197,6 +197,45 @@ def traffic_entry(key, pairs):
     return None
 
 
+def live_traffic(config, kernel_regex, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel measured IN THIS RUN: a child `bench.py --config <c> --no-extras` under
+    `rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum` (a pass of
+    its own: counters are never combined with API tracing), corrected as the microarchitecture guide prescribes -- 128-byte read
+    requests x 128 B + the others x 64 B; 64-byte write requests x 64 B + the others x 32 B -- averaged over the dispatches that
+    match `kernel_regex`.  None when rocprofv3 is missing, fails or times out (the figure of the round's committed pass is used)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="sk_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum",
+               "--kernel-include-regex", kernel_regex, "-f", "csv", "-d", tmp, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "3", "--warmup", "1", "--no-extras"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        acc = {}
+        for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if not acc.get("TCC_EA0_RDREQ_sum"):
+            return None
+        m = {k: sum(v) / len(v) for k, v in acc.items()}
+        rd128, rd = m.get("TCC_EA0_RDREQ_128B_sum", 0.0), m.get("TCC_EA0_RDREQ_sum", 0.0)
+        wr64, wr = m.get("TCC_EA0_WRREQ_64B_sum", 0.0), m.get("TCC_EA0_WRREQ_sum", 0.0)
+        return {"hbm_bytes_per_launch": rd128 * 128 + max(rd - rd128, 0.0) * 64 + wr64 * 64 + max(wr - wr64, 0.0) * 32,
+                "dispatches": len(acc["TCC_EA0_RDREQ_sum"])}
+    except Exception:      # noqa: BLE001 -- a profiler problem must not cost the bench its line
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def traffic_source(key):
     """Which PMC pass (file under profiles/, round, counters) the traffic figure comes from."""
     try:
@@ -317,6 +356,7 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / adjoint / parity / cpu_baseline legs")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the round's committed PMC pass instead of a rocprofv3 child run")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs timed after the headline (N = 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--force-dist", action="store_true",
@@ -447,6 +487,39 @@ def gram_parity(wl, K, n_chk):
     return par
 
 
+def graph_replay_ms(wl, steps):
+    """A training-sized step is launch-bound (dozens of small launches): the same compute_mmd(X, Y).backward() captured ONCE into a
+    hipGraph (torch.cuda.CUDAGraph: the path has no synchronisation, no host read-back and no allocation outside torch's caching
+    allocator) and replayed -- what a training loop with static shapes should do.  (ms per replay, gradient bit-identical to eager?)"""
+    sX = wl.X.detach().clone().requires_grad_(True)
+
+    def step():
+        loss = wl.sk.compute_mmd(sX, wl.Y)
+        loss.backward()
+        return loss.detach()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):            # warm-up on a side stream, as torch's capture protocol asks
+        for _ in range(3):
+            step()
+            sX.grad = None
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    Xe = wl.X.detach().clone().requires_grad_(True)
+    wl.sk.compute_mmd(Xe, wl.Y).backward()
+    return ms, bool(torch.equal(sX.grad, Xe.grad))
+
+
 def other_configs(dev, args):
     """The other BASELINE configs (and two training-sized MMD steps) on this GPU, after the headline's timed region: 1 warm-up
     + 2 timed steps each between synchronisations, with a parity block per config -- so that the driver's default run carries a
@@ -464,6 +537,9 @@ def other_configs(dev, args):
             else:
                 rows = np.array([0, wl.A_total - 1]) if wl.A_total > 128 else np.arange(wl.A_total)
                 ent["parity"] = mmd_parity(wl, out[0], out[1], rows)
+                if wl.A_total <= 128:      # launch-bound sizes: the same step replayed from a hipGraph
+                    gms, same = graph_replay_ms(wl, 50)
+                    ent["hip_graph"] = {"ms_per_step": gms, "value": wl.entries_per_step / (gms * 1e-3), "gradient_bit_identical_to_eager": same}
             res[name] = ent
             del wl, out
             torch.cuda.empty_cache()
@@ -504,9 +580,15 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
         ops = pairs_f * (cells_per_entry * 3 + Mc * Nc * per_coarse)
         tflops = 2 * ops / (avg * 1e-3) / 1e12
         kern = "sk_solve_fwd_%s_%s (k_fwd_fused: static kernel + increments + PDE in one launch)" % (kname, "f64" if s == 8 else "f32")
+        live = None if (args.no_live_traffic or sym) else live_traffic(args.config, "k_fwd_fused")
         result["roofline"] = {
             "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TF,
-            "traffic": traffic_entry(args.config + "_fused", pairs_f), "traffic_source": traffic_source(args.config + "_fused"),
+            "traffic": live["hbm_bytes_per_launch"] if live else traffic_entry(args.config + "_fused", pairs_f),
+            "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum "
+                               "TCC_EA0_WRREQ_64B_sum on a child bench.py --config %s --steps 3 --no-extras, %d dispatches of k_fwd_fused*, "
+                               "request counts corrected per the microarchitecture guide" % (args.config, live["dispatches"])) if live
+            else traffic_source(args.config + "_fused"),
+            "traffic_committed_pass": traffic_entry(args.config + "_fused", pairs_f),
             "kernel": kern, "pairs_per_launch": pairs_f, "fp64_lane_ops_per_launch": ops, "avg_launch_ms": avg,
             "min_launch_ms": float(np.min(ms)),
             "cells_per_s": pairs_f * cells_per_entry / (avg * 1e-3),

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round-3 profiles (GPU box): rocprofv3 kernel trace + stats of bench.py on c3 / c5 / c4, then separate PMC passes
-# (counters never combined with API tracing) restricted to the dominant kernels.  Output: gpurun_out/r03p/
+# A round's profiles (GPU box): rocprofv3 kernel trace + stats of bench.py on c3 / c5 / c4, then separate PMC passes
+# (counters never combined with API tracing) restricted to the dominant kernels.  usage: profile_round.sh <tag>  ->  gpurun_out/<tag>p/
 set -u
-OUT=$PWD/gpurun_out/r03p; rm -rf $OUT; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
+TAG=${1:-r04}
+OUT=$PWD/gpurun_out/${TAG}p; rm -rf $OUT; mkdir -p $OUT; REPO=$PWD; export TMPDIR=/tmp
 cd /tmp
 for cfg in c3 c5 c4; do
   steps=5; warm=1; [ $cfg = c4 ] && steps=2; [ $cfg = c3 ] && steps=40 && warm=10   # (short launches: the clocks take ~10 launches to settle)
@@ -17,7 +18,8 @@ pmc() {  # tag regex bench-args...
     timeout 600 rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "$re" -f csv -d "$OUT/pmc_$tag/$name" -o pmc -- python $REPO/bench.py "$@" > /dev/null 2> "$OUT/pmc_$tag/$name.err" || echo "failed: $tag $set" >> $OUT/failed.txt
   done
 }
-mkdir -p $OUT/pmc_c5 $OUT/pmc_c4 $OUT/pmc_c3
+mkdir -p $OUT/pmc_c5 $OUT/pmc_c4 $OUT/pmc_c3 $OUT/pmc_c2
+pmc c2 "k_fwd_fused" --config c2 --steps 3 --warmup 1 --no-extras
 pmc c5 "k_fwd_fused_mb" --config c5 --steps 2 --warmup 1 --no-extras
 pmc c4 "k_adj_fused|k_fwd_fused|k_fused_rescue|k_screen" --config c4 --steps 1 --warmup 1 --no-extras
 pmc c3 "k_fwd_fused" --config c3 --steps 3 --warmup 1 --no-extras
@@ -42,7 +44,7 @@ for cfg in ("c3","c5","c4"):
         top=list(csv.DictReader(open(f[0])))[0]["Name"]
         d=sorted((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6 for r in csv.DictReader(open(kt[0])) if r["Kernel_Name"]==top)
         print("  per dispatch of the top kernel (ms): first-to-last sorted min %.3f  median %.3f  max %.3f  (n=%d; the first launches of a process run at lower clocks)"%(d[0],d[len(d)//2],d[-1],len(d)))
-for cfg in ("c5","c4","c3"):
+for cfg in ("c5","c4","c3","c2"):
     print("== %s: PMC, averages per dispatch and kernel =="%cfg)
     acc=defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(out,"pmc_"+cfg,"**","*counter_collection.csv"),recursive=True):
@@ -55,8 +57,10 @@ for cfg in ("c5","c4","c3"):
 if os.path.exists(os.path.join(out,"failed.txt")): print(open(os.path.join(out,"failed.txt")).read())
 PY
 cat $OUT/summary.txt | head -150
-# the HBM-streaming solver's own PMC pass, the per-rank shard times, this round's bench lines
-bash tools/pmc_fwd.sh r03fwd > $OUT/pmc_fwd_solver.txt 2>&1
-timeout 900 python tools/r03_shard_times.py $OUT/c4_shard_times.json > $OUT/shard.log 2>&1
-for cfg in c3 c2 c4 c5; do timeout 900 python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; done
-python tools/r03_ab.py c3 c4 > $OUT/ab_r02_vs_r03.txt 2>&1
+# the HBM-streaming solver's own PMC pass, the per-rank shard times, this round's bench lines, traffic.json from THESE counters
+bash tools/pmc_fwd.sh ${TAG}fwd > $OUT/pmc_fwd_solver.txt 2>&1
+python tools/traffic.py $OUT gpurun_out/pmc_${TAG}fwd $TAG > $OUT/traffic.log 2>&1
+timeout 900 python tools/shard_times.py c4 $OUT/c4_shard_times.json > $OUT/shard_c4.log 2>&1
+timeout 900 python tools/shard_times.py c3 $OUT/c3_shard_times.json > $OUT/shard_c3.log 2>&1
+timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+for cfg in c2 c4 c5; do timeout 900 python bench.py --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; done

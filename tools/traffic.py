@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from THIS round's PMC passes (tools/r03_profile.sh): HBM bytes per launch of the kernels bench.py's
+"""profiles/traffic.json from THIS round's PMC passes (tools/profile_round.sh): HBM bytes per launch of the kernels bench.py's
 roofline objects name, as the microarchitecture guide prescribes -- TCC_EA0_RDREQ (128-byte requests x 128 B + the others x 64 B)
 for reads, TCC_EA0_WRREQ (64-byte requests x 64 B + the others x 32 B) for writes, from passes of their own.
-usage: r03_traffic.py <gpurun_out/r03p> <gpurun_out/pmc_r03fwd>"""
+usage: traffic.py <gpurun_out/<tag>p> <gpurun_out/pmc_<tag>fwd> <tag>"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -26,19 +26,21 @@ def entry(c, pairs, source):
 
 def main():
     p3, pf = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
+    rnd = "round " + tag.lstrip("r0")
     out = {}
     c = counters(os.path.join(p3, "pmc_c3"), "k_fwd_fused")
     if c:
-        out["c3_fused"] = entry(c, 262144, "round 3: rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum on "
-                                "k_fwd_fused<double,1,false,true,false,0,8> (bench.py --config c3), tools/r03_profile.sh -> profiles/r03p_rocprof_summary.txt")
+        out["c3_fused"] = entry(c, 262144, rnd + ": rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum on "
+                                "k_fwd_fused<double,1,false,true,false,0,8> (bench.py --config c3), tools/profile_round.sh -> profiles/" + tag + "p_rocprof_summary.txt")
     c = counters(os.path.join(p3, "pmc_c5"), "k_fwd_fused_mb")
     if c:
-        out["c5_fused"] = entry(c, 65536, "round 3: the same counters on k_fwd_fused_mb<float,2,true,1,16> (bench.py --config c5), profiles/r03p_rocprof_summary.txt: "
+        out["c5_fused"] = entry(c, 65536, rnd + ": the same counters on k_fwd_fused_mb<float,2,true,1,16> (bench.py --config c5), profiles/" + tag + "p_rocprof_summary.txt: "
                                 "path slabs re-fetched per band + band-boundary rows written through to L2 and read back")
     c = counters(pf, "k_fwd_wave")
     if c:
-        out["c3"] = entry(c, 131072, "round 3: the same counters on k_fwd_wave (tools/pmc_fwd.sh r03fwd: 131072 pairs of 127 x 127, dyadic 1, fp64), "
-                          "profiles/r03p_pmc_fwd_solver.txt")
+        out["c3"] = entry(c, 131072, rnd + ": the same counters on k_fwd_wave (tools/pmc_fwd.sh: 131072 pairs of 127 x 127, dyadic 1, fp64), "
+                          "profiles/" + tag + "p_pmc_fwd_solver.txt")
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
