@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_PROC_BIND", "spread")   # the CPU baseline's threads: one per hardware thread, not migrating
 os.environ.setdefault("OMP_PLACES", "threads")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle oracle threads sleep: the box's CPU quota is far below its hardware threads
 
 import sigkernel_amd  # noqa: E402
 from sigkernel_amd import _lib  # noqa: E402
@@ -94,6 +95,17 @@ def cpu_model():
     return "unknown"
 
 
+def usable_threads():
+    """Threads the oracle may run on: the hardware threads visible to the process capped by the container's cgroup CPU quota (16 on the
+    GPU boxes, which show 256 hardware threads: 256 OpenMP threads spinning at barriers under a 16-CPU quota were measured to turn
+    a 12 s parity pass into 350 s, one run in two)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    quota = cgroup_cpu_quota()
+    usable = max(1, min(cores, len(os.sched_getaffinity(0)), int(np.ceil(quota)) if quota else cores))
+    return max(1, min(usable, O.max_threads())) if O.max_threads() > 1 else usable
+
+
 def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
     """Time the CPU oracle (kind "port": the reference is Python/Cython and cannot travel) on a bounded sample of the SAME
     workload: the first `rows` rows of X against all of Y, every pair's static kernel + increments + PDE solve inside ONE
@@ -108,8 +120,7 @@ def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
     # threads = the CPUs this process may actually use: the box's hardware threads capped by the container's cgroup CPU quota
     # (16 on the round-3 GPU boxes -- 256 hardware threads are visible, but more than 16 busy threads are throttled: measured
     # 16.6x on 16 threads, 14.8x on 128)
-    usable = max(1, min(cores, len(os.sched_getaffinity(0)), int(np.ceil(quota)) if quota else cores))
-    threads = max(1, min(usable, O.max_threads())) if O.max_threads() > 1 else usable
+    threads = usable_threads()
     B, M, N = Yc.shape[0], Xc.shape[1], Yc.shape[1]
     kind, param = (0, 1.0) if kname == "linear" else (1, 1.0)
     Xn, Yn = Xc.double().numpy(), Yc.double().numpy()
@@ -350,8 +361,8 @@ def timed(step, steps, warmup, dist, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)     # (the first launches of a process run at lower clocks)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -428,11 +439,15 @@ def main():
             "note": "same config, same steps / warmup / barriers, timed right after the headline region"}
         del other
 
+    t_ex = time.perf_counter()
     if rank == 0 and not args.no_extras:
         extras(result, args, wl.cfg, wl.sk1, be, wl.X, wl.Y, wl.Xc, wl.Yc, out, wl.A_total, world, value)
+    t_cf = time.perf_counter()
     if rank == 0 and world == 1 and not args.no_extras and not args.no_configs and args.config == "c3":
         del out
         result["configs"] = other_configs(dev, args)
+    if rank == 0:
+        result["wall_s"] = {"timed_region": elapsed, "extras": t_cf - t_ex, "configs": time.perf_counter() - t_cf}
     if rank == 0:
         print(json.dumps(result))
         sys.stdout.flush()
@@ -448,7 +463,7 @@ def mmd_parity(wl, loss, grad, rows):
     from oracle import oracle as O
     skern = static_kernel(wl.kname)
     A, B = wl.A_total, wl.B
-    nt = os.cpu_count() or 1
+    nt = usable_threads()
     Xr = wl.Xc[rows]
     wxx = np.full((len(rows), A), 1.0 / (A * (A - 1.0)))
     wxx[np.arange(len(rows)), rows] = 0.0
@@ -580,7 +595,8 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
         ops = pairs_f * (cells_per_entry * 3 + Mc * Nc * per_coarse)
         tflops = 2 * ops / (avg * 1e-3) / 1e12
         kern = "sk_solve_fwd_%s_%s (k_fwd_fused: static kernel + increments + PDE in one launch)" % (kname, "f64" if s == 8 else "f32")
-        live = None if (args.no_live_traffic or sym) else live_traffic(args.config, "k_fwd_fused")
+        # (one rank only: with more, the other ranks sit in a collective's barrier while rank 0 profiles -- the committed pass serves)
+        live = None if (args.no_live_traffic or sym or world > 1) else live_traffic(args.config, "k_fwd_fused")
         result["roofline"] = {
             "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TF,
             "traffic": live["hbm_bytes_per_launch"] if live else traffic_entry(args.config + "_fused", pairs_f),
@@ -682,7 +698,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
     gworst, grows = 0.0, []
     if cells_per_entry < 1e6:
         for a in (0, ra - 1):
-            gp = O.gram_grad_points(Xc[a:a + 1], Yc[:32], skern, dyadic, nthreads=os.cpu_count() or 1)   # (1,32,M,D)
+            gp = O.gram_grad_points(Xc[a:a + 1], Yc[:32], skern, dyadic, nthreads=usable_threads())   # (1,32,M,D)
             want = np.einsum("b,bmd->md", w[a, :32].numpy(), gp[0])
             got = grad[a].double().cpu().numpy()
             gworst = max(gworst, float(np.max(np.abs(got - want)) / np.max(np.abs(want))))

@@ -379,7 +379,8 @@ class HipBackend:
             Xr, Yt = _prep_pair(X, Y, False, 1.0, Mrows, Ncp)     # the path points, [A][256][8]; dimension-major [B][8][Ncp]
             if keep_edges and X.dtype == torch.float64:
                 P = A * B if gram else A
-                nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc, int(dyadic), 8))
+                # (node columns: when N - 1 is a multiple of 16 the strip is one column -- one line of units -- wider: rbf_edge_geom)
+                nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc + (1 if Nc % 16 == 0 else 0), int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic),

@@ -113,6 +113,14 @@ inline Strip strip_geom(const Geom &g, int elem_size) {
     st.MMp = (st.nb * L * st.RC) << DY;
     return st;
 }
+// The one-band RBF kernels sweep NODE columns: column 2 NUp of the strip must be padding, which the increment layout has not when
+// N - 1 is a multiple of 16.  Their edges are then kept in the layout of a strip one column wider (one more line of 8 units);
+// sk_strip_edges_bytes(P, Mc, Nc + 1, ...) sizes it.  (The streaming adjoint sees a size it does not expect and sweeps forward itself.)
+inline Geom rbf_edge_geom(const Geom &g) {
+    Geom e = g;
+    if (g.Nc % 16 == 0) { e.Nc += 1; e.NN = e.Nc << e.dyadic; }
+    return e;
+}
 inline size_t strip_edge_doubles(const Geom &g, int elem_size) {
     const Strip st = strip_geom(g, elem_size);
     return st.ok ? (size_t)st.NNp + (size_t)st.MMp : 0;

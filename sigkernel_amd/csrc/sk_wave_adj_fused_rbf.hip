@@ -629,7 +629,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
                               hipStream_t s) {
     const int DY = g.dyadic;
     if (DY < 1 || DY > 2 || B < 0 || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
-    const Strip st = strip_geom(g, 8);   // the layout of the edges; the sweep uses the same lanes and units
+    const Strip st = strip_geom(rbf_edge_geom(g), 8);   // the layout of the edges; the sweep uses the same lanes and units
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
     const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
@@ -745,7 +745,7 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     const int64_t nch = B / ppg;
     const int64_t slot = (int64_t)rows * outw;
     if (gpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
-    const Strip st = strip_geom(g, 8);
+    const Strip st = strip_geom(rbf_edge_geom(g), 8);
     const int64_t Epair = (int64_t)st.NUp * (2 << g.dyadic) + (int64_t)(1 << st.logL) * st.RC * (1 << g.dyadic);   // edge doubles per pair
     for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
         const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;

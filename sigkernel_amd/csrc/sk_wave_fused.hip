@@ -959,7 +959,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.e_NUp = NUp;
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
-        const Strip st = strip_geom(g, 8);
+        const Strip st = strip_geom(KIND == 1 ? rbf_edge_geom(g) : g, 8);
         if (!st.ok || st.nb != 1 || st.RC != RC) return SK_ERR_UNSUPPORTED;
         prm.e_NUp = st.NUp;
         prm.e_L = 1 << st.logL;
