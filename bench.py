@@ -34,14 +34,37 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
 
+
+def _cpu_quota_threads():
+    """Hardware threads this process may really use: those visible, capped by the container's cgroup CPU quota (cgroup v2 cpu.max)."""
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(-(-float(q) // float(per)))))
+    except Exception:      # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+# The GPU boxes show 256 hardware threads under a 16-CPU cgroup quota.  Every OpenMP runtime in the process (torch's intra-op pool,
+# numpy's BLAS, the oracle's libgomp) would start 256 threads that spin at their barriers, burn the quota and get the WHOLE process
+# throttled -- measured: the parity / baseline phases of this script took 12 s in one run and 340 s in the next.  So, BEFORE torch and
+# numpy are imported: as many threads as the quota allows, sleeping when idle, not pinned (the host is shared with other boxes).
+_QUOTA_THREADS = _cpu_quota_threads()
+os.environ.setdefault("OMP_NUM_THREADS", str(_QUOTA_THREADS))
+os.environ.setdefault("MKL_NUM_THREADS", str(_QUOTA_THREADS))
+os.environ.setdefault("OPENBLAS_NUM_THREADS", str(_QUOTA_THREADS))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("OMP_PROC_BIND", "false")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(_QUOTA_THREADS)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("OMP_PROC_BIND", "spread")   # the CPU baseline's threads: one per hardware thread, not migrating
-os.environ.setdefault("OMP_PLACES", "threads")
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle oracle threads sleep: the box's CPU quota is far below its hardware threads
 
 import sigkernel_amd  # noqa: E402
 from sigkernel_amd import _lib  # noqa: E402
@@ -97,13 +120,8 @@ def cpu_model():
 
 def usable_threads():
     """Threads the oracle may run on: the hardware threads visible to the process capped by the container's cgroup CPU quota (16 on the
-    GPU boxes, which show 256 hardware threads: 256 OpenMP threads spinning at barriers under a 16-CPU quota were measured to turn
-    a 12 s parity pass into 350 s, one run in two)."""
-    from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    quota = cgroup_cpu_quota()
-    usable = max(1, min(cores, len(os.sched_getaffinity(0)), int(np.ceil(quota)) if quota else cores))
-    return max(1, min(usable, O.max_threads())) if O.max_threads() > 1 else usable
+    GPU boxes, which show 256 hardware threads; see the top of this file)."""
+    return _QUOTA_THREADS
 
 
 def cpu_baseline(Xc, Yc, kname, dyadic, budget_s=20.0):
@@ -541,6 +559,7 @@ def other_configs(dev, args):
     number for every config, not only the headline."""
     res = {}
     for name, steps, warmup in (("c2", 20, 3), ("mmd32", 10, 2), ("mmd64", 10, 2), ("c5", 2, 1), ("c4", 2, 1)):
+        t_cfg = time.perf_counter()
         try:
             wl = Workload(name, 1, None, dev, None)
             elapsed, out = timed(wl.step, steps, warmup, None, dev)
@@ -558,6 +577,8 @@ def other_configs(dev, args):
             res[name] = ent
             del wl, out
             torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            ent["wall_s"] = time.perf_counter() - t_cfg
         except Exception as e:      # noqa: BLE001 -- a failing secondary config must not cost the headline its line
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
@@ -577,6 +598,14 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
     alg_per_pair = Mc * Nc * s + s                                   # inc_c read once + 1 value out
     reps = max(3, min(args.steps, 10))
     Xr = X[:A]                                                       # one GPU's rows
+    phases, t_ph = {}, [time.perf_counter()]
+
+    def phase(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        phases[name] = now - t_ph[0]
+        t_ph[0] = now
+    result["extras_wall_s"] = phases
 
     # ---- (1) the kernel that dominates the forward step ----------------------------------------------------------------
     fused = _fused_forward(be, sk.static_kernel, Xr, Y, dyadic, False, gram=True) is not None
@@ -618,6 +647,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
                                    "kernel never reads those bytes (see traffic)",
         }
 
+    phase("roofline_fused_incl_live_traffic")
     # ---- (2) the HBM-streaming solver (what north_star describes; every static kernel outside the fused scope):
     #          increments resident in HBM, solver kernel alone ---------------------------------------------------------
     rows = A
@@ -645,6 +675,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
         result["roofline"] = streaming
     del inc
 
+    phase("streaming_solver")
     # ---- (3) the adjoint leg: compute_Gram with a gradient pending + backward, HIP events -------------------------------
     ra = A
     while ra > 8 and 4 * ra * B * M * N * 8 > 40e9 and not fused:
@@ -679,6 +710,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
                 "static kernel move far fewer bytes -- this is the rate-equivalent the survey prescribes",
     }
 
+    phase("adjoint")
     # ---- (4) parity of the timed output and of the gradient -----------------------------------------------------------
     skern = static_kernel(kname)
     rng = np.random.default_rng(0)
@@ -710,6 +742,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
     if mode == "mmd":
         result["parity"]["mmd"] = float(out[0])
 
+    phase("parity_vs_oracle")
     # ---- (5) CPU baseline -----------------------------------------------------------------------------------------------
     if world == 1 and not args.no_cpu_baseline:
         cb, vals, nrows = cpu_baseline(Xc[:A], Yc, kname, dyadic, args.cpu_budget_s)
@@ -718,6 +751,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
         if mode == "gram":
             result["speedup_vs_cpu_baseline"] = value / cb["value"]
             result["speedup_vs_cpu_single_thread"] = value / cb["single_thread_value"]
+        phase("cpu_baseline")
 
 
 if __name__ == "__main__":

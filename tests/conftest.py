@@ -2,9 +2,30 @@ import glob
 import os
 import sys
 
-import numpy as np
-import pytest
-import torch
+
+def _cpu_quota_threads():
+    """Hardware threads the process may really use: those visible, capped by the container's cgroup CPU quota.  (The GPU boxes show 256
+    threads under a 16-CPU quota; OpenMP pools of 256 spinning threads -- torch's, BLAS's, the oracle's -- get the whole process
+    throttled, intermittently by a factor of 30: bench.py met it.)  Set before torch / numpy start their pools."""
+    n = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(-(-float(q) // float(per)))))
+    except Exception:      # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, str(_cpu_quota_threads()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(_cpu_quota_threads())
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
