@@ -52,7 +52,8 @@ def _cpu_quota_threads():
 # numpy's BLAS, the oracle's libgomp) would start 256 threads that spin at their barriers, burn the quota and get the WHOLE process
 # throttled -- measured: the parity / baseline phases of this script took 12 s in one run and 340 s in the next.  So, BEFORE torch and
 # numpy are imported: as many threads as the quota allows, sleeping when idle, not pinned (the host is shared with other boxes).
-_QUOTA_THREADS = _cpu_quota_threads()
+# (N ranks on one node share the quota)
+_QUOTA_THREADS = max(1, _cpu_quota_threads() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
 os.environ.setdefault("OMP_NUM_THREADS", str(_QUOTA_THREADS))
 os.environ.setdefault("MKL_NUM_THREADS", str(_QUOTA_THREADS))
 os.environ.setdefault("OPENBLAS_NUM_THREADS", str(_QUOTA_THREADS))
@@ -288,7 +289,7 @@ def self_launch(gpus):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, SK_BENCH_LAUNCH="self")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on these hosts
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // gpus)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _cpu_quota_threads() // gpus)))
     return subprocess.call(cmd, env=env)
 
 
