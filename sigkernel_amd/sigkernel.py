@@ -615,6 +615,22 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
     return out[0], out[1], out[2]
 
 
+_MMD_STREAMS_MAX_PAIRS = 128 * 128    # pairs per Gram matrix up to which a CAPTURED compute_mmd forks its three matrices onto three streams
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device):
+    """Two side streams per device, created once."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE_STREAMS[key]
+
+
+def routes_allow_streams():
+    return not routes.no_mmd_streams
+
+
 class _NoGradCtx:
     """What the autograd Functions' forward needs of a context when no gradient can be asked for: the call skips
     torch.autograd.Function.apply (a quarter of the host time of a C1-sized call) and returns the same values."""
@@ -698,11 +714,37 @@ class SigKernel:
         return K_XX_m - 2. * torch.mean(K_XY)
 
     def compute_mmd(self, X, Y, max_batch=100):
-        """Unbiased MMD^2 between the samples X and Y (sigkernel.py:180-197)."""
+        """Unbiased MMD^2 between the samples X and Y (sigkernel.py:180-197).
+
+        Training-sized batches (a few thousand pairs per Gram matrix) leave most of the chip idle: each of the three forward
+        launches -- and, in backward, of the two adjoint launches -- is a wave's skew fill plus a pair or two.  While a hipGraph is
+        being CAPTURED (`torch.cuda.graph`: what a training loop with static shapes should replay) the three Gram matrices are
+        therefore put on three streams -- K_YY and K_XY fork from the caller's stream and join it before the reductions; autograd
+        runs each matrix's backward on the stream of its forward -- so the graph holds them as parallel branches: replays 10-15 %
+        faster at 16..64 paths (tools/experiments/r04_mmd_streams.py), bit-identical gradients.  Eager calls stay on one stream:
+        they are bound by the host's launch rate there, and the stream switches cost more than the overlap returns (0.59 -> 0.75 ms
+        at 32 paths); large batches fill the chip with one launch (round 3: no gain from streams at BASELINE configs[3])."""
         assert not Y.requires_grad, "the second input should not require grad"
-        K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
-        K_YY = self.compute_Gram(Y, Y, sym=True, max_batch=max_batch)
-        K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
+        if (X.is_cuda and Y.is_cuda and self.process_group is None and routes_allow_streams()
+                and max(X.shape[0], Y.shape[0]) ** 2 <= _MMD_STREAMS_MAX_PAIRS and X.shape[0] > 1 and Y.shape[0] > 1
+                and torch.cuda.is_current_stream_capturing()):
+            cur = torch.cuda.current_stream(X.device)
+            s_yy, s_xy = _side_streams(X.device)
+            s_yy.wait_stream(cur)
+            s_xy.wait_stream(cur)
+            with torch.cuda.stream(s_yy):
+                K_YY = self.compute_Gram(Y, Y, sym=True, max_batch=max_batch)
+            with torch.cuda.stream(s_xy):
+                K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
+            K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
+            cur.wait_stream(s_yy)
+            cur.wait_stream(s_xy)
+            K_YY.record_stream(cur)       # (allocated on the side streams, consumed on the caller's)
+            K_XY.record_stream(cur)
+        else:
+            K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
+            K_YY = self.compute_Gram(Y, Y, sym=True, max_batch=max_batch)
+            K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
         K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
         K_YY_m = (torch.sum(K_YY) - torch.sum(torch.diag(K_YY))) / (K_YY.shape[0] * (K_YY.shape[0] - 1.))
         return K_XX_m + K_YY_m - 2. * torch.mean(K_XY)

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""compute_mmd(X, Y).backward() on training-sized batches with its three Gram matrices on three streams (default) against one
+stream (routes.no_mmd_streams), eager and replayed from a hipGraph; same box, alternating.  Gradients compared bit for bit."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import sigkernel_amd
+g = torch.Generator().manual_seed(0)
+def walk(A, M, D): return (torch.cumsum(torch.randn(A, M, D, generator=g, dtype=torch.float64), 1) / np.sqrt(M * D)).cuda()
+for A, M, D, d, kern in ((16, 64, 3, 1, "rbf"), (32, 64, 3, 1, "rbf"), (64, 64, 3, 1, "rbf"), (128, 64, 3, 1, "rbf"), (64, 128, 8, 1, "linear"), (32, 32, 4, 2, "rbf")):
+    X, Y = walk(A, M, D), walk(A, M, D)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0) if kern == "rbf" else sigkernel_amd.LinearKernel(), d)
+    def step(Xg):
+        sk.compute_mmd(Xg, Y).backward()
+    res, grads = {}, {}
+    for rnd in range(3):
+        for mode in (True, False):
+            sigkernel_amd.routes.no_mmd_streams = mode
+            Xg = X.clone().requires_grad_(True)
+            for _ in range(5): Xg.grad = None; step(Xg)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(30): Xg.grad = None; step(Xg)
+            torch.cuda.synchronize()
+            res.setdefault(("eager", mode), []).append((time.perf_counter() - t0) / 30 * 1e3)
+            grads[mode] = Xg.grad.clone()
+            # hipGraph replay
+            sX = X.clone().requires_grad_(True)
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3): step(sX); sX.grad = None
+            torch.cuda.current_stream().wait_stream(side)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr): step(sX)
+            for _ in range(3): gr.replay()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(50): gr.replay()
+            torch.cuda.synchronize()
+            res.setdefault(("graph", mode), []).append((time.perf_counter() - t0) / 50 * 1e3)
+            assert torch.equal(sX.grad, grads[mode])
+    same = torch.equal(grads[True], grads[False])
+    print("%-6s A=B=%3d len %3d dim %d d=%d | eager: one stream %.3f ms, three %.3f | hipGraph: one %.3f, three %.3f | gradients bit-identical: %s"
+          % (kern, A, M, D, d, min(res[("eager", True)]), min(res[("eager", False)]), min(res[("graph", True)]), min(res[("graph", False)]), same), flush=True)
