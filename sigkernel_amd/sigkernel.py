@@ -725,11 +725,12 @@ class SigKernel:
         they are bound by the host's launch rate there, and the stream switches cost more than the overlap returns (0.59 -> 0.75 ms
         at 32 paths); large batches fill the chip with one launch (round 3: no gain from streams at BASELINE configs[3])."""
         assert not Y.requires_grad, "the second input should not require grad"
-        if (X.is_cuda and Y.is_cuda and self.process_group is None and routes_allow_streams()
-                and max(X.shape[0], Y.shape[0]) ** 2 <= _MMD_STREAMS_MAX_PAIRS and X.shape[0] > 1 and Y.shape[0] > 1
-                and torch.cuda.is_current_stream_capturing()):
+        small = (X.is_cuda and Y.is_cuda and self.process_group is None and routes_allow_streams()
+                 and max(X.shape[0], Y.shape[0]) ** 2 <= _MMD_STREAMS_MAX_PAIRS and X.shape[0] > 1 and Y.shape[0] > 1)
+        if small:
+            s_yy, s_xy = _side_streams(X.device)      # (created by the warm-up calls that precede a capture, never inside one)
+        if small and torch.cuda.is_current_stream_capturing():
             cur = torch.cuda.current_stream(X.device)
-            s_yy, s_xy = _side_streams(X.device)
             s_yy.wait_stream(cur)
             s_xy.wait_stream(cur)
             with torch.cuda.stream(s_yy):
