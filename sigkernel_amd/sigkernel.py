@@ -11,6 +11,8 @@ Goursat PDE solve and the adjoint PDE run in the HIP kernels of libsigkernel_amd
 * big batches are tiled by an HBM budget (``SigKernel.workspace_bytes``), not by ``max_batch``:
   results never depended on ``max_batch`` (sigkernel.py:31-39, :102-127) and still do not.
 """
+import functools
+
 import torch
 
 from . import _lib
@@ -52,6 +54,12 @@ STREAM, FUSED, FUSED_MB, FUSED_MB_SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _l
 OP_FORWARD, OP_ADJOINT = _lib.OP_FORWARD, _lib.OP_ADJOINT
 
 
+@functools.lru_cache(maxsize=4096)
+def _route_query(route_fn, *key):
+    """sk_route_query is a pure function of its arguments: one ctypes call (1.4 us) per distinct shape, a dictionary look-up after."""
+    return route_fn(*key)
+
+
 def _route(be, op, static_kernel, Xd, Yd, dyadic, naive, gram):
     """Which kernel family serves the call: the library's own answer (sk_route_query, csrc/sk_route.hip -- the one statement of the
     fused kernels' scope) for exactly LinearKernel / exactly RBFKernel, STREAM for every other static kernel; then the route
@@ -61,7 +69,7 @@ def _route(be, op, static_kernel, Xd, Yd, dyadic, naive, gram):
         return STREAM
     if (fused[0] == 1 and routes.no_fused_rbf) or (op == OP_ADJOINT and routes.no_fused_adjoint):
         return STREAM
-    r = be.route(op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, naive, Xd.element_size(), routes.no_stream)
+    r = _route_query(be.route, op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), Xd.element_size(), routes.no_stream)
     if r in (FUSED_MB, FUSED_MB_SWAP) and routes.no_fused_mb:
         return STREAM
     return r
