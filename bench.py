@@ -227,7 +227,7 @@ def traffic_entry(key, pairs):
     return None
 
 
-def live_traffic(config, kernel_regex, timeout_s=150):
+def live_traffic(config, kernel_regex, timeout_s=90):
     """HBM bytes per launch of the dominant kernel measured IN THIS RUN: a child `bench.py --config <c> --no-extras` under
     `rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum` (a pass of
     its own: counters are never combined with API tracing), corrected as the microarchitecture guide prescribes -- 128-byte read
