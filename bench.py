@@ -248,7 +248,20 @@ def live_traffic(config, kernel_regex, timeout_s=90):
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             env.pop(k, None)
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        # (its own process group: on a timeout the profiler AND the python under it are ended -- by the group this call started,
+        # never by a pattern)
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            if proc.wait(timeout=timeout_s) != 0:
+                return None
+        except subprocess.TimeoutExpired:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.wait()
+            return None
         acc = {}
         for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):
