@@ -624,7 +624,9 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
 
 
 _MMD_STREAMS_MAX_PAIRS = 128 * 128    # pairs per Gram matrix up to which a CAPTURED compute_mmd forks its three matrices onto three streams
+_MERGED_MAX_PAIRS = 2 * 128 * 128      # pairs of K(X, [X; Y]) up to which the loss wrappers take the merged route (_SigKernelLoss)
 _SIDE_STREAMS = {}
+_LOSS_WEIGHTS = {}
 
 
 def _side_streams(device):
@@ -637,6 +639,91 @@ def _side_streams(device):
 
 def routes_allow_streams():
     return not routes.no_mmd_streams
+
+
+def _loss_weights(A, B, dtype, device):
+    """Constant weight matrices of the loss wrappers, built once per (A, B, dtype, device):
+       wf (A, A+B)  value:    [ (1 - I) / (A (A-1)) | -2 / (A B) ]   -- K_XX_m - 2 mean(K_XY) = sum(K(X, [X; Y]) * wf)
+       wb (A, A+B)  gradient: [ 2 (1 - I) / (A (A-1)) | -2 / (A B) ] -- d loss / dK with the reference's 2x rule on the K_XX part
+                              (_SigKernelGram.backward doubles when both arguments require grad, sigkernel.py:410-412)
+       wy (B, B)    value:    (1 - I) / (B (B-1))                     -- K_YY_m = sum(K_YY * wy); None for B < 2"""
+    key = (A, B, dtype, device)
+    w = _LOSS_WEIGHTS.get(key)
+    if w is None:
+        if len(_LOSS_WEIGHTS) >= 64:
+            _LOSS_WEIGHTS.clear()
+        wf = torch.empty(A, A + B, dtype=dtype, device=device)
+        wf[:, :A] = (1.0 - torch.eye(A, dtype=dtype, device=device)) / (A * (A - 1.0))
+        wf[:, A:] = -2.0 / (A * float(B))
+        wb = wf.clone()
+        wb[:, :A] *= 2.0
+        wy = (1.0 - torch.eye(B, dtype=dtype, device=device)) / (B * (B - 1.0)) if B > 1 else None
+        w = _LOSS_WEIGHTS[key] = (wf, wb, wy)
+    return w
+
+
+class _SigKernelLoss(torch.autograd.Function):
+    """K_XX_m - 2 mean(K_XY) [+ K_YY_m] for TRAINING-SIZED batches: the value the reference's compute_mmd / compute_scoring_rule /
+    compute_expected_scoring_rule (sigkernel.py:146-197) assemble from three (two) compute_Gram calls, from ONE Gram block
+    K(X, Z), Z = [X; Y], and -- for the MMD -- the triangle of K(Y, Y).
+
+    Why: a Gram matrix of a few thousand pairs is one wave's skew fill plus a pair or two per lane group, so the three forward and
+    two adjoint launches of the reference's composition each leave most of the chip idle, and some sixty small launches (staging,
+    reductions and their autograd) sit between them.  Here K_XX and K_XY are the column blocks of ONE forward launch (with the edges
+    for backward) and their gradients ONE adjoint launch over the same pairs, weighted by the constant d loss / dK (_loss_weights;
+    the reference's 2x rule for K_XX is in the weights); the reductions are two multiply-sums.  Same pairs, same kernels, same
+    per-pair values; only the order in which the (A, A+B) values are summed differs from the reference's formula (last-bit).
+    Without a gradient and with the K_YY term the whole triangle of K(Z, Z) is one launch."""
+
+    @staticmethod
+    def forward(ctx, X, Y, static_kernel, dyadic_order, _naive_solver, workspace_bytes, with_yy):
+        be = _lib.get_backend()
+        A, B = X.shape[0], Y.shape[0]
+        Xd, Yd = X.detach().contiguous(), Y.detach().contiguous()
+        Z = torch.cat((Xd, Yd))
+        wf, wb, wy = _loss_weights(A, B, X.dtype, X.device)
+        ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver, ctx.workspace_bytes = static_kernel, dyadic_order, _naive_solver, workspace_bytes
+        ctx.kept_edges = ctx.K = None
+        need = ctx.needs_input_grad[0]
+        if not need and with_yy:
+            K_ZZ = _gram_symmetric(be, static_kernel, Z, dyadic_order, _naive_solver, workspace_bytes)
+            return (K_ZZ[:A] * wf).sum() + (K_ZZ[A:, A:] * wy).sum()
+        K_YY = None
+        if with_yy:
+            fork = (Yd.is_cuda and routes_allow_streams() and torch.cuda.is_current_stream_capturing())
+            if fork:    # a captured step: K_YY is a parallel branch of the graph (see compute_mmd)
+                cur = torch.cuda.current_stream(Yd.device)
+                s_yy = _side_streams(Yd.device)[0]
+                s_yy.wait_stream(cur)
+                with torch.cuda.stream(s_yy):
+                    K_YY = _gram_symmetric(be, static_kernel, Yd, dyadic_order, _naive_solver, workspace_bytes)
+            else:
+                K_YY = _gram_symmetric(be, static_kernel, Yd, dyadic_order, _naive_solver, workspace_bytes)
+        fused = _fused_static(static_kernel, True) is not None
+        ctx.kept_edges = [] if need else None
+        K_XZ = _gram_block(be, static_kernel, Xd, Z, dyadic_order, _naive_solver, workspace_bytes, (3 if fused else 8) if need else None,
+                           ctx.kept_edges)
+        val = (K_XZ * wf).sum()
+        if with_yy:
+            if fork:
+                cur.wait_stream(s_yy)
+                K_YY.record_stream(cur)
+            val = val + (K_YY * wy).sum()
+        if need:
+            ctx.save_for_backward(X, Z)
+            ctx.K, ctx.wb = K_XZ, wb
+        return val
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        X, Z = ctx.saved_tensors
+        be = _lib.get_backend()
+        go = (ctx.wb * grad_output.to(X.dtype)).contiguous()
+        kept, ctx.kept_edges = ctx.kept_edges, None
+        grad_X = _rows_gradient(be, ctx.static_kernel, X.detach().contiguous(), Z, go, ctx.dyadic_order, ctx._naive_solver, True, kept,
+                                ctx.workspace_bytes, ctx.K)
+        ctx.K = None
+        return grad_X, None, None, None, None, None, None
 
 
 class _NoGradCtx:
@@ -708,6 +795,9 @@ class SigKernel:
     def compute_scoring_rule(self, X, y, max_batch=100):
         """S(X, y) = E[k(X, X)] - 2 E[k(X, y)] with y of shape (1, len_y, dim) (sigkernel.py:146-161)."""
         assert not y.requires_grad, "the second input should not require grad"
+        merged = self._merged_loss(X, y, with_yy=False)
+        if merged is not None:
+            return merged
         K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
         K_Xy = self.compute_Gram(X, y, sym=False, max_batch=max_batch)
         K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
@@ -716,10 +806,29 @@ class SigKernel:
     def compute_expected_scoring_rule(self, X, Y, max_batch=100):
         """S(X, Y) = E_Y[S(X, y)] (sigkernel.py:163-178)."""
         assert not Y.requires_grad, "the second input should not require grad"
+        merged = self._merged_loss(X, Y, with_yy=False)
+        if merged is not None:
+            return merged
         K_XX = self.compute_Gram(X, X, sym=True, max_batch=max_batch)
         K_XY = self.compute_Gram(X, Y, sym=False, max_batch=max_batch)
         K_XX_m = (torch.sum(K_XX) - torch.sum(torch.diag(K_XX))) / (K_XX.shape[0] * (K_XX.shape[0] - 1.))
         return K_XX_m - 2. * torch.mean(K_XY)
+
+    def _merged_loss(self, X, Y, with_yy):
+        """The loss wrappers' merged route for training-sized batches (_SigKernelLoss: one forward and one adjoint launch over
+        K(X, [X; Y])), or None where it does not apply -- paths of different lengths, a process group, more than
+        _MERGED_MAX_PAIRS pairs (there one launch per matrix fills the chip and the triangular K_XX saves more), fewer than two
+        paths (the reference's 0 / 0), malformed inputs (the Gram calls raise for those), `routes.no_merged_loss`."""
+        if routes.no_merged_loss or self.process_group is not None or X.dim() != 3 or Y.dim() != 3:
+            return None
+        A, B = X.shape[0], Y.shape[0]
+        if (X.shape[1:] != Y.shape[1:] or X.shape[1] < 2 or A < 2 or B < (2 if with_yy else 1) or A * (A + B) > _MERGED_MAX_PAIRS
+                or X.dtype != Y.dtype or X.device != Y.device):
+            return None
+        args = (X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes, with_yy)
+        if not _wants_grad(X):
+            return _SigKernelLoss.forward(_NoGradCtx(), *args)
+        return _SigKernelLoss.apply(*args)
 
     def compute_mmd(self, X, Y, max_batch=100):
         """Unbiased MMD^2 between the samples X and Y (sigkernel.py:180-197).
@@ -733,6 +842,9 @@ class SigKernel:
         they are bound by the host's launch rate there, and the stream switches cost more than the overlap returns (0.59 -> 0.75 ms
         at 32 paths); large batches fill the chip with one launch (round 3: no gain from streams at BASELINE configs[3])."""
         assert not Y.requires_grad, "the second input should not require grad"
+        merged = self._merged_loss(X, Y, with_yy=True)
+        if merged is not None:
+            return merged
         small = (X.is_cuda and Y.is_cuda and self.process_group is None and routes_allow_streams()
                  and max(X.shape[0], Y.shape[0]) ** 2 <= _MMD_STREAMS_MAX_PAIRS and X.shape[0] > 1 and Y.shape[0] > 1)
         if small:

@@ -336,6 +336,80 @@ def test_forward_and_training_step_replay_from_a_hip_graph(kind, D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,dt,A,B,M", [("rbf", 3, 1, torch.float64, 32, 32, 64), ("linear", 8, 1, torch.float64, 24, 40, 50), ("rbf", 4, 2, torch.float64, 40, 17, 30),
+                                              ("rbf", 7, 0, torch.float64, 20, 20, 150), ("linear", 12, 1, torch.float64, 16, 16, 40), ("rbf", 3, 1, torch.float32, 32, 32, 64),
+                                              ("rbf", 16, 2, torch.float32, 6, 5, 300)])
+def test_merged_loss_route_on_the_gpu(kind, D, d, dt, A, B, M, monkeypatch):
+    """Training-sized loss wrappers (sigkernel._SigKernelLoss: ONE forward launch with edges and ONE adjoint launch over K(X, [X; Y]))
+    against the reference's composition (routes.no_merged_loss; sigkernel.py:146-197) and against the oracle's closed forms
+    (O.gram_forward: _SigKernelGram.forward, :350-401; O.gram_grad_weighted: prep_backward + backward with the 2x rule, :404-502);
+    captured into a hipGraph, a replay on fresh values reproduces the eager call bit for bit."""
+    gen = torch.Generator().manual_seed(77)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.8)
+    sk = sigkernel_amd.SigKernel(k, d)
+    X, Y = walk(gen, A, M, D).to(dt).to(DEV), walk(gen, B, M, D).to(dt).to(DEV)
+    f32 = dt == torch.float32
+    for fn, Yv, yy in ((sk.compute_mmd, Y, True), (sk.compute_expected_scoring_rule, Y, False), (sk.compute_scoring_rule, Y[:1], False)):
+        out = {}
+        for composed in (False, True):
+            monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", composed)
+            Xg = X.clone().requires_grad_(True)
+            v = fn(Xg, Yv)
+            v.backward()
+            with torch.no_grad():
+                v0 = fn(X, Yv)
+            out[composed] = (float(v.detach()), Xg.grad.double().cpu().numpy(), float(v0))
+        scale = max(1.0, abs(out[True][0]))
+        assert abs(out[False][0] - out[True][0]) <= (2e-5 if f32 else 1e-12) * scale
+        assert abs(out[False][2] - out[False][0]) <= (2e-5 if f32 else 1e-12) * scale
+        assert rel_err(out[False][1], out[True][1]) <= (2e-4 if f32 else 1e-10)
+        # the oracle: K(X, [X; Y]) and its gradient under the weights of the loss
+        Xc, Yc = X.double().cpu(), Yv.double().cpu()
+        Zc = torch.cat([Xc, Yc])
+        Kxz = O.gram_forward(Xc, Zc, k, d, nthreads=NT)
+        Bv = Yc.shape[0]
+        wf = np.concatenate([(1.0 - np.eye(A)) / (A * (A - 1.0)), np.full((A, Bv), -2.0 / (A * Bv))], axis=1)
+        want = float((Kxz * wf).sum())
+        if yy:
+            Kyy = O.gram_forward(Yc, Yc, k, d, nthreads=NT)
+            want += float((Kyy.sum() - np.trace(Kyy)) / (Bv * (Bv - 1.0)))
+        wb = wf.copy()
+        wb[:, :A] *= 2.0
+        gw = O.gram_grad_weighted(Xc, Zc, wb, k, d, nthreads=NT)
+        assert abs(out[False][0] - want) <= (2e-5 if f32 else 1e-11) * max(1.0, abs(want))
+        assert rel_err(out[False][1], gw) <= (2e-4 if f32 else 1e-9)
+    # a captured training step
+    monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", False)
+    sX, sY = X.clone().requires_grad_(True), Y.clone()
+
+    def step():
+        loss = sk.compute_mmd(sX, sY)
+        loss.backward()
+        return loss.detach()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+            sX.grad = None
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gloss = step()
+    X1, Y1 = walk(gen, A, M, D).to(dt).to(DEV), walk(gen, B, M, D).to(dt).to(DEV)
+    for Xv, Yv in ((X1, Y1), (X, Y)):
+        with torch.no_grad():
+            sX.copy_(Xv)
+            sY.copy_(Yv)
+        graph.replay()
+        torch.cuda.synchronize()
+        Xe = Xv.clone().requires_grad_(True)
+        le = sk.compute_mmd(Xe, Yv)
+        le.backward()
+        assert torch.equal(gloss, le.detach()) and torch.equal(sX.grad, Xe.grad)
+
+
+@pytest.mark.gpu
 def test_headline_with_a_second_stream_busy_same_bits_little_slowdown():
     """The fused forward draws its pairs from a per-launch queue, so work someone else has on the chip shifts shares instead of
     stretching the tail: with a second stream kept busy by small launches the headline Gram is bit-identical and < 10 % slower."""

@@ -127,6 +127,47 @@ def test_readme_example(oracle_backend):
     assert abs(float(sk.compute_expected_scoring_rule(X, Z)) - float(c["expected_scoring_rule"])) <= 1e-13
 
 
+@pytest.mark.parametrize("name", ["gram_c2mini_rbf_d1", "gram_c3mini_lin_d1", "gram_c4mini_rbf_d2"])
+def test_merged_loss_route_equals_the_reference_composition(oracle_backend, name, monkeypatch):
+    """compute_mmd / compute_scoring_rule / compute_expected_scoring_rule of training-sized batches go through ONE Gram block
+    K(X, [X; Y]) (sigkernel._SigKernelLoss) instead of the reference's two or three compute_Gram calls (sigkernel.py:146-197):
+    same values (summation order aside) and gradients as that composition (routes.no_merged_loss) and as the reference's fixtures;
+    paths of different lengths, single paths and big batches keep the composition."""
+    from sigkernel_amd import sigkernel as S
+    c = golden(name)
+    n = min(c["X"].shape[1], c["Y"].shape[1])
+    X, Y = torch.from_numpy(c["X"][:, :n].copy()), torch.from_numpy(c["Y"][:, :n].copy())
+    sk = _sk(c)
+    blocks = []
+    real = S._gram_block
+    monkeypatch.setattr(S, "_gram_block", lambda be, k, Xd, Yd, *a, **kw: (blocks.append((Xd.shape[0], Yd.shape[0])), real(be, k, Xd, Yd, *a, **kw))[1])
+    for fn, Yv, yy in ((sk.compute_mmd, Y, True), (sk.compute_expected_scoring_rule, Y, False), (sk.compute_scoring_rule, Y[:1], False)):
+        A, B = X.shape[0], Yv.shape[0]
+        got, grads = [], []
+        for composed in (False, True):
+            monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", composed)
+            del blocks[:]
+            Xg = X.clone().requires_grad_(True)
+            v = fn(Xg, Yv)
+            v.backward()
+            got.append(float(v.detach())), grads.append(Xg.grad.numpy().copy())
+            if not composed:
+                assert blocks == ([(B, B)] if yy else []) + [(A, A + B)], blocks          # one block for K_XX and K_XY (+ K_YY's)
+            with torch.no_grad():
+                assert abs(float(fn(X, Yv)) - got[-1]) <= 1e-13 * max(1.0, abs(got[-1]))
+        assert abs(got[0] - got[1]) <= 1e-13 * max(1.0, abs(got[1]))
+        assert rel_err(grads[0], grads[1]) <= 1e-12
+        if fn == sk.compute_mmd and n == c["X"].shape[1] == c["Y"].shape[1]:
+            assert abs(got[0] - float(c["mmd"])) <= 1e-12 * max(1.0, abs(float(c["mmd"])))
+            assert rel_err(grads[0], c["grad_mmd"]) <= grad_tol(name, "grad_mmd")
+    # outside the merged route: different lengths, a process group's business, too many pairs, one path
+    monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", False)
+    assert sk._merged_loss(X, Y[:, :n - 1], True) is None
+    assert sk._merged_loss(X[:1], Y, True) is None and sk._merged_loss(X, Y[:1], True) is None and sk._merged_loss(X, Y[:1], False) is not None
+    monkeypatch.setattr(S, "_MERGED_MAX_PAIRS", X.shape[0] * (X.shape[0] + Y.shape[0]) - 1)
+    assert sk._merged_loss(X, Y, True) is None
+
+
 def test_results_do_not_depend_on_tiling_or_max_batch(oracle_backend):
     c = golden("gram_c3mini_lin_d1")
     X, Y, w = (torch.from_numpy(c[k]) for k in ("X", "Y", "w"))
