@@ -624,7 +624,6 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
 
 
 _MMD_STREAMS_MAX_PAIRS = 128 * 128    # pairs per Gram matrix up to which a CAPTURED compute_mmd forks its three matrices onto three streams
-_MERGED_MAX_PAIRS = 2 * 128 * 128      # pairs of K(X, [X; Y]) up to which the loss wrappers take the merged route (_SigKernelLoss)
 _SIDE_STREAMS = {}
 _LOSS_WEIGHTS = {}
 
@@ -816,14 +815,18 @@ class SigKernel:
 
     def _merged_loss(self, X, Y, with_yy):
         """The loss wrappers' merged route for training-sized batches (_SigKernelLoss: one forward and one adjoint launch over
-        K(X, [X; Y])), or None where it does not apply -- paths of different lengths, a process group, more than
-        _MERGED_MAX_PAIRS pairs (there one launch per matrix fills the chip and the triangular K_XX saves more), fewer than two
-        paths (the reference's 0 / 0), malformed inputs (the Gram calls raise for those), `routes.no_merged_loss`."""
+        K(X, [X; Y])), or None where it does not apply -- paths of different lengths, a process group, batches whose K_XX the
+        composition solves as a blocked triangle (_SYM_MIN_CELLS grid cells and more: that saves more than the merged launches
+        do; below it, measured on one box from 16 to 512 paths, tools/experiments/r04_merged_loss.py: merged 0.30 / 0.31 / 0.56 /
+        1.27 / 4.16 / 15.1 ms against 0.58 / 0.58 / 0.80 / 1.57 / 4.48 / 15.5 at 16 / 32 / 64 / 128 / 256 / 512 paths of
+        BASELINE configs[1]'s shape), fewer than two paths (the reference's 0 / 0), malformed inputs (the Gram calls raise for
+        those), `routes.no_merged_loss`."""
         if routes.no_merged_loss or self.process_group is not None or X.dim() != 3 or Y.dim() != 3:
             return None
         A, B = X.shape[0], Y.shape[0]
-        if (X.shape[1:] != Y.shape[1:] or X.shape[1] < 2 or A < 2 or B < (2 if with_yy else 1) or A * (A + B) > _MERGED_MAX_PAIRS
-                or X.dtype != Y.dtype or X.device != Y.device):
+        if X.shape[1:] != Y.shape[1:] or X.shape[1] < 2 or A < 2 or B < (2 if with_yy else 1) or X.dtype != Y.dtype or X.device != Y.device:
+            return None
+        if float(A) * A * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 >= _SYM_MIN_CELLS:
             return None
         args = (X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes, with_yy)
         if not _wants_grad(X):

@@ -164,7 +164,7 @@ def test_merged_loss_route_equals_the_reference_composition(oracle_backend, name
     monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", False)
     assert sk._merged_loss(X, Y[:, :n - 1], True) is None
     assert sk._merged_loss(X[:1], Y, True) is None and sk._merged_loss(X, Y[:1], True) is None and sk._merged_loss(X, Y[:1], False) is not None
-    monkeypatch.setattr(S, "_MERGED_MAX_PAIRS", X.shape[0] * (X.shape[0] + Y.shape[0]) - 1)
+    monkeypatch.setattr(S, "_SYM_MIN_CELLS", float(X.shape[0]) ** 2 * ((n - 1) << int(c["dyadic"])) ** 2)
     assert sk._merged_loss(X, Y, True) is None
 
 
