@@ -38,6 +38,11 @@ def _tiles(n_rows, bytes_per_row, budget):
     return [(a, min(a + rows, n_rows)) for a in range(0, n_rows, rows)]
 
 
+def _cap_rows(bytes_per_row, pairs_per_row, budget):
+    """bytes_per_row, raised where needed so that a row tile of `budget` bytes never holds more than _MAX_LAUNCH_PAIRS pairs."""
+    return max(bytes_per_row, -(-int(budget) * int(pairs_per_row) // _MAX_LAUNCH_PAIRS))
+
+
 def _fused_static(static_kernel, gram):
     """(kind, param) when the static kernel is exactly one of the two the fused HIP kernels implement
     (sk_static_increments_*: static kernel + increments in one pass, G_static never materialised), else None.
@@ -186,7 +191,7 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
         pair_bytes = _mb_pair_bytes(be, kind, Xd, Yd, dyadic)
         if pair_bytes is None:
             return None
-        per_row = (Yd.shape[0] if gram else 1) * pair_bytes
+        per_row = _cap_rows((Yd.shape[0] if gram else 1) * pair_bytes, Yd.shape[0] if gram else 1, budget)
         grad = torch.empty_like(Xd)
         for a0, a1, edges in _edge_tiles(kept, A, per_row, budget, strict=True):
             Xt = Xd[a0:a1].contiguous()
@@ -205,7 +210,7 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
                     return None
             grad[a0:a1] = res[0]
         return grad
-    per_row = (64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M      # edges and partial sums only
+    per_row = _cap_rows((64 * Yd.shape[0] + 2048 * M) if gram else 4096 * M, Yd.shape[0] if gram else 1, budget)      # edges and partial sums only
     grad = torch.empty_like(Xd)
     for a0, a1, edges in _edge_tiles(kept, A, per_row, budget):
         Xt = Xd[a0:a1].contiguous()
@@ -306,6 +311,7 @@ _SYM_MIN_ROWS = 32     # rows per block of the triangular adjoint
 
 
 _KEEP_EDGES_FRACTION = 0.5   # of the transient budget: how much may stay allocated between forward and backward
+_MAX_LAUNCH_PAIRS = 1 << 30  # pairs per fused launch (the fused kernels index pairs with 32 bits and refuse 2^31 - 2^20 and more)
 
 
 def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes, rows_factor=None, keep=None):
@@ -315,6 +321,24 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     pair, 8(MM+NN) bytes per pair, which lets backward skip its forward sweep.  The reference keeps the whole solution
     grid for the same purpose (sigkernel.py:248, :397-399)."""
     A, B, M, N = Xd.shape[0], Yd.shape[0], Xd.shape[1], Yd.shape[1]
+    if A * B > _MAX_LAUNCH_PAIRS and A > 1:
+        # more pairs than one fused launch indexes (32 bits): row tiles of at most _MAX_LAUNCH_PAIRS pairs, each on its own route
+        # (46400 x 46400 paths of 16 points, tools/experiments/r04_huge_batch.py: 2.8 s and 26 GB at the peak in three fused tiles against
+        # 5.2 s and 114 GB streamed)
+        rows = max(1, _MAX_LAUNCH_PAIRS // B)
+        K = torch.empty(A, B, dtype=Xd.dtype, device=Xd.device)
+        kept_all = []
+        for a0 in range(0, A, rows):
+            a1 = min(a0 + rows, A)
+            sub = [] if keep is not None else None
+            K[a0:a1] = _gram_block(be, static_kernel, Xd[a0:a1], Yd, dyadic_order, naive, workspace_bytes, rows_factor, sub)
+            if sub:
+                kept_all.extend((a0 + s0, a0 + s1, e) for s0, s1, e in sub)
+        # edges only when every tile kept them for all of its rows (else backward tiles by its own budget and sweeps forward itself)
+        if keep is not None and kept_all and kept_all[0][0] == 0 and kept_all[-1][1] == A \
+                and all(kept_all[i][1] == kept_all[i + 1][0] for i in range(len(kept_all) - 1)):
+            keep.extend(kept_all)
+        return K
     budget = None   # (asked of the device only where it is needed: a small fused call does not pay for hipMemGetInfo)
     if keep is not None and hasattr(be, "solve_fwd_keep_edges"):
         budget = _budget(Xd.device, workspace_bytes)

@@ -409,6 +409,27 @@ def test_merged_loss_route_on_the_gpu(kind, D, d, dt, A, B, M, monkeypatch):
         assert torch.equal(gloss, le.detach()) and torch.equal(sX.grad, Xe.grad)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,M,N", [("linear", 8, 1, 40, 33), ("rbf", 3, 2, 30, 30), ("rbf", 6, 0, 300, 260), ("linear", 20, 1, 25, 25)])
+def test_pair_limit_of_a_launch_tiles_over_rows(kind, D, d, M, N, monkeypatch):
+    """More pairs than one fused launch indexes (_MAX_LAUNCH_PAIRS): row tiles, forward with kept edges and backward alike -- the same
+    bits as the untiled call on every route (one band, multi-band, streamed)."""
+    gen = torch.Generator().manual_seed(8)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.9)
+    sk = sigkernel_amd.SigKernel(k, d)
+    X, Y = walk(gen, 23, M, D).to(DEV), walk(gen, 9, N, D).to(DEV)
+    w = torch.randn(23, 9, generator=gen, dtype=torch.float64).to(DEV)
+    out = []
+    for limit in (1 << 30, 4 * 9 + 1):
+        monkeypatch.setattr(skmod, "_MAX_LAUNCH_PAIRS", limit)
+        Xg = X.clone().requires_grad_(True)
+        K = sk.compute_Gram(Xg, Y)
+        (K * w).sum().backward()
+        out.append((K.detach(), Xg.grad, sk.compute_Gram(X, Y)))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][2], out[1][2])
+    assert rel_err(out[1][1].cpu().numpy(), out[0][1].cpu().numpy()) <= 1e-12      # (partial sums of a row are added per tile)
+
+
 def _second_stream_cases(gen):
     lin, rbf = sigkernel_amd.LinearKernel(), sigkernel_amd.RBFKernel(1.0)
 

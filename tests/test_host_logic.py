@@ -182,6 +182,29 @@ def test_results_do_not_depend_on_tiling_or_max_batch(oracle_backend):
     assert torch.equal(tiny.compute_kernel(X[:4], Y[:4]), _sk(c).compute_kernel(X[:4], Y[:4]))
 
 
+@pytest.mark.parametrize("name", ["gram_c3mini_lin_d1", "gram_c2mini_rbf_d1"])
+def test_more_pairs_than_one_launch_indexes_are_tiled_over_rows(oracle_backend, name, monkeypatch):
+    """The fused kernels index pairs with 32 bits; a Gram call beyond _MAX_LAUNCH_PAIRS is solved in row tiles (forward, kept edges and
+    backward alike), with the same values and gradients."""
+    from sigkernel_amd import sigkernel as S
+    c = golden(name)
+    X, Y, w = (torch.from_numpy(c[k]) for k in ("X", "Y", "w"))
+    want = _sk(c).compute_Gram(X, Y)
+    Xa = X.clone().requires_grad_(True)
+    (_sk(c).compute_Gram(Xa, Y) * w).sum().backward()
+    blocks = []
+    real = S._gram_block
+    monkeypatch.setattr(S, "_MAX_LAUNCH_PAIRS", 2 * Y.shape[0] + 1)            # two rows per tile
+    monkeypatch.setattr(S, "_gram_block", lambda be, k, Xd, Yd, *a, **kw: (blocks.append(Xd.shape[0]), real(be, k, Xd, Yd, *a, **kw))[1])
+    assert torch.equal(_sk(c).compute_Gram(X, Y), want)
+    assert blocks[0] == X.shape[0] and all(b <= 2 for b in blocks[1:]) and sum(blocks[1:]) == X.shape[0]
+    Xb = X.clone().requires_grad_(True)
+    (_sk(c).compute_Gram(Xb, Y) * w).sum().backward()
+    assert rel_err(Xb.grad.numpy(), Xa.grad.numpy()) <= 1e-13
+    assert rel_err(Xb.grad.numpy(), c["grad_w"]) <= grad_tol(name, "grad_w")
+    assert S._cap_rows(10, 1000, 10 ** 6) == 10 ** 9 // (2 * Y.shape[0] + 1) + 1      # a budget tile never exceeds the pair limit
+
+
 def test_no_gradient_for_second_argument_and_asserts(oracle_backend):
     c = golden("gram_lin_d0_ragged")
     X, Y = torch.from_numpy(c["X"]), torch.from_numpy(c["Y"])
