@@ -673,6 +673,9 @@ def _loss_weights(A, B, dtype, device):
     key = (A, B, dtype, device)
     w = _LOSS_WEIGHTS.get(key)
     if w is None:
+        # (built inside a hipGraph capture -- a capture without a warm-up call -- the fills are nodes of that graph and the memory
+        # belongs to its pool: such weights serve the captured call only and are not cached)
+        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if len(_LOSS_WEIGHTS) >= 64:
             _LOSS_WEIGHTS.clear()
         wf = torch.empty(A, A + B, dtype=dtype, device=device)
@@ -681,7 +684,9 @@ def _loss_weights(A, B, dtype, device):
         wb = wf.clone()
         wb[:, :A] *= 2.0
         wy = (1.0 - torch.eye(B, dtype=dtype, device=device)) / (B * (B - 1.0)) if B > 1 else None
-        w = _LOSS_WEIGHTS[key] = (wf, wb, wy)
+        w = (wf, wb, wy)
+        if not capturing:
+            _LOSS_WEIGHTS[key] = w
     return w
 
 
