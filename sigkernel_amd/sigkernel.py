@@ -716,26 +716,15 @@ class _SigKernelLoss(torch.autograd.Function):
         if not need and with_yy:
             K_ZZ = _gram_symmetric(be, static_kernel, Z, dyadic_order, _naive_solver, workspace_bytes)
             return (K_ZZ[:A] * wf).sum() + (K_ZZ[A:, A:] * wy).sum()
-        K_YY = None
-        if with_yy:
-            fork = (Yd.is_cuda and routes_allow_streams() and torch.cuda.is_current_stream_capturing())
-            if fork:    # a captured step: K_YY is a parallel branch of the graph (see compute_mmd)
-                cur = torch.cuda.current_stream(Yd.device)
-                s_yy = _side_streams(Yd.device)[0]
-                s_yy.wait_stream(cur)
-                with torch.cuda.stream(s_yy):
-                    K_YY = _gram_symmetric(be, static_kernel, Yd, dyadic_order, _naive_solver, workspace_bytes)
-            else:
-                K_YY = _gram_symmetric(be, static_kernel, Yd, dyadic_order, _naive_solver, workspace_bytes)
+        # (K_YY on a side stream while a graph is captured -- compute_mmd's composition does that -- buys nothing here: replays of
+        # 0.305 / 0.534 / 1.29 ms forked against 0.309 / 0.561 / 1.28 on one stream at 32 / 64 / 128 paths, tools/experiments/r04_merged_fork.py)
+        K_YY = _gram_symmetric(be, static_kernel, Yd, dyadic_order, _naive_solver, workspace_bytes) if with_yy else None
         fused = _fused_static(static_kernel, True) is not None
         ctx.kept_edges = [] if need else None
         K_XZ = _gram_block(be, static_kernel, Xd, Z, dyadic_order, _naive_solver, workspace_bytes, (3 if fused else 8) if need else None,
                            ctx.kept_edges)
         val = (K_XZ * wf).sum()
         if with_yy:
-            if fork:
-                cur.wait_stream(s_yy)
-                K_YY.record_stream(cur)
             val = val + (K_YY * wy).sum()
         if need:
             ctx.save_for_backward(X, Z)
