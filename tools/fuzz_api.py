@@ -3,7 +3,8 @@
 
 Every case draws a static kernel (LinearKernel with a scale, RBFKernel with a sigma, or a user-defined duck-typed kernel that takes
 the generic route), a dyadic order 0..3, either stencil, fp64 or fp32, batch sizes 1..24, path lengths 2..90 (one case in three with
-equal lengths: the merged loss route; one in seven 100..420 points: several bands per pair), path dimension 1..20, and checks against the oracle's closed forms
+equal lengths: the merged loss route; one in seven 100..420 points: several bands per pair), path dimension 1..20, the default transient budget or a tiny one (every call tiles over rows), the default routes or memory-first
+(routes.no_stream), and checks against the oracle's closed forms
   compute_kernel        values + gradient under random weights            (_SigKernel, sigkernel.py:201-343)
   compute_Gram          values (sym or not) + gradient, 2x rule            (_SigKernelGram, :347-416; prep_backward :419-502)
   compute_mmd, compute_scoring_rule, compute_expected_scoring_rule, compute_distance: values + gradient (:130-197)
@@ -74,6 +75,8 @@ def draw(rng):
         c["A"], c["B"] = min(c["A"], 4), min(c["B"], 4)
     if c["dyadic"] == 3:
         c["M"], c["N"] = min(c["M"], 30), min(c["N"], 30)
+    c["workspace"] = int(rng.choice([0, 0, 1 << 16, 1 << 20]))      # 0: the default budget; small: every call tiles over rows
+    c["memory_first"] = bool(rng.integers(0, 3) == 0)                # routes.no_stream
     if c["kind"] == "cauchy":      # the generic route builds (A, B, M, N, D) differences in torch: keep it small
         c["A"], c["B"], c["M"], c["N"], c["D"] = min(c["A"], 6), min(c["B"], 6), min(c["M"], 30), min(c["N"], 30), min(c["D"], 6)
     return c
@@ -95,7 +98,8 @@ def run_case(c, rng):
     A, B, M, N, D = c["A"], c["B"], c["M"], c["N"], c["D"]
     X, Y = walk(rng, A, M, D).to(dt), walk(rng, B, N, D).to(dt)
     Xo, Yo = X.double(), Y.double()          # the oracle sees exactly the values the device gets
-    sk = sigkernel_amd.SigKernel(k, d, _naive_solver=nv)
+    sk = sigkernel_amd.SigKernel(k, d, _naive_solver=nv, workspace_bytes=c.get("workspace") or None)
+    sigkernel_amd.routes.no_stream = bool(c.get("memory_first"))
     bad = []
 
     def check(what, got, want, tol):
@@ -173,6 +177,7 @@ def run_case(c, rng):
         got3 = sk.compute_kernel_and_derivatives_Gram(dev(X), dev(Y), dev(gam))
         for nm, g3, w3, tol in zip(("k", "k'", "k''"), got3, want3, (1e-10, 1e-6, 1e-3)):
             check("kgrad " + nm, g3.cpu().numpy(), w3, tol)
+    sigkernel_amd.routes.no_stream = False
     return bad
 
 
