@@ -572,9 +572,10 @@ def other_configs(dev, args):
     + 2 timed steps each between synchronisations, with a parity block per config -- so that the driver's default run carries a
     number for every config, not only the headline."""
     res = {}
+    # (mmd32 / mmd64: 5 + 30 steps of ~0.4 ms -- after two warm-ups the allocator and the clocks are not settled: 0.44 instead of 0.31 ms)
     # (c4: two warm-up steps -- after one, the caching allocator may still be growing its pool of 17 GB edge blocks inside the timed
     # steps: 550 instead of 345 ms per step, one run in three)
-    for name, steps, warmup in (("c2", 20, 3), ("mmd32", 10, 2), ("mmd64", 10, 2), ("c5", 2, 1), ("c4", 3, 2)):
+    for name, steps, warmup in (("c2", 20, 3), ("mmd32", 30, 5), ("mmd64", 30, 5), ("c5", 2, 1), ("c4", 3, 2)):
         t_cfg = time.perf_counter()
         try:
             wl = Workload(name, 1, None, dev, None)
