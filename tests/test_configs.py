@@ -393,9 +393,11 @@ def test_merged_loss_route_on_the_gpu(kind, D, d, dt, A, B, M, monkeypatch):
             step()
             sX.grad = None
     torch.cuda.current_stream().wait_stream(side)
+    skmod._LOSS_WEIGHTS.clear()          # the constant weights built INSIDE the capture: nodes of the graph, not cached for eager calls
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         gloss = step()
+    assert not skmod._LOSS_WEIGHTS
     X1, Y1 = walk(gen, A, M, D).to(dt).to(DEV), walk(gen, B, M, D).to(dt).to(DEV)
     for Xv, Yv in ((X1, Y1), (X, Y)):
         with torch.no_grad():
