@@ -514,6 +514,14 @@ def test_second_stream_busy_same_bits_little_slowdown(family):
     assert busy <= 1.15 * alone, (family, alone, busy)      # measured +2 .. +6 % over several boxes
 
 
+def _one_wild_pair(gen, A, B, M, D):
+    """Random walks, except that x_2 and y_5 are the same straight line: k(x_2, y_5) explodes (1e6 .. 1e15), every other pair is tame."""
+    X, Y = walk(gen, A, M, D) * 2, walk(gen, B, M, D) * 2
+    line = torch.arange(M, dtype=torch.float64)[:, None] * 0.6 * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    X[2], Y[5] = line, line.clone()
+    return X, Y
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,d", [("linear", 4, 1), ("rbf", 4, 2), ("rbf", 3, 1)])
 @pytest.mark.parametrize("screen", [1e3, 1e300])
