@@ -35,6 +35,7 @@ constexpr int FD = 8;              // dims carried (inputs are zero-padded to 8)
 constexpr int y_slab_pitch(int nd) { return nd * 128; }   // ND dimension rows of 8 units (the four-dimension variants stage and keep
                                                           // dims 0..3 only); no padding (parity swizzle, see above)
 constexpr int X_SLOTS = 2;   // the window being consumed + the one in flight
+constexpr int x_row_bytes(int nd) { return nd == 4 ? 32 : 64; }
 
 struct FusedParams {
     const double *dXr;   // [A][Mrows][8]: kappa s^2 (x[p+1]-x[p]), kappa = 4^-d / sqrt(12) (sk_linear_prescale); zero rows/dims beyond Mc / D
@@ -164,8 +165,8 @@ __device__ __forceinline__ void lds_load_line(d2_t (&r0)[4], d2_t (&r1)[4], unsi
                  : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3])
                  : "v"(a) : "memory");
 }
-__device__ __forceinline__ void lds_load_half_rows(d2_t (&r0)[2], d2_t (&r1)[2], unsigned a) {   // the first 32 bytes of two 64-byte rows
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:80"
+__device__ __forceinline__ void lds_load_two_half_rows(d2_t (&r0)[2], d2_t (&r1)[2], unsigned a) {   // two consecutive 32-byte rows
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
                  : "+v"(r0[0]), "+v"(r0[1]), "+v"(r1[0]), "+v"(r1[1]) : "v"(a) : "memory");
 }
 template <int N>
@@ -188,7 +189,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
     constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
-    constexpr int XSLAB = RC * 512;   // 8 lanes x RC rows x 64 B
+    // x rows in LDS: 64 bytes (8 dims) each, or -- the four-dimension variants -- the 32 bytes that can be non-zero: with four or
+    // eight pairs per wave (short paths) the x ring was what held a CU to one wave per SIMD at dyadic 0
+    constexpr int XROW = x_row_bytes(ND);
+    constexpr int XSLAB = RC * 8 * XROW;   // 8 lanes x RC rows
     constexpr int Y_SLAB_PITCH = y_slab_pitch(ND);
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // lanes NUp apart start (different) pairs at the same macro-step: one x slab per such "lap" j = lam / NUp
     const int JMAX = (L + NUp - 1) / NUp;
     const unsigned my_x = lds0 + x_base0 + (unsigned)((grp * X_SLOTS * JMAX) * XSLAB + (lam / NUp) * XSLAB) +
-                          (unsigned)((lam & 7) * RC * 64);
+                          (unsigned)((lam & 7) * RC * XROW);
 
     // ---- producers (uniform control; per-lane source offsets) ------------------------------------------------
     // y slab s = virtual units [8s, 8s+8) of every lane group: dims k = lane/8, unit x = lane%8
@@ -374,8 +378,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 char *dst = lds + x_base0 + ((g * X_SLOTS + x_slot) * JMAX + j) * XSLAB;
 #pragma unroll
                 for (int c = 0; c < (XSLAB + 1023) / 1024; ++c)
-                    if (c * 1024 + lane * 16 < XSLAB)
-                        __builtin_amdgcn_global_load_lds(src + c * 1024 + lane * 16, (lds_void *)(dst + c * 1024), 16, 0, 0);
+                    if (c * 1024 + lane * 16 < XSLAB) {
+                        // LDS-DMA lands lane l's 16 bytes at dst + 16 l; XROW = 32: the first two 16-byte pieces of every 64-byte row
+                        const int so = XROW == 64 ? c * 1024 + lane * 16 : (c * 32 + (lane >> 1)) * 64 + (lane & 1) * 16;
+                        __builtin_amdgcn_global_load_lds(src + so, (lds_void *)(dst + c * 1024), 16, 0, 0);
+                    }
             }
         }
         x_slot = x_slot + 1 == X_SLOTS ? 0 : x_slot + 1;
@@ -394,12 +401,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if constexpr (RC % 2 == 0 && ND == 8) {   // two rows per instruction group
 #pragma unroll
             for (int k = 0; k < RC; k += 2) lds_load_line(dxq[k], dxq[k + 1], xa + k * 64u);
-        } else if constexpr (RC % 2 == 0) {
+        } else if constexpr (RC % 2 == 0) {      // ND = 4: 32-byte rows, two of them are 64 contiguous bytes
 #pragma unroll
-            for (int k = 0; k < RC; k += 2) lds_load_half_rows(dxq[k], dxq[k + 1], xa + k * 64u);
+            for (int k = 0; k < RC; k += 2) lds_load_two_half_rows(dxq[k], dxq[k + 1], xa + k * (unsigned)XROW);
         } else {
 #pragma unroll
-            for (int k = 0; k < RC; ++k) lds_load_row<ND / 2>(dxq[k], xa + k * 64u);
+            for (int k = 0; k < RC; ++k) lds_load_row<ND / 2>(dxq[k], xa + k * (unsigned)XROW);
         }
     };
     // RBF: node values of this lane's rows at the columns of units uk, uk + 1, uk + 2 (the last two filled this step), and
@@ -931,7 +938,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     const int G = WAVE / L;
     const int JMAX = (L + NUp - 1) / NUp;
     const int nd = (!g.naive && sizeof(TO) == 8 && D <= 4) ? 4 : 8;   // the variant launch_fused_e picks
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * y_slab_pitch(nd) + X_SLOTS * JMAX * RC * 512);   // (a multiple of 256: the y reads rely on 256-byte aligned slices)
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * y_slab_pitch(nd) + X_SLOTS * JMAX * RC * 8 * x_row_bytes(nd));   // (a multiple of 256: the y reads rely on 256-byte aligned slices)
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     int waves_per_cu = (int)((160 * 1024) / lds_bytes);
