@@ -650,6 +650,7 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
 _MMD_STREAMS_MAX_PAIRS = 128 * 128    # pairs per Gram matrix up to which a CAPTURED compute_mmd forks its three matrices onto three streams
 _SIDE_STREAMS = {}
 _LOSS_WEIGHTS = {}
+_PAIRED_MERGE_CELLS = 2e9   # grid cells of a paired batch below which compute_distance solves k(X, X) and k(X, Y) as one batch
 
 
 def _side_streams(device):
@@ -804,6 +805,15 @@ class SigKernel:
     def compute_distance(self, X, Y, max_batch=100):
         """(batch,) paired squared distances reduced to their mean, as the reference does (sigkernel.py:130-144)."""
         assert not Y.requires_grad, "the second input should not require grad"
+        n = X.shape[0] if X.dim() == 3 else 0
+        if (not routes.no_merged_loss and X.dim() == 3 and X.shape == Y.shape and X.dtype == Y.dtype and X.device == Y.device and n > 0
+                and X.shape[1] >= 2 and float(n) * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 < _PAIRED_MERGE_CELLS):
+            # training-sized batches: k(x_i, x_i) and k(x_i, y_i) as ONE paired batch of 2n pairs -- one forward and one adjoint launch
+            # instead of two each (launch- and fill-bound at these sizes); the same per-pair values, and the gradient reaches X through
+            # the first argument of both halves, as in the reference's three calls (_SigKernel returns none for a second argument)
+            K2 = self.compute_kernel(torch.cat((X, X)), torch.cat((X.detach(), Y)), max_batch)
+            K_YY = self.compute_kernel(Y, Y, max_batch)
+            return torch.mean(K2[:n]) + torch.mean(K_YY) - 2. * torch.mean(K2[n:])
         K_XX = self.compute_kernel(X, X, max_batch)
         K_YY = self.compute_kernel(Y, Y, max_batch)
         K_XY = self.compute_kernel(X, Y, max_batch)

@@ -168,6 +168,24 @@ def test_merged_loss_route_equals_the_reference_composition(oracle_backend, name
     assert sk._merged_loss(X, Y, True) is None
 
 
+def test_compute_distance_merged_pairs_equal_the_reference_composition(oracle_backend, monkeypatch):
+    """compute_distance of a training-sized batch solves k(x_i, x_i) and k(x_i, y_i) as one paired batch of 2n pairs: the same value
+    and gradient as the reference's three compute_kernel calls (sigkernel.py:130-144; routes.no_merged_loss)."""
+    c = golden("gram_c3mini_lin_d1")
+    n = min(c["X"].shape[0], c["Y"].shape[0])
+    m = min(c["X"].shape[1], c["Y"].shape[1])
+    X, Y = torch.from_numpy(c["X"][:n, :m].copy()), torch.from_numpy(c["Y"][:n, :m].copy())
+    out = []
+    for composed in (False, True):
+        monkeypatch.setattr(sigkernel_amd.routes, "no_merged_loss", composed)
+        Xg = X.clone().requires_grad_(True)
+        v = _sk(c).compute_distance(Xg, Y)
+        v.backward()
+        out.append((float(v.detach()), Xg.grad.numpy().copy()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-14 * max(1.0, abs(out[1][0]))
+    assert rel_err(out[0][1], out[1][1]) <= 1e-13
+
+
 def test_results_do_not_depend_on_tiling_or_max_batch(oracle_backend):
     c = golden("gram_c3mini_lin_d1")
     X, Y, w = (torch.from_numpy(c[k]) for k in ("X", "Y", "w"))

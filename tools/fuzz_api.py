@@ -146,6 +146,12 @@ def run_case(c, rng):
         check("kernel", kk.detach().cpu().numpy(), kw, ftol)
         gp = np.stack([O.gram_grad_weighted(Xo[i:i + 1], Yo[i:i + 1], np.array([[v[i]]]), _Paired(k), d, naive=nv)[0] for i in range(n)])
         check("kernel grad", Xg.grad.cpu().numpy(), gp, gtol)
+        if M == N:      # (the gradient of the distance: first arguments of k(x_i, x_i) and k(x_i, y_i) only, as the reference's _SigKernel)
+            Xg = dev(X[:n], True)
+            sk.compute_distance(Xg, dev(Y[:n])).backward()
+            gd = np.stack([O.gram_grad_weighted(Xo[i:i + 1], Xo[i:i + 1], np.array([[1.0 / n]]), _Paired(k), d, naive=nv)[0]
+                           + O.gram_grad_weighted(Xo[i:i + 1], Yo[i:i + 1], np.array([[-2.0 / n]]), _Paired(k), d, naive=nv)[0] for i in range(n)])
+            check("distance grad", Xg.grad.cpu().numpy(), gd, gtol)
         check("distance", float(sk.compute_distance(dev(X[:n]), dev(Y[:n]))),
               O.solve_coarse(O.increments(k.batch_kernel(Xo[:n], Xo[:n]).numpy()), d, nv).mean()
               + O.solve_coarse(O.increments(k.batch_kernel(Yo[:n], Yo[:n]).numpy()), d, nv).mean() - 2.0 * kw.mean(), 50 * ftol)
