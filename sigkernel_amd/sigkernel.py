@@ -279,6 +279,22 @@ class _SigKernel(torch.autograd.Function):
         if M < 2 or N < 2 or A == 0:  # a single point: the grid is its boundary, k = 1 (sigkernel.py:212-253 with MM = 0);
             return torch.ones(A, dtype=X.dtype, device=X.device)   # an empty batch: an empty result, like the CPU reference
         Xd, Yd = X.detach(), Y.detach()
+        ctx.kept_edges = None
+        if X.requires_grad and hasattr(be, "solve_fwd_keep_edges"):
+            # a gradient is pending: the forward keeps the terminal edges of every pair (8 (MM + NN) bytes each; a paired batch is
+            # small), so that backward is ONE adjoint launch instead of a second forward sweep + the adjoint
+            edge_bytes = 8.0 * A * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
+            if _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic_order, _naive_solver, False) == FUSED_MB:
+                pair_bytes = _mb_pair_bytes(be, _fused_static(static_kernel, False)[0], Xd, Yd, dyadic_order)
+                edge_bytes = float(A) * (pair_bytes or 0)
+            if edge_bytes <= _KEEP_EDGES_FRACTION * _budget(X.device, workspace_bytes):
+                res = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False, keep_edges=True)
+                if res is not None:
+                    K, edges = res
+                    if edges is not None:
+                        ctx.kept_edges = [(0, A, edges)]
+                    ctx.K = K.detach()
+                    return K
         K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False)
         if K is not None:
             ctx.K = K.detach() if X.requires_grad else None     # forward values: what arms the fused adjoint's device-side rescue
@@ -298,7 +314,8 @@ class _SigKernel(torch.autograd.Function):
         A, M, N = X.shape[0], X.shape[1], Y.shape[1]
         if M >= 2 and N >= 2 and A > 0:
             go = grad_output.to(X.dtype).contiguous()
-            grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, False, None,
+            kept, ctx.kept_edges = getattr(ctx, "kept_edges", None), None
+            grad_X = _rows_gradient(be, sk, X.detach().contiguous(), Y.detach().contiguous(), go, d, naive, False, kept,
                                     ctx.workspace_bytes, getattr(ctx, "K", None))
         else:
             grad_X = torch.zeros_like(X)     # single points / an empty batch: k = 1 whatever X is
