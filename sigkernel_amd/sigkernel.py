@@ -91,10 +91,18 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
     kind, param = fused
     Xd, Yd = Xd.contiguous(), Yd.contiguous()
     one_band = be.solve_fwd_fused_linear if kind == 0 else be.solve_fwd_fused_rbf
+    f32 = Xd.dtype == torch.float32
     if keep_edges:
         ra = _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic, naive, gram)
         res = None
-        if ra == FUSED:
+        if ra == FUSED and f32:
+            # fp32 paths are staged and swept in fp64 whatever their dtype, and the one-band adjoint reads fp64 edges: the forward of
+            # the up-cast paths gives the same values (rounded to fp32 below exactly as the fp32-output variant rounds them) AND the
+            # edges, so that backward does not sweep forward a second time (Gram + backward 17.2 -> 13.5 ms at 512 x 512 pairs of C4's shape)
+            res = one_band(Xd.double(), Yd.double(), param, dyadic, naive, gram, keep_edges=True)
+            if res is not None:
+                res = (res[0].to(Xd.dtype), res[1])
+        elif ra == FUSED:
             res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
         elif ra == FUSED_MB:
             res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, keep_edges=True)
@@ -108,6 +116,13 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
         res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
         if res is not None:
             return res
+    if rf != FUSED and f32 and kind == 1 and dyadic == 0 and not keep_edges and \
+            _route_query(be.route, OP_FORWARD, kind, Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), 8, routes.no_stream) == FUSED \
+            and not routes.no_fused_rbf:
+        # the one-band RBF kernel at dyadic 0 is built for fp64 paths only: fp32 paths take it up-cast (they are staged in fp64 anyway)
+        res = one_band(Xd.double(), Yd.double(), param, dyadic, naive, gram)
+        if res is not None:
+            return res.to(Xd.dtype)
     if rf == FUSED:
         res = one_band(Xd, Yd, param, dyadic, naive, gram)
     elif rf in (FUSED_MB, FUSED_MB_SWAP):
@@ -216,7 +231,7 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
         Xt = Xd[a0:a1].contiguous()
         Yt = Yd if gram else Yd[a0:a1].contiguous()
         Kt = None if Kvals is None else Kvals[a0:a1]
-        if edges is None or Xd.dtype != torch.float64:     # fp32 paths are swept in fp64: edges of the up-cast paths
+        if edges is None:     # (fp32 paths are swept in fp64: edges of the up-cast paths -- which is what their forward kept)
             fwd = be.solve_fwd_fused_linear if linear else be.solve_fwd_fused_rbf
             res = fwd(Xt.double(), Yt.double(), param, dyadic, naive, gram, keep_edges=True)
             edges = res[1] if res is not None else None
