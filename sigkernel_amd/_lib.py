@@ -889,6 +889,12 @@ class HipBackend:
             P_ = inc_c.numel() // (inc_c.shape[-2] * inc_c.shape[-1])
             if edges.numel() * 8 != int(load().sk_strip_edges_bytes(P_, inc_c.shape[-2], inc_c.shape[-1], int(dyadic), inc_c.element_size())):
                 edges = None
+        if dyadic > 2 and edges is None and not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+            # the fast adjoint keeps two PDE states in registers and is built for dyadic orders 0..2; the stored-grid kernel is ~100x
+            # slower (256 x 256 pairs of 100 points at dyadic 3: 2.6 s).  Dyadic order d on inc_c IS dyadic order 2 on inc_c
+            # replicated 2^(d-2) x 2^(d-2) and scaled by 4^-(d-2) (the reference's own tile(), sigkernel.py:218, :364; powers of two:
+            # the same fine grid bit for bit), and W folds back by summing the blocks
+            return self._solve_adj_refined(inc_c, dyadic, naive, flags, return_residual)
         if (inc_c.dtype == torch.float32 and dyadic == 2 and edges is None and not (flags & (FLAG_SIMPLE | FLAG_EXACT))):
             # the fused adjoint has no fp32 variant at dyadic 2 (16-column blocks do not fit the register file) and the
             # stored-grid kernel is ~100x slower: run the fp64 kernel on up-cast increments, in pair chunks of bounded size
@@ -1100,6 +1106,32 @@ class HipBackend:
             err[p0:p1] = e
             del buf, W
         res = (out.reshape(batch), Wp.reshape(batch + (Mc, ldw))[..., :Nc])
+        return res + (err.reshape(batch),) if return_residual else res
+
+
+    def _solve_adj_refined(self, inc_c, dyadic, naive, flags, return_residual):
+        Mc, Nc = inc_c.shape[-2:]
+        batch = inc_c.shape[:-2]
+        P = inc_c.numel() // (Mc * Nc)
+        dev = inc_c.device
+        f = 1 << (int(dyadic) - 2)
+        flat = inc_c.reshape(P, Mc, Nc)
+        ldr = _padded_ld(Nc * f, 8)
+        out = torch.empty(P, dtype=inc_c.dtype, device=dev)
+        W = torch.empty(P, Mc, Nc, dtype=inc_c.dtype, device=dev)
+        err = torch.empty(P, dtype=torch.float64, device=dev)
+        step = max(1, int(self.UPCAST_CHUNK_BYTES // (Mc * f * ldr * 8)))
+        scale = 1.0 / (f * f)
+        for p0 in range(0, P, step):
+            p1 = min(P, p0 + step)
+            buf = torch.zeros(p1 - p0, Mc * f, ldr, dtype=torch.float64, device=dev)
+            buf[..., :Nc * f] = (flat[p0:p1].double() * scale).repeat_interleave(f, dim=1).repeat_interleave(f, dim=2)
+            o, Wr, e = self.solve_adj(buf[..., :Nc * f], 2, naive, flags, return_residual=True)
+            out[p0:p1] = o
+            W[p0:p1] = (Wr.reshape(p1 - p0, Mc, f, Nc, f).sum(dim=(2, 4)) * scale).to(inc_c.dtype)
+            err[p0:p1] = e
+            del buf, Wr
+        res = (out.reshape(batch), W.reshape(batch + (Mc, Nc)))
         return res + (err.reshape(batch),) if return_residual else res
 
 
