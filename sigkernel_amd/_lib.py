@@ -836,6 +836,15 @@ class HipBackend:
 
     def solve_fwd(self, inc_c, dyadic, naive=False, flags=0, want_grid=False, want_edges=False):
         """inc_c [..., Mc, Nc] -> final [...]; optionally (grid [..., MM+1, NN+1], edges [..., MM+NN+2])."""
+        if dyadic > 3 and not (want_grid or want_edges) and not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+            # the streaming solver is built for dyadic orders 0..3: above that, dyadic 3 on refined increments (see _refined)
+            Mc, Nc = inc_c.shape[-2:]
+            batch = inc_c.shape[:-2]
+            flat = inc_c.reshape(-1, Mc, Nc)
+            out = torch.empty(flat.shape[0], dtype=inc_c.dtype, device=inc_c.device)
+            for p0, p1, buf in self._refined(flat, 1 << (int(dyadic) - 3)):
+                out[p0:p1] = self.solve_fwd(buf, 3, naive, flags)
+            return out.reshape(batch)
         inc_c, ld = _row_stride(inc_c, "inc_c")
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
@@ -1054,6 +1063,24 @@ class HipBackend:
         """inc3 [3, ..., Mc, Nc] (increments of k, d/dgamma, d2/dgamma2) -> (k, k_gamma, k_gamma_gamma), [...] each."""
         if inc3.shape[0] != 3:
             raise ValueError("inc3 must stack the three increment arrays on dim 0")
+        if dyadic > 2 and not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
+            # the fast three-state solver is built for dyadic orders 0..2: above that, dyadic 2 on refined increments (the reference
+            # tiles all three arrays alike, sigkernel.py:543-566)
+            Mc, Nc = inc3.shape[-2:]
+            batch = inc3.shape[1:-2]
+            flat = inc3.reshape(3, -1, Mc, Nc)
+            out = torch.empty(3, flat.shape[1], dtype=inc3.dtype, device=inc3.device)
+            f = 1 << (int(dyadic) - 2)
+            ldr = _padded_ld(Nc * f, 8)
+            step = max(1, int(self.UPCAST_CHUNK_BYTES // (3 * Mc * f * ldr * 8)))
+            for p0 in range(0, flat.shape[1], step):
+                p1 = min(flat.shape[1], p0 + step)
+                buf = torch.zeros(3, p1 - p0, Mc * f, ldr, dtype=torch.float64, device=inc3.device)
+                buf[..., :Nc * f] = (flat[:, p0:p1].double() * (1.0 / (f * f))).repeat_interleave(f, dim=2).repeat_interleave(f, dim=3)
+                k, kd, kdd = self.solve_deriv(buf[..., :Nc * f], 2, flags)
+                out[0, p0:p1], out[1, p0:p1], out[2, p0:p1] = k, kd, kdd
+                del buf
+            return out[0].reshape(batch), out[1].reshape(batch), out[2].reshape(batch)
         if inc3.dtype == torch.float32 and dyadic == 2 and not (flags & (FLAG_SIMPLE | FLAG_EXACT)):
             # no fp32 fast kernel at dyadic 2 (register file): the fp64 one on up-cast increments, in bounded chunks
             Mc, Nc = inc3.shape[-2:]
@@ -1109,6 +1136,19 @@ class HipBackend:
         return res + (err.reshape(batch),) if return_residual else res
 
 
+    def _refined(self, flat, f, chunk_bytes=None):
+        """Chunks (p0, p1, refined) of flat [P, Mc, Nc]: every increment replicated f x f and scaled by 1 / f^2 (powers of two: exact), in
+        fp64, rows zero-padded to whole 128-byte lines -- dyadic order d on flat is dyadic order d - log2 f on these, the same fine grid
+        bit for bit (the reference's own tile(), sigkernel.py:218, :364)."""
+        P, Mc, Nc = flat.shape
+        ldr = _padded_ld(Nc * f, 8)
+        step = max(1, int((chunk_bytes or self.UPCAST_CHUNK_BYTES) // (Mc * f * ldr * 8)))
+        for p0 in range(0, P, step):
+            p1 = min(P, p0 + step)
+            buf = torch.zeros(p1 - p0, Mc * f, ldr, dtype=torch.float64, device=flat.device)
+            buf[..., :Nc * f] = (flat[p0:p1].double() * (1.0 / (f * f))).repeat_interleave(f, dim=1).repeat_interleave(f, dim=2)
+            yield p0, p1, buf[..., :Nc * f]
+
     def _solve_adj_refined(self, inc_c, dyadic, naive, flags, return_residual):
         Mc, Nc = inc_c.shape[-2:]
         batch = inc_c.shape[:-2]
@@ -1116,17 +1156,12 @@ class HipBackend:
         dev = inc_c.device
         f = 1 << (int(dyadic) - 2)
         flat = inc_c.reshape(P, Mc, Nc)
-        ldr = _padded_ld(Nc * f, 8)
         out = torch.empty(P, dtype=inc_c.dtype, device=dev)
         W = torch.empty(P, Mc, Nc, dtype=inc_c.dtype, device=dev)
         err = torch.empty(P, dtype=torch.float64, device=dev)
-        step = max(1, int(self.UPCAST_CHUNK_BYTES // (Mc * f * ldr * 8)))
         scale = 1.0 / (f * f)
-        for p0 in range(0, P, step):
-            p1 = min(P, p0 + step)
-            buf = torch.zeros(p1 - p0, Mc * f, ldr, dtype=torch.float64, device=dev)
-            buf[..., :Nc * f] = (flat[p0:p1].double() * scale).repeat_interleave(f, dim=1).repeat_interleave(f, dim=2)
-            o, Wr, e = self.solve_adj(buf[..., :Nc * f], 2, naive, flags, return_residual=True)
+        for p0, p1, buf in self._refined(flat, f):
+            o, Wr, e = self.solve_adj(buf, 2, naive, flags, return_residual=True)
             out[p0:p1] = o
             W[p0:p1] = (Wr.reshape(p1 - p0, Mc, f, Nc, f).sum(dim=(2, 4)) * scale).to(inc_c.dtype)
             err[p0:p1] = e
