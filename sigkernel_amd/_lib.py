@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsigkernel_amd.so")
 SK_OK = 0
 # sk_route_query: operations and answers (include/sigkernel_amd.h)
 OP_FORWARD, OP_ADJOINT = 0, 1
-ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP = 0, 1, 2, 3
+ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP, ROUTE_FUSED_SWAP = 0, 1, 2, 3, 4
 ROUTE_NO_STREAM = 1
 SCHEME_DEFAULT = 0
 SCHEME_NAIVE = 1
@@ -279,7 +279,7 @@ class HipBackend:
 
     @staticmethod
     def route(op, kind, D, M, N, dyadic, naive, elem_size, no_stream=False):
-        """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP.
+        """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP / _FUSED_SWAP.
         no_stream: never STREAM where a fused kernel exists (by default short paths, on which the multi-band kernels would mostly
         sweep padding, take the faster streaming route)."""
         return int(load().sk_route_query(int(op), int(kind), int(D), int(M), int(N), int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT,

@@ -56,6 +56,7 @@ def _fused_static(static_kernel, gram):
 
 
 STREAM, FUSED, FUSED_MB, FUSED_MB_SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
+FUSED_SWAP = _lib.ROUTE_FUSED_SWAP
 OP_FORWARD, OP_ADJOINT = _lib.OP_FORWARD, _lib.OP_ADJOINT
 
 
@@ -116,15 +117,21 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
         res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
         if res is not None:
             return res
-    if rf != FUSED and f32 and kind == 1 and dyadic == 0 and not keep_edges and \
-            _route_query(be.route, OP_FORWARD, kind, Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), 8, routes.no_stream) == FUSED \
-            and not routes.no_fused_rbf:
+    if rf not in (FUSED, FUSED_SWAP) and f32 and kind == 1 and dyadic == 0 and not keep_edges and not routes.no_fused_rbf:
         # the one-band RBF kernel at dyadic 0 is built for fp64 paths only: fp32 paths take it up-cast (they are staged in fp64 anyway)
-        res = one_band(Xd.double(), Yd.double(), param, dyadic, naive, gram)
-        if res is not None:
-            return res.to(Xd.dtype)
+        r8 = _route_query(be.route, OP_FORWARD, kind, Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), 8, routes.no_stream)
+        if r8 in (FUSED, FUSED_SWAP):
+            res = one_band(Xd.double(), Yd.double(), param, dyadic, naive, gram) if r8 == FUSED else \
+                one_band(Yd.double(), Xd.double(), param, dyadic, naive, gram)
+            if res is not None:
+                return (res.t().contiguous() if (r8 == FUSED_SWAP and gram) else res).to(Xd.dtype)
     if rf == FUSED:
         res = one_band(Xd, Yd, param, dyadic, naive, gram)
+    elif rf == FUSED_SWAP:
+        # long first paths, short second ones: k(y, x) through the one-band kernel (k and both static kernels are symmetric)
+        res = one_band(Yd, Xd, param, dyadic, naive, gram)
+        if res is not None and gram:
+            res = res.t().contiguous()
     elif rf in (FUSED_MB, FUSED_MB_SWAP):
         res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, swap=rf == FUSED_MB_SWAP)
     if res is None:

@@ -16,6 +16,7 @@ from sigkernel_amd import _lib
 from conftest import rel_err
 
 STREAM, FUSED, MB, SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
+FSWAP = _lib.ROUTE_FUSED_SWAP
 FWD, ADJ = _lib.OP_FORWARD, _lib.OP_ADJOINT
 
 # (op, kind, D, M, N, dyadic, naive, elem_size) -> (default route, route with SK_ROUTE_NO_STREAM)
@@ -45,6 +46,9 @@ TABLE = [
     ((ADJ, 1, 16, 512, 512, 2, False, 8), MB, MB), ((FWD, 1, 12, 128, 128, 1, False, 4), MB, MB),
     # multi-band forward, orientation by swept macro-steps (bands x max(80, units))
     ((FWD, 0, 12, 20, 700, 1, False, 8), STREAM, MB), ((FWD, 0, 12, 700, 100, 1, False, 8), SWAP, SWAP), ((FWD, 1, 12, 300, 290, 1, False, 4), MB, MB),
+    # long first paths, short second ones: the one-band forward on (y, x) (k is symmetric); never for a gradient, never beyond dim 8
+    ((FWD, 0, 3, 700, 20, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((FWD, 0, 8, 1000, 129, 1, False, 4), FSWAP, FSWAP),
+    ((FWD, 1, 4, 1000, 256, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 5, 1000, 256, 0, False, 8), MB, MB), ((ADJ, 0, 3, 700, 20, 0, False, 8), STREAM, MB),
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
@@ -78,7 +82,7 @@ def test_linear_and_rbf_up_to_16_dims_can_always_run_fused():
         d, naive, es = int(rng.integers(0, 3)), bool(rng.integers(0, 2)), int(rng.choice([4, 8]))
         r = be.route(op, kind, D, M, N, d, naive, es, no_stream=True)
         assert r != STREAM, (op, kind, D, M, N, d, naive, es)
-        assert op == FWD or r != SWAP
+        assert op == FWD or r not in (SWAP, FSWAP)
         r0 = be.route(op, kind, D, M, N, d, naive, es)
         assert r0 in (STREAM, r)                              # the default only ever falls back to streaming
         if r0 == STREAM:
@@ -231,3 +235,31 @@ def test_randomised_api_cases_against_the_oracle():
         if bad:
             failures.append((i, c, bad))
     assert not failures, failures
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,M,N,dt", [("linear", 3, 0, 300, 20, torch.float64), ("rbf", 3, 1, 200, 64, torch.float64), ("linear", 8, 2, 90, 33, torch.float32),
+                                             ("rbf", 4, 0, 400, 100, torch.float32), ("rbf", 2, 2, 70, 10, torch.float64)])
+def test_one_band_forward_on_swapped_arguments(kind, D, d, M, N, dt):
+    """SK_ROUTE_FUSED_SWAP: long first paths against short second ones go through the one-band kernel as k(y, x) -- Gram (transposed
+    back), paired batch, with and without a gradient pending (the adjoint is never swapped), against the oracle."""
+    from oracle import oracle as O
+    gen = torch.Generator().manual_seed(3)
+    k = sigkernel_amd.LinearKernel(0.9) if kind == "linear" else sigkernel_amd.RBFKernel(1.2)
+    be = _lib.get_backend()
+    assert be.route(FWD, 0 if kind == "linear" else 1, D, M, N, d, False, 8) == FSWAP
+    X, Y = _walk(gen, 5, M, D).to(dt), _walk(gen, 7, N, D).to(dt)
+    sk = sigkernel_amd.SigKernel(k, d)
+    ftol, gtol = (3e-4, 3e-3) if dt == torch.float32 else (1e-11, 1e-9)
+    want = O.gram_forward(X.double(), Y.double(), _gram_kernel(k), d)
+    K = sk.compute_Gram(X.to(DEV), Y.to(DEV))
+    assert K.shape == (5, 7) and K.is_contiguous() and rel_err(K.double().cpu().numpy(), want) <= ftol
+    w = torch.randn(5, 7, generator=gen, dtype=torch.float64)
+    Xg = X.to(DEV).requires_grad_(True)
+    Kg = sk.compute_Gram(Xg, Y.to(DEV))
+    (Kg * w.to(dt).to(DEV)).sum().backward()
+    assert rel_err(Kg.detach().double().cpu().numpy(), want) <= ftol
+    assert rel_err(Xg.grad.double().cpu().numpy(), O.gram_grad_weighted(X.double(), Y.double(), w.numpy(), _gram_kernel(k), d)) <= gtol
+    kp = sk.compute_kernel(X.to(DEV), Y[:5].to(DEV))
+    kw = O.solve_coarse(O.increments(k.batch_kernel(X.double(), Y[:5].double()).numpy()), d, False)
+    assert rel_err(kp.double().cpu().numpy(), kw) <= ftol
