@@ -777,8 +777,19 @@ class HipBackend:
                     _check(fl(_ptr(dYt), ldy, _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M - 1, N - 1, D, _ptr(T), _stream(X)),
                            "sk_linear_adjoint")
                 else:
-                    _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D,
-                              _ptr(T), _stream(X)), "sk_static_adjoint")
+                    # wide paths: T[a] = sum_b scale[a, b] W[a, b] (Mc x Nc) @ dY[b] (Nc x D) IS a batched matrix product -- a plain
+                    # library GEMM (rocBLAS under torch.matmul), 3-10x faster than sk_static_adjoint's generic contraction here
+                    # (256 x 256 pairs of 100 points: dim 12 / 20 / 32 7.2 / 24.4 / 42.9 -> 2.3 / 2.5 / 4.9 ms, equal to 1e-15)
+                    dY = Y[:, 1:] - Y[:, :-1]
+                    Wv = W[..., :N - 1]
+                    if gram:
+                        Tm = torch.matmul(Wv, dY)                                   # (A, B, Mc, D)
+                        T = (Tm * scale[:, :, None, None]).sum(1) if scale is not None else Tm.sum(1)
+                        del Tm
+                    else:
+                        T = torch.matmul(Wv, dY)                                    # (A, Mc, D)
+                        if scale is not None:
+                            T = T * scale[:, None, None]
                 g = torch.zeros(A, M, D, dtype=X.dtype, device=X.device)
                 g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
                 g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
