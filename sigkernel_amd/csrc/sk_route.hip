@@ -11,8 +11,8 @@
 //
 //   forward (SK_OP_FORWARD: sigkernel.py:216-234, :362-382)
 //     FUSED      one band per pair, path dim <= 8 (csrc/sk_wave_fused.hip):  rows <= 64 RC (RC = 4 / 2 / 1 coarse rows per lane at
-//                d = 0 / 1 / 2; rows = M - 1 linear, M rbf);  rbf at d = 0: only dim <= 4, default stencil, fp64 (the 8-dim variants
-//                spill registers)
+//                d = 0 / 1 / 2; rows = M - 1 linear, M rbf);  rbf at d = 0 beyond dim 4 / the default stencil / fp64 paths: two rows per
+//                lane (rows <= 128; the four-row 8-dim variants spill registers), and no edges kept
 //     FUSED_SWAP the same kernel on (y, x) when only the SECOND paths fit one band (k(x, y) = k(y, x); a Gram caller transposes)
 //     FUSED_MB   any number of bands, path dim <= 16, any M, N (csrc/sk_wave_fused_mb.hip); _SWAP: solved as k(y, x) -- the kernel
 //                and both static kernels are symmetric -- when that orientation sweeps at most 80 % of the macro-steps
@@ -75,13 +75,13 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
     const int Mc = M - 1, Nc = N - 1;
     if (op == SK_OP_FORWARD) {
         const int rows = kind == 1 ? M : Mc;
-        bool one_band = D <= 8 && rows <= 64 * rc_of(d);
-        if (kind == 1 && d == 0 && (D > 4 || naive || elem_size != 8)) one_band = false;
+        // (rbf at d = 0 beyond dim 4 / the default stencil / fp64 paths: the variant with TWO coarse rows per lane, 128 node rows)
+        const bool two_rows = kind == 1 && d == 0 && (D > 4 || naive || elem_size != 8);
+        bool one_band = D <= 8 && rows <= 64 * (two_rows ? 2 : rc_of(d));
         if (one_band) return SK_ROUTE_FUSED;
         {   // the same kernel on (y, x): k and both static kernels are symmetric; rows then come from the SECOND path
             const int rows_s = kind == 1 ? N : Nc;
-            bool one_band_s = D <= 8 && rows_s <= 64 * rc_of(d);
-            if (kind == 1 && d == 0 && (D > 4 || naive || elem_size != 8)) one_band_s = false;
+            const bool one_band_s = D <= 8 && rows_s <= 64 * (two_rows ? 2 : rc_of(d));
             if (one_band_s) return SK_ROUTE_FUSED_SWAP;
         }
         const bool swap = 5 * mb_steps(kind, Nc, Mc, d) <= 4 * mb_steps(kind, Mc, Nc, d);

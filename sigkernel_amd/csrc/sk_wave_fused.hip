@@ -181,14 +181,17 @@ __device__ __forceinline__ void lds_load_row<2>(d2_t (&r)[2], unsigned a) {
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "+v"(r[0]), "+v"(r[1]) : "v"(a) : "memory");
 }
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
+// RCX: coarse rows per lane when not the strip kernels' own (Tile<DY>::RC) -- 2 for the RBF kernel at dyadic 0 with 8 staged dims,
+// whose four-row form spills (such a variant cannot keep edges: the adjoints read the strip layout)
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND, int RCX = 0>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
     constexpr bool AHEAD = !(RBF && EDGES && ND == 8);   // y units read one macro-step ahead: 2 * ND more VGPRs, which the RBF kernel
                                               // that also keeps edges does not have below the 3-waves-per-SIMD line (168)
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
-    constexpr int RC = Tile<DY>::RC, R = Tile<DY>::R, S = CW << DY, r = 1 << DY;
+    constexpr int RC = RCX ? RCX : Tile<DY>::RC, R = RC << DY, S = CW << DY, r = 1 << DY;
+    static_assert(!(RCX && EDGES), "edges are kept in the strip kernels' layout");
     // x rows in LDS: 64 bytes (8 dims) each, or -- the four-dimension variants -- the 32 bytes that can be non-zero: with four or
     // eight pairs per wave (short paths) the x ring was what held a CU to one wave per SIMD at dyadic 0
     constexpr int XROW = x_row_bytes(ND);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool MID = false;   // fetch_next in the middle of a step instead of at its end (see there)
     // x rows may stay in flight across the loop edge -- not in the variant that is short of registers, where the allocator
     // moves the destinations of pending loads (tools/check_async_hazards.py)
-    constexpr bool INFLIGHT_X = !(KIND == 1 && DY == 0 && ND == 8);
+    constexpr bool INFLIGHT_X = !(KIND == 1 && DY == 0 && ND == 8 && RCX == 0);
     int tm = 0, tq = 0;
     int c_u0 = lam % NUp, c_uk0 = (lam + LAG) % NUp;
     int c_out = lam == prm.lam_f ? (lam + LAG + prm.u_f) % NUp : -1;
@@ -797,9 +800,9 @@ struct FusedPlan {
     int waves_per_cu;   // from LDS and the measured optimum; still to be capped by the variant's VGPR use
 };
 
-template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND, int RCX = 0>
 int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
-    auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND>;
+    auto kern = k_fwd_fused<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND, RCX>;
     // persistent waves: all of them must be resident at once, so the variant's VGPR count caps the waves per SIMD
     // (512 VGPRs per lane and SIMD; a variant over 168 holds two waves per SIMD, not three)
     // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
@@ -893,8 +896,11 @@ int launch_fused_e(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     }
     // RBF at dyadic 0 with 8 staged dims in fp64 compiles to 280-290 registers with spills: no variant for it (reads left in flight
     // are unsafe there, tools/check_async_hazards.py: scan_pressure) -- such calls take sk_solve_fwd_static_* or the unfused route
-    if constexpr (KIND == 1 && DY == 0) return SK_ERR_UNSUPPORTED;
-    else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
+    // -- with TWO rows per lane it fits (pairs of up to 128 points; no edges: launch_fwd_fused sized the plan for it)
+    if constexpr (KIND == 1 && DY == 0) {
+        if constexpr (EDGES) return SK_ERR_UNSUPPORTED;
+        else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, false, KIND, 8, 2>(prm, pl, s);
+    } else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
@@ -922,7 +928,11 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (tri && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
     const int DY = g.dyadic;
     if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
-    const int RC = DY == 0 ? 4 : DY == 1 ? 2 : 1;
+    // (RBF at dyadic 0 beyond the four-dimension fp64 default-stencil variant: the two-row form, see launch_fused_e)
+    const bool four_dim = !g.naive && sizeof(TO) == 8 && D <= 4;
+    const bool rbf0_two_rows = KIND == 1 && DY == 0 && !four_dim;
+    if (rbf0_two_rows && strip_edges) return SK_ERR_UNSUPPORTED;
+    const int RC = DY == 0 ? (rbf0_two_rows ? 2 : 4) : DY == 1 ? 2 : 1;
     // linear: one unit = two increment columns.  RBF: one unit = two NODE columns, and the sweep of a pair's last unit
     // reads one node column of the following unit, which therefore has to exist as padding inside the pair's stream;
     // likewise the lanes of a pair must cover M node rows, not M - 1 increment rows

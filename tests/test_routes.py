@@ -31,15 +31,16 @@ TABLE = [
     ((FWD, 0, 8, 257, 40, 0, False, 8), FUSED, FUSED), ((FWD, 0, 8, 258, 260, 0, False, 8), MB, MB),
     ((FWD, 1, 4, 256, 40, 0, False, 8), FUSED, FUSED), ((FWD, 1, 4, 500, 500, 0, False, 8), MB, MB),
     ((FWD, 0, 8, 65, 40, 2, False, 8), FUSED, FUSED), ((FWD, 0, 8, 129, 129, 1, True, 4), FUSED, FUSED),
-    # rbf at dyadic 0: the one-band kernel exists for dim <= 4, default stencil, fp64 only.  The reference's example workload -- RBF,
+    # rbf at dyadic 0: four rows per lane (256 node rows) for dim <= 4, default stencil, fp64; two rows per lane (128) beyond.  The reference's example workload -- RBF,
     # dyadic 0, lead-lag + time paths (dim 5..8) of a few hundred points, examples/time_series_classification.py:186-197 -- is
     # multi-band; short such paths stream by default
     ((FWD, 1, 7, 297, 297, 0, False, 8), MB, MB), ((FWD, 1, 7, 199, 199, 0, False, 8), MB, MB),
-    ((FWD, 1, 5, 100, 100, 0, False, 8), STREAM, MB), ((FWD, 1, 4, 100, 100, 0, True, 8), STREAM, MB), ((FWD, 1, 4, 100, 100, 0, False, 4), STREAM, MB),
+    ((FWD, 1, 5, 100, 100, 0, False, 8), FUSED, FUSED), ((FWD, 1, 4, 100, 100, 0, True, 8), FUSED, FUSED), ((FWD, 1, 4, 100, 100, 0, False, 4), FUSED, FUSED),
+    ((FWD, 1, 5, 129, 100, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 5, 129, 129, 0, False, 8), STREAM, MB), ((FWD, 1, 4, 200, 200, 0, False, 4), MB, MB),
     # wide paths: multi-band where the sweep is not mostly padding (efficiency rows / (bands 64 RC) x units / max(80, units) >= 0.45;
     # rbf forward 0.5) -- measured crossovers, profiles/r04_ab_routes.txt
     ((FWD, 0, 12, 128, 128, 1, False, 8), MB, MB), ((FWD, 0, 12, 40, 40, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 30, 30, 0, True, 8), STREAM, MB),
-    ((FWD, 1, 7, 128, 128, 0, False, 8), STREAM, MB),
+    ((FWD, 1, 7, 128, 128, 0, False, 8), FUSED, FUSED),
     # rbf with 9..16 dims of fp64 paths (16 staged fp64 dims, one wave per SIMD): streamed forward, multi-band adjoint on full bands only;
     # fp32 paths (fp32 ring, two waves: BASELINE configs[4]) as everything else
     ((FWD, 1, 12, 128, 128, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 512, 512, 2, False, 8), STREAM, MB), ((ADJ, 1, 12, 128, 128, 2, False, 8), STREAM, MB),
