@@ -346,8 +346,10 @@ int sk_solve_fwd_linear_f32(const double *dXr, const double *dYt, int64_t A, int
  *   Xr [A][Mrows][8] fp64: the path POINTS x_p, p < M = Mc + 1, zero padding rows / dims (path dim <= 8);
  *   Yt [Bn][8][Ncp] fp64: y_q, q < N = Nc + 1, dimension-major, zero-padded; Ncp = N rounded up to a multiple of 16;
  *   inv_sigma = 1 / sigma;  B > 0: Gram, B == 0: paired;  out_final [P];  D as for sk_solve_fwd_linear_*.
- * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M > 256/128/64 for dyadic 0/1/2):
- * use sk_static_increments_* + sk_solve_fwd_*. */
+ * SK_ERR_UNSUPPORTED when dyadic > 2 or a pair needs more than one band (M > 256/128/64 for dyadic 0/1/2; at dyadic 0 the
+ * four-rows-per-lane kernel is built for D <= 4, the default scheme and fp64 output: D 5..8, SK_SCHEME_NAIVE and sk_solve_fwd_rbf_f32
+ * take two rows per lane there, M <= 128, and sk_solve_fwd_rbf_edges_f64 does not cover them): use sk_static_increments_* +
+ * sk_solve_fwd_*, or sk_solve_fwd_static_*; sk_route_query says which. */
 int sk_solve_fwd_rbf_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                          int dyadic, int scheme, double inv_sigma, double *out_final, void *queue, void *stream);
 int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
