@@ -675,7 +675,7 @@ class HipBackend:
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if D > 8 or dyadic not in (1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
+        if D > 8 or dyadic not in (0, 1, 2) or (dyadic == 0 and (D > 4 or naive or M > 128)) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
             return None
         if yside and (not gram or D > 4):
             return None

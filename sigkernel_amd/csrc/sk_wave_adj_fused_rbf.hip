@@ -22,7 +22,8 @@
 // Decomposition, edges, self-check: as sk_wave_adj_fused.hip (PPG consecutive pairs of ONE x_a per lane group, partial
 // sums stored per group and added by the host in a fixed order; terminal edges from sk_solve_fwd_rbf_edges_f64; the
 // terminal ROW arrives through LDS chunks as in sk_wave_adj.hip).
-// Scope: fp64, dyadic 1..2, path dim <= 8 (ND = 4 variants for dim <= 4), one band per pair with M <= L RC, N - 1 <= 2 NUp - 1.
+// Scope: fp64, dyadic 1..2, path dim <= 8 (ND = 4 variants for dim <= 4), one band per pair with M <= L RC, N - 1 <= 2 NUp - 1;
+// dyadic 0: dim <= 4, default stencil, two coarse rows per lane (M <= 128).
 #include "sk_wave_common.h"
 
 namespace sk {
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     constexpr int OUTW = ND + 2;
     constexpr int ECG = (4 * S + 1) * 16;    // terminal-row chunk of one lane group (sk_wave_adj.hip)
     constexpr int NPC = 4 * S + 1;
-    static_assert(R == 4, "the column-edge reads below take five doubles out of three aligned 16-byte pieces");
+    static_assert(R == 4 || R == 2, "the column-edge reads below take R + 2 doubles out of aligned 16-byte pieces");
     static_assert(!YSIDE || ND == 4, "the second-argument sums are built for paths of dim <= 4");
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
@@ -354,13 +355,20 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
                 yp_prev = yp_cur;
                 yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YW) : nullptr;
             }
-            double col[6];
+            double col[R + 2];
             {
-                d2_t c3[3];
                 const unsigned ca_ = my_col + x_rd;
-                asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
-                col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+                if constexpr (R == 4) {
+                    d2_t c3[3];
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c3[0]), "=&v"(c3[1]), "=&v"(c3[2]) : "v"(ca_) : "memory");
+                    col[0] = c3[0][0]; col[1] = c3[0][1]; col[2] = c3[1][0]; col[3] = c3[1][1]; col[4] = c3[2][0]; col[5] = c3[2][1];
+                } else {      // two fine rows per lane (dyadic 0, two coarse rows)
+                    d2_t c2[2];
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(c2[0]), "=&v"(c2[1]) : "v"(ca_) : "memory");
+                    col[0] = c2[0][0]; col[1] = c2[0][1]; col[2] = c2[1][0]; col[3] = c2[1][1];
+                }
             }
             // col[1 + m] = K[MMp - lam R - R + m][NN], m = 0..R: the lane's fine rows bottom to top; K[0][NN] = 1 is not stored
             cornerR = 1.0;
@@ -628,10 +636,15 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
                               int64_t force_nch, const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes,
                               hipStream_t s) {
     const int DY = g.dyadic;
-    if (DY < 1 || DY > 2 || B < 0 || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
+    if (DY < 0 || DY > 2 || B < 0 || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(rbf_edge_geom(g), 8);   // the layout of the edges; the sweep uses the same lanes and units
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
-    const int RC = st.RC, NUp = st.NUp, logL = st.logL, L = 1 << logL, G = WAVE / L;
+    // dyadic 0: the strip kernels give a lane four coarse rows, which this kernel's accumulators do not fit (95-128 VGPRs spilled:
+    // measured no faster than the streaming route); it sweeps TWO rows per lane with twice the lanes -- the same padded rows, so the
+    // edge layout is the strip kernels' own (pairs of up to 128 points; dim <= 4 and the default stencil: what the forward that keeps
+    // these edges is built for)
+    if (DY == 0 && (D > 4 || g.naive || st.logL > 5)) return SK_ERR_UNSUPPORTED;
+    const int RC = DY == 0 ? 2 : st.RC, NUp = st.NUp, logL = DY == 0 ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
     if (g.Nc > 2 * NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC + 1) return SK_ERR_UNSUPPORTED;   // (+ 1: the node row above the first lane's)
@@ -641,7 +654,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     if (yside && (ND != 4 || B <= 0)) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
-    const int xslab = DY == 1 ? XSlab<2, 4>::BYTES : XSlab<1, 4>::BYTES;
+    const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? XSlab<2, 4>::BYTES : XSlab<1, 4>::BYTES;
     const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * xslab) + (size_t)2 * G * (4 * S + 1) * 16 +
                              (ypart ? 5 * YC_PIECE : 0);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
@@ -691,7 +704,10 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     int rc;
-    if (ypart) {
+    if (DY == 0) {
+        if (ypart) rc = full ? launch_adjr<0, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, true>(prm, lds_block, s);
+        else rc = full ? launch_adjr<0, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, false>(prm, lds_block, s);
+    } else if (ypart) {
         if (DY == 1) rc = full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);
         else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
     } else if (DY == 1) {

@@ -53,9 +53,10 @@ TABLE = [
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
-    # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64
+    # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: default stencil, M <= 128 (two rows per lane)
     ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), STREAM, MB),
-    ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), STREAM, MB), ((ADJ, 1, 3, 128, 128, 0, False, 8), MB, MB),
+    ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), STREAM, MB),
+    ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
     # never swapped: the gradient is the first argument's
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
