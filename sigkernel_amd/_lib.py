@@ -160,6 +160,15 @@ def _dev(t, name):
     return t
 
 
+def _rbf_extra_row(Mc, dyadic):
+    """1 when the one-band RBF kernels keep their edges in the layout of a strip one row taller (csrc/sk_internal.h: rbf_edge_geom)."""
+    rc = 4 >> min(int(dyadic), 2)
+    cap = 8 * rc
+    while cap < Mc:
+        cap *= 2
+    return 1 if (cap == Mc and cap < 64 * rc) else 0
+
+
 def _padded_ld(n, elem_size):
     """Row stride (elements) that pads every increment row to whole 128-byte cache lines: the LDS-DMA kernels
     fetch rows line by line, and the adjoint sweep needs the (zero) padding to exist."""
@@ -380,7 +389,8 @@ class HipBackend:
             if keep_edges and X.dtype == torch.float64:
                 P = A * B if gram else A
                 # (node columns: when N - 1 is a multiple of 16 the strip is one column -- one line of units -- wider: rbf_edge_geom)
-                nbytes = int(lib.sk_strip_edges_bytes(P, Mc, Nc + (1 if Nc % 16 == 0 else 0), int(dyadic), 8))
+                # (node rows: when M - 1 fills the strip's lanes exactly -- RC 2^k rows -- the strip is one row taller: rbf_edge_geom)
+                nbytes = int(lib.sk_strip_edges_bytes(P, Mc + _rbf_extra_row(Mc, dyadic), Nc + (1 if Nc % 16 == 0 else 0), int(dyadic), 8))
                 if nbytes:
                     edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
                     rc = lib.sk_solve_fwd_rbf_edges_f64(_ptr(Xr), _ptr(Yt), A, B if gram else 0, Mrows, Mc, Nc, Ncp, D, int(dyadic),
@@ -675,7 +685,7 @@ class HipBackend:
         A, M, D = X.shape
         B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
-        if D > 8 or dyadic not in (0, 1, 2) or (dyadic == 0 and (D > 4 or naive or M > 128)) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
+        if D > 8 or dyadic not in (0, 1, 2) or (dyadic == 0 and (naive or M > 128)) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
             return None
         if yside and (not gram or D > 4):
             return None

@@ -116,9 +116,15 @@ inline Strip strip_geom(const Geom &g, int elem_size) {
 // The one-band RBF kernels sweep NODE columns: column 2 NUp of the strip must be padding, which the increment layout has not when
 // N - 1 is a multiple of 16.  Their edges are then kept in the layout of a strip one column wider (one more line of 8 units);
 // sk_strip_edges_bytes(P, Mc, Nc + 1, ...) sizes it.  (The streaming adjoint sees a size it does not expect and sweeps forward itself.)
+// Likewise they sweep NODE rows, M = Mc + 1 of them: when the increment rows fill the strip's lanes exactly (Mc = RC 2^k), the node rows
+// need the next power of two of lanes, and the edges are kept in the layout of a strip one row taller (its padded rows doubled).
 inline Geom rbf_edge_geom(const Geom &g) {
     Geom e = g;
     if (g.Nc % 16 == 0) { e.Nc += 1; e.NN = e.Nc << e.dyadic; }
+    const int rc = g.dyadic == 0 ? 4 : g.dyadic == 1 ? 2 : 1;
+    int cap = 8 * rc;
+    while (cap < g.Mc) cap *= 2;
+    if (cap == g.Mc && cap < 64 * rc) { e.Mc += 1; e.MM = e.Mc << e.dyadic; }
     return e;
 }
 inline size_t strip_edge_doubles(const Geom &g, int elem_size) {

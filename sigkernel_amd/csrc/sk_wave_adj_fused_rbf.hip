@@ -23,7 +23,7 @@
 // sums stored per group and added by the host in a fixed order; terminal edges from sk_solve_fwd_rbf_edges_f64; the
 // terminal ROW arrives through LDS chunks as in sk_wave_adj.hip).
 // Scope: fp64, dyadic 1..2, path dim <= 8 (ND = 4 variants for dim <= 4), one band per pair with M <= L RC, N - 1 <= 2 NUp - 1;
-// dyadic 0: dim <= 4, default stencil, two coarse rows per lane (M <= 128).
+// dyadic 0: default stencil, two coarse rows per lane (M <= 128).
 #include "sk_wave_common.h"
 
 namespace sk {
@@ -641,9 +641,9 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     if (!st.ok || st.nb != 1) return SK_ERR_UNSUPPORTED;
     // dyadic 0: the strip kernels give a lane four coarse rows, which this kernel's accumulators do not fit (95-128 VGPRs spilled:
     // measured no faster than the streaming route); it sweeps TWO rows per lane with twice the lanes -- the same padded rows, so the
-    // edge layout is the strip kernels' own (pairs of up to 128 points; dim <= 4 and the default stencil: what the forward that keeps
-    // these edges is built for)
-    if (DY == 0 && (D > 4 || g.naive || st.logL > 5)) return SK_ERR_UNSUPPORTED;
+    // edge layout is the strip kernels' own (pairs of up to 128 points; the default stencil: what the forward that keeps these edges
+    // is built for; dim 5..8: 18 VGPRs spilled, like the dyadic-2 variants of that width)
+    if (DY == 0 && (g.naive || st.logL > 5)) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? 2 : st.RC, NUp = st.NUp, logL = DY == 0 ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
     if (g.Nc > 2 * NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
@@ -706,6 +706,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     int rc;
     if (DY == 0) {
         if (ypart) rc = full ? launch_adjr<0, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, true>(prm, lds_block, s);
+        else if (ND == 8) rc = full ? launch_adjr<0, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, false>(prm, lds_block, s);
         else rc = full ? launch_adjr<0, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, false>(prm, lds_block, s);
     } else if (ypart) {
         if (DY == 1) rc = full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);

@@ -182,7 +182,7 @@ __device__ __forceinline__ void lds_load_row<2>(d2_t (&r)[2], unsigned a) {
 }
 
 // RCX: coarse rows per lane when not the strip kernels' own (Tile<DY>::RC) -- 2 for the RBF kernel at dyadic 0 with 8 staged dims,
-// whose four-row form spills (such a variant cannot keep edges: the adjoints read the strip layout)
+// whose four-row form spills (its edges go into the strip layout all the same: e_L, see launch_fwd_fused)
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND, int RCX = 0>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr bool RBF = KIND == 1;   // ND: dimensions that can be non-zero (4 or 8); the arrays always carry FD = 8
@@ -191,7 +191,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     constexpr int LAG = RBF ? 2 : 0;   // macro-steps by which the block sweep trails the node evaluation (see the header)
     constexpr int CW = 2;
     constexpr int RC = RCX ? RCX : Tile<DY>::RC, R = RC << DY, S = CW << DY, r = 1 << DY;
-    static_assert(!(RCX && EDGES), "edges are kept in the strip kernels' layout");
+    // (RCX with EDGES: the launcher sets e_L so that e_L R is the strip layout's padded row count -- the rows this variant's lanes
+    // do not cover are padding)
     // x rows in LDS: 64 bytes (8 dims) each, or -- the four-dimension variants -- the 32 bytes that can be non-zero: with four or
     // eight pairs per wave (short paths) the x ring was what held a CU to one wave per SIMD at dyadic 0
     constexpr int XROW = x_row_bytes(ND);
@@ -898,8 +899,8 @@ int launch_fused_e(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     // are unsafe there, tools/check_async_hazards.py: scan_pressure) -- such calls take sk_solve_fwd_static_* or the unfused route
     // -- with TWO rows per lane it fits (pairs of up to 128 points; no edges: launch_fwd_fused sized the plan for it)
     if constexpr (KIND == 1 && DY == 0) {
-        if constexpr (EDGES) return SK_ERR_UNSUPPORTED;
-        else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, false, KIND, 8, 2>(prm, pl, s);
+        if constexpr (EDGES && (NAIVE || sizeof(TO) != 8)) return SK_ERR_UNSUPPORTED;   // (the adjoint that reads them: default stencil)
+        else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8, 2>(prm, pl, s);
     } else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
 }
 
@@ -931,7 +932,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     // (RBF at dyadic 0 beyond the four-dimension fp64 default-stencil variant: the two-row form, see launch_fused_e)
     const bool four_dim = !g.naive && sizeof(TO) == 8 && D <= 4;
     const bool rbf0_two_rows = KIND == 1 && DY == 0 && !four_dim;
-    if (rbf0_two_rows && strip_edges) return SK_ERR_UNSUPPORTED;
+    if (rbf0_two_rows && strip_edges && (g.naive || sizeof(TO) != 8)) return SK_ERR_UNSUPPORTED;
     const int RC = DY == 0 ? (rbf0_two_rows ? 2 : 4) : DY == 1 ? 2 : 1;
     // linear: one unit = two increment columns.  RBF: one unit = two NODE columns, and the sweep of a pair's last unit
     // reads one node column of the following unit, which therefore has to exist as padding inside the pair's stream;
@@ -942,6 +943,13 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (Ncp < NUp * 2 || (Ncp & 1)) return SK_ERR_UNSUPPORTED;
     int logL = 3;
     while (logL < 6 && (RC << logL) < rows) ++logL;
+    if (rbf0_two_rows && strip_edges) {
+        // the edges are read in the strip layout, whose padded rows (K constant along the zero increments of the padding) must all
+        // be WRITTEN: this variant's lanes have to cover them -- twice the strip kernels' lanes
+        const Strip st = strip_geom(rbf_edge_geom(g), 8);
+        if (!st.ok || st.nb != 1 || st.logL > 5) return SK_ERR_UNSUPPORTED;
+        logL = st.logL + 1;
+    }
     const int L = 1 << logL;
     if (L * RC < rows) return SK_ERR_UNSUPPORTED;   // more than one band per pair
     if (Mrows < L * RC) return SK_ERR_UNSUPPORTED;
@@ -977,9 +985,9 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
         const Strip st = strip_geom(KIND == 1 ? rbf_edge_geom(g) : g, 8);
-        if (!st.ok || st.nb != 1 || st.RC != RC) return SK_ERR_UNSUPPORTED;
+        if (!st.ok || st.nb != 1 || (st.RC != RC && !rbf0_two_rows)) return SK_ERR_UNSUPPORTED;
         prm.e_NUp = st.NUp;
-        prm.e_L = 1 << st.logL;
+        prm.e_L = (1 << st.logL) * (st.RC / RC);      // e_L x (this kernel's rows per lane) = the strip layout's padded rows
     }
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = ((g.Mc - 1) / RC) % L;

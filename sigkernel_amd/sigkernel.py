@@ -488,7 +488,7 @@ def _sym_triangle_ok(be, static_kernel, Xd, dyadic, naive):
         return False
     route = _route(be, OP_ADJOINT, static_kernel, Xd, Xd, dyadic, naive, True)
     if route == FUSED:
-        return fused[0] == 1 and Xd.dtype == torch.float64 and hasattr(be, "second_argument_gradient")
+        return fused[0] == 1 and Xd.dtype == torch.float64 and Xd.shape[2] <= 4 and hasattr(be, "second_argument_gradient")   # (the second-argument sums: dim <= 4)
     if route == STREAM:
         return Xd.shape[2] <= (8 if fused[0] == 0 else 32)
     return False

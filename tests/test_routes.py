@@ -53,10 +53,10 @@ TABLE = [
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
-    # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: default stencil, M <= 128 (two rows per lane)
+    # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: dim <= 8, default stencil, M <= 128 (two rows per lane)
     ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), STREAM, MB),
     ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), STREAM, MB),
-    ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), STREAM, MB),
+    ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 128, 300, 0, False, 4), FUSED, FUSED), ((ADJ, 1, 9, 40, 40, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
     # never swapped: the gradient is the first argument's
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
@@ -265,3 +265,27 @@ def test_one_band_forward_on_swapped_arguments(kind, D, d, M, N, dt):
     kp = sk.compute_kernel(X.to(DEV), Y[:5].to(DEV))
     kw = O.solve_coarse(O.increments(k.batch_kernel(X.double(), Y[:5].double()).numpy()), d, False)
     assert rel_err(kp.double().cpu().numpy(), kw) <= ftol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_tame_pairs_never_need_the_rescue(kind):
+    """The fused adjoints re-solve pairs that fail their self-check with stored grids ON THE DEVICE -- which also makes a layout
+    mismatch between a forward's edges and the adjoint that reads them look like a (slow, still exact) success: round 4 met exactly
+    that (padded rows of the strip layout left unwritten at M <= 16: every pair rescued, parity green, 150x slower).  On tame random
+    walks no pair may be flagged, whatever the one-band / multi-band shape."""
+    gen = torch.Generator().manual_seed(11)
+    be = _lib.get_backend()
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.9)
+    for d in (0, 1, 2):
+        for D in (2, 4, 5, 8, 12):
+            for (M, N) in ((5, 9), (16, 16), (17, 30), (33, 64), (64, 20), (128, 40), (200, 150)):
+                X, Y = _walk(gen, 6, M, D).to(DEV), _walk(gen, 5, N, D).to(DEV)
+                if be.route(ADJ, 0 if kind == "linear" else 1, D, M, N, d, False, 8) not in (FUSED, MB):
+                    continue
+                be.last_fused_err = None
+                Xg = X.clone().requires_grad_(True)
+                sigkernel_amd.SigKernel(k, d).compute_Gram(Xg, Y).sum().backward()
+                err = be.last_fused_err
+                assert err is not None, (kind, d, D, M, N)
+                assert float(err.min()) >= 0.0 and float(err.max()) <= _lib.HipBackend.ADJ_RESIDUAL_TOL, (kind, d, D, M, N, float(err.min()), float(err.max()))
