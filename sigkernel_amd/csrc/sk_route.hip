@@ -19,7 +19,7 @@
 //   adjoint (SK_OP_ADJOINT: sigkernel.py:257-343, :404-502; the forward of a call with a gradient pending keeps the edges of the
 //   SAME family: sk_solve_fwd_{linear,rbf}_edges_f64 for FUSED, sk_solve_fwd_static_* with edges for FUSED_MB)
 //     FUSED      linear: dim <= 8, M - 1 <= 128 (64 at d = 2) (csrc/sk_wave_adj_fused.hip);
-//                rbf: dim <= 4, d = 1..2, M <= 128 / 64; d = 0: dim <= 8, default stencil, M <= 128, two rows per lane (csrc/sk_wave_adj_fused_rbf.hip;
+//                rbf: dim <= 4, d = 1..2, M <= 128 / 64; dim 5..8 at d = 1: M <= 64 (one row per lane); d = 0: dim <= 8, default stencil, M <= 128, two rows per lane (csrc/sk_wave_adj_fused_rbf.hip;
 //                its 8-dim variants spill and lose)
 //     FUSED_MB   dim <= 16, d = 0..2, any M, N (csrc/sk_wave_adj_fused_mb.hip; rbf at d = 0: two coarse rows per lane); never swapped
 //                (the gradient is the first argument's)
@@ -94,6 +94,7 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         if (kind == 0 && D <= 8 && Mc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED;
         if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d)) return SK_ROUTE_FUSED;
         if (kind == 1 && D <= 8 && d == 0 && !naive && M <= 128) return SK_ROUTE_FUSED;   // two coarse rows per lane
+        if (kind == 1 && D <= 8 && d == 1 && M <= 64) return SK_ROUTE_FUSED;               // dim 5..8: one coarse row per lane
         if (may_stream && mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)) < mb_min_eff(op, kind, D, elem_size)) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }

@@ -644,17 +644,20 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     // edge layout is the strip kernels' own (pairs of up to 128 points; the default stencil: what the forward that keeps these edges
     // is built for; dim 5..8: 18 VGPRs spilled, like the dyadic-2 variants of that width)
     if (DY == 0 && (g.naive || st.logL > 5)) return SK_ERR_UNSUPPORTED;
-    const int RC = DY == 0 ? 2 : st.RC, NUp = st.NUp, logL = DY == 0 ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
+    // dyadic 1 with 8 staged dims: two coarse rows of 8 dims per lane spill 84-113 VGPRs (and lose to the multi-band kernel); ONE row
+    // per lane on twice the lanes fits (238 VGPRs) -- pairs of up to 64 points, the strip layout as it is (SK_ADJR_ALL: the old form)
+    const bool half_rows = DY == 0 || (DY == 1 && D > 4 && !knobs().adjr_all);
+    if (half_rows && st.logL > 5) return SK_ERR_UNSUPPORTED;
+    const int RC = half_rows ? st.RC / 2 : st.RC, NUp = st.NUp, logL = half_rows ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
     if (g.Nc > 2 * NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC + 1) return SK_ERR_UNSUPPORTED;   // (+ 1: the node row above the first lane's)
     const int ND = D <= 4 ? 4 : 8;
-    if (ND == 8 && DY == 1 && !knobs().adjr_all) return SK_ERR_UNSUPPORTED;   // two coarse rows of 8 dims per lane: 77 VGPRs spilled
     const bool yside = ypart != nullptr || ycols_out != nullptr;
     if (yside && (ND != 4 || B <= 0)) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
-    const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? XSlab<2, 4>::BYTES : XSlab<1, 4>::BYTES;
+    const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? (half_rows ? XSlab<1, 2>::BYTES : XSlab<2, 4>::BYTES) : XSlab<1, 4>::BYTES;
     const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * xslab) + (size_t)2 * G * (4 * S + 1) * 16 +
                              (ypart ? 5 * YC_PIECE : 0);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
@@ -713,6 +716,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
     } else if (DY == 1) {
         if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
+        else if (half_rows) rc = full ? launch_adjr<1, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, false>(prm, lds_block, s);
         else rc = full ? launch_adjr<1, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 8, false>(prm, lds_block, s);
     } else {
         if (ND == 4) rc = full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);

@@ -54,7 +54,7 @@ TABLE = [
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
     # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: dim <= 8, default stencil, M <= 128 (two rows per lane)
-    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), STREAM, MB),
+    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 65, 64, 1, True, 8), STREAM, MB), ((ADJ, 1, 7, 40, 300, 1, True, 4), FUSED, FUSED),
     ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 128, 300, 0, False, 4), FUSED, FUSED), ((ADJ, 1, 9, 40, 40, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
