@@ -173,7 +173,7 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  *   scale [P] nullable (upstream gradient per pair).  gpart [gpart_doubles] receives partial sums over b, viewed as
  *   [A][B / *ppg_out][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
  *   dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == NULL: size query only.  err [P] zero-initialised: self-check residual
- *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2 (either scheme, path dim <= 8) and dyadic 0 (default scheme, path
+ *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2 (either scheme, path dim <= 8; dim 5..8 at dyadic 1: one coarse row per lane, M <= 64) and dyadic 0 (default scheme, path
  *   dim <= 8, M <= 128: two coarse rows per lane on the strip kernels' edge layout), one band per pair with
  *   M <= lanes x rows per lane (edges: sk_strip_edges_bytes(P, Mc, Nc, ...) -- with Nc + 1 in place of Nc when Nc is a multiple
  *   of 16: the sweep needs a padding NODE column behind the last unit, as sk_solve_fwd_rbf_edges_f64 keeps them); otherwise SK_ERR_UNSUPPORTED
