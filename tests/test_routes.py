@@ -279,7 +279,7 @@ def test_tame_pairs_never_need_the_rescue(kind):
     k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.9)
     for d in (0, 1, 2):
         for D in (2, 4, 5, 8, 12):
-            for (M, N) in ((5, 9), (16, 16), (17, 30), (33, 64), (64, 20), (128, 40), (200, 150)):
+            for (M, N) in ((5, 9), (16, 16), (17, 30), (33, 64), (64, 20), (65, 33), (128, 40), (129, 17), (200, 150), (40, 300)):
                 X, Y = _walk(gen, 6, M, D).to(DEV), _walk(gen, 5, N, D).to(DEV)
                 if be.route(ADJ, 0 if kind == "linear" else 1, D, M, N, d, False, 8) not in (FUSED, MB):
                     continue
