@@ -289,3 +289,56 @@ def test_tame_pairs_never_need_the_rescue(kind):
                 err = be.last_fused_err
                 assert err is not None, (kind, d, D, M, N)
                 assert float(err.min()) >= 0.0 and float(err.max()) <= _lib.HipBackend.ADJ_RESIDUAL_TOL, (kind, d, D, M, N, float(err.min()), float(err.max()))
+
+
+@pytest.mark.gpu
+def test_no_forward_launcher_declines_what_the_route_promises():
+    """Wherever sk_route_query answers a fused route for a forward, the launcher takes the call (a decline would fall back to the
+    streaming route silently: correct, slower, and invisible to the parity tests)."""
+    from sigkernel_amd.sigkernel import _fused_forward
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(1)
+    lens = (2, 3, 9, 16, 17, 33, 64, 65, 128, 129, 256, 257, 300)
+    declined = []
+    for kind in (0, 1):
+        k = sigkernel_amd.LinearKernel() if kind == 0 else sigkernel_amd.RBFKernel(1.1)
+        for d in (0, 1, 2):
+            for D in (1, 4, 5, 8, 9, 16):
+                for naive, dt in ((False, torch.float64), (True, torch.float32)):
+                    for M in lens:
+                        for N in lens[::2]:
+                            r = be.route(FWD, kind, D, M, N, d, naive, 8 if dt == torch.float64 else 4)
+                            if r == STREAM:
+                                continue
+                            X, Y = _walk(gen, 2, M, D, dt).to(DEV), _walk(gen, 3, N, D, dt).to(DEV)
+                            if _fused_forward(be, k, X, Y, d, naive, True) is None:
+                                declined.append((kind, d, D, naive, M, N, r))
+    assert not declined, declined[:20]
+
+
+@pytest.mark.gpu
+def test_no_adjoint_launcher_declines_what_the_route_promises():
+    """The same for gradients: wherever the ADJOINT route is fused, the fused adjoint runs (its residuals are recorded) and no pair of
+    these tame walks needs the rescue."""
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(2)
+    lens = (2, 3, 9, 16, 17, 33, 64, 65, 128, 129, 257)
+    bad = []
+    for kind in (0, 1):
+        k = sigkernel_amd.LinearKernel() if kind == 0 else sigkernel_amd.RBFKernel(1.1)
+        for d in (0, 1, 2):
+            for D in (1, 4, 5, 8, 9, 16):
+                for naive in (False, True):
+                    sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
+                    for M in lens:
+                        for N in lens[1::3]:
+                            if be.route(ADJ, kind, D, M, N, d, naive, 8) == STREAM:
+                                continue
+                            X, Y = _walk(gen, 2, M, D).to(DEV), _walk(gen, 3, N, D).to(DEV)
+                            be.last_fused_err = None
+                            Xg = X.clone().requires_grad_(True)
+                            sk.compute_Gram(Xg, Y).sum().backward()
+                            err = be.last_fused_err
+                            if err is None or not (float(err.min()) >= 0.0 and float(err.max()) <= _lib.HipBackend.ADJ_RESIDUAL_TOL):
+                                bad.append((kind, d, D, naive, M, N, None if err is None else (float(err.min()), float(err.max()))))
+    assert not bad, bad[:20]
