@@ -50,3 +50,53 @@ def test_world_size_mismatch_is_refused():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"], env=env, capture_output=True,
                          text=True, timeout=120)
     assert out.returncode != 0 and "does not match WORLD_SIZE" in out.stderr
+
+
+def _dist_configs_worker(rank, world, port, out_dir):
+    """bench.dist_configs -- the N > 1 line's `configs` block -- on two gloo ranks, CPU tensors and the oracle-backed fake back-end
+    (tests/fake_backend.py), with REDUCED shapes of BASELINE configs[3] and [4]: the same function, Workload, timing and parity code
+    the GPU run executes at full size."""
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from sigkernel_amd import _lib
+        from fake_backend import OracleBackend
+        _lib.set_backend(OracleBackend())
+        shapes = {"c4": dict(bench.CONFIGS["c4"], A=6, B=5, M=7, N=7, D=2),
+                  "c5": dict(bench.CONFIGS["c5"], A=5, B=4, M=9, N=8, D=3, dtype=torch.float64)}
+        res = bench.dist_configs(world, rank, torch.device("cpu"), dist.group.WORLD, dist, plan=(("c4", 1, 1), ("c5", 1, 0)), shapes=shapes)
+        with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+            json.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_n_gt_1_line_carries_c4_and_c5():
+    """BASELINE configs[3] is THE 8-GPU config: the N > 1 bench line must time it (and configs[4]) under the process group and say
+    which world size it saw."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_dist_configs_worker, args=(2, port, tmp), nprocs=2, join=True)
+        r0 = json.load(open(os.path.join(tmp, "rank0.json")))
+        r1 = json.load(open(os.path.join(tmp, "rank1.json")))
+    for name in ("c4", "c5"):
+        ent = r0[name]
+        assert "error" not in ent, ent
+        assert ent["world_size_seen"] == 2 and ent["n_gpus"] == 2 and ent["scaling"] == "strong" and ent["ms_per_step"] > 0
+        assert "sharded over 2" in ent["parallelism"] and ent["backend"] == "gloo"
+        assert "parity" in ent and "parity" not in r1[name]          # rank 0 checks; the others only take part
+    assert r0["c4"]["parity"]["grad_ok"] and r0["c4"]["parity"]["mmd_ok"]
+    assert r0["c5"]["parity"]["ok"]
+    assert r0["c4"]["rows_per_gpu"] == 3 and r0["c5"]["rows_per_gpu"] == 3
