@@ -495,6 +495,42 @@ int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc
 int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
                        int dyadic, int flags, float *out_k, float *out_kd, float *out_kdd, void *stream);
 
+/* ---- one-launch glue of the loss wrappers (csrc/sk_loss.hip) -----------------------------------------------------
+ * compute_mmd / compute_scoring_rule / compute_expected_scoring_rule (sigkernel.py:146-197) assemble their value from two or
+ * three compute_Gram calls and some twenty elementwise / reduction kernels; on MI355X every dispatch costs 4-5 us, a third of a
+ * training-sized step.  These entry points make each stage ONE launch; all are deterministic (no atomics, fixed reduction order).
+ *
+ * sk_prep_cat_*: Z = [X; Y] (X [A,M,D], Y [B,M,D], same length) staged in BOTH layouts from the two batches -- no concatenated
+ *   copy: out_rows [A+B][rows][fd] (scaled by scale_rows), optionally out_rows2 (the same scaled by scale_rows2: the linear
+ *   adjoint's rows carry s^2, the forward's kappa s^2), out_cols [A+B][fd][cols] (unscaled); diff as sk_prep_paths_*.
+ * sk_solve_fwd_loss_f64: ONE fused forward launch over the LOSS LAYOUT of pairs: the rectangle K(Z[0..A), Z) -- A (A+B) pairs,
+ *   pair (a, b) at a (A+B) + b, whose column blocks are K(X, X) and K(X, Y) -- followed by the STRICT upper triangle (i < j,
+ *   row-major) of K(Y, Y), tri_n (tri_n - 1) / 2 pairs (tri_n = B, or 0: no K_YY term; the diagonals never enter the unbiased
+ *   statistics, sigkernel.py:194-197).  out [P] in pair order; edges (nullable) receives the terminal edges of the RECTANGLE pairs
+ *   only, in the layout sk_solve_fwd_{linear,rbf}_edges_f64 writes (sk_strip_edges_bytes for A (A+B) pairs) -- the triangle
+ *   carries no gradient (the second argument of compute_mmd must not require one, sigkernel.py:188).  Replaces the three
+ *   _SigKernelGram.forward calls of sigkernel.py:190-192.  kind 0: Zr = kappa s^2 differences (sk_linear_prescale), Zt differences;
+ *   kind 1: points, param = 1 / sigma.  SK_ERR_UNSUPPORTED outside the one-band kernels' scope.
+ * sk_loss_value_f64: value[0] = sum_{a != b} K_XX[a,b] / (A (A-1)) - 2 mean(K_XY) [+ sum_{i != j} K_YY[i,j] / (B (B-1)) when
+ *   with_yy] from that output (sigkernel.py:194-197, :160-161, :177-178).
+ * sk_loss_weights_f64: go [A (A+B)] = grad_out[0] * d value / dK of the rectangle, the K_XX block doubled as the reference's
+ *   backward doubles a Gram whose both arguments require a gradient (sigkernel.py:410-412); grad_out: a DEVICE scalar (nullable = 1).
+ * sk_rbf_adjoint_finish_f64 / sk_linear_adjoint_finish_f64: the partial sums of sk_rbf_adjoint_fused_f64 (gpart
+ *   [A][chunks][rows][outw]) / sk_linear_adjoint_fused_f64 (tpart [A][chunks][rows][8]) -> dL/dX [A,M,D], chunks added in ascending
+ *   order; X: the fp64 points (rbf); scale2 = s^4 / s^2-staging factor of the linear rows (the wrapper's `param ** 2`). */
+int sk_prep_cat_f64(const double *X, int64_t A, const double *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
+int sk_prep_cat_f32(const float *X, int64_t A, const float *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
+int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, int64_t A, int64_t B, int64_t tri_n, int Mrows, int Mc,
+                          int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream);
+int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, void *stream);
+int sk_loss_weights_f64(int64_t A, int64_t B, const double *grad_out, double *go, void *stream);
+int sk_rbf_adjoint_finish_f64(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
+                              double *grad, void *stream);
+int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
+                                 void *stream);
+
 /* ---- launch planning, host only (no device work; exposed so that the partition of the pairs can be tested without a GPU) ----
  * The persistent kernels share P pairs among `waves` waves of G lane groups each; when a launch fills the chip with whole
  * workgroups (waves == resident = n_cu * waves per CU) the shares depend on the wave's age rank.

@@ -110,6 +110,13 @@ SIGNATURES = {
     "sk_static_deriv_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int,
                                               ctypes.c_double, _vp, _vp, _vp, _i64, _vp]),
     "sk_solve_deriv_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_prep_cat_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
+    "sk_prep_cat_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
+    "sk_solve_fwd_loss_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_loss_value_f64": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "sk_loss_weights_f64": (_int, [_i64, _i64, _vp, _vp, _vp]),
+    "sk_rbf_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _vp, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_linear_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, ctypes.c_double, _vp, _vp]),
     "sk_solve_deriv_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
@@ -407,6 +414,72 @@ class HipBackend:
         _check(rc, "sk_solve_fwd_rbf")
         return (out, None) if keep_edges else out
 
+    def loss_forward(self, kind, param, X, Y, dyadic, naive, with_yy, keep_edges):
+        """The loss wrappers' forward in THREE launches (csrc/sk_loss.hip): [X; Y] staged in both layouts straight from the two
+        batches (sk_prep_cat_*), the rectangle K(X, [X; Y]) and -- with_yy -- the strict triangle of K(Y, Y) in ONE fused forward
+        launch (sk_solve_fwd_loss_f64), the scalar K_XX_m - 2 mean(K_XY) [+ K_YY_m] (sk_loss_value_f64).  fp64 paths of one length
+        within the one-band fused kernels' scope; None otherwise.  Returns (value 0-dim, out [P] in pair order, edges of the
+        rectangle pairs or None, staged = (rows of the forward, cols, rows of the adjoint))."""
+        _dev(X, "X")
+        _dev(Y, "Y")
+        A, M, D = X.shape
+        B = Y.shape[0]
+        Mc = M - 1
+        rows_needed = Mc if kind == 0 else M
+        if X.dtype != torch.float64 or Y.dtype != torch.float64 or Y.shape[1] != M or D > 8 or dyadic > 2 or Mc < 1 or A < 1 or B < 1:
+            return None
+        if rows_needed > 64 * (4 >> min(dyadic, 2)) or (kind == 1 and not float(param) > 0):
+            return None
+        dev = X.device
+        lib = load()
+        Mrows, Ncp = 256, ((Mc if kind == 0 else M) + 15) // 16 * 16
+        Z = A + B
+        P_rect = A * Z
+        P = P_rect + (B * (B - 1) // 2 if with_yy else 0)
+        scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
+        with _device(dev):
+            two_rows = kind == 0 and keep_edges      # the linear adjoint's rows carry s^2, the forward's kappa s^2
+            nr = Z * Mrows * 8
+            buf = torch.empty(nr * (2 if two_rows else 1) + Z * 8 * Ncp, dtype=torch.float64, device=dev)
+            Zr = buf[:nr].view(Z, Mrows, 8)
+            Zr2 = buf[nr:2 * nr].view(Z, Mrows, 8) if two_rows else None
+            Zt = buf[nr * (2 if two_rows else 1):].view(Z, 8, Ncp)
+            if kind == 0:
+                kappa = float(lib.sk_linear_prescale(int(dyadic)))
+                s_rows, s_rows2, diff = kappa * float(param) ** 2, float(param) ** 2, 1
+            else:
+                s_rows, s_rows2, diff = 1.0, 1.0, 0
+            _check(lib.sk_prep_cat_f64(_ptr(X), A, _ptr(Y), B, M, D, diff, s_rows, s_rows2, _ptr(Zr), _ptr(Zr2), Mrows, _ptr(Zt), Ncp, 8,
+                                       _stream(X)), "sk_prep_cat")
+            edges = None
+            if keep_edges:
+                if kind == 0:
+                    nbytes = int(lib.sk_strip_edges_bytes(P_rect, Mc, Mc, int(dyadic), 8))
+                else:
+                    nbytes = int(lib.sk_strip_edges_bytes(P_rect, Mc + _rbf_extra_row(Mc, dyadic), Mc + (1 if Mc % 16 == 0 else 0), int(dyadic), 8))
+                if not nbytes:
+                    return None
+                edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+            out = torch.empty(P, dtype=torch.float64, device=dev)
+            rc = lib.sk_solve_fwd_loss_f64(int(kind), 1.0 / float(param) if kind == 1 else 0.0, _ptr(Zr), _ptr(Zt), A, B, B if with_yy else 0,
+                                           Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(_queue(dev, P)), _stream(X))
+            if rc == 2:
+                return None
+            _check(rc, "sk_solve_fwd_loss")
+            value = torch.empty((), dtype=torch.float64, device=dev)
+            _check(lib.sk_loss_value_f64(_ptr(out), A, B, int(bool(with_yy)), _ptr(value), _stream(X)), "sk_loss_value")
+        return value, out, edges, (Zr, Zt, Zr2 if two_rows else Zr)
+
+    @staticmethod
+    def loss_weights(A, B, grad_output, dev):
+        """grad_output (a 0-dim device tensor) times d value / dK of the rectangle K(X, [X; Y]), the K_XX block doubled
+        (sk_loss_weights_f64): the upstream gradient of the fused adjoint, one launch, nothing read back."""
+        go = torch.empty(A * (A + B), dtype=torch.float64, device=dev)
+        g = grad_output.detach().to(torch.float64).contiguous()
+        with _device(dev):
+            _check(load().sk_loss_weights_f64(A, B, _ptr(g), _ptr(go), _stream(go)), "sk_loss_weights")
+        return go
+
     def solve_fwd_fused_sym(self, kind, param, X, dyadic, naive):
         """Symmetric Gram matrix K[a][b] = k(x_a, x_b) of ONE batch with the static kernel formed inside the solver: only the pairs
         on and above the diagonal are solved, in one launch, each written twice (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*).
@@ -614,7 +687,7 @@ class HipBackend:
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), _WorstResidual(err)
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False, staged=None):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
@@ -623,9 +696,12 @@ class HipBackend:
         sweep, solves them with stored grids and adds their exact share, and the gradient is valid as returned -- nothing for the
         host to check, no synchronisation.  gram=False: paired batch, Y [A,N,D], scale [A]."""
         _dev(X, "X")
-        _dev(Y, "Y")
         A, M, D = X.shape
-        B, N = Y.shape[0], Y.shape[1]
+        if staged is not None:      # (dXr [>= A][256][8] with s^2, dYt [B][8][Ncp], B, N): staged by the caller (loss_forward)
+            dXr, dYt, B, N = staged
+        else:
+            _dev(Y, "Y")
+            B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic not in (0, 1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or Mc > (64 if dyadic == 2 else 128):
             return None
@@ -637,9 +713,10 @@ class HipBackend:
         P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
         with _device(dev):
-            # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
-            dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
-            dYt = _prep_paths(Y, True, True, 1.0, Ncp)
+            if staged is None:
+                # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
+                dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
+                dYt = _prep_paths(Y, True, True, 1.0, Ncp)
             args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(edges),
                     _ptr(scale))
             rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), None, 0.0, 0.0, None, 0,
@@ -650,8 +727,9 @@ class HipBackend:
             chunks = B // ppg.value if gram else 1
             self.last_fused_ppg = ppg.value      # (pairs per lane-group chunk of the last fused adjoint: what the tests look at)
             tpart = torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
-            err = torch.zeros(P, dtype=torch.float64, device=dev)
             kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev)
+            # (with the rescue armed, its screening pass writes every residual entry before the sweep)
+            err = torch.empty(P, dtype=torch.float64, device=dev) if kf is not None else torch.zeros(P, dtype=torch.float64, device=dev)
             rc = lib.sk_linear_adjoint_fused_f64(*args, _ptr(tpart), tpart.numel(), _ptr(err), ctypes.byref(ppg), ctypes.byref(rows),
                                                  _ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes,
                                                  _stream(X))
@@ -660,18 +738,18 @@ class HipBackend:
             _check(rc, "sk_linear_adjoint_fused")
         # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device (diagnostics; with
         # `kfinal` the rescue has already dealt with exploding pairs: entries of -1 are pairs it took out of the sweep)
+            # the chunks of an a added in ascending order, the flipped rows back to p, d inc[p,q] / d x[p+1] = +s^2 dy[q],
+            # / d x[p] = -s^2 dy[q]: one launch (sk_linear_adjoint_finish_f64)
+            g = torch.empty(A, M, D, dtype=torch.float64, device=dev)
+            _check(lib.sk_linear_adjoint_finish_f64(_ptr(tpart), A, chunks, rows.value, M, D, float(param) ** 2, _ptr(g), _stream(X)),
+                   "sk_linear_adjoint_finish")
         res = _WorstResidual(err)
         self.last_fused_err = err
-        T = tpart.sum(1).flip(1)[:, :Mc, :D]     # chunks of an a added in a fixed order; flipped rows back to p
-        g = torch.zeros(A, M, D, dtype=torch.float64, device=dev)
-        g[:, 1:] += T          # d inc[p,q] / d x[p+1] = +s^2 dy[q]
-        g[:, :-1] -= T         # d inc[p,q] / d x[p]   = -s^2 dy[q]
-        if float(param) != 1.0:
-            g = g * (float(param) ** 2)
-        g = g.to(X.dtype)
+        if g.dtype != X.dtype:
+            g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False, staged=None):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
@@ -681,9 +759,12 @@ class HipBackend:
         per node of y_b, WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1) (see
         second_argument_gradient)."""
         _dev(X, "X")
-        _dev(Y, "Y")
         A, M, D = X.shape
-        B, N = Y.shape[0], Y.shape[1]
+        if staged is not None:      # (Xr [>= A][256][8], Yt [B][8][Ncp], B, N): staged by the caller (loss_forward)
+            Xr, Yt, B, N = staged
+        else:
+            _dev(Y, "Y")
+            B, N = Y.shape[0], Y.shape[1]
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic not in (0, 1, 2) or (dyadic == 0 and (naive or M > 128)) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
             return None
@@ -697,8 +778,9 @@ class HipBackend:
         P, Bk = (A * B, B) if gram else (A, 0)
         ppg, rows, outw, ycols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         with _device(dev):
-            Xr = _prep_paths(X, False, False, 1.0, Mrows)
-            Yt = _prep_paths(Y, False, True, 1.0, Ncp)
+            if staged is None:
+                Xr = _prep_paths(X, False, False, 1.0, Mrows)
+                Yt = _prep_paths(Y, False, True, 1.0, Ncp)
             args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, float(sigma),
                     _ptr(edges), _ptr(scale))
             head = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None)
@@ -710,24 +792,29 @@ class HipBackend:
             chunks = B // ppg.value if gram else 1
             self.last_fused_ppg = ppg.value
             gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
-            err = torch.zeros(P, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read
             ypart = torch.empty(A, B, ycols.value, 6, dtype=torch.float64, device=dev) if yside else None
             kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev)
+            # (with the rescue armed, its screening pass writes every residual entry before the sweep)
+            err = torch.empty(P, dtype=torch.float64, device=dev) if kf is not None else torch.zeros(P, dtype=torch.float64, device=dev)
             tail = head + (_ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
             rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ypart),
                                               ypart.numel() if yside else 0, *tail)
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused")
+            # chunks of an a added in ascending order, then sum_c V G (-2/sigma) (x_r - y_c): one launch (sk_rbf_adjoint_finish_f64)
+            X64 = X if X.dtype == torch.float64 else X.double()
+            g = torch.empty(A, M, D, dtype=torch.float64, device=dev)
+            _check(lib.sk_rbf_adjoint_finish_f64(_ptr(gpart), A, chunks, rows.value, outw.value, _ptr(X64), M, D, float(sigma), _ptr(g),
+                                                 _stream(X)), "sk_rbf_adjoint_finish")
         res = _WorstResidual(err)
         self.last_fused_err = err
-        T = gpart.sum(1)[:, :M]                                   # chunks of an a added in a fixed order
-        cs, accd = T[..., 0:1], T[..., 2:2 + D]
-        g = (-2.0 / float(sigma)) * (X.double() * cs - accd)     # sum_c V G (-2/sigma) (x_r - y_c)
+        if g.dtype != X.dtype:
+            g = g.to(X.dtype)
         if yside:
-            return g.to(X.dtype), res, ypart[:, :, :N, :2 + D]
-        return g.to(X.dtype), res
+            return g, res, ypart[:, :, :N, :2 + D]
+        return g, res
 
     @staticmethod
     def second_argument_gradient(ysums, Y, sigma, weight, b0=0):

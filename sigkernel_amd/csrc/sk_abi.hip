@@ -158,6 +158,7 @@ Knobs parse_knobs() {
     k.derivf_wpc = knob_int("SK_DERIVF_WPC"); k.derivf_wpb = knob_int("SK_DERIVF_WPB"); k.derivf_noshift = knob_int("SK_DERIVF_NOSHIFT");
     k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
+    k.fused_mid = getenv("SK_FUSED_MID") ? knob_int("SK_FUSED_MID") : 1;
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");
     k.rank_w = knob_shares("SK_RANK_W"); k.wave_rank_w = knob_shares("SK_WAVE_RANK_W"); k.adj_rank_w = knob_shares("SK_ADJ_RANK_W");
     k.adjf_rank_w = knob_shares("SK_ADJF_RANK_W"); k.adjr_rank_w = knob_shares("SK_ADJR_RANK_W");
@@ -657,6 +658,56 @@ int sk_solve_deriv_f64(const double *inc, const double *inc_d, const double *inc
 int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd, int64_t ld, int64_t P, int Mc, int Nc,
                        int dyadic, int flags, float *out_k, float *out_kd, float *out_kdd, void *stream) {
     return solve_deriv<float>(inc, inc_d, inc_dd, ld, P, Mc, Nc, dyadic, flags, out_k, out_kd, out_kdd, stream);
+}
+
+int sk_prep_cat_f64(const double *X, int64_t A, const double *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream) {
+    if ((A > 0 && !X) || (B > 0 && !Y) || !out_rows || !out_cols || A < 0 || B < 0 || M < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
+    if (rows < (diff ? M - 1 : M) || cols < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (A + B == 0) return SK_OK;
+    return launch_prep_cat<double>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, (hipStream_t)stream);
+}
+int sk_prep_cat_f32(const float *X, int64_t A, const float *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream) {
+    if ((A > 0 && !X) || (B > 0 && !Y) || !out_rows || !out_cols || A < 0 || B < 0 || M < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
+    if (rows < (diff ? M - 1 : M) || cols < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (A + B == 0) return SK_OK;
+    return launch_prep_cat<float>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, (hipStream_t)stream);
+}
+
+int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, int64_t A, int64_t B, int64_t tri_n, int Mrows, int Mc,
+                          int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream) {
+    if (D < 1 || !Zr || !Zt || !out || A < 1 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
+    if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
+    if (tri_n != 0 && tri_n != B) return SK_ERR_BAD_ARG;
+    if (dyadic > 2) return SK_ERR_UNSUPPORTED;
+    const int64_t Bz = A + B;
+    const int64_t loss[2] = {tri_n, A};
+    const Geom g = make_geom(A * Bz + (tri_n > 1 ? tri_n * (tri_n - 1) / 2 : 0), Mc, Nc, dyadic, scheme);
+    if (kind == 0) return launch_fwd_fused_linear<double>(Zr, Zt, A, Bz, Mrows, Ncp, D, g, out, edges, queue, (hipStream_t)stream, 2, loss);
+    return launch_fwd_fused_rbf<double>(Zr, Zt, A, Bz, Mrows, Ncp, D, g, param, out, edges, queue, (hipStream_t)stream, 2, loss);
+}
+
+int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, void *stream) {
+    if (!out || !value || A < 1 || B < 1) return SK_ERR_BAD_ARG;
+    return launch_loss_value(out, A, B, with_yy, value, (hipStream_t)stream);
+}
+int sk_loss_weights_f64(int64_t A, int64_t B, const double *grad_out, double *go, void *stream) {
+    if (!go || A < 1 || B < 1) return SK_ERR_BAD_ARG;
+    return launch_loss_weights(A, B, grad_out, go, (hipStream_t)stream);
+}
+int sk_rbf_adjoint_finish_f64(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
+                              double *grad, void *stream) {
+    if (!gpart || !X || !grad || A < 0 || chunks < 1 || M < 1 || D < 1 || rows < M || outw < 2 + D || !(sigma > 0.0)) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_rbf_adjoint_finish(gpart, A, chunks, rows, outw, X, M, D, sigma, grad, (hipStream_t)stream);
+}
+int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
+                                 void *stream) {
+    if (!tpart || !grad || A < 0 || chunks < 1 || M < 2 || D < 1 || D > 8 || rows < M - 1) return SK_ERR_BAD_ARG;
+    if (A == 0) return SK_OK;
+    return launch_linear_adjoint_finish(tpart, A, chunks, rows, M, D, scale2, grad, (hipStream_t)stream);
 }
 
 }  // extern "C"

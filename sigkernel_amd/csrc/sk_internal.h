@@ -18,7 +18,7 @@ struct Knobs {
     int adjmb_wpc, adjmb_wpb, adjmb_q_static;     // sk_wave_adj_fused_mb.hip
     int derivf_wpc, derivf_wpb, derivf_noshift;   // sk_wave_deriv_fused.hip
     int deriv_pf, deriv_wpc, deriv_wpb;
-    int fused_wpc, fused_wpb, fused_q_static;
+    int fused_wpc, fused_wpb, fused_q_static, fused_mid;
     int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
 };
@@ -145,11 +145,24 @@ int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld,
 // ---- sk_wave_fused.hip: forward solver with the linear static kernel fused in (no increments in HBM) ----
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0);
+                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0, const int64_t *loss = nullptr);
 
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0);
+                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0, const int64_t *loss = nullptr);
+// (tri = 2, loss = {tri_n, tri_off}: the LOSS layout -- both staged arrays hold one batch Z of B paths; A B rectangle pairs (rows
+// Z[0 .. A)), which keep their edges, then the strict upper triangle of Z[tri_off .. tri_off + tri_n), which does not; out [P] linear)
+
+// ---- sk_loss.hip: the glue of the loss wrappers (compute_mmd / scoring rules) as single launches ----
+template <typename T>
+int launch_prep_cat(const T *X, int64_t A, const T *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2, double *out_rows,
+                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, hipStream_t s);
+int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, hipStream_t s);
+int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go, hipStream_t s);
+int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
+                              double *grad, hipStream_t s);
+int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
+                                 hipStream_t s);
 
 // ---- sk_wave_fused_mb.hip: the same for pairs that need several bands, and path dims up to 16 (kind 0 linear, 1 rbf) ----
 template <typename TO>

@@ -1,0 +1,178 @@
+// sk_loss.hip -- the glue of a training-sized loss step as single launches.
+//
+// compute_mmd(X, Y).backward() on a few dozen paths is three PDE launches and, in the reference's composition
+// (sigkernel.py:180-197 over three compute_Gram calls, :404-416 for their backward), some twenty elementwise / reduction
+// kernels of a few microseconds each around them: concatenation, staging of each batch twice, multiply + sum per matrix,
+// the weights of d loss / dK, the fold of the adjoint's partial sums into dL/dX.  On MI355X every dispatch costs 4-5 us whatever
+// it does, so at 32 x 32 paths a third of the step was glue.  Here each of those stages is ONE launch:
+//   k_prep_cat            Z = [X; Y] staged for the fused kernels in both layouts (rows [A+B][rows][8], cols [A+B][8][cols]),
+//                         straight from the two batches -- no concatenated copy;
+//   k_loss_value          the scalar  sum_{a != b} K_XX / (A (A-1))  -  2 mean(K_XY)  [+ sum_{i != j} K_YY / (B (B-1))]  from the
+//                         output of sk_solve_fwd_loss_f64 (rectangle K(X, [X; Y]) + strict triangle of K(Y, Y)), in a fixed order;
+//   k_loss_weights        d loss / dK of the rectangle times the upstream gradient (a device scalar: no host read-back), with the
+//                         reference's 2x rule for the K_XX block (sigkernel.py:410-412);
+//   k_*_adjoint_finish    the fused adjoints' partial sums [A][chunks][rows][w] -> dL/dX (A, M, D), chunks added in ascending order.
+// All results are deterministic (no atomics; fixed reduction trees).
+#include "sk_internal.h"
+
+namespace sk {
+namespace {
+
+template <typename T, bool DIFF>
+__global__ __launch_bounds__(256) void k_prep_cat(const T *__restrict__ X, int64_t A, const T *__restrict__ Y, int64_t B, int M, int D,
+                                                  double scale_rows, double scale_rows2, double *__restrict__ out_rows,
+                                                  double *__restrict__ out_rows2, int rows, double *__restrict__ out_cols, int cols, int FDp) {
+    const int64_t Z = A + B;
+    const int64_t nr = Z * (int64_t)rows * FDp, nc = Z * (int64_t)cols * FDp;
+    const int nvalid = DIFF ? M - 1 : M;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr + nc; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t z;
+        int p, j;
+        const bool is_row = i < nr;
+        if (is_row) {          // [z][p][j]
+            z = i / ((int64_t)rows * FDp);
+            const int rem = (int)(i - z * (int64_t)rows * FDp);
+            p = rem / FDp;
+            j = rem - p * FDp;
+        } else {               // [z][j][q], q < cols
+            const int64_t k = i - nr;
+            z = k / ((int64_t)cols * FDp);
+            const int rem = (int)(k - z * (int64_t)cols * FDp);
+            j = rem / cols;
+            p = rem - j * cols;
+        }
+        double v = 0.0;
+        if (p < nvalid && j < D) {
+            const T *x = (z < A ? X + z * (int64_t)M * D : Y + (z - A) * (int64_t)M * D) + (int64_t)p * D + j;
+            v = DIFF ? ((double)x[D] - (double)x[0]) : (double)x[0];
+        }
+        if (is_row) {
+            out_rows[i] = v * scale_rows;
+            if (out_rows2) out_rows2[i] = v * scale_rows2;
+        } else {
+            out_cols[i - nr] = v;
+        }
+    }
+}
+
+constexpr int LV_THREADS = 1024;
+
+// one workgroup: thread t adds entries t, t + 1024, ... of each part in ascending order, then a fixed tree over the threads
+__global__ __launch_bounds__(LV_THREADS) void k_loss_value(const double *__restrict__ out, int64_t A, int64_t B, int with_yy,
+                                                           double *__restrict__ value) {
+    __shared__ double red[LV_THREADS];
+    const int64_t Bz = A + B, P_rect = A * Bz, P_tri = with_yy && B > 1 ? B * (B - 1) / 2 : 0;
+    const double wxx = A > 1 ? 1.0 / ((double)A * (double)(A - 1)) : 0.0, wxy = -2.0 / ((double)A * (double)B);
+    const double wyy = B > 1 ? 2.0 / ((double)B * (double)(B - 1)) : 0.0;
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;
+    for (int64_t p = threadIdx.x; p < P_rect; p += LV_THREADS) {
+        const int64_t a = p / Bz, b = p - a * Bz;
+        const double k = out[p];
+        if (b >= A) sxy += k;
+        else if (b != a) sxx += k;
+    }
+    for (int64_t q = threadIdx.x; q < P_tri; q += LV_THREADS) syy += out[P_rect + q];
+    red[threadIdx.x] = sxx * wxx + sxy * wxy + syy * wyy;
+    __syncthreads();
+    for (int s = LV_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *value = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_loss_weights(int64_t A, int64_t B, const double *__restrict__ grad_out, double *__restrict__ go) {
+    const int64_t Bz = A + B, P_rect = A * Bz;
+    const double g = grad_out ? *grad_out : 1.0;
+    const double wxx = A > 1 ? 2.0 / ((double)A * (double)(A - 1)) : 0.0, wxy = -2.0 / ((double)A * (double)B);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P_rect; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = p / Bz, b = p - a * Bz;
+        go[p] = g * (b >= A ? wxy : (b != a ? wxx : 0.0));
+    }
+}
+
+// gpart [A][chunks][rows][outw]: node row r < M of x_a: cs = sum_c [a][c][r][0], accd[j] = sum_c [a][c][r][2 + j];
+// dL/dx_a[r][j] = (-2 / sigma) (x_a[r][j] cs - accd[j])
+__global__ __launch_bounds__(256) void k_rbf_adjoint_finish(const double *__restrict__ gpart, int64_t A, int64_t chunks, int rows, int outw,
+                                                            const double *__restrict__ X, int M, int D, double c, double *__restrict__ grad) {
+    const int64_t n = A * (int64_t)M * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = i / ((int64_t)M * D);
+        const int rem = (int)(i - a * (int64_t)M * D);
+        const int r = rem / D, j = rem - r * D;
+        const double *src = gpart + (a * chunks * rows + r) * (int64_t)outw;
+        double cs = 0.0, acc = 0.0;
+        for (int64_t ch = 0; ch < chunks; ++ch) {
+            cs += src[ch * (int64_t)rows * outw];
+            acc += src[ch * (int64_t)rows * outw + 2 + j];
+        }
+        grad[i] = c * (X[i] * cs - acc);
+    }
+}
+
+// tpart [A][chunks][rows][8], coarse rows FLIPPED (row rows - 1 - p holds coarse row p): T[a][p][j] = sum_c [a][c][rows - 1 - p][j];
+// dL/dx_a[r][j] = scale2 (T[a][r - 1][j] - T[a][r][j])  (d inc[p][q] / d x[p + 1] = + s^2 dy[q], / d x[p] = - s^2 dy[q])
+__global__ __launch_bounds__(256) void k_linear_adjoint_finish(const double *__restrict__ tpart, int64_t A, int64_t chunks, int rows, int M, int D,
+                                                               double scale2, double *__restrict__ grad) {
+    const int64_t n = A * (int64_t)M * D;
+    const int Mc = M - 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = i / ((int64_t)M * D);
+        const int rem = (int)(i - a * (int64_t)M * D);
+        const int r = rem / D, j = rem - r * D;
+        const double *src = tpart + a * chunks * rows * (int64_t)8 + j;
+        double up = 0.0, dn = 0.0;     // T[r - 1], T[r]
+        for (int64_t ch = 0; ch < chunks; ++ch) {
+            if (r >= 1) up += src[(ch * rows + (rows - r)) * (int64_t)8];
+            if (r < Mc) dn += src[(ch * rows + (rows - 1 - r)) * (int64_t)8];
+        }
+        grad[i] = scale2 * (up - dn);
+    }
+}
+
+inline unsigned grid_for(int64_t n) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+template <typename T>
+int launch_prep_cat(const T *X, int64_t A, const T *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2, double *out_rows,
+                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, hipStream_t s) {
+    const int64_t n = (A + B) * (int64_t)(rows + cols) * FDp;
+    if (diff) hipLaunchKernelGGL((k_prep_cat<T, true>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp);
+    else hipLaunchKernelGGL((k_prep_cat<T, false>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp);
+    return check_launch();
+}
+template int launch_prep_cat<double>(const double *, int64_t, const double *, int64_t, int, int, int, double, double, double *, double *, int, double *,
+                                     int, int, hipStream_t);
+template int launch_prep_cat<float>(const float *, int64_t, const float *, int64_t, int, int, int, double, double, double *, double *, int, double *,
+                                    int, int, hipStream_t);
+
+int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, A, B, with_yy, value);
+    return check_launch();
+}
+
+int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go, hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_weights, dim3(grid_for(A * (A + B))), dim3(256), 0, s, A, B, grad_out, go);
+    return check_launch();
+}
+
+int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
+                              double *grad, hipStream_t s) {
+    hipLaunchKernelGGL(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
+                       -2.0 / sigma, grad);
+    return check_launch();
+}
+
+int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, grad);
+    return check_launch();
+}
+
+}  // namespace sk

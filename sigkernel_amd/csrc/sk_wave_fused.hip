@@ -51,6 +51,11 @@ struct FusedParams {
     int e_NUp, e_L;      // EDGES: units per row / lanes per pair of the strip layout the adjoint reads (strip_geom)
     int tri;             // 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
                          // path batch (A = B); out is [A][A] and receives both (a, b) and (b, a)
+                         // 2: the LOSS layout (sk_solve_fwd_loss_f64): both staged arrays hold ONE batch Z; pairs [0, P_rect) are the
+                         // rectangle (p / B, p % B) -- rows Z[0 .. P_rect / B) against all B paths -- and pairs [P_rect, P) the STRICT
+                         // upper triangle (i < j, row-major) of the tri_n paths from Z[tri_off] on; out is [P], in pair order
+    int64_t P_rect, tri_n, tri_off;
+    int64_t P_edges;     // EDGES: only pairs [0, P_edges) keep their edges (the loss layout's rectangle; P otherwise)
     WaveGroup wg;
     // The pairs of a launch are dealt to the waves as a stream of chunks (PairStream, below): chunk 0 of every wave is fixed --
     // C0 pairs per lane group, wave w starts at pair w G C0 -- and the rest is drawn, 2^logC pairs per lane group at a time,
@@ -60,6 +65,12 @@ struct FusedParams {
     int64_t q_first;     // first pair handed out by the counter (= waves G C0)
     int C0, logC;
     int n_big;           // queue == nullptr: waves [0, n_big) take C0 + 1 pairs per lane group (wave w starts at G (w C0 + min(w, n_big)))
+    // queue == nullptr, rk_n > 0: shares by wave AGE RANK instead (sk_wave_common.h: the SIMD arbiter favours its oldest wave, so equal
+    // shares leave a SIMD with two waves, then one, for the last third of a launch): a wave of rank r = w / rk_wpr takes rk_cnt[r]
+    // pairs per lane group from pair rk_base[r] + (w - r rk_wpr) G rk_cnt[r] on
+    int rk_n, rk_wpr;
+    int rk_cnt[4];
+    unsigned rk_base[4];
 };
 
 template <int N>
@@ -255,12 +266,22 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // live in VGPRs and every producer call computes its addresses with vector instructions.)
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
+    const unsigned Pe32 = EDGES ? (unsigned)prm.P_edges : 0u;    // pairs from here on keep no edges (the loss layout's triangle)
     // (launches without a queue deal the pairs out as evenly as whole pairs allow: the first n_big waves take one pair more
     // per lane group than the others -- everything below, t_end included, follows from this wave's own C0.  Spreading those
     // waves evenly over the wave numbers instead was measured slower: 0.215 vs 0.197 ms on 128 x 128 symmetric pairs.)
     const int w32 = __builtin_amdgcn_readfirstlane((int)wave_id);
-    const int C0 = __builtin_amdgcn_readfirstlane(prm.C0 + (w32 < prm.n_big ? 1 : 0)), logC = prm.logC, CQ = 1 << logC;
-    unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane(G * (w32 * prm.C0 + (w32 < prm.n_big ? w32 : prm.n_big))), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
+    int c0_ = prm.C0 + (w32 < prm.n_big ? 1 : 0);
+    unsigned cb0_ = (unsigned)(G * (w32 * prm.C0 + (w32 < prm.n_big ? w32 : prm.n_big)));
+    if (prm.rk_n > 0) {   // shares by age rank (scalar selects: rk_n <= 4)
+        int rr = w32 / prm.rk_wpr;
+        rr = rr >= prm.rk_n ? prm.rk_n - 1 : rr;
+        c0_ = rr == 0 ? prm.rk_cnt[0] : rr == 1 ? prm.rk_cnt[1] : rr == 2 ? prm.rk_cnt[2] : prm.rk_cnt[3];
+        const unsigned bs = rr == 0 ? prm.rk_base[0] : rr == 1 ? prm.rk_base[1] : rr == 2 ? prm.rk_base[2] : prm.rk_base[3];
+        cb0_ = bs + (unsigned)((w32 - rr * prm.rk_wpr) * G * c0_);
+    }
+    const int C0 = __builtin_amdgcn_readfirstlane(c0_), logC = prm.logC, CQ = 1 << logC;
+    unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cb0_), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
     int have = 1;                     // chunks known so far
     int t_end = 0x7fffffff;           // macro-steps this wave runs: known once a draw comes back empty
     // (masks, not a chain of selects: hipcc turns `k == 0 ? cb0 : k == 1 ? cb1 : ...` into an indexed array in scratch memory)
@@ -341,12 +362,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        if (prm.tri) { int64_t a, b; tri_split(p, prm.B, a, b); return b; }
+        if (prm.tri == 1) { int64_t a, b; tri_split(p, prm.B, a, b); return b; }
+        if (prm.tri == 2 && p >= prm.P_rect) { int64_t a, b; tri_split(p - prm.P_rect, prm.tri_n - 1, a, b); return prm.tri_off + b + 1; }
         return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        if (prm.tri) { int64_t a, b; tri_split(p, prm.B, a, b); return a; }
+        if (prm.tri == 1) { int64_t a, b; tri_split(p, prm.B, a, b); return a; }
+        if (prm.tri == 2 && p >= prm.P_rect) { int64_t a, b; tri_split(p - prm.P_rect, prm.tri_n - 1, a, b); return prm.tri_off + a; }
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
     };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
@@ -449,11 +472,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (EDGES) {
             if (ep_left > 0) {
                 ep_left -= 1;
-                ep_p = (ep_p != NOPAIR && ep_p + 1u < P32) ? ep_p + 1u : NOPAIR;
+                ep_p = (ep_p != NOPAIR && ep_p + 1u < Pe32) ? ep_p + 1u : NOPAIR;
                 ep_cur += EP;
             } else {
                 asm volatile("");
                 ep_p = stream_pair_left(grp, pk, ep_left);
+                if (ep_p >= Pe32) ep_p = NOPAIR;
                 ep_cur = prm.edges + (int64_t)(ep_p != NOPAIR ? ep_p : 0u) * EP;
             }
         }
@@ -727,7 +751,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                if (prm.tri) {      // the pair and its mirror image
+                if (prm.tri == 1) {      // the pair and its mirror image
                     int64_t a, b;
                     tri_split(pair_v, prm.B, a, b);
                     static_cast<TO *>(prm.out)[a * prm.B + b] = (TO)v;
@@ -878,7 +902,40 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
         if (base == 0) waves = prm.n_big;                          // no more waves than the pairs need
         prm.logC = logC;      // (the chunks after the first are all empty here, but the ring must not wrap onto the first)
         prm.q_first = pl.P;
+        // A launch that fills the chip with a dozen pairs per wave and more, but too few for the queue (a 64-row shard of the
+        // headline Gram: 10.7 pairs per wave): shares by wave age rank, sized so that the waves of a SIMD finish together --
+        // (share + the skew's fill) proportional to the measured issue shares of the ranks (SK_FUSED_RANK_W overrides them,
+        // SK_FUSED_MID=0 restores the equal shares)
+        const int nr = waves_per_cu / 4;
+        const WaveGroup wg0 = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
+        const int64_t wpr = (int64_t)device_cu_count() * wg0.wpb;
+        const int64_t T = (pl.P + wpr * pl.G - 1) / (wpr * pl.G);      // pairs per lane group summed over the ranks of one SIMD slot
+        if (knobs().fused_mid != 0 && waves == max_waves && waves_per_cu % 4 == 0 && nr >= 2 && nr <= 4 && wg0.wpb == 4 &&
+            wpr * nr == waves && T >= 4 * nr) {
+            static constexpr double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
+            double w[4];
+            for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
+            rank_override(knobs().fused_rank_w, nr, w);
+            const double fill = (double)(pl.L - 1 + pl.lag), total = (double)T * pl.NUp + nr * fill;
+            int64_t used = 0;
+            bool ok = true;
+            for (int r = 0; r < nr; ++r) {
+                int64_t c = r + 1 < nr ? (int64_t)((w[r] * total - fill) / pl.NUp + 0.5) : T - used;
+                if (c < 1 || used + c > T - (nr - 1 - r)) { ok = false; break; }
+                prm.rk_cnt[r] = (int)c;
+                prm.rk_base[r] = (unsigned)(used * wpr * pl.G);
+                used += c;
+            }
+            if (ok && (uint64_t)T * (uint64_t)wpr * (uint64_t)pl.G < 0x7ff00000ULL) {
+                prm.rk_n = nr;
+                prm.rk_wpr = (int)wpr;
+                int cmax = 0;
+                for (int r = 0; r < nr; ++r) cmax = prm.rk_cnt[r] > cmax ? prm.rk_cnt[r] : cmax;
+                per = cmax;
+            }
+        }
     }
+    if (per > 0x1fffffff / pl.NUp) return SK_ERR_UNSUPPORTED;
     prm.wg = wave_group(pl.lds_bytes, waves, knobs().fused_wpb);
     prm.PPG = (int)per;
     prm.n_steps = 0;
@@ -925,8 +982,12 @@ int launch_fused_dy(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) 
 // SK_ERR_UNSUPPORTED outside the kernel's scope.
 template <typename TO, int KIND>
 int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                     double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0) {
-    if (tri && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
+                     double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0, const int64_t *loss = nullptr) {
+    if (tri == 1 && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
+    // the loss layout: loss = {tri_n, tri_off}; A rows against the B paths of the one batch, then the strict triangle of tri_n of them
+    if (tri == 2 && (!loss || B <= 0 || loss[0] < 0 || loss[1] < 0 || loss[0] + loss[1] > B || A > B ||
+                     g.P != A * B + (loss[0] > 1 ? loss[0] * (loss[0] - 1) / 2 : 0)))
+        return SK_ERR_BAD_ARG;
     const int DY = g.dyadic;
     if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
     // (RBF at dyadic 0 beyond the four-dimension fp64 default-stencil variant: the two-row form, see launch_fused_e)
@@ -979,7 +1040,13 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.inv_sigma = inv_sigma;
     prm.dims = D;
+    prm.rk_n = 0; prm.rk_wpr = 1;
+    for (int r = 0; r < 4; ++r) { prm.rk_cnt[r] = 0; prm.rk_base[r] = 0; }
     prm.tri = tri;
+    prm.P_rect = tri == 2 ? A * B : g.P;
+    prm.tri_n = tri == 2 ? loss[0] : 0;
+    prm.tri_off = tri == 2 ? loss[1] : 0;
+    prm.P_edges = prm.P_rect;
     prm.queue = (unsigned long long *)queue;
     prm.e_NUp = NUp;
     prm.e_L = L;
@@ -1005,23 +1072,23 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
 
 template <typename TO>
 int launch_fwd_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri) {
-    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, queue, s, tri);
+                            TO *out, double *strip_edges, void *queue, hipStream_t s, int tri, const int64_t *loss) {
+    return launch_fwd_fused<TO, 0>(dXr, dYt, A, B, Mrows, Ncp, D, g, 0.0, out, strip_edges, queue, s, tri, loss);
 }
 // Xr [A][Mrows][8]: path points x_p (zero rows / dims beyond M / D); Yt [Bn][8][Ncp]: y_q, dimension-major
 template <typename TO>
 int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
-                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri) {
-    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, queue, s, tri);
+                         double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri, const int64_t *loss) {
+    return launch_fwd_fused<TO, 1>(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, out, strip_edges, queue, s, tri, loss);
 }
 
 template int launch_fwd_fused_linear<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double *,
-                                             double *, void *, hipStream_t, int);
+                                             double *, void *, hipStream_t, int, const int64_t *);
 template int launch_fwd_fused_linear<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, float *,
-                                            double *, void *, hipStream_t, int);
+                                            double *, void *, hipStream_t, int, const int64_t *);
 template int launch_fwd_fused_rbf<double>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, double *,
-                                          double *, void *, hipStream_t, int);
+                                          double *, void *, hipStream_t, int, const int64_t *);
 template int launch_fwd_fused_rbf<float>(const double *, const double *, int64_t, int64_t, int, int, int, const Geom &, double, float *,
-                                         double *, void *, hipStream_t, int);
+                                         double *, void *, hipStream_t, int, const int64_t *);
 
 }  // namespace sk

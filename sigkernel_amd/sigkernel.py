@@ -715,9 +715,9 @@ def _loss_weights(A, B, dtype, device):
     if w is None:
         # (built inside a hipGraph capture -- a capture without a warm-up call -- the fills are nodes of that graph and the memory
         # belongs to its pool: such weights serve the captured call only and are not cached)
+        # NEVER evicted: a captured hipGraph holds the cached tensors by address (an eviction would let the allocator hand their
+        # blocks out again under an already captured training step); A (A + B) elements per distinct batch shape
         capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if len(_LOSS_WEIGHTS) >= 64:
-            _LOSS_WEIGHTS.clear()
         wf = torch.empty(A, A + B, dtype=dtype, device=device)
         wf[:, :A] = (1.0 - torch.eye(A, dtype=dtype, device=device)) / (A * (A - 1.0))
         wf[:, A:] = -2.0 / (A * float(B))
@@ -726,6 +726,8 @@ def _loss_weights(A, B, dtype, device):
         wy = (1.0 - torch.eye(B, dtype=dtype, device=device)) / (B * (B - 1.0)) if B > 1 else None
         w = (wf, wb, wy)
         if not capturing:
+            if device.type == "cuda":
+                torch.cuda.current_stream(device).synchronize()    # once per shape: later calls may read them from any stream
             _LOSS_WEIGHTS[key] = w
     return w
 
@@ -748,11 +750,22 @@ class _SigKernelLoss(torch.autograd.Function):
         be = _lib.get_backend()
         A, B = X.shape[0], Y.shape[0]
         Xd, Yd = X.detach().contiguous(), Y.detach().contiguous()
+        ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver, ctx.workspace_bytes = static_kernel, dyadic_order, _naive_solver, workspace_bytes
+        ctx.kept_edges = ctx.K = ctx.launch = None
+        need = ctx.needs_input_grad[0]
+        fast = _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, need)
+        if fast is not None:
+            # the one-launch glue (csrc/sk_loss.hip): staging of [X; Y] (no concatenated copy), K(X, [X; Y]) and the strict triangle of
+            # K(Y, Y) in ONE forward launch, the scalar in one reduction -- three launches where the route below issues a dozen
+            res = be.loss_forward(fast[0], fast[1], Xd, Yd, dyadic_order, _naive_solver, with_yy, keep_edges=need)
+            if res is not None:
+                val, out, edges, staged = res
+                if need:
+                    ctx.save_for_backward(X)
+                    ctx.launch = (fast, out, edges, staged, A, B, Xd.shape[1])
+                return val
         Z = torch.cat((Xd, Yd))
         wf, wb, wy = _loss_weights(A, B, X.dtype, X.device)
-        ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver, ctx.workspace_bytes = static_kernel, dyadic_order, _naive_solver, workspace_bytes
-        ctx.kept_edges = ctx.K = None
-        need = ctx.needs_input_grad[0]
         if not need and with_yy:
             K_ZZ = _gram_symmetric(be, static_kernel, Z, dyadic_order, _naive_solver, workspace_bytes)
             return (K_ZZ[:A] * wf).sum() + (K_ZZ[A:, A:] * wy).sum()
@@ -773,14 +786,43 @@ class _SigKernelLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        X, Z = ctx.saved_tensors
         be = _lib.get_backend()
+        if ctx.launch is not None:
+            # weights (one launch, the upstream scalar stays on the device) -> ONE fused adjoint over the rectangle's pairs, from the
+            # arrays the forward staged and the edges it kept -> the fold of its partial sums into dL/dX (one launch)
+            (X,) = ctx.saved_tensors
+            (kind, param), out, edges, (Zr, Zt, Zr_adj), A, B, M = ctx.launch
+            Xd = X.detach().contiguous()
+            go = be.loss_weights(A, B, grad_output, Xd.device)
+            adj = be.linear_adjoint_fused if kind == 0 else be.rbf_adjoint_fused
+            res = adj(Xd, None, param, ctx.dyadic_order, edges, go, gram=True, kfinal=out[:A * (A + B)], naive=ctx._naive_solver,
+                      staged=(Zr_adj, Zt, A + B, M))
+            if res is None:      # (sk_route_query named the one-band adjoint for this shape: its launcher must not decline)
+                raise RuntimeError("sigkernel_amd: the fused adjoint declined a shape sk_route_query routed to it")
+            return res[0], None, None, None, None, None, None
+        X, Z = ctx.saved_tensors
         go = (ctx.wb * grad_output.to(X.dtype)).contiguous()
         kept, ctx.kept_edges = ctx.kept_edges, None
         grad_X = _rows_gradient(be, ctx.static_kernel, X.detach().contiguous(), Z, go, ctx.dyadic_order, ctx._naive_solver, True, kept,
                                 ctx.workspace_bytes, ctx.K)
         ctx.K = None
         return grad_X, None, None, None, None, None, None
+
+
+def _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic, naive, need_grad):
+    """(kind, param) when a loss wrapper's call can take the one-launch glue of csrc/sk_loss.hip: exactly LinearKernel / RBFKernel,
+    fp64 paths of one length, the ONE-BAND fused kernels for the forward and -- with a gradient pending -- for the adjoint too
+    (sk_route_query on the rectangle's shape); None otherwise (the merged route's torch glue serves everything else)."""
+    if routes.no_loss_launch or not hasattr(be, "loss_forward") or Xd.dtype != torch.float64 or Xd.shape[1:] != Yd.shape[1:]:
+        return None
+    fused = _fused_static(static_kernel, True)
+    if fused is None:
+        return None
+    if _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, True) != FUSED:
+        return None
+    if need_grad and _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic, naive, True) != FUSED:
+        return None
+    return fused
 
 
 class _NoGradCtx:

@@ -412,6 +412,56 @@ def test_merged_loss_route_on_the_gpu(kind, D, d, dt, A, B, M, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,A,B,M,naive", [("rbf", 3, 1, 32, 32, 64, False), ("rbf", 3, 1, 64, 64, 64, False), ("linear", 8, 1, 24, 40, 50, False),
+                                                  ("rbf", 4, 2, 40, 17, 30, False), ("rbf", 2, 0, 9, 2, 20, False), ("linear", 5, 0, 2, 3, 120, True),
+                                                  ("rbf", 8, 1, 7, 5, 33, True), ("linear", 3, 2, 130, 3, 12, False), ("rbf", 1, 2, 3, 130, 9, False)])
+def test_loss_launch_route_on_the_gpu(kind, D, d, A, B, M, naive, monkeypatch):
+    """The one-launch glue of the loss wrappers (csrc/sk_loss.hip: sk_prep_cat, sk_solve_fwd_loss_f64 -- the rectangle K(X, [X; Y]) and
+    the strict triangle of K(Y, Y) as ONE launch --, sk_loss_value, sk_loss_weights, sk_*_adjoint_finish) against the same merged
+    route through torch ops (routes.no_loss_launch) and against the oracle's closed forms (O.gram_forward: sigkernel.py:350-401;
+    O.gram_grad_weighted: :404-502 with the 2x rule); a second backward through the same graph gives the same bits."""
+    gen = torch.Generator().manual_seed(91)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.7)
+    sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
+    X, Y = walk(gen, A, M, D).to(DEV), walk(gen, B, M, D).to(DEV)
+    be = _lib.get_backend()
+    for fn, Yv, yy in ((sk.compute_mmd, Y, True), (sk.compute_expected_scoring_rule, Y, False), (sk.compute_scoring_rule, Y[:1], False)):
+        if yy and Yv.shape[0] < 2:
+            continue
+        out = {}
+        for off in (False, True):
+            monkeypatch.setattr(sigkernel_amd.routes, "no_loss_launch", off)
+            Xg = X.clone().requires_grad_(True)
+            v = fn(Xg, Yv)
+            if not off:      # the route under test is the one taken
+                assert skmod._loss_launch_ok(be, k, X, Yv, d, naive, True) is not None
+            (g1,) = torch.autograd.grad(v, Xg, retain_graph=True)
+            (g2,) = torch.autograd.grad(v, Xg)
+            assert torch.equal(g1, g2)
+            with torch.no_grad():
+                v0 = fn(X, Yv)
+            out[off] = (float(v.detach()), g1.cpu().numpy(), float(v0))
+        scale = max(1.0, abs(out[True][0]))
+        assert abs(out[False][0] - out[True][0]) <= 1e-12 * scale
+        assert abs(out[False][2] - out[False][0]) <= 1e-12 * scale
+        assert rel_err(out[False][1], out[True][1]) <= 1e-10
+        Xc, Yc = X.cpu(), Yv.cpu()
+        Zc = torch.cat([Xc, Yc])
+        Kxz = O.gram_forward(Xc, Zc, k, d, naive=naive, nthreads=NT)
+        Bv = Yc.shape[0]
+        wf = np.concatenate([(1.0 - np.eye(A)) / (A * (A - 1.0)), np.full((A, Bv), -2.0 / (A * Bv))], axis=1)
+        want = float((Kxz * wf).sum())
+        if yy:
+            Kyy = O.gram_forward(Yc, Yc, k, d, naive=naive, nthreads=NT)
+            want += float((Kyy.sum() - np.trace(Kyy)) / (Bv * (Bv - 1.0)))
+        wb = wf.copy()
+        wb[:, :A] *= 2.0
+        gw = O.gram_grad_weighted(Xc, Zc, wb, k, d, naive=naive, nthreads=NT)
+        assert abs(out[False][0] - want) <= 1e-11 * max(1.0, abs(want))
+        assert rel_err(out[False][1], gw) <= 1e-9
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,d,M,N", [("linear", 8, 1, 40, 33), ("rbf", 3, 2, 30, 30), ("rbf", 6, 0, 300, 260), ("linear", 20, 1, 25, 25)])
 def test_pair_limit_of_a_launch_tiles_over_rows(kind, D, d, M, N, monkeypatch):
     """More pairs than one fused launch indexes (_MAX_LAUNCH_PAIRS): row tiles, forward with kept edges and backward alike -- the same

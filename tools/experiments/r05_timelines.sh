@@ -10,9 +10,9 @@ run() {  # tag first-kernel args...
   echo "== $tag ==" >> $R
   python $REPO/tools/step_timeline.py $OUT/$tag "$key" >> $R 2>&1
 }
-run mmd32 CatArrayBatchedCopy mmd 32
-run mmd64 CatArrayBatchedCopy mmd 64
-run mmd128 CatArrayBatchedCopy mmd 128
+run mmd32 k_prep_cat mmd 32
+run mmd64 k_prep_cat mmd 64
+run mmd128 k_prep_cat mmd 128
 run c2 k_prep c2
 run shard64 k_prep_pair shard 64
 run shard128 k_prep_pair shard 128
