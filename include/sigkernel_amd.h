@@ -512,24 +512,27 @@ int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd
  *   _SigKernelGram.forward calls of sigkernel.py:190-192.  kind 0: Zr = kappa s^2 differences (sk_linear_prescale), Zt differences;
  *   kind 1: points, param = 1 / sigma.  SK_ERR_UNSUPPORTED outside the one-band kernels' scope.
  * sk_loss_value_f64: value[0] = sum_{a != b} K_XX[a,b] / (A (A-1)) - 2 mean(K_XY) [+ sum_{i != j} K_YY[i,j] / (B (B-1)) when
- *   with_yy] from that output (sigkernel.py:194-197, :160-161, :177-178).
- * sk_loss_weights_f64: go [A (A+B)] = grad_out[0] * d value / dK of the rectangle, the K_XX block doubled as the reference's
- *   backward doubles a Gram whose both arguments require a gradient (sigkernel.py:410-412); grad_out: a DEVICE scalar (nullable = 1).
+ *   with_yy] from that output (sigkernel.py:194-197, :160-161, :177-178); wb (nullable, [A (A+B)]): d value / dK of the rectangle
+ *   with the K_XX block doubled (the reference's backward doubles a Gram whose both arguments require a gradient,
+ *   sigkernel.py:410-412), written by the same launch -- the constant upstream weights of the adjoint.
+ * sk_loss_weights_f64: go [A (A+B)] = grad_out[0] * those weights; grad_out: a DEVICE scalar (nullable = 1).  (The wrappers
+ *   pass the scalar to sk_*_adjoint_finish_f64 instead -- the adjoint is linear in it -- and keep this for callers that need go.)
  * sk_rbf_adjoint_finish_f64 / sk_linear_adjoint_finish_f64: the partial sums of sk_rbf_adjoint_fused_f64 (gpart
  *   [A][chunks][rows][outw]) / sk_linear_adjoint_fused_f64 (tpart [A][chunks][rows][8]) -> dL/dX [A,M,D], chunks added in ascending
- *   order; X: the fp64 points (rbf); scale2 = s^4 / s^2-staging factor of the linear rows (the wrapper's `param ** 2`). */
+ *   order; X: the fp64 points (rbf); scale2 = s^4 / s^2-staging factor of the linear rows (the wrapper's `param ** 2`);
+ *   gscale: a DEVICE scalar (nullable = 1) multiplied into the result. */
 int sk_prep_cat_f64(const double *X, int64_t A, const double *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
                     double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
 int sk_prep_cat_f32(const float *X, int64_t A, const float *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
                     double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
 int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, int64_t A, int64_t B, int64_t tri_n, int Mrows, int Mc,
                           int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream);
-int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, void *stream);
+int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, void *stream);
 int sk_loss_weights_f64(int64_t A, int64_t B, const double *grad_out, double *go, void *stream);
 int sk_rbf_adjoint_finish_f64(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
-                              double *grad, void *stream);
-int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
-                                 void *stream);
+                              const double *gscale, double *grad, void *stream);
+int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
+                                 double *grad, void *stream);
 
 /* ---- launch planning, host only (no device work; exposed so that the partition of the pairs can be tested without a GPU) ----
  * The persistent kernels share P pairs among `waves` waves of G lane groups each; when a launch fills the chip with whole

@@ -113,10 +113,10 @@ SIGNATURES = {
     "sk_prep_cat_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
     "sk_prep_cat_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
     "sk_solve_fwd_loss_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_loss_value_f64": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "sk_loss_value_f64": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "sk_loss_weights_f64": (_int, [_i64, _i64, _vp, _vp, _vp]),
-    "sk_rbf_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _vp, _int, _int, ctypes.c_double, _vp, _vp]),
-    "sk_linear_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, ctypes.c_double, _vp, _vp]),
+    "sk_rbf_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _vp, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_linear_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_deriv_f32": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
 }
 
@@ -419,7 +419,8 @@ class HipBackend:
         batches (sk_prep_cat_*), the rectangle K(X, [X; Y]) and -- with_yy -- the strict triangle of K(Y, Y) in ONE fused forward
         launch (sk_solve_fwd_loss_f64), the scalar K_XX_m - 2 mean(K_XY) [+ K_YY_m] (sk_loss_value_f64).  fp64 paths of one length
         within the one-band fused kernels' scope; None otherwise.  Returns (value 0-dim, out [P] in pair order, edges of the
-        rectangle pairs or None, staged = (rows of the forward, cols, rows of the adjoint))."""
+        rectangle pairs or None, staged = (rows of the forward, cols, rows of the adjoint), wb = d value / dK of the rectangle with the
+        reference's 2x rule on the K_XX block, or None without edges)."""
         _dev(X, "X")
         _dev(Y, "Y")
         A, M, D = X.shape
@@ -467,8 +468,9 @@ class HipBackend:
                 return None
             _check(rc, "sk_solve_fwd_loss")
             value = torch.empty((), dtype=torch.float64, device=dev)
-            _check(lib.sk_loss_value_f64(_ptr(out), A, B, int(bool(with_yy)), _ptr(value), _stream(X)), "sk_loss_value")
-        return value, out, edges, (Zr, Zt, Zr2 if two_rows else Zr)
+            wb = torch.empty(P_rect, dtype=torch.float64, device=dev) if keep_edges else None   # d value / dK: the adjoint's weights
+            _check(lib.sk_loss_value_f64(_ptr(out), A, B, int(bool(with_yy)), _ptr(value), _ptr(wb), _stream(X)), "sk_loss_value")
+        return value, out, edges, (Zr, Zt, Zr2 if two_rows else Zr), wb
 
     @staticmethod
     def loss_weights(A, B, grad_output, dev):
@@ -497,11 +499,11 @@ class HipBackend:
         with _device(X.device):
             if kind == 0:
                 kappa = float(lib.sk_linear_prescale(int(dyadic)))
-                Xr, Xt = _prep_paths(X, True, False, kappa * float(param) ** 2, Mrows), _prep_paths(X, True, True, 1.0, Ncp)
+                Xr, Xt = _prep_pair(X, X, True, kappa * float(param) ** 2, Mrows, Ncp)
                 rc = getattr(lib, "sk_solve_fwd_linear_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic),
                                                                            scheme, _ptr(out), _ptr(_queue(X.device)), _stream(X))
             else:
-                Xr, Xt = _prep_paths(X, False, False, 1.0, Mrows), _prep_paths(X, False, True, 1.0, Ncp)
+                Xr, Xt = _prep_pair(X, X, False, 1.0, Mrows, Ncp)
                 rc = getattr(lib, "sk_solve_fwd_rbf_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme,
                                                                         1.0 / float(param), _ptr(out), _ptr(_queue(X.device)), _stream(X))
         if rc == 2:
@@ -687,7 +689,7 @@ class HipBackend:
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), _WorstResidual(err)
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False, staged=None):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False, staged=None, gscale=None):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
@@ -714,9 +716,8 @@ class HipBackend:
         ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
         with _device(dev):
             if staged is None:
-                # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them
-                dXr = _prep_paths(X, True, False, float(param) ** 2, Mrows)
-                dYt = _prep_paths(Y, True, True, 1.0, Ncp)
+                # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them (both arrays in one launch)
+                dXr, dYt = _prep_pair(X, Y, True, float(param) ** 2, Mrows, Ncp)
             args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(edges),
                     _ptr(scale))
             rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), None, 0.0, 0.0, None, 0,
@@ -741,7 +742,7 @@ class HipBackend:
             # the chunks of an a added in ascending order, the flipped rows back to p, d inc[p,q] / d x[p+1] = +s^2 dy[q],
             # / d x[p] = -s^2 dy[q]: one launch (sk_linear_adjoint_finish_f64)
             g = torch.empty(A, M, D, dtype=torch.float64, device=dev)
-            _check(lib.sk_linear_adjoint_finish_f64(_ptr(tpart), A, chunks, rows.value, M, D, float(param) ** 2, _ptr(g), _stream(X)),
+            _check(lib.sk_linear_adjoint_finish_f64(_ptr(tpart), A, chunks, rows.value, M, D, float(param) ** 2, _ptr(gscale), _ptr(g), _stream(X)),
                    "sk_linear_adjoint_finish")
         res = _WorstResidual(err)
         self.last_fused_err = err
@@ -749,7 +750,7 @@ class HipBackend:
             g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False, staged=None):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False, staged=None, gscale=None):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
@@ -779,8 +780,7 @@ class HipBackend:
         ppg, rows, outw, ycols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         with _device(dev):
             if staged is None:
-                Xr = _prep_paths(X, False, False, 1.0, Mrows)
-                Yt = _prep_paths(Y, False, True, 1.0, Ncp)
+                Xr, Yt = _prep_pair(X, Y, False, 1.0, Mrows, Ncp)
             args = (_ptr(Xr), _ptr(Yt), A, Bk, Mrows, Mc, Nc, Ncp, D, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, float(sigma),
                     _ptr(edges), _ptr(scale))
             head = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(outw), ctypes.byref(ycols) if yside else None)
@@ -806,7 +806,7 @@ class HipBackend:
             # chunks of an a added in ascending order, then sum_c V G (-2/sigma) (x_r - y_c): one launch (sk_rbf_adjoint_finish_f64)
             X64 = X if X.dtype == torch.float64 else X.double()
             g = torch.empty(A, M, D, dtype=torch.float64, device=dev)
-            _check(lib.sk_rbf_adjoint_finish_f64(_ptr(gpart), A, chunks, rows.value, outw.value, _ptr(X64), M, D, float(sigma), _ptr(g),
+            _check(lib.sk_rbf_adjoint_finish_f64(_ptr(gpart), A, chunks, rows.value, outw.value, _ptr(X64), M, D, float(sigma), _ptr(gscale), _ptr(g),
                                                  _stream(X)), "sk_rbf_adjoint_finish")
         res = _WorstResidual(err)
         self.last_fused_err = err

@@ -689,25 +689,25 @@ int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double
     return launch_fwd_fused_rbf<double>(Zr, Zt, A, Bz, Mrows, Ncp, D, g, param, out, edges, queue, (hipStream_t)stream, 2, loss);
 }
 
-int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, void *stream) {
+int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, void *stream) {
     if (!out || !value || A < 1 || B < 1) return SK_ERR_BAD_ARG;
-    return launch_loss_value(out, A, B, with_yy, value, (hipStream_t)stream);
+    return launch_loss_value(out, A, B, with_yy, value, wb, (hipStream_t)stream);
 }
 int sk_loss_weights_f64(int64_t A, int64_t B, const double *grad_out, double *go, void *stream) {
     if (!go || A < 1 || B < 1) return SK_ERR_BAD_ARG;
     return launch_loss_weights(A, B, grad_out, go, (hipStream_t)stream);
 }
 int sk_rbf_adjoint_finish_f64(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
-                              double *grad, void *stream) {
+                              const double *gscale, double *grad, void *stream) {
     if (!gpart || !X || !grad || A < 0 || chunks < 1 || M < 1 || D < 1 || rows < M || outw < 2 + D || !(sigma > 0.0)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
-    return launch_rbf_adjoint_finish(gpart, A, chunks, rows, outw, X, M, D, sigma, grad, (hipStream_t)stream);
+    return launch_rbf_adjoint_finish(gpart, A, chunks, rows, outw, X, M, D, sigma, gscale, grad, (hipStream_t)stream);
 }
-int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
-                                 void *stream) {
+int sk_linear_adjoint_finish_f64(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
+                                 double *grad, void *stream) {
     if (!tpart || !grad || A < 0 || chunks < 1 || M < 2 || D < 1 || D > 8 || rows < M - 1) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
-    return launch_linear_adjoint_finish(tpart, A, chunks, rows, M, D, scale2, grad, (hipStream_t)stream);
+    return launch_linear_adjoint_finish(tpart, A, chunks, rows, M, D, scale2, gscale, grad, (hipStream_t)stream);
 }
 
 }  // extern "C"

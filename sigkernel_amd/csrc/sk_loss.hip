@@ -56,22 +56,47 @@ __global__ __launch_bounds__(256) void k_prep_cat(const T *__restrict__ X, int64
 }
 
 constexpr int LV_THREADS = 1024;
+constexpr int LV_BATCH = 8;
 
-// one workgroup: thread t adds entries t, t + 1024, ... of each part in ascending order, then a fixed tree over the threads
-__global__ __launch_bounds__(LV_THREADS) void k_loss_value(const double *__restrict__ out, int64_t A, int64_t B, int with_yy,
-                                                           double *__restrict__ value) {
+// one workgroup: thread t adds entries t, t + 1024, ... of each part in ascending order (loads in batches of eight: a launch this
+// small is bound by the latency of its dependent load -> add chain), then a fixed tree over the threads.  wb (nullable, [A (A+B)]):
+// d value / dK of the rectangle with the K_XX block doubled -- the upstream gradient of the adjoint, written on the way.
+__global__ __launch_bounds__(LV_THREADS) void k_loss_value(const double *__restrict__ out, int A, int B, int with_yy,
+                                                           double *__restrict__ value, double *__restrict__ wb) {
     __shared__ double red[LV_THREADS];
-    const int64_t Bz = A + B, P_rect = A * Bz, P_tri = with_yy && B > 1 ? B * (B - 1) / 2 : 0;
+    const unsigned Bz = (unsigned)(A + B), P_rect = (unsigned)A * Bz, P_tri = with_yy && B > 1 ? (unsigned)B * (unsigned)(B - 1) / 2 : 0;
     const double wxx = A > 1 ? 1.0 / ((double)A * (double)(A - 1)) : 0.0, wxy = -2.0 / ((double)A * (double)B);
     const double wyy = B > 1 ? 2.0 / ((double)B * (double)(B - 1)) : 0.0;
     double sxx = 0.0, sxy = 0.0, syy = 0.0;
-    for (int64_t p = threadIdx.x; p < P_rect; p += LV_THREADS) {
-        const int64_t a = p / Bz, b = p - a * Bz;
-        const double k = out[p];
-        if (b >= A) sxy += k;
-        else if (b != a) sxx += k;
+    for (unsigned p0 = threadIdx.x; p0 < P_rect; p0 += LV_THREADS * LV_BATCH) {
+        double k[LV_BATCH];
+#pragma unroll
+        for (int i = 0; i < LV_BATCH; ++i) {
+            const unsigned p = p0 + (unsigned)i * LV_THREADS;
+            k[i] = p < P_rect ? out[p] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < LV_BATCH; ++i) {
+            const unsigned p = p0 + (unsigned)i * LV_THREADS;
+            if (p < P_rect) {
+                const unsigned a = p / Bz, b = p - a * Bz;
+                const bool xy = b >= (unsigned)A, diag = b == a;
+                if (xy) sxy += k[i];
+                else if (!diag) sxx += k[i];
+                if (wb) wb[p] = xy ? wxy : (diag ? 0.0 : 2.0 * wxx);
+            }
+        }
     }
-    for (int64_t q = threadIdx.x; q < P_tri; q += LV_THREADS) syy += out[P_rect + q];
+    for (unsigned q0 = threadIdx.x; q0 < P_tri; q0 += LV_THREADS * LV_BATCH) {
+        double k[LV_BATCH];
+#pragma unroll
+        for (int i = 0; i < LV_BATCH; ++i) {
+            const unsigned q = q0 + (unsigned)i * LV_THREADS;
+            k[i] = q < P_tri ? out[P_rect + q] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < LV_BATCH; ++i) syy += k[i];
+    }
     red[threadIdx.x] = sxx * wxx + sxy * wxy + syy * wyy;
     __syncthreads();
     for (int s = LV_THREADS / 2; s > 0; s >>= 1) {
@@ -91,42 +116,63 @@ __global__ __launch_bounds__(256) void k_loss_weights(int64_t A, int64_t B, cons
     }
 }
 
+constexpr int FIN_BATCH = 8;
+
 // gpart [A][chunks][rows][outw]: node row r < M of x_a: cs = sum_c [a][c][r][0], accd[j] = sum_c [a][c][r][2 + j];
-// dL/dx_a[r][j] = (-2 / sigma) (x_a[r][j] cs - accd[j])
+// dL/dx_a[r][j] = gscale (-2 / sigma) (x_a[r][j] cs - accd[j]); gscale: a device scalar (nullable = 1) -- the adjoint is linear in the
+// upstream gradient, so a scalar factor of it can be applied here instead of to every pair's weight
 __global__ __launch_bounds__(256) void k_rbf_adjoint_finish(const double *__restrict__ gpart, int64_t A, int64_t chunks, int rows, int outw,
-                                                            const double *__restrict__ X, int M, int D, double c, double *__restrict__ grad) {
+                                                            const double *__restrict__ X, int M, int D, double c,
+                                                            const double *__restrict__ gscale, double *__restrict__ grad) {
     const int64_t n = A * (int64_t)M * D;
+    const double gs = gscale ? *gscale : 1.0;
+    const int64_t step = (int64_t)rows * outw;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t a = i / ((int64_t)M * D);
         const int rem = (int)(i - a * (int64_t)M * D);
         const int r = rem / D, j = rem - r * D;
         const double *src = gpart + (a * chunks * rows + r) * (int64_t)outw;
         double cs = 0.0, acc = 0.0;
-        for (int64_t ch = 0; ch < chunks; ++ch) {
-            cs += src[ch * (int64_t)rows * outw];
-            acc += src[ch * (int64_t)rows * outw + 2 + j];
+        for (int64_t ch0 = 0; ch0 < chunks; ch0 += FIN_BATCH) {     // chunks in ascending order, eight loads in flight at a time
+            double u[FIN_BATCH], v[FIN_BATCH];
+#pragma unroll
+            for (int k = 0; k < FIN_BATCH; ++k) {
+                const bool in = ch0 + k < chunks;
+                u[k] = in ? src[(ch0 + k) * step] : 0.0;
+                v[k] = in ? src[(ch0 + k) * step + 2 + j] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < FIN_BATCH; ++k) { cs += u[k]; acc += v[k]; }
         }
-        grad[i] = c * (X[i] * cs - acc);
+        grad[i] = gs * (c * (X[i] * cs - acc));
     }
 }
 
 // tpart [A][chunks][rows][8], coarse rows FLIPPED (row rows - 1 - p holds coarse row p): T[a][p][j] = sum_c [a][c][rows - 1 - p][j];
-// dL/dx_a[r][j] = scale2 (T[a][r - 1][j] - T[a][r][j])  (d inc[p][q] / d x[p + 1] = + s^2 dy[q], / d x[p] = - s^2 dy[q])
+// dL/dx_a[r][j] = gscale scale2 (T[a][r - 1][j] - T[a][r][j])  (d inc[p][q] / d x[p + 1] = + s^2 dy[q], / d x[p] = - s^2 dy[q])
 __global__ __launch_bounds__(256) void k_linear_adjoint_finish(const double *__restrict__ tpart, int64_t A, int64_t chunks, int rows, int M, int D,
-                                                               double scale2, double *__restrict__ grad) {
+                                                               double scale2, const double *__restrict__ gscale, double *__restrict__ grad) {
     const int64_t n = A * (int64_t)M * D;
     const int Mc = M - 1;
+    const double gs = gscale ? *gscale : 1.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t a = i / ((int64_t)M * D);
         const int rem = (int)(i - a * (int64_t)M * D);
         const int r = rem / D, j = rem - r * D;
         const double *src = tpart + a * chunks * rows * (int64_t)8 + j;
         double up = 0.0, dn = 0.0;     // T[r - 1], T[r]
-        for (int64_t ch = 0; ch < chunks; ++ch) {
-            if (r >= 1) up += src[(ch * rows + (rows - r)) * (int64_t)8];
-            if (r < Mc) dn += src[(ch * rows + (rows - 1 - r)) * (int64_t)8];
+        for (int64_t ch0 = 0; ch0 < chunks; ch0 += FIN_BATCH) {
+            double u[FIN_BATCH], v[FIN_BATCH];
+#pragma unroll
+            for (int k = 0; k < FIN_BATCH; ++k) {
+                const bool in = ch0 + k < chunks;
+                u[k] = in && r >= 1 ? src[((ch0 + k) * rows + (rows - r)) * (int64_t)8] : 0.0;
+                v[k] = in && r < Mc ? src[((ch0 + k) * rows + (rows - 1 - r)) * (int64_t)8] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < FIN_BATCH; ++k) { up += u[k]; dn += v[k]; }
         }
-        grad[i] = scale2 * (up - dn);
+        grad[i] = gs * (scale2 * (up - dn));
     }
 }
 
@@ -152,8 +198,9 @@ template int launch_prep_cat<double>(const double *, int64_t, const double *, in
 template int launch_prep_cat<float>(const float *, int64_t, const float *, int64_t, int, int, int, double, double, double *, double *, int, double *,
                                     int, int, hipStream_t);
 
-int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, A, B, with_yy, value);
+int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, hipStream_t s) {
+    if ((A + B) * A + B * B >= 0x7fffffffLL) return SK_ERR_UNSUPPORTED;     // (32-bit indices; the loss wrappers' merged route ends far below)
+    hipLaunchKernelGGL(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, (int)A, (int)B, with_yy, value, wb);
     return check_launch();
 }
 
@@ -163,15 +210,15 @@ int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go
 }
 
 int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
-                              double *grad, hipStream_t s) {
+                              const double *gscale, double *grad, hipStream_t s) {
     hipLaunchKernelGGL(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
-                       -2.0 / sigma, grad);
+                       -2.0 / sigma, gscale, grad);
     return check_launch();
 }
 
-int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, double *grad,
-                                 hipStream_t s) {
-    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, grad);
+int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
+                                 double *grad, hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
     return check_launch();
 }
 

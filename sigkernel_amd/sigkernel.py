@@ -759,10 +759,10 @@ class _SigKernelLoss(torch.autograd.Function):
             # K(Y, Y) in ONE forward launch, the scalar in one reduction -- three launches where the route below issues a dozen
             res = be.loss_forward(fast[0], fast[1], Xd, Yd, dyadic_order, _naive_solver, with_yy, keep_edges=need)
             if res is not None:
-                val, out, edges, staged = res
+                val, out, edges, staged, wb = res
                 if need:
                     ctx.save_for_backward(X)
-                    ctx.launch = (fast, out, edges, staged, A, B, Xd.shape[1])
+                    ctx.launch = (fast, out, edges, staged, wb, A, B, Xd.shape[1])
                 return val
         Z = torch.cat((Xd, Yd))
         wf, wb, wy = _loss_weights(A, B, X.dtype, X.device)
@@ -788,15 +788,16 @@ class _SigKernelLoss(torch.autograd.Function):
     def backward(ctx, grad_output):
         be = _lib.get_backend()
         if ctx.launch is not None:
-            # weights (one launch, the upstream scalar stays on the device) -> ONE fused adjoint over the rectangle's pairs, from the
-            # arrays the forward staged and the edges it kept -> the fold of its partial sums into dL/dX (one launch)
+            # ONE fused adjoint over the rectangle's pairs, weighted by the constant d value / dK the forward's reduction left, from the
+            # arrays the forward staged and the edges it kept; the upstream scalar stays on the device and multiplies the fold of the
+            # partial sums into dL/dX (the adjoint is linear in it): screen + sweep + rescue + fold, four launches
             (X,) = ctx.saved_tensors
-            (kind, param), out, edges, (Zr, Zt, Zr_adj), A, B, M = ctx.launch
+            (kind, param), out, edges, (Zr, Zt, Zr_adj), wb, A, B, M = ctx.launch
             Xd = X.detach().contiguous()
-            go = be.loss_weights(A, B, grad_output, Xd.device)
+            gs = grad_output.detach().to(torch.float64).contiguous()
             adj = be.linear_adjoint_fused if kind == 0 else be.rbf_adjoint_fused
-            res = adj(Xd, None, param, ctx.dyadic_order, edges, go, gram=True, kfinal=out[:A * (A + B)], naive=ctx._naive_solver,
-                      staged=(Zr_adj, Zt, A + B, M))
+            res = adj(Xd, None, param, ctx.dyadic_order, edges, wb, gram=True, kfinal=out[:A * (A + B)], naive=ctx._naive_solver,
+                      staged=(Zr_adj, Zt, A + B, M), gscale=gs)
             if res is None:      # (sk_route_query named the one-band adjoint for this shape: its launcher must not decline)
                 raise RuntimeError("sigkernel_amd: the fused adjoint declined a shape sk_route_query routed to it")
             return res[0], None, None, None, None, None, None
