@@ -15,10 +15,10 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .sigkernel import (_SigKernelGram, _budget, _fused_static, _gram_block, _sym_fused_gradient, _sym_triangle_ok,
+from .sigkernel import (_SigKernel, _SigKernelGram, _budget, _fused_static, _gram_block, _sym_fused_gradient, _sym_triangle_ok,
                         _sym_unfused_gradient, k_kgrad)
 
-__all__ = ["row_range", "sharded_gram", "ShardedGram", "ShardedSymGram", "sharded_kgrad"]
+__all__ = ["row_range", "sharded_gram", "sharded_kernel", "ShardedGram", "ShardedPaired", "ShardedSymGram", "sharded_kgrad"]
 
 
 def row_range(n_rows, rank, world):
@@ -115,6 +115,56 @@ class ShardedGram(torch.autograd.Function):
         if ctx.needs_input_grad[1]:      # the reference's 2x rule (sigkernel.py:410-412)
             grad_X = 2 * grad_X
         return grad_X, None, None, None, None, None, None, None
+
+
+class ShardedPaired(torch.autograd.Function):
+    """compute_kernel (the paired batch k(x_i, y_i), sigkernel.py:23-40 / _SigKernel :201-343) with the P = A pairs sharded over a
+    process group exactly like Gram rows: rank r solves pairs [r ceil(A/R), ...) with no data-path collective, ONE all-gather of the
+    (A/R,) values gives every rank the full vector; in backward the gradient rows are rank-local (row i needs only grad_output[i])
+    and a second all-gather of the (A/R, M, D) rows returns the full grad_X.  No gradient for Y, as in the reference (:343)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, static_kernel, dyadic_order, _naive_solver, workspace_bytes, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        A = X.shape[0]
+        lo, hi, chunk = row_range(A, rank, world)
+        ctx.args = (group, A)
+        ctx.local = None
+        ctx.meta = (tuple(X.shape[1:]), X.dtype, X.device)
+        if hi > lo:
+            Xl = X.detach()[lo:hi].contiguous().requires_grad_(X.requires_grad)
+            with torch.enable_grad():      # the local graph is kept: its forward keeps the edges, backward is one adjoint launch
+                Kl = _SigKernel.apply(Xl, Y.detach()[lo:hi].contiguous(), static_kernel, dyadic_order, _naive_solver, workspace_bytes)
+            if X.requires_grad:
+                ctx.local = (Xl, Kl)
+            Kloc = Kl.detach()
+        else:
+            Kloc = torch.empty((0,), dtype=X.dtype, device=X.device)
+        return _all_gather_rows(Kloc, A, chunk, group)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        group, A = ctx.args
+        tail, dtype, device = ctx.meta
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        lo, hi, chunk = row_range(A, rank, world)
+        if hi > lo and ctx.local is not None:
+            Xl, Kl = ctx.local
+            (gl,) = torch.autograd.grad(Kl, Xl, grad_output[lo:hi].to(dtype), retain_graph=True)
+        else:
+            if hi > lo and ctx.needs_input_grad[0]:
+                raise RuntimeError("ShardedPaired.backward: the local graph of this rank's pairs is gone")
+            gl = torch.zeros((hi - lo,) + tail, dtype=dtype, device=device)
+        return _all_gather_rows(gl, A, chunk, group), None, None, None, None, None, None
+
+
+def sharded_kernel(sigkernel, X, Y, group=None):
+    """Full (A,) vector k(x_i, y_i) on every rank; each rank solves only its pairs."""
+    if not dist.is_initialized():
+        raise RuntimeError("sharded_kernel needs torch.distributed to be initialised (one process per GPU)")
+    from .sigkernel import _check_inputs
+    _check_inputs(X, Y, paired=True)
+    return ShardedPaired.apply(X, Y, sigkernel.static_kernel, sigkernel.dyadic_order, sigkernel._naive_solver, sigkernel.workspace_bytes, group)
 
 
 def _folded_blocks(A, rank, world):

@@ -860,7 +860,11 @@ class SigKernel:
     def compute_kernel(self, X, Y, max_batch=100):
         """X (batch, len_x, dim), Y (batch, len_y, dim) -> (batch,) vector k(X^i_T, Y^i_T).
 
-        ``max_batch`` is kept for signature compatibility (sigkernel.py:23); tiling is by HBM budget."""
+        ``max_batch`` is kept for signature compatibility (sigkernel.py:23); tiling is by HBM budget.  Under a process group the
+        pairs are sharded over the ranks like Gram rows (sigkernel_amd.distributed.ShardedPaired)."""
+        if self.process_group is not None:
+            from .distributed import sharded_kernel
+            return sharded_kernel(self, X, Y, self.process_group)
         if not _wants_grad(X, Y):
             return _SigKernel.forward(_NoGradCtx(), X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)
         return _SigKernel.apply(X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes)

@@ -81,6 +81,56 @@ def test_row_range_partitions_all_rows():
             assert rows == list(range(n))
 
 
+def _paired_worker(rank, world, port, name, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sigkernel_amd
+        from sigkernel_amd import _lib
+        from fake_backend import OracleBackend
+        _lib.set_backend(OracleBackend())
+        c = golden(name)
+        n = c["paired"].shape[0]
+        X, Y, wp = torch.from_numpy(c["X"][:n]), torch.from_numpy(c["Y"][:n]), torch.from_numpy(c["wp"])
+        sk = sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"]), _naive_solver=bool(c["naive"]), process_group=dist.group.WORLD)
+        Xg = X.clone().requires_grad_(True)
+        Kp = sk.compute_kernel(Xg, Y)
+        (g1,) = torch.autograd.grad((Kp * wp).sum(), Xg, retain_graph=True)
+        (g2,) = torch.autograd.grad((Kp * wp).sum(), Xg)
+        res = {"paired": Kp.detach().numpy(), "grad_paired": g1.numpy(), "grad_again": g2.numpy()}
+        if X.shape == Y.shape:
+            Xd = X.clone().requires_grad_(True)
+            dd = sk.compute_distance(Xd, Y)
+            dd.backward()
+            one = sigkernel_amd.SigKernel(make_kernel(c), int(c["dyadic"]), _naive_solver=bool(c["naive"]))
+            Xe = X.clone().requires_grad_(True)
+            de = one.compute_distance(Xe, Y)
+            de.backward()
+            res.update(dist=dd.detach().numpy(), dist_one=de.detach().numpy(), gdist=Xd.grad.numpy(), gdist_one=Xe.grad.numpy())
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("gram_c2mini_rbf_d1", 2), ("gram_c2mini_rbf_d1", 3), ("gram_lin_d0_ragged", 2), ("gram_lin_d0_ragged", 4)])
+def test_sharded_paired_batch_matches_reference(tmp_path, name, world):
+    """compute_kernel / compute_distance under a process group: the P = A pairs shard over the ranks like Gram rows (one all-gather of
+    the values, one of the gradient rows; sigkernel.py:23-40) -- every rank ends with the reference's full vector and gradient, also
+    when some ranks own no pair (3 pairs on 4 ranks)."""
+    mp.spawn(_paired_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    c = golden(name)
+    for r in range(world):
+        got = dict(np.load(tmp_path / ("rank%d.npz" % r)))
+        assert rel_err(got["paired"], c["paired"]) <= 1e-13
+        assert rel_err(got["grad_paired"], c["grad_paired"]) <= grad_tol(name, "grad_paired")
+        assert np.array_equal(got["grad_again"], got["grad_paired"])
+        if "dist" in got:
+            assert abs(float(got["dist"]) - float(got["dist_one"])) <= 1e-13 and rel_err(got["gdist"], got["gdist_one"]) <= 1e-12
+
+
 def _nccl_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -184,6 +234,12 @@ def _hip_gloo_worker(rank, world, port, out_dir):
             mmd = sk.compute_mmd(Xg, Y)
             mmd.backward()
             res[name + ".mmd"], res[name + ".grad_mmd"] = mmd.detach().cpu().numpy(), Xg.grad.cpu().numpy()
+            # the paired batch, sharded like Gram rows (ShardedPaired)
+            n = c["paired"].shape[0]
+            Xg = X[:n].clone().requires_grad_(True)
+            Kp = sk.compute_kernel(Xg, Y[:n])
+            (Kp * torch.from_numpy(c["wp"]).cuda()).sum().backward()
+            res[name + ".paired"], res[name + ".grad_paired"] = Kp.detach().cpu().numpy(), Xg.grad.cpu().numpy()
         # LinearKernel with path dim 9..32 and a gradient under a process group -- compute_mmd's K_XX is
         # compute_Gram(X, X, sym=True); the triangle has no second-argument kernel for such paths and must not be chosen
         X12, Y12 = _wide_paths()
@@ -213,6 +269,8 @@ def test_sharded_gram_two_ranks_sharing_one_gpu(tmp_path):
             assert rel_err(got[name + ".grad_w"], c["grad_w"]) <= grad_tol(name, "grad_w")
             assert abs(float(got[name + ".mmd"]) - float(c["mmd"])) <= 1e-11
             assert rel_err(got[name + ".grad_mmd"], c["grad_mmd"]) <= grad_tol(name, "grad_mmd")
+            assert rel_err(got[name + ".paired"], c["paired"]) <= 1e-11
+            assert rel_err(got[name + ".grad_paired"], c["grad_paired"]) <= grad_tol(name, "grad_paired")
         import sigkernel_amd
         from oracle import oracle as O
         X12, Y12 = _wide_paths()
