@@ -381,6 +381,13 @@ int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int 
  *   workspace: sk_solve_fwd_static_workspace_bytes(...) bytes (one band-boundary row per resident wave; 0 = unsupported).
  * SK_ERR_UNSUPPORTED: dyadic > 2, D > 16. */
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
+/* FEW pairs of LONG paths (fewer pairs than half the resident waves, second paths of ~500 points and more, no edges kept): the
+ * BANDS of a pair run on different waves -- band b + 1 trails band b through the pair's boundary row in HBM and a progress
+ * counter, work handed out band-major by one ticket counter (an item only waits for a smaller ticket: no deadlock whatever is
+ * resident) -- instead of one wave sweeping the bands of its pair one after the other; the same arithmetic in the same order, bit
+ * for bit.  The workspace above includes its rows.  Returns the bands per pair when a launch of P pairs takes that mode, else 0
+ * (cython_backend.pyx:64-119 has no length limit; its one thread per pair is what this replaces).  SK_FUSEDMB_SPLIT=0 disables. */
+int sk_solve_fwd_static_split(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
 /* Ncp = 2 NUp: columns per dimension row of Yt (zero-padded), the same for sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64. */
 int sk_solve_fwd_static_cols(int kind, int Nc);

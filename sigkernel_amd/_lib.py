@@ -66,6 +66,7 @@ SIGNATURES = {
     "sk_prep_pair_f32": (_int, [_vp, _i64, _int, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _int, _vp, _int, _int, _vp]),
     "sk_solve_fwd_static_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
     "sk_solve_fwd_static_rows": (_int, [_int, _int, _int]),
+    "sk_solve_fwd_static_split": (_int, [_int, _i64, _int, _int, _int, _int]),
     "sk_solve_fwd_static_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, _vp,
                                        _vp, _vp, _sz, _vp]),
     "sk_solve_fwd_static_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int,

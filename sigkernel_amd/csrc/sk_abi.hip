@@ -160,6 +160,8 @@ Knobs parse_knobs() {
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
     k.fused_mid = getenv("SK_FUSED_MID") ? knob_int("SK_FUSED_MID") : 1;
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");
+    k.fusedmb_split = getenv("SK_FUSEDMB_SPLIT") ? knob_int("SK_FUSEDMB_SPLIT") : 1;
+    k.fusedmb_lead = knob_int("SK_FUSEDMB_LEAD");
     k.rank_w = knob_shares("SK_RANK_W"); k.wave_rank_w = knob_shares("SK_WAVE_RANK_W"); k.adj_rank_w = knob_shares("SK_ADJ_RANK_W");
     k.adjf_rank_w = knob_shares("SK_ADJF_RANK_W"); k.adjr_rank_w = knob_shares("SK_ADJR_RANK_W");
     k.deriv_rank_w = knob_shares("SK_DERIV_RANK_W"); k.fused_rank_w = knob_shares("SK_FUSED_RANK_W");
@@ -366,6 +368,10 @@ int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t 
 size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
     if (P <= 0 || Mc < 1 || Nc < 1) return 0;
     return fused_mb_workspace_bytes(kind, P, Mc, Nc, dyadic, D);
+}
+int sk_solve_fwd_static_split(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
+    if (P <= 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 2 || (kind != 0 && kind != 1)) return 0;
+    return fused_mb_split(kind, P, Mc, Nc, dyadic, D);
 }
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
     if (Mc < 1 || dyadic < 0 || dyadic > 2) return 0;

@@ -19,7 +19,7 @@ struct Knobs {
     int derivf_wpc, derivf_wpb, derivf_noshift;   // sk_wave_deriv_fused.hip
     int deriv_pf, deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static, fused_mid;
-    int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static;
+    int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static, fusedmb_split, fusedmb_lead;
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
 };
 const Knobs &knobs();                      // sk_abi.hip
@@ -169,6 +169,7 @@ template <typename TO>
 int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows, int Ncp, int D,
                         int fd, const Geom &g, double inv_sigma, TO *out, double *edges, void *ws, size_t ws_bytes, hipStream_t s);
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
+int fused_mb_split(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int fused_mb_rows(int kind, int Mc, int dyadic, bool edges = false);
 int fused_mb_cols(int kind, int Nc);
 

@@ -58,7 +58,24 @@ struct FusedMbParams {
     int64_t q_first;
     int C0;
     int naive;          // _naive_solver stencil (cython_backend.pyx:114): the g^2 / 12 terms drop out of both coefficients
+    // SPLIT mode (few pairs of long paths: fewer pairs than resident waves): the BANDS of a pair run on different waves.  A stream
+    // position is then one ITEM = (band, pair), item id = band Pn + pair, handed out in increasing order by the launch's counter
+    // (band-major: every pair's band 0 first); the kernel runs with nb = 1 -- every position is one row unit -- and takes a
+    // position's TRUE band from the item.  Band b's bottom row goes to the item's own row in `rows` ([items][NUp][E], written
+    // through), its progress (chunks of 8 units flushed) to `prog`; the wave that sweeps band b + 1 of the pair trails it through
+    // that counter, a few chunks behind.  An item only ever waits for an item with a SMALLER id, which a running wave holds
+    // (it drew the ticket) or has finished: no deadlock whatever is resident.
+    int split;
+    int64_t Pn;          // pairs of the launch (P keeps the number of ITEMS in split mode)
+    int nb_true;         // bands per pair
+    double *rows;        // [items][row_stride]
+    int64_t row_stride;  // doubles per item row (NUp E)
+    unsigned *prog;      // [items] chunks flushed, zeroed by the launcher
+    int lead;            // chunks a band must be ahead of the band below it before that band's next window is fetched (the counter
+                         // is then polled once per `lead` windows, not once per window); <= MB_LEAD
 };
+
+constexpr int MB_LEAD = 8;   // the largest `lead` (SK_FUSEDMB_LEAD; default 4): what the launcher's length limit is sized for
 
 // 16-byte asynchronous global load past the L1 (sc0 sc1: the line was written by another lane of this wave a few
 // macro-steps ago and must come from L2).  Destination handling as in sk_wave_common.h (load_async / async_wait).
@@ -241,8 +258,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
     const int C0 = prm.C0;
+    const bool split = prm.split != 0;
+    const unsigned Pn32 = (unsigned)prm.Pn;
     const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * C0));
     unsigned cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR, cb0 = NOPAIR;   // drawn pair of position C0 + j in cb[j & 3]
+    int tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;                            // split mode: the TRUE band of that position's item
     int have = 0;                     // drawn positions known so far
     int t_end = 0x7fffffff;
     const int tail = (MB_L - 1) + (KIND == 1 ? 1 : 0);
@@ -251,6 +271,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (i < C0) { const unsigned p = base0 + (unsigned)i; return p < P32 ? p : NOPAIR; }
         const int kk = (i - C0) & 3;
         return (cb0 & -(unsigned)(kk == 0)) | (cb1 & -(unsigned)(kk == 1)) | (cb2 & -(unsigned)(kk == 2)) | (cb3 & -(unsigned)(kk == 3));
+    };
+    auto stream_band = [&](int i) __attribute__((always_inline)) -> int {    // split mode (C0 = 0): 0 for positions without an item
+        if (i < 0) return 0;
+        const int kk = i & 3;
+        return (tb0 & -(int)(kk == 0)) | (tb1 & -(int)(kk == 1)) | (tb2 & -(int)(kk == 2)) | (tb3 & -(int)(kk == 3));
     };
     auto ensure = [&](int f) __attribute__((always_inline)) {
         while (C0 + have <= f) {
@@ -266,6 +291,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             if (b == NOPAIR && t_end == 0x7fffffff) t_end = (C0 + have) * prm.nb * prm.NUp + tail;
             const int kk = have & 3;
             const unsigned m0 = -(unsigned)(kk == 0), m1 = -(unsigned)(kk == 1), m2 = -(unsigned)(kk == 2), m3 = -(unsigned)(kk == 3);
+            if (split) {   // item -> (true band, pair); the ring keeps the pair, the band beside it
+                const int bq = b == NOPAIR ? 0 : (int)(b / Pn32);
+                if (b != NOPAIR) b -= (unsigned)bq * Pn32;
+                tb0 = __builtin_amdgcn_readfirstlane((tb0 & ~(int)m0) | (bq & (int)m0));
+                tb1 = __builtin_amdgcn_readfirstlane((tb1 & ~(int)m1) | (bq & (int)m1));
+                tb2 = __builtin_amdgcn_readfirstlane((tb2 & ~(int)m2) | (bq & (int)m2));
+                tb3 = __builtin_amdgcn_readfirstlane((tb3 & ~(int)m3) | (bq & (int)m3));
+            }
             cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb0 & ~m0) | (b & m0)));
             cb1 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb1 & ~m1) | (b & m1)));
             cb2 = (unsigned)__builtin_amdgcn_readfirstlane((int)((cb2 & ~m2) | (b & m2)));
@@ -275,6 +308,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     };
     const int my_uf = lam == prm.lam_f ? prm.u_f : -1;
     const unsigned my_x = lds0 + X_BASE + (unsigned)((lam & 7) * RC * XROW);
+    int tband = 0;   // split mode: the true band of this lane's path-read cursor (`band` itself stays 0: nb = 1)
 
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
@@ -331,7 +365,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         const int64_t p = spx == NOPAIR ? 0 : (int64_t)spx;
         const int64_t a = split_a(p);
         const int lamj = x_lam0 < L ? x_lam0 : 0;     // nobody starts: fetch something valid
-        const char *src = reinterpret_cast<const char *>(prm.Xr + (a * prm.Mrows + (int64_t)(x_band * L + lamj) * RC + (RBF ? 1 : 0)) * FD);
+        const int xb = split ? stream_band(x_pi) : x_band;     // the band whose rows the window's row unit sweeps
+        const char *src = reinterpret_cast<const char *>(prm.Xr + (a * prm.Mrows + (int64_t)(xb * L + lamj) * RC + (RBF ? 1 : 0)) * FD);
         char *dst = lds + X_BASE + x_slot * XSLAB;
 #pragma unroll
         for (int c = 0; c < NDMA_X; ++c) {
@@ -348,12 +383,16 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             // K[0][.] = 1 is the top boundary of band 0: entries whose K part belongs to a sweep in band 0 come from the ones
             // chunk behind the row, so that the consumer needs no select.  The sweep trails the window's row unit by LAG
             // units: with LAG = 1 entry 0 of a row unit's first window still belongs to the PREVIOUS band's sweep.
-            const bool ones_rest = x_band == 0;
-            const bool ones_first = LAG == 0 || x_lam0 > 0 ? ones_rest : x_band == (nb > 1 ? 1 : 0);
+            // (split mode: the row of the item one band up -- item id - Pn --, polled for by wait_producer; the K part of a row's
+            // entry 0 belongs to the sweep of the PREVIOUS position's last unit, which is padding there (the launcher sees to it): any
+            // finite value serves)
+            const bool ones_rest = xb == 0;
+            const bool ones_first = split || LAG == 0 || x_lam0 > 0 ? ones_rest : x_band == (nb > 1 ? 1 : 0);
             const int piece = lam * 2;                           // doubles from the chunk's start
             const bool first_k = piece < S;                      // K part of entry 0
             const bool ones = first_k ? ones_first : ones_rest;  // (node parts of band-0 windows are never used)
-            const double *sb = (ones ? wsrow + (int64_t)NUp * E : wsrow + (int64_t)x_lam0 * E) + piece;
+            const double *row = split ? prm.rows + ((int64_t)(xb - 1) * prm.Pn + (spx == NOPAIR ? 0 : (int64_t)spx)) * prm.row_stride : wsrow;
+            const double *sb = (ones ? wsrow + (int64_t)NUp * E : row + (int64_t)x_lam0 * E) + piece;
             __builtin_amdgcn_global_load_lds(sb, (lds_void *)(lds + BI_BASE + x_slot * CHUNK), 16, 0, 17);
         }
         x_slot ^= 1;
@@ -370,14 +409,57 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         // lane 63's stream unit at macro-step t is t - 63; its first whole chunk [0, 8) is complete at t = 70
         f_pos = 0;
     }
+    int f_i = 0;                 // split mode: the stream position of the bottom lane's row unit
+    unsigned *pub_ptr = nullptr; // ... the progress counter a flush has yet to publish (after the wait for its stores), and the count
+    unsigned pub_cnt = 0;
     auto flush_chunk = [&]() {
+        double *frow = wsrow;
+        if (split) {
+            const unsigned fp = stream_pair(f_i);
+            if (fp != NOPAIR) {
+                const int64_t item = (int64_t)stream_band(f_i) * prm.Pn + fp;
+                frow = prm.rows + item * prm.row_stride;
+                pub_ptr = prm.prog + item;
+                pub_cnt = (unsigned)(f_pos >> 3) + 1u;
+            }
+        }
         if (lam < CHUNK / 16) {
             d2_t v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + BO_BASE + (unsigned)(lam * 16)) : "memory");
-            store_through(wsrow + (int64_t)f_pos * E + lam * 2, v);
+            store_through(frow + (int64_t)f_pos * E + lam * 2, v);
         }
         f_pos += 8;
-        if (f_pos == NUp) f_pos = 0;
+        if (f_pos == NUp) { f_pos = 0; f_i += 1; }
+    };
+    // split mode, at a window boundary AFTER the wait for everything in flight: the chunk flushed one macro-step ago is in memory
+    auto publish = [&]() {
+        if (pub_ptr) {
+            if (lam == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(pub_ptr), "v"(pub_cnt) : "memory");
+            pub_ptr = nullptr;
+        }
+    };
+    // split mode, before the window (x_pi, x_lam0) is fetched: the band above must have flushed its chunk -- and MB_LEAD more, so that
+    // the counter is read once per `lead` windows.  (The wait below also drains this wave's own DMA queue: call it first.)
+    int seen_pos = -1;
+    unsigned seen = 0;
+    auto wait_producer = [&]() {
+        ensure(x_pi);
+        const unsigned sp = stream_pair(x_pi);
+        const int xb = stream_band(x_pi);
+        if (sp == NOPAIR || xb == 0) return;
+        const unsigned total = (unsigned)(NUp >> 3);
+        const unsigned need = (unsigned)(x_lam0 >> 3) + 1u;
+        if (seen_pos != x_pi) { seen_pos = x_pi; seen = 0; }
+        if (seen >= need) return;
+        const unsigned want = need + (unsigned)prm.lead < total ? need + (unsigned)prm.lead : total;
+        const unsigned *pp = prm.prog + ((int64_t)(xb - 1) * prm.Pn + sp);
+        for (;;) {
+            unsigned v;
+            asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pp) : "memory");
+            seen = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            if (seen >= want) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
     };
 
     double xr[RC][FD], xsn[RC];   // Y32: xsn = -|x_row|^2 / sigma
@@ -408,12 +490,15 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     if (lam < CHUNK / 16) store_through(wsrow + (int64_t)NUp * E + lam * 2, d2_t{1.0, 1.0});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (split) wait_producer();
     issue_y();
     issue_x();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (split) wait_producer();
     issue_y();
     issue_x();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (split) tband = stream_band(ps);   // (lane 0 starts in position 0; the others pick theirs up when their unit wraps)
 
     for (int t = 0; t < t_end; ++t) {
         // -- lane 0: the boundary entry of its unit u (K row for the sweep of uk, node pair at the columns of unit u), from
@@ -509,7 +594,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             // the row above at the columns of unit u = uk + 1: the lane above evaluated them one macro-step ago
             abv[2] = dpp_shr1(own[RC - 1][0], bnd[NP - 1][0]);   // lane 0 keeps the boundary entry's node pair
             abv[3] = dpp_shr1(own[RC - 1][1], bnd[NP - 1][1]);
-            if (is_top && band == 0) {   // node row 0 of the pair: nobody above has it
+            if (is_top && (split ? tband : band) == 0) {   // node row 0 of the pair: nobody above has it
                 double x0[FD];
                 lds_read_xrow<FD>(x0, lds0 + T_BASE + (unsigned)((ps & 1) * XROW));
                 if constexpr (Y32) {
@@ -652,6 +737,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (uk == my_uf) {
             int pv = psk, bv = bandk;
             asm volatile("" : "+v"(pv), "+v"(bv));
+            if (split) bv = stream_band(pv);
             const unsigned pair_v = bv == prm.band_f ? stream_pair(pv) : NOPAIR;
             if (pair_v != NOPAIR) {
                 double v = cand[0][0];
@@ -692,6 +778,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                 u = 0;
                 band += 1;
                 if (band == nb) { band = 0; ps += 1; }
+                if (split) tband = stream_band(ps);
             }
         }
         if (!RBF) { uk = u; bandk = band; psk = ps; }
@@ -701,11 +788,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (((t + 1) & 7) == 7 && t >= L - 1 + 7) flush_chunk();
         if (((t + 1) & 7) == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (split) {
+                publish();
+                wait_producer();
+            }
             issue_y();
             issue_x();
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (split) {
+        publish();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 }
 
 template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false, int RCX = Tile<DY>::RC>
@@ -725,9 +820,22 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     if (P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;            // (pair indices are 32-bit inside the kernel)
     int64_t per = (P + waves - 1) / waves;                       // the equal share, pairs per wave
     if (per > 0x1fffffff / ((int64_t)prm.nb * prm.NUp)) return SK_ERR_UNSUPPORTED;
-    if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double) + 64) return SK_ERR_WORKSPACE;
     const int pct = knobs().fusedmb_q_static > 0 ? (knobs().fusedmb_q_static > 100 ? 100 : knobs().fusedmb_q_static) : 50;
-    if (waves == max_waves && per >= 8 && pct < 100) {
+    if (prm.split) {
+        // every position is a ticket: [per-wave rows (only their chunk of ones is used)][item rows][progress counters][the counter]
+        if constexpr (EDGES) return SK_ERR_UNSUPPORTED;
+        const size_t wave_doubles = (size_t)waves * (size_t)prm.ws_stride, row_doubles = (size_t)P * (size_t)prm.row_stride;
+        const size_t prog_bytes = ((size_t)P * sizeof(unsigned) + 63) / 64 * 64;
+        if (!ws || ws_bytes < (wave_doubles + row_doubles) * sizeof(double) + prog_bytes + 64) return SK_ERR_WORKSPACE;
+        prm.rows = ws + wave_doubles;
+        prm.prog = reinterpret_cast<unsigned *>(ws + wave_doubles + row_doubles);
+        prm.queue = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(prm.prog) + prog_bytes);
+        prm.C0 = 0;
+        prm.q_first = 0;
+        if (hipMemsetAsync(prm.prog, 0, prog_bytes + sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
+    } else if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double) + 64) {
+        return SK_ERR_WORKSPACE;
+    } else if (waves == max_waves && per >= 8 && pct < 100) {
         // the launch fills the chip: `pct` per cent of the equal share is dealt out up front, the rest is drawn pair by pair
         prm.C0 = (int)(per * pct / 100);
         prm.queue = reinterpret_cast<unsigned long long *>(ws + (size_t)waves * (size_t)prm.ws_stride);
@@ -757,7 +865,7 @@ struct MbPlan {
     bool ok;
 };
 
-MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bool edges = false) {
+MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bool edges = false, bool split = false) {
     MbPlan pl{};
     pl.ok = false;
     if (dyadic < 0 || dyadic > 2 || D < 1 || D > 16 || (kind != 0 && kind != 1)) return pl;
@@ -769,6 +877,9 @@ MbPlan mb_plan(int kind, int Mc, int Nc, int dyadic, int D, bool y32 = false, bo
     // band boundary slack, and at most one row unit starting per window (see the header): a shorter second path is swept with
     // padding units behind it -- causality keeps K[MM][NN] what it is, the EDGES variant masks the padding's increments
     if (pl.NUp < MB_L + 16) pl.NUp = MB_L + 16;
+    // split mode: the RBF sweep trails the node evaluation by one unit, and the sweep of a pair's LAST real unit must end inside its
+    // own stream position (the next position is another pair's band): one padding unit behind it
+    if (split && kind == 1 && pl.NUp < (Nc - 1) / 2 + 2) pl.NUp += LINE_UNITS;
     pl.nb = (Mc + (edges && kind == 1 ? 1 : 0) + MB_L * pl.RC - 1) / (MB_L * pl.RC);   // edges: the bands of sk_wave_adj_fused_mb.hip (rbf: node rows)
     const size_t xslab = (size_t)8 * pl.RC * pl.fd * 8;
     const size_t chunk = (size_t)8 * (pl.S + (kind == 1 ? 2 : 0)) * 8;
@@ -824,19 +935,48 @@ int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y3
 
 }  // namespace
 
-// Workspace (bytes) of sk_solve_fwd_static_*: one boundary row per resident wave; 0 outside the kernel's scope.
+// SPLIT mode (see FusedMbParams): worth it when the pairs alone leave at least half of the resident waves idle and a band is long
+// enough for the trailing to be cheap (and for the deadlock argument: a band's first MB_LEAD + 16 chunks never reach into the
+// last eight of the band above); SK_FUSEDMB_SPLIT=0 switches it off.  Bytes of the item rows, or 0.
+constexpr size_t MB_SPLIT_MAX_BYTES = (size_t)2 << 30;
+size_t mb_split_rows_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D, bool y32, bool edges) {
+    if (edges || knobs().fusedmb_split == 0) return 0;
+    const MbPlan pl = mb_plan(kind, Mc, Nc, dyadic, D, y32, false, true);
+    if (!pl.ok || pl.nb < 2 || pl.NUp < 8 * (MB_LEAD + 24)) return 0;
+    const int64_t resident = (int64_t)device_cu_count() * pl.waves_per_cu;
+    if (P * 2 > resident || P * (int64_t)pl.nb >= 0x7ff00000LL) return 0;
+    const size_t bytes = (size_t)P * pl.nb * (size_t)pl.NUp * (pl.S + (kind == 1 ? 2 : 0)) * sizeof(double);
+    return bytes <= MB_SPLIT_MAX_BYTES ? bytes : 0;
+}
+
+// Workspace (bytes) of sk_solve_fwd_static_*: one boundary row per resident wave (+ split mode: one per band of every pair and the
+// progress counters); 0 outside the kernel's scope.
 size_t fused_mb_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
     const MbPlan pl = mb_plan(kind, Mc, Nc, dyadic, D);
     if (!pl.ok || P <= 0) return 0;
     const int64_t max_waves = (int64_t)device_cu_count() * 16;   // an upper bound on the resident waves whatever the variant's register count
     const int64_t waves = P < max_waves ? P : max_waves;
-    return (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the launch's work counter
+    size_t bytes = (size_t)waves * (size_t)pl.ws_stride * sizeof(double) + 64;   // + the launch's work counter
+    const size_t rows = mb_split_rows_bytes(kind, P, Mc, Nc, dyadic, D, false, false);
+    if (rows) {
+        const MbPlan ps = mb_plan(kind, Mc, Nc, dyadic, D, false, false, true);
+        const int64_t items = P * ps.nb, w2 = items < max_waves ? items : max_waves;
+        const size_t split_bytes = (size_t)w2 * (size_t)ps.ws_stride * sizeof(double) + rows + ((size_t)items * sizeof(unsigned) + 63) / 64 * 64 + 64;
+        if (split_bytes > bytes) bytes = split_bytes;
+    }
+    return bytes;
+}
+// bands per pair when a launch of P pairs (fp64 staging, no edges) runs the bands of a pair on several waves; 0: one wave per pair
+int fused_mb_split(int kind, int64_t P, int Mc, int Nc, int dyadic, int D) {
+    if (!mb_split_rows_bytes(kind, P, Mc, Nc, dyadic, D, false, false)) return 0;
+    return mb_plan(kind, Mc, Nc, dyadic, D, false, false, true).nb;
 }
 // columns (Ncp = 2 NUp) the caller must provide per dimension row of Yt: the units of a band incl. the padding of short second paths
 int fused_mb_cols(int kind, int Nc) {
     const int NU = kind == 1 ? (Nc + 2) / 2 : (Nc + 1) / 2;
     int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (NUp < MB_L + 16) NUp = MB_L + 16;
+    if (kind == 1 && NUp < (Nc - 1) / 2 + 2) NUp += LINE_UNITS;   // (the padding unit split mode sweeps behind a pair's last real one)
     return 2 * NUp;
 }
 // rows the caller must provide per path in Xr (node / difference rows incl. the padding the last band reads)
@@ -853,13 +993,32 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f
     // dimension-major fp64 array of fd / 2 rows, which is how the kernel addresses it
     const double *Yt = static_cast<const double *>(Yt_any);
     const bool y32 = yt_f32 != 0;
-    const MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32, edges != nullptr);
+    MbPlan pl = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32, edges != nullptr);
     if (!pl.ok || fd != pl.fd) return SK_ERR_UNSUPPORTED;
     if (Ncp < pl.NUp * 2 || (Ncp & 1) || Mrows < fused_mb_rows(kind, g.Mc, g.dyadic, edges != nullptr)) return SK_ERR_UNSUPPORTED;
     FusedMbParams prm{};
     prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.edges = edges; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb; prm.inv_sigma = inv_sigma; prm.ws_stride = pl.ws_stride;
     prm.naive = g.naive;
+    prm.split = 0; prm.Pn = g.P; prm.nb_true = pl.nb; prm.rows = nullptr; prm.row_stride = 0; prm.prog = nullptr;
+    int64_t P_launch = g.P;
+    const size_t split_rows = mb_split_rows_bytes(kind, g.P, g.Mc, g.Nc, g.dyadic, D, y32, edges != nullptr);
+    if (split_rows) {
+        const MbPlan ps = mb_plan(kind, g.Mc, g.Nc, g.dyadic, D, y32, false, true);
+        const int64_t items = g.P * ps.nb, max_waves = (int64_t)device_cu_count() * 16, w2 = items < max_waves ? items : max_waves;
+        const size_t need = (size_t)w2 * (size_t)ps.ws_stride * sizeof(double) + split_rows + ((size_t)items * sizeof(unsigned) + 63) / 64 * 64 + 64;
+        if (Ncp >= ps.NUp * 2 && ws_bytes >= need) {   // (a caller that sized Yt / the workspace for the one-wave sweep gets that sweep)
+            pl = ps;
+            prm.split = 1;
+            prm.lead = knobs().fusedmb_lead > 0 ? (knobs().fusedmb_lead > MB_LEAD ? MB_LEAD : knobs().fusedmb_lead) : 4;
+            prm.NUp = ps.NUp;
+            prm.nb = 1;                      // every stream position is one row unit: an item (band, pair)
+            prm.ws_stride = ps.ws_stride;
+            prm.row_stride = (int64_t)ps.NUp * (ps.S + (kind == 1 ? 2 : 0));
+            prm.P = items;
+            P_launch = items;
+        }
+    }
     const int row_unit = (g.Mc - 1) / pl.RC;      // lane-row that holds the last coarse row
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = row_unit % MB_L;
@@ -869,15 +1028,15 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f
     double *w = static_cast<double *>(ws);
     if (kind == 0) {
         switch (g.dyadic) {
-            case 0: return launch_mb_dy<TO, 0, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
-            case 1: return launch_mb_dy<TO, 1, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
-            default: return launch_mb_dy<TO, 2, 0>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+            case 0: return launch_mb_dy<TO, 0, 0>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
+            case 1: return launch_mb_dy<TO, 1, 0>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
+            default: return launch_mb_dy<TO, 2, 0>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
         }
     }
     switch (g.dyadic) {
-        case 0: return launch_mb_dy<TO, 0, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
-        case 1: return launch_mb_dy<TO, 1, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
-        default: return launch_mb_dy<TO, 2, 1>(prm, pl, g.naive, y32, g.P, w, ws_bytes, s);
+        case 0: return launch_mb_dy<TO, 0, 1>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
+        case 1: return launch_mb_dy<TO, 1, 1>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
+        default: return launch_mb_dy<TO, 2, 1>(prm, pl, g.naive, y32, P_launch, w, ws_bytes, s);
     }
 }
 

@@ -461,6 +461,44 @@ def test_loss_launch_route_on_the_gpu(kind, D, d, A, B, M, naive, monkeypatch):
         assert rel_err(out[False][1], gw) <= 1e-9
 
 
+def _mb_split_knob(on):
+    os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
+    _lib.load().sk_reload_knobs()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,A,B,M,N,dt", [("rbf", 3, 1, 2, 2, 2048, 2048, torch.float64), ("linear", 8, 1, 3, 2, 700, 1100, torch.float64),
+                                                 ("rbf", 4, 0, 1, 5, 1030, 1024, torch.float64), ("linear", 4, 0, 2, 3, 1500, 515, torch.float64),
+                                                 ("rbf", 2, 2, 1, 1, 300, 600, torch.float64), ("rbf", 16, 2, 2, 3, 200, 512, torch.float32),
+                                                 ("linear", 12, 2, 1, 2, 129, 2000, torch.float64), ("rbf", 9, 1, 4, 1, 400, 544, torch.float64)])
+def test_bands_of_a_pair_on_several_waves(kind, D, d, A, B, M, N, dt):
+    """Few pairs of long paths (csrc/sk_wave_fused_mb.hip, split mode): the bands of a pair on different waves, trailing each other
+    through the pair's boundary rows and a progress counter -- bit-identical to the one-wave-per-pair sweep (SK_FUSEDMB_SPLIT=0),
+    bitwise reproducible, and equal to the oracle (cython_backend.pyx:64-119: no length limit); second paths of 2^k points (N - 1 = 15
+    mod 16: the padding unit behind the last real one) included."""
+    gen = torch.Generator().manual_seed(M + N + D)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.8)
+    sk = sigkernel_amd.SigKernel(k, d)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    X, Y = Xc.to(dt).to(DEV), Yc.to(dt).to(DEV)
+    lib = _lib.load()
+    try:
+        _mb_split_knob(True)
+        assert lib.sk_solve_fwd_static_split(0 if kind == "linear" else 1, A * B, M - 1, N - 1, d, D) >= 2      # the mode under test is the one taken
+        K = sk.compute_Gram(X, Y)
+        K2 = sk.compute_Gram(X, Y)
+        Kp = sk.compute_kernel(X[:1], Y[:1])
+        _mb_split_knob(False)
+        assert lib.sk_solve_fwd_static_split(0 if kind == "linear" else 1, A * B, M - 1, N - 1, d, D) == 0
+        K1 = sk.compute_Gram(X, Y)
+    finally:
+        os.environ.pop("SK_FUSEDMB_SPLIT", None)
+        lib.sk_reload_knobs()
+    assert torch.equal(K, K1) and torch.equal(K, K2) and torch.equal(Kp[0], K[0, 0])
+    want = O.gram_forward(Xc.to(dt), Yc.to(dt), k, d, nthreads=NT)
+    assert rel_err(K.double().cpu().numpy(), want) <= (1e-4 if dt == torch.float32 else 1e-11)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,d,M,N", [("linear", 8, 1, 40, 33), ("rbf", 3, 2, 30, 30), ("rbf", 6, 0, 300, 260), ("linear", 20, 1, 25, 25)])
 def test_pair_limit_of_a_launch_tiles_over_rows(kind, D, d, M, N, monkeypatch):
@@ -915,7 +953,7 @@ def test_every_inline_asm_kernel_family_a_hundred_times():
     build-time hazard lint (csrc/Makefile): what the lint cannot prove, a race would have to survive 100 times."""
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "det_sweep.py"), "--families"], capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "14 combinations x 100 runs, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "17 combinations x 100 runs, 0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -21,7 +21,10 @@ if FAMILIES:
               ("rbf", 0, 12, (60, 170), torch.float64, True), ("linear", 1, 12, (257, 161), torch.float64, False),
               ("linear", 2, 6, (150, 20), torch.float32, False), ("rbf", 1, 12, (130, 129), torch.float64, False),
               ("rbf", 2, 12, (150, 161), torch.float32, False), ("rbf", 1, 7, (64, 64), torch.float64, False),
-              ("linear", 1, 20, (40, 33), torch.float64, False), ("rbf", 2, 20, (33, 40), torch.float32, False)]
+              ("linear", 1, 20, (40, 33), torch.float64, False), ("rbf", 2, 20, (33, 40), torch.float32, False),
+              # few pairs of long paths: the bands of a pair on several waves (sk_wave_fused_mb.hip, split mode: the call without a gradient)
+              ("linear", 1, 6, (300, 520), torch.float64, False), ("rbf", 0, 3, (600, 530), torch.float64, False),
+              ("rbf", 2, 12, (150, 512), torch.float32, False)]
 else:
     RUNS = 4
     combos = itertools.product(("linear", "rbf"), (0, 1, 2), (2, 4, 6, 8, 12), ((20, 33), (64, 64), (33, 170), (130, 129), (257, 161)),
@@ -40,7 +43,7 @@ for kname, d, D, (M, N), dt, naive in combos:
         K = sk.compute_Gram(Xg, Y); (K * w).sum().backward()
         Xs = X.clone().requires_grad_(True)
         m = sk.compute_mmd(Xs, Y); m.backward()
-        out = [K.detach(), Xg.grad, m.detach().reshape(1), Xs.grad]
+        out = [K.detach(), Xg.grad, m.detach().reshape(1), Xs.grad, sk.compute_Gram(X, Y)]
         if not naive and M <= 130: out += list(sk.compute_kernel_and_derivatives_Gram(X, Y, gam))
         return torch.cat([t.double().flatten() for t in out])
     first = once()

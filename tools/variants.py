@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""(CPU) Every kernel instance of the build: VGPRs (arch + accum), SGPRs, scratch bytes, static LDS -- from the gfx950 ISA that
+csrc/Makefile keeps in csrc/obj (-save-temps).  usage: variants.py [--csv] [substring ...]
+With --check <file>: fails when an instance's scratch bytes grew against the committed table (profiles/r05_variants.txt)."""
+import glob, os, re, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, "sigkernel_amd", "csrc", "obj")
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        return [o.replace("void sk::(anonymous namespace)::", "").replace("sk::(anonymous namespace)::", "") for o in out[:len(names)]]
+    except Exception:
+        return names
+
+def table():
+    rows = []
+    for f in sorted(glob.glob(os.path.join(OBJ, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))):
+        unit = os.path.basename(f).split("-hip-")[0]
+        txt = open(f).read()
+        for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", txt, re.S):
+            name, body = m.group(1), m.group(2)
+            def val(key, d=0):
+                mm = re.search(r"\.amdhsa_%s (\d+)" % key, body)
+                return int(mm.group(1)) if mm else d
+            rows.append(dict(unit=unit, name=name, vgpr=val("next_free_vgpr"), accum=val("accum_offset"), sgpr=val("next_free_sgpr"),
+                             scratch=val("private_segment_fixed_size"), lds=val("group_segment_fixed_size")))
+    for r, d in zip(rows, demangle([r["name"] for r in rows])):
+        r["pretty"] = re.sub(r"\(.*", "", d)
+    return rows
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    rows = table()
+    if "--check" in sys.argv:
+        ref = {}
+        for ln in open(args[0]):
+            p = ln.rstrip("\n").split("\t")
+            if len(p) >= 6 and p[0] != "unit":
+                ref[p[-1]] = int(p[4])
+        bad = [(r["name"], ref[r["name"]], r["scratch"]) for r in rows if r["name"] in ref and r["scratch"] > ref[r["name"]]]
+        new_spill = [(r["name"], 0, r["scratch"]) for r in rows if r["name"] not in ref and r["scratch"] > 0]
+        for n, a, b in bad + new_spill:
+            print("scratch grew: %s %d -> %d bytes" % (n, a, b))
+        sys.exit(1 if bad or new_spill else 0)
+    if args:
+        rows = [r for r in rows if all(a in r["pretty"] or a in r["unit"] for a in args)]
+    print("unit\tvgpr\taccum_off\tsgpr\tscratch\tlds\tinstance\tmangled")
+    for r in rows:
+        print("%s\t%d\t%d\t%d\t%d\t%d\t%s\t%s" % (r["unit"], r["vgpr"], r["accum"], r["sgpr"], r["scratch"], r["lds"], r["pretty"], r["name"]))
+    print("# %d kernel instances, %d with scratch" % (len(rows), sum(1 for r in rows if r["scratch"])), file=sys.stderr)
+
+if __name__ == "__main__":
+    main()
