@@ -86,6 +86,13 @@ const char *sk_build_info(void);
  * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never
  * SK_ROUTE_STREAM: every such call CAN run with nothing of size pairs x M x N in HBM. */
 #define SK_ROUTE_NO_STREAM 1
+/* The COST table: every measured crossover the library (sk_route_query, the launchers) and the host layer (symmetric blocks, merged
+ * loss, paired merge) decide by, with the same-box A/B measurement each came from -- entries 0 .. n-1 (sk_cost_name returns NULL past
+ * the end).  Scope rules say what a kernel CAN do; these say when it is the faster choice.  tools/crossovers.py re-measures them on
+ * the box at hand.  The reference has no counterpart (it has one route per device, sigkernel.py:220-246). */
+double sk_cost_query(int which);
+const char *sk_cost_name(int which);
+const char *sk_cost_note(int which);
 #define SK_OP_FORWARD 0
 #define SK_OP_ADJOINT 1
 #define SK_ROUTE_STREAM 0

@@ -37,6 +37,9 @@ SIGNATURES = {
     "sk_version": (_int, []),
     "sk_build_info": (ctypes.c_char_p, []),
     "sk_route_query": (_int, [_int, _int, _int, _int, _int, _int, _int, _int, _int]),
+    "sk_cost_query": (ctypes.c_double, [_int]),
+    "sk_cost_name": (ctypes.c_char_p, [_int]),
+    "sk_cost_note": (ctypes.c_char_p, [_int]),
     "sk_solve_fwd_static_cols": (_int, [_int, _int]),
     "sk_reload_knobs": (None, []),
     "sk_linear_prescale": (ctypes.c_double, [_int]),
@@ -141,6 +144,29 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+_COSTS = None
+
+
+def costs():
+    """{name: (value, note)} -- the library's cost table (sk_cost_query, csrc/sk_route.hip): every measured crossover the launchers and
+    the host layer decide by, with the measurement each came from."""
+    global _COSTS
+    if _COSTS is None:
+        lib, table, i = load(), {}, 0
+        while True:
+            name = lib.sk_cost_name(i)
+            if not name:
+                break
+            table[name.decode()] = (float(lib.sk_cost_query(i)), lib.sk_cost_note(i).decode())
+            i += 1
+        _COSTS = table
+    return _COSTS
+
+
+def cost(name):
+    return costs()[name][0]
 
 
 def _check(status, what):

@@ -380,6 +380,9 @@ int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic) {
 int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme, int elem_size, int flags) {
     return route_query(op, kind, D, M, N, dyadic, scheme == SK_SCHEME_NAIVE, elem_size, flags);
 }
+double sk_cost_query(int which) { return cost_value(which); }
+const char *sk_cost_name(int which) { return cost_name(which); }
+const char *sk_cost_note(int which) { return cost_note(which); }
 int sk_solve_fwd_static_cols(int kind, int Nc) {
     if (Nc < 1 || (kind != 0 && kind != 1)) return 0;
     return fused_mb_cols(kind, Nc);

@@ -23,6 +23,11 @@ struct Knobs {
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;
 };
 const Knobs &knobs();                      // sk_abi.hip
+// sk_route.hip: the cost table (measured crossovers the library and the host layer decide by)
+double cost_value(int which);
+const char *cost_name(int which);
+const char *cost_note(int which);
+double cost_by_name(const char *name);
 int device_cu_count();                     // sk_abi.hip: compute units of the current device (256 on MI355X), cached per device
 
 // The fused adjoints' decomposition (sk_wave_common.h: chunk_split / chunk_share): a lane group sweeps one CHUNK of the B pairs

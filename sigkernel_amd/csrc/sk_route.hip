@@ -28,15 +28,14 @@
 //
 // CHOICE (the default, without SK_ROUTE_NO_STREAM).  The multi-band kernels sweep a pair with all 64 lanes over bands of 64 RC rows
 // and at least 80 units of two columns: on SHORT paths most of that sweep is padding, and the streaming route -- whose transient
-// memory the host layer bounds by tiling over rows anyway -- is several times faster (measured, same box, 256 x 256 pairs,
-// profiles/r04_ab_routes.txt: linear dim 12, 40 x 40 points: 0.88 ms streamed against 3.9 ms multi-band; rbf dim 7, 64 x 64, d = 1
-// with a gradient: 4.0 against 12.2 ms; at 128 x 128 points the multi-band route wins: 12.2 against 14.0 ms).  So FUSED_MB is only
-// answered when the sweep's efficiency  rows / (bands 64 RC) x units / max(80, units)  reaches 0.45 (forward with the rbf kernel:
-// 0.5; rbf with 9..16 dims of fp64 paths, whose 16 staged fp64 dimensions leave one wave per SIMD: never for the forward, 0.9 for
-// the adjoint -- mb_min_eff has the numbers); below that the answer is STREAM.  The crossover sits at efficiency ~0.5 for every
-// other adjoint measured.  A deployment that must not hold increments at all (memory
-// first) passes SK_ROUTE_NO_STREAM (host layer: sigkernel_amd.routes.no_stream / SK_NO_STREAM=1).
+// memory the host layer bounds by tiling over rows anyway -- is faster.  Two numbers of the cost table below decide (measured,
+// same box, 128 x 128 pairs, profiles/r05_thresholds.txt): STREAM while both paths have at most `stream_one_strip_cells` increments
+// (the streaming kernels' one-strip regime: they win there at ANY efficiency, up to 2x), and beyond that while the sweep's efficiency
+//   rows / (bands 64 RC) x units / max(80, units)   stays below `mb_min_eff`; FUSED_MB otherwise (0.5..0.9x the streamed time from
+// ~140 points on, forward and adjoint, both static kernels, 8 or 16 staged dims).  A deployment that must not hold increments at all
+// (memory first) passes SK_ROUTE_NO_STREAM (host layer: sigkernel_amd.routes.no_stream / SK_NO_STREAM=1).
 #include "sk_internal.h"
+#include <cstring>
 
 namespace sk {
 
@@ -60,14 +59,66 @@ inline double mb_efficiency(int kind, int Mc, int Nc, int d, int rc) {
     if (nup < MB_MIN_UNITS) nup = MB_MIN_UNITS;
     return (double)rows / (double)(nb * 64 * rc) * (double)nu / (double)nup;
 }
-// least sweep efficiency at which the multi-band kernels are the default (measured crossovers, profiles/r04_ab_routes.txt)
-inline double mb_min_eff(int op, int kind, int D, int elem_size) {
-    if (kind == 1 && D > 8 && elem_size == 8)   // 16 staged fp64 dims: one wave per SIMD (the fp32 ring of fp32 inputs holds two) --
-        return op == SK_OP_FORWARD ? 1.01 : 0.9;   // forward 7.4 against 5.1 ms streamed at 0.8; with a gradient 35.7 against 27.5 at 0.8
-    if (kind == 1 && op == SK_OP_FORWARD) return 0.5;   // at 0.4: 5.4 against 3.8 ms (dim 7, d = 0, 128 points)
-    return 0.45;
+// ---- the COST table: every measured crossover the library and the host layer decide by, in one place ----------------------------
+// (scope rules say what a kernel CAN do; these say when it is the faster choice.  Each entry carries the same-box A/B measurement it
+// came from; tools/crossovers.py re-measures them on the box at hand and says which sit within noise of flipping.  Box-to-box
+// spread is +-5 %, so an entry whose two sides differ by less is a preference, not a cliff.)
+struct CostEntry { const char *name; double value; const char *note; };
+const CostEntry COSTS[] = {
+    {"mb_min_eff", 0.45,
+     "least sweep efficiency rows / (bands 64 RC) x units / max(80, units) at which the multi-band fused kernels are the default instead of the "
+     "streaming route (forward and adjoint, both static kernels); r05_thresholds, 128 x 128 pairs, same box: linear dim 12 d = 0: 128 points "
+     "(0.40) 1.38 ms multi-band vs 1.18 streamed, 140 points (0.48) 1.37 vs 2.04; rbf dim 7 d = 0, 140 points (0.48) 1.64 vs 2.06; with a "
+     "gradient linear dim 12 d = 1, 140 points (0.48) 7.7 vs 9.0 ms"},
+    {"stream_one_strip_cells", 128,
+     "... but never while BOTH paths have at most this many increments: there the streaming kernels sweep a pair in one strip and win whatever "
+     "the efficiency (r05_thresholds: linear dim 12 d = 1 with a gradient, 128 points (0.79): 4.14 ms multi-band vs 3.52 streamed, 100 points "
+     "(0.48) 4.14 vs 2.75; rbf dim 12 d = 1, 128 points 5.99 vs 5.36; rbf dim 7 d = 1, 110 points 3.59 vs 3.27) -- round 4's per-kernel "
+     "thresholds (0.5 / 0.9 / never) were this cliff seen through the efficiency"},
+    {"mb_min_eff_rbf16_forward", 0.85,
+     "the rbf FORWARD with 9..16 dims of fp64 paths (16 staged fp64 dims leave the multi-band kernel one wave per SIMD) needs fuller bands: "
+     "r05_thresholds2, 64 x 64 pairs, dim 16: d = 2: 140 points (0.64) 1.25 ms multi-band vs 1.13 streamed, 200 (0.75) 1.95 vs 1.82, 300 (0.93) "
+     "3.30 vs 3.46, 512 (1.0) 8.2 vs 11.1; d = 0: 140 (0.48) 0.95 vs 0.79, 300 (0.77) 2.59 vs 2.79; with a gradient the multi-band route wins "
+     "from 140 points on (0.77 .. 0.39x) and takes the common threshold"},
+    {"mb_swap_steps_ratio", 0.8, "forward: solve k(y, x) when that orientation sweeps at most this share of the macro-steps of k(x, y)"},
+    {"sym_tiles", 8, "row blocks of compute_Gram(X, X, sym=True) beyond the one-band triangle launch: (T + 1) / (2 T) of the square is solved; "
+     "16 with a gradient on 64 T rows and more (C4: -1 %)"},
+    {"sym_min_cells", 5e9,
+     "grid cells of K_XX from which the blocked triangle (and, for the loss wrappers, the composition of three Gram calls) beats one launch over "
+     "the square / the merged block K(X, [X; Y]): 128 x 128 pairs of 64 points take 0.4 ms in one launch, 0.8 ms in 8 blocks; merged loss "
+     "15.1 vs 15.5 ms composed at 512 x 512 (4e9 cells, r04_merged_loss), C4 (2.7e11) 349 ms composed"},
+    {"sym_min_rows", 32, "least rows per block of the triangular adjoint: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms"},
+    {"paired_merge_cells", 2e9,
+     "grid cells of a paired batch below which compute_distance solves k(X, X) and k(X, Y) as ONE batch of 2n pairs (launch- and fill-bound there)"},
+    {"mmd_streams_max_pairs", 16384,
+     "pairs per Gram matrix up to which a CAPTURED composed compute_mmd forks its three matrices onto three streams (replays 10-15 % faster at 16..64 paths)"},
+    {"keep_edges_fraction", 0.5, "share of the transient budget the edges kept between forward and backward may take"},
+    {"fused_mid_min_pairs_per_rank", 4,
+     "pairs per lane group and rank from which a no-queue fused forward that fills the chip deals out shares by wave age rank: 64-row shard of the "
+     "headline Gram 0.695 -> 0.640 ms, 128 + 128 path mmd step 1.237 -> 1.171 ms (r05, same box)"},
+    {"mb_split_max_resident_share", 0.5,
+     "few pairs of long paths: bands of a pair on several waves when the pairs fill at most this share of the resident waves (r05: 16 x 16 pairs "
+     "of 4096 points 18.7 -> 4.7 ms; 32 x 32 pairs of 700 points 2.18 -> 1.96 ms)"},
+    {"mb_split_min_units", 256, "... and a band has at least this many two-column units (second paths of ~512 points): the trailing is cheap, and "
+     "a band's first windows never reach into the last chunks of the band above"},
+};
+constexpr int N_COSTS = (int)(sizeof(COSTS) / sizeof(COSTS[0]));
+inline double cost(const char *name) {
+    for (int i = 0; i < N_COSTS; ++i)
+        if (!strcmp(COSTS[i].name, name)) return COSTS[i].value;
+    return 0.0;
+}
+// whether the streaming route is the default over the multi-band kernels at this shape
+inline bool prefer_stream(int Mc, int Nc, double eff, bool rbf16_forward = false) {
+    const int strip = (int)cost("stream_one_strip_cells");
+    return (Mc <= strip && Nc <= strip) || eff < cost(rbf16_forward ? "mb_min_eff_rbf16_forward" : "mb_min_eff");
 }
 }  // namespace
+
+double cost_value(int which) { return which >= 0 && which < N_COSTS ? COSTS[which].value : 0.0; }
+const char *cost_name(int which) { return which >= 0 && which < N_COSTS ? COSTS[which].name : nullptr; }
+const char *cost_note(int which) { return which >= 0 && which < N_COSTS ? COSTS[which].note : nullptr; }
+double cost_by_name(const char *name) { return cost(name); }
 
 int route_query(int op, int kind, int D, int M, int N, int d, int naive, int elem_size, int flags) {
     const bool may_stream = !(flags & SK_ROUTE_NO_STREAM);
@@ -85,9 +136,9 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
             const bool one_band_s = D <= 8 && rows_s <= 64 * (two_rows ? 2 : rc_of(d));
             if (one_band_s) return SK_ROUTE_FUSED_SWAP;
         }
-        const bool swap = 5 * mb_steps(kind, Nc, Mc, d) <= 4 * mb_steps(kind, Mc, Nc, d);
+        const bool swap = (double)mb_steps(kind, Nc, Mc, d) <= cost("mb_swap_steps_ratio") * (double)mb_steps(kind, Mc, Nc, d);
         const double eff = swap ? mb_efficiency(kind, Nc, Mc, d, rc_of(d)) : mb_efficiency(kind, Mc, Nc, d, rc_of(d));
-        if (may_stream && eff < mb_min_eff(op, kind, D, elem_size)) return SK_ROUTE_STREAM;
+        if (may_stream && prefer_stream(Mc, Nc, eff, kind == 1 && D > 8 && elem_size == 8)) return SK_ROUTE_STREAM;
         return swap ? SK_ROUTE_FUSED_MB_SWAP : SK_ROUTE_FUSED_MB;
     }
     if (op == SK_OP_ADJOINT) {
@@ -95,7 +146,7 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d)) return SK_ROUTE_FUSED;
         if (kind == 1 && D <= 8 && d == 0 && !naive && M <= 128) return SK_ROUTE_FUSED;   // two coarse rows per lane
         if (kind == 1 && D <= 8 && d == 1 && M <= 64) return SK_ROUTE_FUSED;               // dim 5..8: one coarse row per lane
-        if (may_stream && mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)) < mb_min_eff(op, kind, D, elem_size)) return SK_ROUTE_STREAM;
+        if (may_stream && prefer_stream(Mc, Nc, mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)))) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }
     return SK_ROUTE_STREAM;

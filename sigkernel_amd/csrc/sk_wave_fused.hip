@@ -49,13 +49,13 @@ struct FusedParams {
     double inv_sigma;    // RBF: G = exp(-|x - y|^2 * inv_sigma)
     int dims;            // path dimensions that can be non-zero (<= 8)
     int e_NUp, e_L;      // EDGES: units per row / lanes per pair of the strip layout the adjoint reads (strip_geom)
-    int tri;             // 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
+    int tri;             // bits 0..1: 1: the P = A (A + 1) / 2 pairs enumerate the upper triangle (a <= b, row-major) of an A x A Gram of ONE
                          // path batch (A = B); out is [A][A] and receives both (a, b) and (b, a)
-                         // 2: the LOSS layout (sk_solve_fwd_loss_f64): both staged arrays hold ONE batch Z; pairs [0, P_rect) are the
-                         // rectangle (p / B, p % B) -- rows Z[0 .. P_rect / B) against all B paths -- and pairs [P_rect, P) the STRICT
-                         // upper triangle (i < j, row-major) of the tri_n paths from Z[tri_off] on; out is [P], in pair order
-    int64_t P_rect, tri_n, tri_off;
-    int64_t P_edges;     // EDGES: only pairs [0, P_edges) keep their edges (the loss layout's rectangle; P otherwise)
+                         // 2: the LOSS layout (sk_solve_fwd_loss_f64): both staged arrays hold ONE batch Z of B paths; pairs [0, A B)
+                         // are the rectangle (p / B, p % B) -- rows Z[0 .. A) against all of Z -- and the pairs behind them the STRICT
+                         // upper triangle (i < j, row-major) of the tri_n paths from Z[A] on; out is [P], in pair order; with EDGES only
+                         // the rectangle's pairs keep theirs.  A = bits 2..16, tri_n = bits 17..31 (both < 32768): ONE scalar register
+                         // for a mode most launches do not use -- the step loop of this kernel lives at the limit of the scalar file
     WaveGroup wg;
     // The pairs of a launch are dealt to the waves as a stream of chunks (PairStream, below): chunk 0 of every wave is fixed --
     // C0 pairs per lane group, wave w starts at pair w G C0 -- and the rest is drawn, 2^logC pairs per lane group at a time,
@@ -68,9 +68,8 @@ struct FusedParams {
     // queue == nullptr, rk_n > 0: shares by wave AGE RANK instead (sk_wave_common.h: the SIMD arbiter favours its oldest wave, so equal
     // shares leave a SIMD with two waves, then one, for the last third of a launch): a wave of rank r = w / rk_wpr takes rk_cnt[r]
     // pairs per lane group from pair rk_base[r] + (w - r rk_wpr) G rk_cnt[r] on
-    int rk_n, rk_wpr;
-    int rk_cnt[4];
-    unsigned rk_base[4];
+    int rk_n, rk_wpr;                 // (cnt packed 4 x 16 bits; rk_base[r] = G rk_wpr (cnt[0] + .. + cnt[r-1]) follows from them)
+    unsigned long long rk_cnt;
 };
 
 template <int N>
@@ -266,7 +265,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // live in VGPRs and every producer call computes its addresses with vector instructions.)
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
-    const unsigned Pe32 = EDGES ? (unsigned)prm.P_edges : 0u;    // pairs from here on keep no edges (the loss layout's triangle)
+    // pairs from here on keep no edges (the loss layout's triangle); worked out where it is needed, not kept in a scalar register
+    auto edge_pairs = [&]() __attribute__((always_inline)) -> unsigned {
+        return (prm.tri & 3) == 2 ? (unsigned)((prm.tri >> 2) & 0x7fff) * (unsigned)prm.B : P32;
+    };
     // (launches without a queue deal the pairs out as evenly as whole pairs allow: the first n_big waves take one pair more
     // per lane group than the others -- everything below, t_end included, follows from this wave's own C0.  Spreading those
     // waves evenly over the wave numbers instead was measured slower: 0.215 vs 0.197 ms on 128 x 128 symmetric pairs.)
@@ -276,9 +278,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     if (prm.rk_n > 0) {   // shares by age rank (scalar selects: rk_n <= 4)
         int rr = w32 / prm.rk_wpr;
         rr = rr >= prm.rk_n ? prm.rk_n - 1 : rr;
-        c0_ = rr == 0 ? prm.rk_cnt[0] : rr == 1 ? prm.rk_cnt[1] : rr == 2 ? prm.rk_cnt[2] : prm.rk_cnt[3];
-        const unsigned bs = rr == 0 ? prm.rk_base[0] : rr == 1 ? prm.rk_base[1] : rr == 2 ? prm.rk_base[2] : prm.rk_base[3];
-        cb0_ = bs + (unsigned)((w32 - rr * prm.rk_wpr) * G * c0_);
+        const unsigned long long pk = prm.rk_cnt;
+        c0_ = (int)((pk >> (16 * rr)) & 0xffffu);
+        const unsigned long long below = pk & ((1ull << (16 * rr)) - 1ull);      // the counts of the older ranks
+        const unsigned used = (unsigned)(below & 0xffffu) + (unsigned)((below >> 16) & 0xffffu) + (unsigned)((below >> 32) & 0xffffu);
+        cb0_ = (used * (unsigned)prm.rk_wpr + (unsigned)((w32 - rr * prm.rk_wpr) * c0_)) * (unsigned)G;
     }
     const int C0 = __builtin_amdgcn_readfirstlane(c0_), logC = prm.logC, CQ = 1 << logC;
     unsigned cb0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cb0_), cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR;   // chunk k in cb[k & 3]
@@ -360,18 +364,29 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // by NUp), and the pair -> (a, b) split uses 32-bit arithmetic whenever the pair count allows: the 64-bit division
     // sequence is ~150 scalar instructions, and there are G of them per call.
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
-    auto split_b = [&](int64_t p) -> int64_t {
+    // (one triangle enumeration serves both layouts: the symmetric Gram is an empty rectangle + the INCLUSIVE triangle of all B paths,
+    // the loss layout A rows x B + the STRICT triangle of tri_n paths from Z[A] on = the inclusive one of tri_n - 1 with b shifted by one)
+    auto split_ab = [&](int64_t p, bool want_b) __attribute__((always_inline)) -> int64_t {
         if (prm.B <= 0) return p;
-        if (prm.tri == 1) { int64_t a, b; tri_split(p, prm.B, a, b); return b; }
-        if (prm.tri == 2 && p >= prm.P_rect) { int64_t a, b; tri_split(p - prm.P_rect, prm.tri_n - 1, a, b); return prm.tri_off + b + 1; }
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
-    };
-    auto split_a = [&](int64_t p) -> int64_t {
-        if (prm.B <= 0) return p;
-        if (prm.tri == 1) { int64_t a, b; tri_split(p, prm.B, a, b); return a; }
-        if (prm.tri == 2 && p >= prm.P_rect) { int64_t a, b; tri_split(p - prm.P_rect, prm.tri_n - 1, a, b); return prm.tri_off + a; }
+        // (an opaque copy: the layout's constants are then worked out HERE, eight macro-steps apart, instead of being hoisted out of the
+        // step loop into scalar registers the loop does not have -- they came back as v_readlane in every macro-step)
+        int tri_now = prm.tri;
+        asm volatile("" : "+s"(tri_now));
+        const int mode = tri_now & 3;
+        if (mode) {
+            const int64_t A_ = mode == 2 ? (tri_now >> 2) & 0x7fff : 0, strict = mode == 2 ? 1 : 0;
+            const int64_t n_ = mode == 2 ? (tri_now >> 17) & 0x7fff : prm.B, P_rect = A_ * prm.B;
+            if (p >= P_rect) {
+                int64_t a, b;
+                tri_split(p - P_rect, n_ - strict, a, b);
+                return A_ + (want_b ? b + strict : a);
+            }
+        }
+        if (want_b) return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
     };
+    auto split_b = [&](int64_t p) -> int64_t { return split_ab(p, true); };
+    auto split_a = [&](int64_t p) -> int64_t { return split_ab(p, false); };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;   // next y slab: pair-in-group, first unit (NUp % 8 == 0: no straddling),
     auto issue_y = [&]() __attribute__((always_inline)) {                            // ring slot, parity of the virtual slab number
         ensure(y_pi);
@@ -472,12 +487,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (EDGES) {
             if (ep_left > 0) {
                 ep_left -= 1;
-                ep_p = (ep_p != NOPAIR && ep_p + 1u < Pe32) ? ep_p + 1u : NOPAIR;
+                ep_p = (ep_p != NOPAIR && ep_p + 1u < edge_pairs()) ? ep_p + 1u : NOPAIR;
                 ep_cur += EP;
             } else {
                 asm volatile("");
                 ep_p = stream_pair_left(grp, pk, ep_left);
-                if (ep_p >= Pe32) ep_p = NOPAIR;
+                if (ep_p >= edge_pairs()) ep_p = NOPAIR;
                 ep_cur = prm.edges + (int64_t)(ep_p != NOPAIR ? ep_p : 0u) * EP;
             }
         }
@@ -751,7 +766,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                if (prm.tri == 1) {      // the pair and its mirror image
+                if ((prm.tri & 3) == 1) {      // the pair and its mirror image
                     int64_t a, b;
                     tri_split(pair_v, prm.B, a, b);
                     static_cast<TO *>(prm.out)[a * prm.B + b] = (TO)v;
@@ -911,26 +926,26 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
         const int64_t wpr = (int64_t)device_cu_count() * wg0.wpb;
         const int64_t T = (pl.P + wpr * pl.G - 1) / (wpr * pl.G);      // pairs per lane group summed over the ranks of one SIMD slot
         if (knobs().fused_mid != 0 && waves == max_waves && waves_per_cu % 4 == 0 && nr >= 2 && nr <= 4 && wg0.wpb == 4 &&
-            wpr * nr == waves && T >= 4 * nr) {
+            wpr * nr == waves && T >= (int64_t)cost_by_name("fused_mid_min_pairs_per_rank") * nr) {
             static constexpr double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
             double w[4];
             for (int r = 0; r < 4; ++r) w[r] = dflt[nr][r];
             rank_override(knobs().fused_rank_w, nr, w);
             const double fill = (double)(pl.L - 1 + pl.lag), total = (double)T * pl.NUp + nr * fill;
-            int64_t used = 0;
+            int64_t used = 0, cmax = 0;
+            unsigned long long pack = 0;
             bool ok = true;
             for (int r = 0; r < nr; ++r) {
                 int64_t c = r + 1 < nr ? (int64_t)((w[r] * total - fill) / pl.NUp + 0.5) : T - used;
-                if (c < 1 || used + c > T - (nr - 1 - r)) { ok = false; break; }
-                prm.rk_cnt[r] = (int)c;
-                prm.rk_base[r] = (unsigned)(used * wpr * pl.G);
+                if (c < 1 || c > 0xffff || used + c > T - (nr - 1 - r)) { ok = false; break; }
+                pack |= (unsigned long long)c << (16 * r);
+                cmax = c > cmax ? c : cmax;
                 used += c;
             }
             if (ok && (uint64_t)T * (uint64_t)wpr * (uint64_t)pl.G < 0x7ff00000ULL) {
                 prm.rk_n = nr;
                 prm.rk_wpr = (int)wpr;
-                int cmax = 0;
-                for (int r = 0; r < nr; ++r) cmax = prm.rk_cnt[r] > cmax ? prm.rk_cnt[r] : cmax;
+                prm.rk_cnt = pack;
                 per = cmax;
             }
         }
@@ -985,9 +1000,10 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
                      double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0, const int64_t *loss = nullptr) {
     if (tri == 1 && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
     // the loss layout: loss = {tri_n, tri_off}; A rows against the B paths of the one batch, then the strict triangle of tri_n of them
-    if (tri == 2 && (!loss || B <= 0 || loss[0] < 0 || loss[1] < 0 || loss[0] + loss[1] > B || A > B ||
+    if (tri == 2 && (!loss || B <= 0 || loss[0] < 0 || loss[1] != A || loss[0] + loss[1] > B || A > B ||
                      g.P != A * B + (loss[0] > 1 ? loss[0] * (loss[0] - 1) / 2 : 0)))
         return SK_ERR_BAD_ARG;
+    if (tri == 2 && (A > 0x7fff || loss[0] > 0x7fff || A * B >= 0x7ff00000LL)) return SK_ERR_UNSUPPORTED;   // (packed into prm.tri)
     const int DY = g.dyadic;
     if (DY > 2 || D < 1 || D > FD) return SK_ERR_UNSUPPORTED;
     // (RBF at dyadic 0 beyond the four-dimension fp64 default-stencil variant: the two-row form, see launch_fused_e)
@@ -1040,13 +1056,8 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.inv_sigma = inv_sigma;
     prm.dims = D;
-    prm.rk_n = 0; prm.rk_wpr = 1;
-    for (int r = 0; r < 4; ++r) { prm.rk_cnt[r] = 0; prm.rk_base[r] = 0; }
-    prm.tri = tri;
-    prm.P_rect = tri == 2 ? A * B : g.P;
-    prm.tri_n = tri == 2 ? loss[0] : 0;
-    prm.tri_off = tri == 2 ? loss[1] : 0;
-    prm.P_edges = prm.P_rect;
+    prm.rk_n = 0; prm.rk_wpr = 1; prm.rk_cnt = 0;
+    prm.tri = tri == 2 ? (2 | ((int)A << 2) | ((int)loss[0] << 17)) : tri;
     prm.queue = (unsigned long long *)queue;
     prm.e_NUp = NUp;
     prm.e_L = L;

@@ -196,7 +196,9 @@ __device__ __forceinline__ void lds_pend_take(d2_t (&o)[NP], d2_t (&t)[NP]) { as
 // neighbouring slabs) hit different halves of the bank row without the parity swizzle of the fp64 ring.
 // RCX: coarse rows per lane; the strip kernels' Tile<DY>::RC, except for the RBF edges at dyadic 0, which are kept for
 // k_adj_fused_rbf_mb<0, 2, ..> (two rows per lane there: four would need > 256 registers) in ITS bands of 128 rows
-template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES, int RCX = Tile<DY>::RC>
+// SPLIT: the bands of a pair on several waves (FusedMbParams::split; a variant of its own: its ring of item bands, row pointers and
+// progress bookkeeping would otherwise sit in the scalar registers of every launch -- measured as a runtime flag: C5 80.9 -> 83.5 ms)
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES, int RCX = Tile<DY>::RC, bool SPLIT = false>
 __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams prm) {
     // The _naive_solver stencil (k10 + k01)(1 + g/2) - k00 is the default one with c_12 = 0: a = 1 + g/2 + 0 g^2 and b = 1 - 0 g^2 = 1
     // exactly (finite g), so diag * b = diag -- a launch-time constant instead of a second set of kernel variants
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     constexpr unsigned NOPAIR = 0xffffffffu;
     const unsigned P32 = (unsigned)prm.P;
     const int C0 = prm.C0;
-    const bool split = prm.split != 0;
+    constexpr bool split = SPLIT;
     const unsigned Pn32 = (unsigned)prm.Pn;
     const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wave_id * C0));
     unsigned cb1 = NOPAIR, cb2 = NOPAIR, cb3 = NOPAIR, cb0 = NOPAIR;   // drawn pair of position C0 + j in cb[j & 3]
@@ -803,9 +805,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     }
 }
 
-template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false, int RCX = Tile<DY>::RC>
+template <typename TO, int DY, bool Y32, int KIND, int FD, bool EDGES = false, int RCX = Tile<DY>::RC, bool SPLIT = false>
 int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_cu, double *ws, size_t ws_bytes, hipStream_t s) {
-    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD, EDGES, RCX>;
+    if constexpr (!SPLIT && !EDGES) {
+        if (prm.split) return launch_mb_one<TO, DY, Y32, KIND, FD, false, RCX, true>(prm, P, lds_bytes, waves_per_cu, ws, ws_bytes, s);
+    }
+    auto kern = k_fwd_fused_mb<TO, DY, Y32, KIND, FD, EDGES, RCX, SPLIT>;
     // (a property of this variant's code object, the same on every gfx950 device: an immutable constant initialised once,
     // thread-safely, at the variant's first launch -- not mutable library state)
     static const int vgprs = [&] {
@@ -823,7 +828,7 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     const int pct = knobs().fusedmb_q_static > 0 ? (knobs().fusedmb_q_static > 100 ? 100 : knobs().fusedmb_q_static) : 50;
     if (prm.split) {
         // every position is a ticket: [per-wave rows (only their chunk of ones is used)][item rows][progress counters][the counter]
-        if constexpr (EDGES) return SK_ERR_UNSUPPORTED;
+        if constexpr (!SPLIT) return SK_ERR_UNSUPPORTED;
         const size_t wave_doubles = (size_t)waves * (size_t)prm.ws_stride, row_doubles = (size_t)P * (size_t)prm.row_stride;
         const size_t prog_bytes = ((size_t)P * sizeof(unsigned) + 63) / 64 * 64;
         if (!ws || ws_bytes < (wave_doubles + row_doubles) * sizeof(double) + prog_bytes + 64) return SK_ERR_WORKSPACE;
@@ -942,9 +947,9 @@ constexpr size_t MB_SPLIT_MAX_BYTES = (size_t)2 << 30;
 size_t mb_split_rows_bytes(int kind, int64_t P, int Mc, int Nc, int dyadic, int D, bool y32, bool edges) {
     if (edges || knobs().fusedmb_split == 0) return 0;
     const MbPlan pl = mb_plan(kind, Mc, Nc, dyadic, D, y32, false, true);
-    if (!pl.ok || pl.nb < 2 || pl.NUp < 8 * (MB_LEAD + 24)) return 0;
+    if (!pl.ok || pl.nb < 2 || pl.NUp < 8 * (MB_LEAD + 24) || pl.NUp < (int)cost_by_name("mb_split_min_units")) return 0;
     const int64_t resident = (int64_t)device_cu_count() * pl.waves_per_cu;
-    if (P * 2 > resident || P * (int64_t)pl.nb >= 0x7ff00000LL) return 0;
+    if ((double)P > cost_by_name("mb_split_max_resident_share") * (double)resident || P * (int64_t)pl.nb >= 0x7ff00000LL) return 0;
     const size_t bytes = (size_t)P * pl.nb * (size_t)pl.NUp * (pl.S + (kind == 1 ? 2 : 0)) * sizeof(double);
     return bytes <= MB_SPLIT_MAX_BYTES ? bytes : 0;
 }

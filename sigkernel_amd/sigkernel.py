@@ -309,7 +309,7 @@ class _SigKernel(torch.autograd.Function):
             if _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic_order, _naive_solver, False) == FUSED_MB:
                 pair_bytes = _mb_pair_bytes(be, _fused_static(static_kernel, False)[0], Xd, Yd, dyadic_order)
                 edge_bytes = float(A) * (pair_bytes or 0)
-            if edge_bytes <= _KEEP_EDGES_FRACTION * _budget(X.device, workspace_bytes):
+            if edge_bytes <= _cost("keep_edges_fraction") * _budget(X.device, workspace_bytes):
                 res = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False, keep_edges=True)
                 if res is not None:
                     K, edges = res
@@ -344,12 +344,21 @@ class _SigKernel(torch.autograd.Function):
         return grad_X, None, None, None, None, None
 
 
-_SYM_TILES = 8   # row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
-_SYM_MIN_CELLS = 5e9   # below this the extra launches cost more than the saved solves
-_SYM_MIN_ROWS = 32     # rows per block of the triangular adjoint
+# Cost rules (WHEN a route is the faster one -- not scope rules) live in ONE table, the library's (sk_cost_query, csrc/sk_route.hip: value +
+# the A/B measurement behind it; tools/crossovers.py re-measures them).  None = the table's value; tests set an attribute to override.
+_SYM_TILES = None              # "sym_tiles": row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
+_SYM_MIN_CELLS = None          # "sym_min_cells": below this the extra launches cost more than the saved solves
+_SYM_MIN_ROWS = None           # "sym_min_rows": rows per block of the triangular adjoint
+_KEEP_EDGES_FRACTION = None    # "keep_edges_fraction": of the transient budget, what may stay allocated between forward and backward
+_PAIRED_MERGE_CELLS = None     # "paired_merge_cells"
+_MMD_STREAMS_MAX_PAIRS = None  # "mmd_streams_max_pairs"
 
 
-_KEEP_EDGES_FRACTION = 0.5   # of the transient budget: how much may stay allocated between forward and backward
+def _cost(name):
+    v = globals()["_" + name.upper()]
+    return _lib.cost(name) if v is None else v
+
+
 _MAX_LAUNCH_PAIRS = 1 << 30  # pairs per fused launch (the fused kernels index pairs with 32 bits and refuse 2^31 - 2^20 and more)
 
 
@@ -386,7 +395,7 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
             # the multi-band forward keeps every band's bottom row: nb / 2 times the terminal row and column alone
             pair_bytes = _mb_pair_bytes(be, _fused_static(static_kernel, True)[0], Xd, Yd, dyadic_order)
             edge_bytes = float(A) * B * (pair_bytes or 0)
-        if edge_bytes > _KEEP_EDGES_FRACTION * budget:
+        if edge_bytes > _cost("keep_edges_fraction") * budget:
             keep = None
     else:
         keep = None
@@ -435,13 +444,14 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     cells = float(A) * A * ((Xd.shape[1] - 1) << dyadic_order) ** 2
     # 8 block launches instead of 1: only worth it when the solve dwarfs the launches (measured: 128 x 128 pairs of
     # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
-    T = _SYM_TILES if (A >= 8 * _SYM_TILES and cells >= _SYM_MIN_CELLS) else 1
+    tiles = int(_cost("sym_tiles"))
+    T = tiles if (A >= 8 * tiles and cells >= _cost("sym_min_cells")) else 1
     if T > 1 and A >= 64 * T and keep_blocks is not None:
         T *= 2        # big batches with the fused adjoint: 16 row blocks solve 53 % of the square instead of 56 % (C4: -1 %)
     if keep_blocks is not None and T > 1:
         # with the adjoint in the blocks too, small blocks lose more to launches and pipeline fill than the triangle saves
         # (measured: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms): at least _SYM_MIN_ROWS rows each
-        T = max(1, min(T, A // _SYM_MIN_ROWS))
+        T = max(1, min(T, A // int(_cost("sym_min_rows"))))
     step = -(-A // T)
     for r0 in range(0, A, step):
         r1 = min(r0 + step, A)
@@ -686,10 +696,8 @@ def k_kgrad(X, Y, gamma, dyadic_order, static_kernel, eps=1e-4, workspace_bytes=
     return out[0], out[1], out[2]
 
 
-_MMD_STREAMS_MAX_PAIRS = 128 * 128    # pairs per Gram matrix up to which a CAPTURED compute_mmd forks its three matrices onto three streams
 _SIDE_STREAMS = {}
 _LOSS_WEIGHTS = {}
-_PAIRED_MERGE_CELLS = 2e9   # grid cells of a paired batch below which compute_distance solves k(X, X) and k(X, Y) as one batch
 
 
 def _side_streams(device):
@@ -893,7 +901,7 @@ class SigKernel:
         assert not Y.requires_grad, "the second input should not require grad"
         n = X.shape[0] if X.dim() == 3 else 0
         if (not routes.no_merged_loss and X.dim() == 3 and X.shape == Y.shape and X.dtype == Y.dtype and X.device == Y.device and n > 0
-                and X.shape[1] >= 2 and float(n) * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 < _PAIRED_MERGE_CELLS):
+                and X.shape[1] >= 2 and float(n) * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 < _cost("paired_merge_cells")):
             # training-sized batches: k(x_i, x_i) and k(x_i, y_i) as ONE paired batch of 2n pairs -- one forward and one adjoint launch
             # instead of two each (launch- and fill-bound at these sizes); the same per-pair values, and the gradient reaches X through
             # the first argument of both halves, as in the reference's three calls (_SigKernel returns none for a second argument)
@@ -940,7 +948,7 @@ class SigKernel:
         A, B = X.shape[0], Y.shape[0]
         if X.shape[1:] != Y.shape[1:] or X.shape[1] < 2 or A < 2 or B < (2 if with_yy else 1) or X.dtype != Y.dtype or X.device != Y.device:
             return None
-        if float(A) * A * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 >= _SYM_MIN_CELLS:
+        if float(A) * A * float((X.shape[1] - 1) << int(self.dyadic_order)) ** 2 >= _cost("sym_min_cells"):
             return None
         args = (X, Y, self.static_kernel, self.dyadic_order, self._naive_solver, self.workspace_bytes, with_yy)
         if not _wants_grad(X):
@@ -963,7 +971,7 @@ class SigKernel:
         if merged is not None:
             return merged
         small = (X.is_cuda and Y.is_cuda and self.process_group is None and routes_allow_streams()
-                 and max(X.shape[0], Y.shape[0]) ** 2 <= _MMD_STREAMS_MAX_PAIRS and X.shape[0] > 1 and Y.shape[0] > 1)
+                 and max(X.shape[0], Y.shape[0]) ** 2 <= _cost("mmd_streams_max_pairs") and X.shape[0] > 1 and Y.shape[0] > 1)
         if small:
             s_yy, s_xy = _side_streams(X.device)      # (created by the warm-up calls that precede a capture, never inside one)
         if small and torch.cuda.is_current_stream_capturing():

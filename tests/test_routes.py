@@ -37,14 +37,15 @@ TABLE = [
     ((FWD, 1, 7, 297, 297, 0, False, 8), MB, MB), ((FWD, 1, 7, 199, 199, 0, False, 8), MB, MB),
     ((FWD, 1, 5, 100, 100, 0, False, 8), FUSED, FUSED), ((FWD, 1, 4, 100, 100, 0, True, 8), FUSED, FUSED), ((FWD, 1, 4, 100, 100, 0, False, 4), FUSED, FUSED),
     ((FWD, 1, 5, 129, 100, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 5, 129, 129, 0, False, 8), STREAM, MB), ((FWD, 1, 4, 200, 200, 0, False, 4), MB, MB),
-    # wide paths: multi-band where the sweep is not mostly padding (efficiency rows / (bands 64 RC) x units / max(80, units) >= 0.45;
-    # rbf forward 0.5) -- measured crossovers, profiles/r04_ab_routes.txt
-    ((FWD, 0, 12, 128, 128, 1, False, 8), MB, MB), ((FWD, 0, 12, 40, 40, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 30, 30, 0, True, 8), STREAM, MB),
+    # wide paths: streamed while both paths have at most 128 increments (the streaming kernels' one-strip regime), multi-band beyond where
+    # the sweep is not mostly padding (efficiency rows / (bands 64 RC) x units / max(80, units) >= 0.45; the rbf forward on 16 staged fp64
+    # dims: 0.85) -- measured crossovers, profiles/r05_thresholds.txt
+    ((FWD, 0, 12, 128, 128, 1, False, 8), STREAM, MB), ((FWD, 0, 12, 140, 140, 1, False, 8), MB, MB), ((FWD, 0, 12, 40, 40, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 30, 30, 0, True, 8), STREAM, MB),
     ((FWD, 1, 7, 128, 128, 0, False, 8), FUSED, FUSED),
     # rbf with 9..16 dims of fp64 paths (16 staged fp64 dims, one wave per SIMD): streamed forward, multi-band adjoint on full bands only;
     # fp32 paths (fp32 ring, two waves: BASELINE configs[4]) as everything else
-    ((FWD, 1, 12, 128, 128, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 512, 512, 2, False, 8), STREAM, MB), ((ADJ, 1, 12, 128, 128, 2, False, 8), STREAM, MB),
-    ((ADJ, 1, 16, 512, 512, 2, False, 8), MB, MB), ((FWD, 1, 12, 128, 128, 1, False, 4), MB, MB),
+    ((FWD, 1, 12, 128, 128, 1, False, 8), STREAM, MB), ((FWD, 1, 16, 512, 512, 2, False, 8), MB, MB), ((FWD, 1, 16, 200, 200, 2, False, 8), STREAM, MB), ((ADJ, 1, 16, 200, 200, 2, False, 8), MB, MB), ((ADJ, 1, 12, 128, 128, 2, False, 8), STREAM, MB),
+    ((ADJ, 1, 16, 512, 512, 2, False, 8), MB, MB), ((FWD, 1, 12, 128, 128, 1, False, 4), STREAM, MB), ((FWD, 1, 12, 140, 140, 1, False, 4), MB, MB),
     # multi-band forward, orientation by swept macro-steps (bands x max(80, units))
     ((FWD, 0, 12, 20, 700, 1, False, 8), STREAM, MB), ((FWD, 0, 12, 700, 100, 1, False, 8), SWAP, SWAP), ((FWD, 1, 12, 300, 290, 1, False, 4), MB, MB),
     # long first paths, short second ones: the one-band forward on (y, x) (k is symmetric); never for a gradient, never beyond dim 8
@@ -52,10 +53,10 @@ TABLE = [
     ((FWD, 1, 4, 1000, 256, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 5, 1000, 256, 0, False, 8), MB, MB), ((ADJ, 0, 3, 700, 20, 0, False, 8), STREAM, MB),
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
-    ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), MB, MB),
+    ((ADJ, 0, 8, 66, 30, 2, False, 8), STREAM, MB), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 140, 140, 1, False, 8), MB, MB),
     # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: dim <= 8, default stencil, M <= 128 (two rows per lane)
     ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 65, 64, 1, True, 8), STREAM, MB), ((ADJ, 1, 7, 40, 300, 1, True, 4), FUSED, FUSED),
-    ((ADJ, 1, 7, 128, 128, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), STREAM, MB),
+    ((ADJ, 1, 7, 128, 128, 1, False, 8), STREAM, MB), ((ADJ, 1, 7, 140, 140, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 128, 300, 0, False, 4), FUSED, FUSED), ((ADJ, 1, 9, 40, 40, 0, False, 8), STREAM, MB),
     ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
     # never swapped: the gradient is the first argument's
@@ -102,6 +103,24 @@ def test_host_layer_has_no_scope_rules_of_its_own():
         src = inspect.getsource(mod)
         assert "_adjoint_ok" not in src and "_adjoint_mb_ok" not in src
     assert "be.route" in inspect.getsource(sigkernel._route)
+
+
+def test_cost_rules_live_in_one_table():
+    """WHEN a route is the faster one (sweep-efficiency thresholds of the multi-band kernels, blocked symmetric Grams, merged loss /
+    paired batches, age-rank shares, bands on several waves) is decided by ONE table, the library's (sk_cost_query): the host layer
+    holds no number of its own -- its module attributes are None (= the table) unless a test overrides them -- and every entry says
+    which measurement it came from."""
+    import re
+    from sigkernel_amd import _lib, sigkernel
+    table = _lib.costs()
+    for name in ("mb_min_eff", "stream_one_strip_cells", "mb_min_eff_rbf16_forward", "sym_tiles", "sym_min_cells", "sym_min_rows", "paired_merge_cells",
+                 "mmd_streams_max_pairs", "keep_edges_fraction", "fused_mid_min_pairs_per_rank", "mb_split_max_resident_share"):
+        value, note = table[name]
+        assert value > 0 and len(note) > 40, name
+    for attr in ("_SYM_TILES", "_SYM_MIN_CELLS", "_SYM_MIN_ROWS", "_PAIRED_MERGE_CELLS", "_MMD_STREAMS_MAX_PAIRS", "_KEEP_EDGES_FRACTION"):
+        assert getattr(sigkernel, attr) is None and sigkernel._cost(attr[1:].lower()) == table[attr[1:].lower()][0]
+    src = open(sigkernel.__file__).read()
+    assert not re.search(r"^_[A-Z_]+ = [0-9][0-9e.* ]*(#|$)", src.replace("_DEFAULT_WORKSPACE = 48 << 30", "").replace("_MAX_LAUNCH_PAIRS = 1 << 30", ""), re.M)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

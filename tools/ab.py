@@ -36,13 +36,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         else:
             def fn():
                 Xg = X.detach().requires_grad_(True); (sk.compute_Gram(Xg, Y) * w).sum().backward(); return Xg.grad
+    elif cfg in ("mmd32", "mmd64", "mmd128"):
+        n_ = int(cfg[3:]); X, Y = walk(n_, 64, 3), walk(n_, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1)
+        def fn():
+            Xg = X.detach().requires_grad_(True); sk.compute_mmd(Xg, Y).backward(); return Xg.grad
+    elif cfg.startswith("shard"):      # rows of the headline Gram one of 512 / rows ranks solves
+        X, Y = walk(int(cfg[5:]), 128, 8), walk(512, 128, 8); sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 1); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c4fwd":
         X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
     else:
         X, Y = walk(2048, 64, 4), walk(2048, 64, 4); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2)
         def fn():
             Xg = X.detach().requires_grad_(True); sk.compute_mmd(Xg, Y).backward(); return Xg.grad
-    n = 30 if cfg in ("c3", "c2", "c2big") else 6
+    n = 30 if cfg in ("c3", "c2", "c2big") or cfg.startswith("mmd") or cfg.startswith("shard") else 6
     if ":" in cfg: n = 10
     for _ in range(max(3, n // 3)): out = fn()
     torch.cuda.synchronize()

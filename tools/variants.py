@@ -6,10 +6,17 @@ import glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJ = os.path.join(ROOT, "sigkernel_amd", "csrc", "obj")
 
+def norm(name):
+    """demangled kernel name -> its instance name without the parameter list (the same for hipcc's listing and rocprofv3's tables)"""
+    n = name.replace("void ", "").replace("sk::(anonymous namespace)::", "").replace("sk::", "")
+    i = n.find(">(")
+    return n[:i + 1] if i >= 0 else n.split("(")[0]
+
+
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-        return [o.replace("void sk::(anonymous namespace)::", "").replace("sk::(anonymous namespace)::", "") for o in out[:len(names)]]
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        return out[:len(names)]
     except Exception:
         return names
 
@@ -26,7 +33,7 @@ def table():
             rows.append(dict(unit=unit, name=name, vgpr=val("next_free_vgpr"), accum=val("accum_offset"), sgpr=val("next_free_sgpr"),
                              scratch=val("private_segment_fixed_size"), lds=val("group_segment_fixed_size")))
     for r, d in zip(rows, demangle([r["name"] for r in rows])):
-        r["pretty"] = re.sub(r"\(.*", "", d)
+        r["pretty"] = norm(d)
     return rows
 
 def main():
@@ -43,12 +50,23 @@ def main():
         for n, a, b in bad + new_spill:
             print("scratch grew: %s %d -> %d bytes" % (n, a, b))
         sys.exit(1 if bad or new_spill else 0)
+    reached = None
+    if "--reached" in sys.argv:      # a rocprofv3 kernel_stats.csv of tools/reach_sweep.py: which instances the public API's routes launch
+        import csv
+        f = sys.argv[sys.argv.index("--reached") + 1]
+        args = [a for a in args if a != f]
+        reached = {}
+        for r in csv.DictReader(open(f)):
+            n = norm(r["Name"])
+            reached[n] = reached.get(n, 0) + int(r["Calls"])
     if args:
         rows = [r for r in rows if all(a in r["pretty"] or a in r["unit"] for a in args)]
-    print("unit\tvgpr\taccum_off\tsgpr\tscratch\tlds\tinstance\tmangled")
+    print("unit\tvgpr\taccum_off\tsgpr\tscratch\tlds\t%sinstance\tmangled" % ("launches\t" if reached is not None else ""))
     for r in rows:
-        print("%s\t%d\t%d\t%d\t%d\t%d\t%s\t%s" % (r["unit"], r["vgpr"], r["accum"], r["sgpr"], r["scratch"], r["lds"], r["pretty"], r["name"]))
-    print("# %d kernel instances, %d with scratch" % (len(rows), sum(1 for r in rows if r["scratch"])), file=sys.stderr)
+        extra = ("%d\t" % reached.get(r["pretty"], 0)) if reached is not None else ""
+        print("%s\t%d\t%d\t%d\t%d\t%d\t%s%s\t%s" % (r["unit"], r["vgpr"], r["accum"], r["sgpr"], r["scratch"], r["lds"], extra, r["pretty"], r["name"]))
+    print("# %d kernel instances, %d with scratch%s" % (len(rows), sum(1 for r in rows if r["scratch"]),
+          (", %d never launched by the sweep" % sum(1 for r in rows if not reached.get(r["pretty"]))) if reached is not None else ""), file=sys.stderr)
 
 if __name__ == "__main__":
     main()
