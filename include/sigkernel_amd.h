@@ -95,6 +95,8 @@ const char *sk_cost_name(int which);
 const char *sk_cost_note(int which);
 #define SK_OP_FORWARD 0
 #define SK_OP_ADJOINT 1
+#define SK_OP_ADJOINT_SYM 2   /* compute_Gram(X, X, sym=True) with a gradient (sigkernel.py:404-416 on the symmetric call): SK_ROUTE_FUSED =
+                                 the TRIANGLE through sk_rbf_adjoint_fused_f64 with the second-argument sums; else all pairs */
 #define SK_ROUTE_STREAM 0
 #define SK_ROUTE_FUSED 1
 #define SK_ROUTE_FUSED_MB 2

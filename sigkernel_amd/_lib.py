@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsigkernel_amd.so")
 
 SK_OK = 0
 # sk_route_query: operations and answers (include/sigkernel_amd.h)
-OP_FORWARD, OP_ADJOINT = 0, 1
+OP_FORWARD, OP_ADJOINT, OP_ADJOINT_SYM = 0, 1, 2
 ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP, ROUTE_FUSED_SWAP = 0, 1, 2, 3, 4
 ROUTE_NO_STREAM = 1
 SCHEME_DEFAULT = 0

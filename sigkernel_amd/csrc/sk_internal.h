@@ -14,7 +14,7 @@ struct Knobs {
     int wave_pf, wave_wpc, wave_wpb;
     int adj_wpc, adj_wpb;
     int adjf_wpc, adjf_wpb;
-    int adjr_wpc, adjr_wpb, adjr_all;
+    int adjr_wpc, adjr_wpb;
     int adjmb_wpc, adjmb_wpb, adjmb_q_static;     // sk_wave_adj_fused_mb.hip
     int derivf_wpc, derivf_wpb, derivf_noshift;   // sk_wave_deriv_fused.hip
     int deriv_pf, deriv_wpc, deriv_wpb;

@@ -67,7 +67,7 @@ struct CostEntry { const char *name; double value; const char *note; };
 const CostEntry COSTS[] = {
     {"mb_min_eff", 0.45,
      "least sweep efficiency rows / (bands 64 RC) x units / max(80, units) at which the multi-band fused kernels are the default instead of the "
-     "streaming route (forward and adjoint, both static kernels); r05_thresholds, 128 x 128 pairs, same box: linear dim 12 d = 0: 128 points "
+     "streaming route (forward and adjoint, LinearKernel and RBFKernel alike); r05_thresholds, 128 x 128 pairs, same box: linear dim 12 d = 0: 128 points "
      "(0.40) 1.38 ms multi-band vs 1.18 streamed, 140 points (0.48) 1.37 vs 2.04; rbf dim 7 d = 0, 140 points (0.48) 1.64 vs 2.06; with a "
      "gradient linear dim 12 d = 1, 140 points (0.48) 7.7 vs 9.0 ms"},
     {"stream_one_strip_cells", 128,
@@ -140,6 +140,16 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         const double eff = swap ? mb_efficiency(kind, Nc, Mc, d, rc_of(d)) : mb_efficiency(kind, Mc, Nc, d, rc_of(d));
         if (may_stream && prefer_stream(Mc, Nc, eff, kind == 1 && D > 8 && elem_size == 8)) return SK_ROUTE_STREAM;
         return swap ? SK_ROUTE_FUSED_MB_SWAP : SK_ROUTE_FUSED_MB;
+    }
+    if (op == SK_OP_ADJOINT_SYM) {
+        // compute_Gram(X, X, sym=True) with a gradient: FUSED = the triangle through the one-band rbf adjoint with the second-argument
+        // sums (a pair above the diagonal also stands for its mirror image); anything else = all pairs / the caller's other routes.
+        // fp64 paths, dim <= 4; one coarse row per lane at dyadic 1 and 2 (M <= 64), two at dyadic 0 (M <= 128) -- the two-row form
+        // at dyadic 1 spilled and lost to all pairs, profiles/r05_yside_ab.txt
+        if (kind == 1 && D <= 4 && elem_size == 8 && route_query(SK_OP_ADJOINT, kind, D, M, N, d, naive, elem_size, flags) == SK_ROUTE_FUSED &&
+            M == N && M <= (d == 0 ? 128 : 64))
+            return SK_ROUTE_FUSED;
+        return SK_ROUTE_STREAM;
     }
     if (op == SK_OP_ADJOINT) {
         if (kind == 0 && D <= 8 && Mc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED;

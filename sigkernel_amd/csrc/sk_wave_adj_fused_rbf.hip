@@ -645,8 +645,15 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     // is built for; dim 5..8: 18 VGPRs spilled, like the dyadic-2 variants of that width)
     if (DY == 0 && (g.naive || st.logL > 5)) return SK_ERR_UNSUPPORTED;
     // dyadic 1 with 8 staged dims: two coarse rows of 8 dims per lane spill 84-113 VGPRs (and lose to the multi-band kernel); ONE row
-    // per lane on twice the lanes fits (238 VGPRs) -- pairs of up to 64 points, the strip layout as it is (SK_ADJR_ALL: the old form)
-    const bool half_rows = DY == 0 || (DY == 1 && D > 4 && !knobs().adjr_all);
+    // per lane on twice the lanes fits (238 VGPRs) -- pairs of up to 64 points, the strip layout as it is.  (The two-row form and the
+    // dyadic-2 variant of that width spilled 84-280 bytes and no route of sk_route_query reached them: removed in round 5,
+    // profiles/r05_variants.txt; such calls take the multi-band adjoint or stream.)
+    if (DY == 2 && D > 4) return SK_ERR_UNSUPPORTED;
+    // ... and so do the second-argument sums at dyadic 1: with two rows per lane that variant spilled 168-176 bytes and ran 2.5x
+    // slower per pair than the plain one (the triangle it serves lost to all pairs: 42 against 27 ms on 1024 paths of 64 points,
+    // profiles/r05_yside_ab.txt); one row per lane fits -- pairs of up to 64 points; longer paths take all pairs (sigkernel.py)
+    const bool yside_req = ypart != nullptr || ycols_out != nullptr;
+    const bool half_rows = DY == 0 || (DY == 1 && (D > 4 || yside_req));
     if (half_rows && st.logL > 5) return SK_ERR_UNSUPPORTED;
     const int RC = half_rows ? st.RC / 2 : st.RC, NUp = st.NUp, logL = half_rows ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
@@ -712,15 +719,13 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         else if (ND == 8) rc = full ? launch_adjr<0, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, false>(prm, lds_block, s);
         else rc = full ? launch_adjr<0, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, false>(prm, lds_block, s);
     } else if (ypart) {
-        if (DY == 1) rc = full ? launch_adjr<1, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, true>(prm, lds_block, s);
+        if (DY == 1) rc = full ? launch_adjr<1, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 4, true>(prm, lds_block, s);
         else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
     } else if (DY == 1) {
         if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
-        else if (half_rows) rc = full ? launch_adjr<1, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, false>(prm, lds_block, s);
-        else rc = full ? launch_adjr<1, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 8, false>(prm, lds_block, s);
+        else rc = full ? launch_adjr<1, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, false>(prm, lds_block, s);
     } else {
-        if (ND == 4) rc = full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
-        else rc = full ? launch_adjr<2, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 8, false>(prm, lds_block, s);
+        rc = full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
     }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
     return launch_fused_rescue(1, Xr, Yt, scale_orig, err, rescue->tol, gpart, ypart, A, B, Mrows, Ncp, D, g, L * RC + 1, OUTW, 2 * NUp, inv_sigma,

@@ -57,7 +57,7 @@ def _fused_static(static_kernel, gram):
 
 STREAM, FUSED, FUSED_MB, FUSED_MB_SWAP = _lib.ROUTE_STREAM, _lib.ROUTE_FUSED, _lib.ROUTE_FUSED_MB, _lib.ROUTE_FUSED_MB_SWAP
 FUSED_SWAP = _lib.ROUTE_FUSED_SWAP
-OP_FORWARD, OP_ADJOINT = _lib.OP_FORWARD, _lib.OP_ADJOINT
+OP_FORWARD, OP_ADJOINT, OP_ADJOINT_SYM = _lib.OP_FORWARD, _lib.OP_ADJOINT, _lib.OP_ADJOINT_SYM
 
 
 @functools.lru_cache(maxsize=4096)
@@ -488,7 +488,8 @@ def _edge_tiles(kept, n_rows, per_row, budget, strict=False):
 def _sym_triangle_ok(be, static_kernel, Xd, dyadic, naive):
     """Whether compute_Gram(X, X, sym=True) WITH a gradient solves the triangle only (a pair above the diagonal also stands for its
     mirror image, through the second-argument contraction of the same adjoint sweep), by the ADJOINT route of the shape:
-      FUSED, RBFKernel, fp64   yes -- sk_rbf_adjoint_fused_f64 with the second-argument sums (_sym_fused_gradient; dim <= 4 by the route)
+      FUSED, RBFKernel, fp64   yes where sk_route_query(SK_OP_ADJOINT_SYM) says so -- sk_rbf_adjoint_fused_f64 with the second-argument sums
+                               (_sym_fused_gradient; dim <= 4, 64 points at dyadic 1..2, 128 at dyadic 0); all pairs beyond
       FUSED, LinearKernel      no  -- the fused adjoint on ALL pairs is faster than any triangle route (14 vs 20 ms at the C3 shape)
       FUSED_MB                 no  -- likewise (C5's shape: 0.29 s on all pairs against 0.46 s on the streamed triangle)
       STREAM (fused static kernels beyond dim 16 / dyadic 2, or a route switch): yes where sk_static_adjoint2 exists (linear: dim <= 8)
@@ -497,8 +498,8 @@ def _sym_triangle_ok(be, static_kernel, Xd, dyadic, naive):
     if fused is None or not hasattr(be, "static_adjoint2"):
         return False
     route = _route(be, OP_ADJOINT, static_kernel, Xd, Xd, dyadic, naive, True)
-    if route == FUSED:
-        return fused[0] == 1 and Xd.dtype == torch.float64 and Xd.shape[2] <= 4 and hasattr(be, "second_argument_gradient")   # (the second-argument sums: dim <= 4)
+    if route == FUSED:      # (the library says where the second-argument sums exist and pay: sk_route_query(SK_OP_ADJOINT_SYM))
+        return hasattr(be, "second_argument_gradient") and _route(be, OP_ADJOINT_SYM, static_kernel, Xd, Xd, dyadic, naive, True) == FUSED
     if route == STREAM:
         return Xd.shape[2] <= (8 if fused[0] == 0 else 32)
     return False

@@ -1,6 +1,8 @@
 """The C-ABI library builds, loads and exports every symbol include/sigkernel_amd.h declares.
 No compute calls: this runs without a GPU."""
 import ctypes
+import glob
+import sys
 import os
 import re
 
@@ -244,3 +246,21 @@ def test_host_layer_reads_its_route_switches_once(monkeypatch):
     r.reload()
     assert r.no_fused_rbf and not r.no_fused_mb                    # ... until asked
     assert set(_routes._ENV) == set(_routes.Routes.__slots__)
+
+
+def test_kernel_variants_stay_within_their_budget():
+    """Every kernel instance of the build (tools/variants.py over the ISA csrc/Makefile keeps): none may start spilling or spill more
+    than the committed table says (profiles/r05_variants.txt: VGPRs, scratch bytes per instance; the seven that spill are named in
+    DESIGN.md with the A/B that keeps them), and the instance count / library size stay under the round's budget -- a new route pays
+    for its variants by removing others."""
+    import subprocess
+    obj = os.path.join(ROOT, "sigkernel_amd", "csrc", "obj")
+    if not glob.glob(os.path.join(obj, "*gfx950.s")):
+        pytest.skip("no ISA listings (the library was built elsewhere)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py"), "--check", os.path.join(ROOT, "profiles", "r05_variants.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py")], capture_output=True, text=True)
+    n = len([ln for ln in r.stdout.splitlines()[1:] if ln.strip()])
+    assert 0 < n <= 660, n
+    assert os.path.getsize(os.path.join(ROOT, "sigkernel_amd", "libsigkernel_amd.so")) <= 10 * (1 << 20)

@@ -61,6 +61,11 @@ TABLE = [
     ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
     # never swapped: the gradient is the first argument's
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
+    # compute_Gram(X, X, sym=True) with a gradient (SK_OP_ADJOINT_SYM): the triangle with the second-argument sums for rbf, fp64, dim <= 4,
+    # 64 points at dyadic 1..2 / 128 at dyadic 0; all pairs otherwise (profiles/r05_yside_ab.txt)
+    ((2, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED), ((2, 1, 3, 65, 65, 1, False, 8), STREAM, STREAM), ((2, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED),
+    ((2, 1, 4, 128, 128, 0, False, 8), FUSED, FUSED), ((2, 1, 5, 64, 64, 1, False, 8), STREAM, STREAM), ((2, 0, 3, 64, 64, 1, False, 8), STREAM, STREAM),
+    ((2, 1, 3, 64, 64, 1, False, 4), STREAM, STREAM),
     # outside: other kernels, dim > 16, dyadic > 2, single points
     ((FWD, 2, 3, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 17, 30, 30, 1, False, 8), STREAM, STREAM),
     ((ADJ, 1, 17, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 3, 30, 30, 3, False, 8), STREAM, STREAM),

@@ -10,6 +10,7 @@ import sigkernel_amd
 def walk(g, A, M, D, dt): return (torch.cumsum(torch.randn(A, M, D, generator=g, dtype=torch.float64), 1) / np.sqrt(M * D)).to(dt).cuda()
 g = torch.Generator().manual_seed(0)
 shapes = ((8, 8), (20, 33), (64, 64), (65, 65), (100, 90), (128, 128), (129, 40), (40, 129), (257, 161), (300, 520))
+if len(sys.argv) > 1: shapes = shapes[int(sys.argv[1])::int(sys.argv[2])]      # a slice of the shapes: reach_sweep.py <first> <stride>
 n = 0
 for kname, D, d, naive, dt in itertools.product(("linear", "rbf"), (3, 5, 9, 20), (0, 1, 2, 3), (False, True), (torch.float64, torch.float32)):
     k = sigkernel_amd.RBFKernel(0.9) if kname == "rbf" else sigkernel_amd.LinearKernel()
@@ -29,6 +30,7 @@ for kname, D, d, naive, dt in itertools.product(("linear", "rbf"), (3, 5, 9, 20)
         if not naive and max(M, N) <= 130 and d <= 2:
             sk.compute_kernel_and_derivatives_Gram(X, Y, torch.randn(A, M, D, generator=g).to(dt).cuda())
         n += 1
+        if n % 50 == 0: print(n, "combinations", flush=True)
 # big batches (work queue, age-rank shares, triangular blocks), long paths (bands on several waves)
 for kname, D, d, A, M in (("linear", 8, 1, 512, 128), ("rbf", 4, 2, 512, 64), ("rbf", 3, 1, 128, 64), ("rbf", 16, 2, 64, 512), ("linear", 4, 0, 8, 2048), ("rbf", 3, 1, 4, 1500)):
     k = sigkernel_amd.RBFKernel(1.0) if kname == "rbf" else sigkernel_amd.LinearKernel()

@@ -56,9 +56,10 @@ def main():
         f = sys.argv[sys.argv.index("--reached") + 1]
         args = [a for a in args if a != f]
         reached = {}
-        for r in csv.DictReader(open(f)):
-            n = norm(r["Name"])
-            reached[n] = reached.get(n, 0) + int(r["Calls"])
+        for ff in sorted(glob.glob(os.path.join(f, "**", "*kernel_stats.csv"), recursive=True)) if os.path.isdir(f) else [f]:
+            for r in csv.DictReader(open(ff)):
+                n = norm(r["Name"])
+                reached[n] = reached.get(n, 0) + int(r["Calls"])
     if args:
         rows = [r for r in rows if all(a in r["pretty"] or a in r["unit"] for a in args)]
     print("unit\tvgpr\taccum_off\tsgpr\tscratch\tlds\t%sinstance\tmangled" % ("launches\t" if reached is not None else ""))
