@@ -367,14 +367,16 @@ int sk_solve_fwd_rbf_f32(const double *Xr, const double *Yt, int64_t A, int64_t 
 /* Symmetric Gram matrix of ONE path batch with the fused kernels above: only the A (A + 1) / 2 pairs on and above the diagonal are
  * solved (what the reference's CPU solver does for sym=True, cython_backend.pyx:74-97; its GPU path ignores `sym`), in ONE launch,
  * and each value is written to out[a][b] and out[b][a]: out [A][A] is exactly symmetric.  dXr / dXt (Xr / Xt): the row-major and
- * the dimension-major staging of the SAME paths, as sk_solve_fwd_linear_* (sk_solve_fwd_rbf_*) take them; Mc = Nc = M - 1. */
-int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+ * the dimension-major staging of the SAME paths, as sk_solve_fwd_linear_* (sk_solve_fwd_rbf_*) take them; Mc = Nc = M - 1.
+ * pair_tab: the triangle's pairs as [A (A + 1) / 2][2] int32 (a, b), written by sk_prep_cat_* (tri_n = -1) RIGHT BEHIND dXt / Xt
+ * (pair_tab == (int *)(Xt + A 8 Ncp)): the kernel looks pairs up there instead of inverting the triangular numbering itself. */
+int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                                 int scheme, double *out, void *queue, void *stream);
-int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                                 int scheme, float *out, void *queue, void *stream);
-int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                              int scheme, double inv_sigma, double *out, void *queue, void *stream);
-int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                              int scheme, double inv_sigma, float *out, void *queue, void *stream);
 
 /* Forward solve with the static kernel fused in for LONG or WIDE paths (csrc/sk_wave_fused_mb.hip): any number of bands per
@@ -518,7 +520,10 @@ int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd
  *
  * sk_prep_cat_*: Z = [X; Y] (X [A,M,D], Y [B,M,D], same length) staged in BOTH layouts from the two batches -- no concatenated
  *   copy: out_rows [A+B][rows][fd] (scaled by scale_rows), optionally out_rows2 (the same scaled by scale_rows2: the linear
- *   adjoint's rows carry s^2, the forward's kappa s^2), out_cols [A+B][fd][cols] (unscaled); diff as sk_prep_paths_*.
+ *   adjoint's rows carry s^2, the forward's kappa s^2), out_cols [A+B][fd][cols] (unscaled); diff as sk_prep_paths_*.  pair_tab
+ *   (nullable): the pairs of a triangular layout as [P][2] int32 (a, b), written by the same launch -- tri_n >= 0: the loss layout
+ *   below; tri_n = -1: the inclusive upper triangle of all A + B paths (sk_solve_fwd_*_sym_*); sk_solve_fwd_loss_f64 wants it
+ *   RIGHT BEHIND out_cols (pair_tab == (int *)(out_cols + (A+B) fd cols), fd = 8): its kernel finds the table from the columns' address.
  * sk_solve_fwd_loss_f64: ONE fused forward launch over the LOSS LAYOUT of pairs: the rectangle K(Z[0..A), Z) -- A (A+B) pairs,
  *   pair (a, b) at a (A+B) + b, whose column blocks are K(X, X) and K(X, Y) -- followed by the STRICT upper triangle (i < j,
  *   row-major) of K(Y, Y), tri_n (tri_n - 1) / 2 pairs (tri_n = B, or 0: no K_YY term; the diagonals never enter the unbiased
@@ -538,11 +543,11 @@ int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd
  *   order; X: the fp64 points (rbf); scale2 = s^4 / s^2-staging factor of the linear rows (the wrapper's `param ** 2`);
  *   gscale: a DEVICE scalar (nullable = 1) multiplied into the result. */
 int sk_prep_cat_f64(const double *X, int64_t A, const double *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
-                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, int *pair_tab, int64_t tri_n, void *stream);
 int sk_prep_cat_f32(const float *X, int64_t A, const float *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
-                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream);
-int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, int64_t A, int64_t B, int64_t tri_n, int Mrows, int Mc,
-                          int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream);
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, int *pair_tab, int64_t tri_n, void *stream);
+int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, const int *pair_tab, int64_t A, int64_t B, int64_t tri_n,
+                          int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream);
 int sk_loss_value_f64(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, void *stream);
 int sk_loss_weights_f64(int64_t A, int64_t B, const double *grad_out, double *go, void *stream);
 int sk_rbf_adjoint_finish_f64(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,

@@ -83,10 +83,10 @@ SIGNATURES = {
     "sk_rbf_adjoint_fused_mb_layout": (_int, [_i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sk_rbf_adjoint_fused_mb_f64": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp,
                                            _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
-    "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
-    "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
-    "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
-    "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_sym_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_linear_sym_f32": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f64": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
+    "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
@@ -114,9 +114,9 @@ SIGNATURES = {
     "sk_static_deriv_increments_f32": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _vp, _i64, _i64, _int, _int, _int,
                                               ctypes.c_double, _vp, _vp, _vp, _i64, _vp]),
     "sk_solve_deriv_f64": (_int, [_vp, _vp, _vp, _i64, _i64, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_prep_cat_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
-    "sk_prep_cat_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp]),
-    "sk_solve_fwd_loss_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "sk_prep_cat_f64": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp]),
+    "sk_prep_cat_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp, _vp, _int, _vp, _int, _int, _vp, _i64, _vp]),
+    "sk_solve_fwd_loss_f64": (_int, [_int, ctypes.c_double, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "sk_loss_value_f64": (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "sk_loss_weights_f64": (_int, [_i64, _i64, _vp, _vp, _vp]),
     "sk_rbf_adjoint_finish_f64": (_int, [_vp, _i64, _i64, _int, _int, _vp, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
@@ -467,18 +467,21 @@ class HipBackend:
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         with _device(dev):
             two_rows = kind == 0 and keep_edges      # the linear adjoint's rows carry s^2, the forward's kappa s^2
-            nr = Z * Mrows * 8
-            buf = torch.empty(nr * (2 if two_rows else 1) + Z * 8 * Ncp, dtype=torch.float64, device=dev)
+            nr, nt = Z * Mrows * 8, Z * 8 * Ncp
+            # one allocation: rows [| rows of the adjoint] | columns | the pair table [P][2] int32 right behind the columns
+            buf = torch.empty(nr * (2 if two_rows else 1) + nt + P, dtype=torch.float64, device=dev)
             Zr = buf[:nr].view(Z, Mrows, 8)
             Zr2 = buf[nr:2 * nr].view(Z, Mrows, 8) if two_rows else None
-            Zt = buf[nr * (2 if two_rows else 1):].view(Z, 8, Ncp)
+            t0 = nr * (2 if two_rows else 1)
+            Zt = buf[t0:t0 + nt].view(Z, 8, Ncp)
+            tab = buf[t0 + nt:]
             if kind == 0:
                 kappa = float(lib.sk_linear_prescale(int(dyadic)))
                 s_rows, s_rows2, diff = kappa * float(param) ** 2, float(param) ** 2, 1
             else:
                 s_rows, s_rows2, diff = 1.0, 1.0, 0
             _check(lib.sk_prep_cat_f64(_ptr(X), A, _ptr(Y), B, M, D, diff, s_rows, s_rows2, _ptr(Zr), _ptr(Zr2), Mrows, _ptr(Zt), Ncp, 8,
-                                       _stream(X)), "sk_prep_cat")
+                                       _ptr(tab), B if with_yy else 0, _stream(X)), "sk_prep_cat")
             edges = None
             if keep_edges:
                 if kind == 0:
@@ -489,7 +492,7 @@ class HipBackend:
                     return None
                 edges = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
             out = torch.empty(P, dtype=torch.float64, device=dev)
-            rc = lib.sk_solve_fwd_loss_f64(int(kind), 1.0 / float(param) if kind == 1 else 0.0, _ptr(Zr), _ptr(Zt), A, B, B if with_yy else 0,
+            rc = lib.sk_solve_fwd_loss_f64(int(kind), 1.0 / float(param) if kind == 1 else 0.0, _ptr(Zr), _ptr(Zt), _ptr(tab), A, B, B if with_yy else 0,
                                            Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme, _ptr(out), _ptr(edges), _ptr(_queue(dev, P)), _stream(X))
             if rc == 2:
                 return None
@@ -509,6 +512,8 @@ class HipBackend:
             _check(load().sk_loss_weights_f64(A, B, _ptr(g), _ptr(go), _stream(go)), "sk_loss_weights")
         return go
 
+    SYM_TABLE_MAX_PAIRS = 1 << 26
+
     def solve_fwd_fused_sym(self, kind, param, X, dyadic, naive):
         """Symmetric Gram matrix K[a][b] = k(x_a, x_b) of ONE batch with the static kernel formed inside the solver: only the pairs
         on and above the diagonal are solved, in one launch, each written twice (sk_solve_fwd_linear_sym_* / sk_solve_fwd_rbf_sym_*).
@@ -520,18 +525,28 @@ class HipBackend:
         if D > 8 or dyadic > 2 or Mc < 1 or rows > 64 * (4 >> min(dyadic, 2)) or (kind == 1 and not float(param) > 0):
             return None
         Mrows, Ncp = 256, ((Mc if kind == 0 else M) + 15) // 16 * 16
+        P = A * (A + 1) // 2
+        if P > self.SYM_TABLE_MAX_PAIRS:      # (the pair table is 8 bytes per pair: beyond 0.5 GiB the caller's blocked triangle serves)
+            return None
         out = torch.empty(A, A, dtype=X.dtype, device=X.device)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
         lib = load()
         with _device(X.device):
+            # one allocation, ONE staging launch (sk_prep_cat_*): rows | columns | the triangle's pairs [P][2] int32 right behind them
+            nr, nt = A * Mrows * 8, A * 8 * Ncp
+            buf = torch.empty(nr + nt + P, dtype=torch.float64, device=X.device)
+            Xr, Xt, tab = buf[:nr], buf[nr:nr + nt], buf[nr + nt:]
             if kind == 0:
-                kappa = float(lib.sk_linear_prescale(int(dyadic)))
-                Xr, Xt = _prep_pair(X, X, True, kappa * float(param) ** 2, Mrows, Ncp)
-                rc = getattr(lib, "sk_solve_fwd_linear_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic),
+                s_rows, diff = float(lib.sk_linear_prescale(int(dyadic))) * float(param) ** 2, 1
+            else:
+                s_rows, diff = 1.0, 0
+            _check(getattr(lib, "sk_prep_cat_" + _suffix(X))(_ptr(X), A, None, 0, M, D, diff, s_rows, 1.0, _ptr(Xr), None, Mrows, _ptr(Xt), Ncp, 8,
+                                                             _ptr(tab), -1, _stream(X)), "sk_prep_cat")
+            if kind == 0:
+                rc = getattr(lib, "sk_solve_fwd_linear_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), _ptr(tab), A, Mrows, Mc, Mc, Ncp, D, int(dyadic),
                                                                            scheme, _ptr(out), _ptr(_queue(X.device)), _stream(X))
             else:
-                Xr, Xt = _prep_pair(X, X, False, 1.0, Mrows, Ncp)
-                rc = getattr(lib, "sk_solve_fwd_rbf_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), A, Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme,
+                rc = getattr(lib, "sk_solve_fwd_rbf_sym_" + _suffix(X))(_ptr(Xr), _ptr(Xt), _ptr(tab), A, Mrows, Mc, Mc, Ncp, D, int(dyadic), scheme,
                                                                         1.0 / float(param), _ptr(out), _ptr(_queue(X.device)), _stream(X))
         if rc == 2:
             return None

@@ -117,9 +117,11 @@ int solve_fwd_static(int kind, double param, const double *Xr, const void *Yt, i
 
 // symmetric Gram of ONE path batch: only the A (A + 1) / 2 pairs on and above the diagonal are solved, each written twice
 template <typename TO>
-int solve_fwd_sym(int kind, const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int solve_fwd_sym(int kind, const double *Xr, const double *Xt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                   int scheme, double inv_sigma, TO *out, void *queue, void *stream) {
     if (D < 1 || !Xr || !Xt || !out || A < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    // the pair table of sk_prep_cat_* (tri_n = -1) lies right behind the staged columns: the kernel finds it from Xt
+    if (reinterpret_cast<const void *>(pair_tab) != reinterpret_cast<const void *>(Xt + A * (int64_t)8 * Ncp)) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
     if (kind == 1 && (!(inv_sigma > 0.0) || !(inv_sigma < 1e300))) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
@@ -400,21 +402,21 @@ int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void
                                    workspace_bytes, stream);
 }
 
-int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int sk_solve_fwd_linear_sym_f64(const double *dXr, const double *dXt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                                 int scheme, double *out, void *queue, void *stream) {
-    return solve_fwd_sym<double>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
+    return solve_fwd_sym<double>(0, dXr, dXt, pair_tab, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
 }
-int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+int sk_solve_fwd_linear_sym_f32(const double *dXr, const double *dXt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
                                 int scheme, float *out, void *queue, void *stream) {
-    return solve_fwd_sym<float>(0, dXr, dXt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
+    return solve_fwd_sym<float>(0, dXr, dXt, pair_tab, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, 0.0, out, queue, stream);
 }
-int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, double *out, void *queue, void *stream) {
-    return solve_fwd_sym<double>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
+int sk_solve_fwd_rbf_sym_f64(const double *Xr, const double *Xt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, double inv_sigma, double *out, void *queue, void *stream) {
+    return solve_fwd_sym<double>(1, Xr, Xt, pair_tab, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
 }
-int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
-                             int scheme, double inv_sigma, float *out, void *queue, void *stream) {
-    return solve_fwd_sym<float>(1, Xr, Xt, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
+int sk_solve_fwd_rbf_sym_f32(const double *Xr, const double *Xt, const int *pair_tab, int64_t A, int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic,
+                                int scheme, double inv_sigma, float *out, void *queue, void *stream) {
+    return solve_fwd_sym<float>(1, Xr, Xt, pair_tab, A, Mrows, Mc, Nc, Ncp, D, dyadic, scheme, inv_sigma, out, queue, stream);
 }
 
 int sk_solve_fwd_rbf_edges_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
@@ -670,23 +672,30 @@ int sk_solve_deriv_f32(const float *inc, const float *inc_d, const float *inc_dd
 }
 
 int sk_prep_cat_f64(const double *X, int64_t A, const double *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
-                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream) {
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, int *pair_tab, int64_t tri_n, void *stream) {
     if ((A > 0 && !X) || (B > 0 && !Y) || !out_rows || !out_cols || A < 0 || B < 0 || M < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
     if (rows < (diff ? M - 1 : M) || cols < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (pair_tab && (tri_n < -1 || tri_n > B || A + B > 0x7fffffffLL)) return SK_ERR_BAD_ARG;
     if (A + B == 0) return SK_OK;
-    return launch_prep_cat<double>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, (hipStream_t)stream);
+    return launch_prep_cat<double>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, pair_tab, tri_n,
+                               (hipStream_t)stream);
 }
 int sk_prep_cat_f32(const float *X, int64_t A, const float *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2,
-                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, void *stream) {
+                    double *out_rows, double *out_rows2, int rows, double *out_cols, int cols, int fd, int *pair_tab, int64_t tri_n, void *stream) {
     if ((A > 0 && !X) || (B > 0 && !Y) || !out_rows || !out_cols || A < 0 || B < 0 || M < 1 || D < 1 || fd < D) return SK_ERR_BAD_ARG;
     if (rows < (diff ? M - 1 : M) || cols < (diff ? M - 1 : M) || (diff && M < 2)) return SK_ERR_BAD_ARG;
+    if (pair_tab && (tri_n < -1 || tri_n > B || A + B > 0x7fffffffLL)) return SK_ERR_BAD_ARG;
     if (A + B == 0) return SK_OK;
-    return launch_prep_cat<float>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, (hipStream_t)stream);
+    return launch_prep_cat<float>(X, A, Y, B, M, D, diff != 0, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, fd, pair_tab, tri_n,
+                               (hipStream_t)stream);
 }
 
-int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, int64_t A, int64_t B, int64_t tri_n, int Mrows, int Mc,
-                          int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream) {
+int sk_solve_fwd_loss_f64(int kind, double param, const double *Zr, const double *Zt, const int *pair_tab, int64_t A, int64_t B, int64_t tri_n,
+                          int Mrows, int Mc, int Nc, int Ncp, int D, int dyadic, int scheme, double *out, double *edges, void *queue, void *stream) {
     if (D < 1 || !Zr || !Zt || !out || A < 1 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
+    // the pair table of sk_prep_cat_* lies right behind the staged columns (the kernel finds it from Zt: no pointer of its own in the
+    // scalar registers of every launch)
+    if (reinterpret_cast<const void *>(pair_tab) != reinterpret_cast<const void *>(Zt + (A + B) * (int64_t)8 * Ncp)) return SK_ERR_BAD_ARG;
     if ((kind != 0 && kind != 1) || (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE)) return SK_ERR_BAD_ARG;
     if (kind == 1 && (!(param > 0.0) || !(param < 1e300))) return SK_ERR_BAD_ARG;
     if (tri_n != 0 && tri_n != B) return SK_ERR_BAD_ARG;

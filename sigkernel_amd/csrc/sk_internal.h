@@ -161,7 +161,7 @@ int launch_fwd_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
 // ---- sk_loss.hip: the glue of the loss wrappers (compute_mmd / scoring rules) as single launches ----
 template <typename T>
 int launch_prep_cat(const T *X, int64_t A, const T *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2, double *out_rows,
-                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, hipStream_t s);
+                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, int *pair_tab, int64_t tri_n, hipStream_t s);
 int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, hipStream_t s);
 int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go, hipStream_t s);
 int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,

@@ -21,10 +21,35 @@ namespace {
 template <typename T, bool DIFF>
 __global__ __launch_bounds__(256) void k_prep_cat(const T *__restrict__ X, int64_t A, const T *__restrict__ Y, int64_t B, int M, int D,
                                                   double scale_rows, double scale_rows2, double *__restrict__ out_rows,
-                                                  double *__restrict__ out_rows2, int rows, double *__restrict__ out_cols, int cols, int FDp) {
+                                                  double *__restrict__ out_rows2, int rows, double *__restrict__ out_cols, int cols, int FDp,
+                                                  int *__restrict__ pair_tab, int64_t tri_n) {
     const int64_t Z = A + B;
     const int64_t nr = Z * (int64_t)rows * FDp, nc = Z * (int64_t)cols * FDp;
     const int nvalid = DIFF ? M - 1 : M;
+    // the pairs of a triangular layout, (a, b) per pair.  tri_n >= 0, the LOSS layout: the rectangle A x (A + B), then the strict upper
+    // triangle (i < j, row-major) of the tri_n paths from Z[A] on;  tri_n = -1, the SYMMETRIC Gram: the inclusive upper triangle (a <= b,
+    // row-major) of all A + B paths
+    const bool sym = tri_n < 0;
+    const int64_t P_rect = pair_tab && !sym ? A * Z : 0;
+    const int64_t P_all = !pair_tab ? 0 : sym ? Z * (Z + 1) / 2 : P_rect + (tri_n > 1 ? tri_n * (tri_n - 1) / 2 : 0);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P_all; p += (int64_t)gridDim.x * blockDim.x) {
+        int64_t a, b;
+        if (p < P_rect) {
+            a = p / Z;
+            b = p - a * Z;
+        } else {          // pair q of the inclusive triangle of n1 paths; the strict triangle of n = that of n - 1 with b shifted by one
+            const int64_t q = p - P_rect, n1 = sym ? Z : tri_n - 1, off = sym ? 0 : A, shift = sym ? 0 : 1;
+            const double t = (double)(2 * n1 + 1);
+            int64_t r = (int64_t)((t - sqrt(t * t - 8.0 * (double)q)) * 0.5);
+            r = r < 0 ? 0 : (r >= n1 ? n1 - 1 : r);
+            while (r > 0 && r * n1 - r * (r - 1) / 2 > q) --r;
+            while (r + 1 < n1 && (r + 1) * n1 - (r + 1) * r / 2 <= q) ++r;
+            a = off + r;
+            b = off + r + (q - (r * n1 - r * (r - 1) / 2)) + shift;
+        }
+        pair_tab[2 * p] = (int)a;
+        pair_tab[2 * p + 1] = (int)b;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nr + nc; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t z;
         int p, j;
@@ -187,16 +212,16 @@ inline unsigned grid_for(int64_t n) {
 
 template <typename T>
 int launch_prep_cat(const T *X, int64_t A, const T *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2, double *out_rows,
-                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, hipStream_t s) {
+                    double *out_rows2, int rows, double *out_cols, int cols, int FDp, int *pair_tab, int64_t tri_n, hipStream_t s) {
     const int64_t n = (A + B) * (int64_t)(rows + cols) * FDp;
-    if (diff) hipLaunchKernelGGL((k_prep_cat<T, true>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp);
-    else hipLaunchKernelGGL((k_prep_cat<T, false>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp);
+    if (diff) hipLaunchKernelGGL((k_prep_cat<T, true>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
+    else hipLaunchKernelGGL((k_prep_cat<T, false>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
     return check_launch();
 }
 template int launch_prep_cat<double>(const double *, int64_t, const double *, int64_t, int, int, int, double, double, double *, double *, int, double *,
-                                     int, int, hipStream_t);
+                                     int, int, int *, int64_t, hipStream_t);
 template int launch_prep_cat<float>(const float *, int64_t, const float *, int64_t, int, int, int, double, double, double *, double *, int, double *,
-                                    int, int, hipStream_t);
+                                    int, int, int *, int64_t, hipStream_t);
 
 int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, hipStream_t s) {
     if ((A + B) * A + B * B >= 0x7fffffffLL) return SK_ERR_UNSUPPORTED;     // (32-bit indices; the loss wrappers' merged route ends far below)

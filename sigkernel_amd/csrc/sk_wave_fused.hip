@@ -149,17 +149,6 @@ __device__ __forceinline__ void lds_read_units<4>(d2_t (&v)[4], unsigned a) {
                  : "memory");
 }
 
-// pair p of the row-major upper triangle (diagonal included) of an A x A matrix -> (a, b), a <= b
-__device__ __forceinline__ void tri_split(int64_t p, int64_t A, int64_t &a, int64_t &b) {
-    const double t = (double)(2 * A + 1);
-    int64_t r = (int64_t)((t - sqrt(t * t - 8.0 * (double)p)) * 0.5);
-    r = r < 0 ? 0 : (r >= A ? A - 1 : r);
-    while (r > 0 && r * A - r * (r - 1) / 2 > p) --r;                       // first pair of row r: r A - r (r - 1) / 2
-    while (r + 1 < A && (r + 1) * A - (r + 1) * r / 2 <= p) ++r;
-    a = r;
-    b = r + (p - (r * A - r * (r - 1) / 2));
-}
-
 // x-row reloads straight into the row registers (read-write operands: under a divergent branch the inactive lanes keep theirs).
 // No wait inside: lds_rows_wait (or any later s_waitcnt lgkmcnt(0) that precedes the first use) hands the rows over.
 __device__ __forceinline__ void lds_rows_wait(d2_t (&r)[4]) {
@@ -364,23 +353,15 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // by NUp), and the pair -> (a, b) split uses 32-bit arithmetic whenever the pair count allows: the 64-bit division
     // sequence is ~150 scalar instructions, and there are G of them per call.
     const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
-    // (one triangle enumeration serves both layouts: the symmetric Gram is an empty rectangle + the INCLUSIVE triangle of all B paths,
-    // the loss layout A rows x B + the STRICT triangle of tri_n paths from Z[A] on = the inclusive one of tri_n - 1 with b shifted by one)
+    // (the pairs of the triangular layouts -- symmetric Gram, loss layout -- come from a table [P][2] of int32 (a, b) that sk_prep_cat_*
+    // writes right BEHIND the staged columns: found from dYt, B and Ncp, which the producers hold anyway.  The triangle arithmetic
+    // inside this kernel -- a square root and two correction loops per look-up, inlined four times -- sat in the scalar registers of
+    // EVERY launch: 25 v_readlane / v_writelane in the headline variant against 17 without it, profiles/r05_ab_r04_vs_r05.txt)
     auto split_ab = [&](int64_t p, bool want_b) __attribute__((always_inline)) -> int64_t {
         if (prm.B <= 0) return p;
-        // (an opaque copy: the layout's constants are then worked out HERE, eight macro-steps apart, instead of being hoisted out of the
-        // step loop into scalar registers the loop does not have -- they came back as v_readlane in every macro-step)
-        int tri_now = prm.tri;
-        asm volatile("" : "+s"(tri_now));
-        const int mode = tri_now & 3;
-        if (mode) {
-            const int64_t A_ = mode == 2 ? (tri_now >> 2) & 0x7fff : 0, strict = mode == 2 ? 1 : 0;
-            const int64_t n_ = mode == 2 ? (tri_now >> 17) & 0x7fff : prm.B, P_rect = A_ * prm.B;
-            if (p >= P_rect) {
-                int64_t a, b;
-                tri_split(p - P_rect, n_ - strict, a, b);
-                return A_ + (want_b ? b + strict : a);
-            }
+        if (prm.tri) {
+            const int *tab = reinterpret_cast<const int *>(prm.dYt + prm.B * (int64_t)FD * prm.Ncp);
+            return (int64_t)tab[2 * p + (want_b ? 1 : 0)];
         }
         if (want_b) return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
         return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
@@ -767,8 +748,8 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
                 if ((prm.tri & 3) == 1) {      // the pair and its mirror image
-                    int64_t a, b;
-                    tri_split(pair_v, prm.B, a, b);
+                    const int *tab = reinterpret_cast<const int *>(prm.dYt + prm.B * (int64_t)FD * prm.Ncp);
+                    const int64_t a = tab[2 * pair_v], b = tab[2 * pair_v + 1];
                     static_cast<TO *>(prm.out)[a * prm.B + b] = (TO)v;
                     static_cast<TO *>(prm.out)[b * prm.B + a] = (TO)v;
                 } else {
@@ -998,6 +979,7 @@ int launch_fused_dy(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) 
 template <typename TO, int KIND>
 int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                      double inv_sigma, TO *out, double *strip_edges, void *queue, hipStream_t s, int tri = 0, const int64_t *loss = nullptr) {
+    // (tri = 2: the caller -- sk_solve_fwd_loss_f64 -- has checked that the pair table lies behind dYt)
     if (tri == 1 && (strip_edges || A != B || g.P != A * (A + 1) / 2)) return SK_ERR_UNSUPPORTED;
     // the loss layout: loss = {tri_n, tri_off}; A rows against the B paths of the one batch, then the strict triangle of tri_n of them
     if (tri == 2 && (!loss || B <= 0 || loss[0] < 0 || loss[1] != A || loss[0] + loss[1] > B || A > B ||
