@@ -117,14 +117,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     // ---- producers: the rings of sk_wave_fused.hip, filled in FLIPPED order ------------------------------------------------
     // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
     // columns stay in original order inside the 16-byte unit, as in the increment matrix the unfused kernel reads)
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {   // B == 0: paired, pair p = (x_p, y_p)
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+        return (int64_t)((uint32_t)p % (uint32_t)prm.B);   // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P)
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
@@ -485,7 +484,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
                     break;
                 }
     }
-    if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+    if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
     const int64_t groups = g.P / PPG;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC;

@@ -199,14 +199,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu((FD ==
         }
     };
 
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+        return (int64_t)((uint32_t)p % (uint32_t)prm.B);   // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P)
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
     double *const wsrow = prm.ws + wave_id * prm.ws_stride;
 
@@ -836,14 +835,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(FD == 
         }
     };
 
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+        return (int64_t)((uint32_t)p % (uint32_t)prm.B);   // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P)
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
     double *const wsrow = prm.ws + wave_id * prm.ws_stride;
     const unsigned my_x = lds0 + X_BASE + (unsigned)(lam7 * RC * XROW);

@@ -172,14 +172,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int k = 0; k < RC; ++k) row_ok[k] = Mcp - 1 - (lam * RC + k) < prm.Mc;
 
     // ---- producers: the rings of sk_wave_fused.hip (points), filled in FLIPPED order --------------------------------------
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+        return (int64_t)((uint32_t)p % (uint32_t)prm.B);   // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P)
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
     int y_pi = 0, y_u0 = 0, y_slot = 0, y_par = 0;
     auto issue_y = [&]() {
@@ -691,7 +690,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
                     break;
                 }
     }
-    if (PPG > 0x3fffffff / NUp) return SK_ERR_UNSUPPORTED;
+    if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
     const int64_t groups = g.P / PPG;
     const int OUTW = ND + 2;
     if (ppg_out) *ppg_out = (int)PPG;

@@ -352,7 +352,6 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // The producers run once per 8 macro-steps with wave-uniform control.  Their cursors advance incrementally (no division
     // by NUp), and the pair -> (a, b) split uses 32-bit arithmetic whenever the pair count allows: the 64-bit division
     // sequence is ~150 scalar instructions, and there are G of them per call.
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     // (the pairs of the triangular layouts -- symmetric Gram, loss layout -- come from a table [P][2] of int32 (a, b) that sk_prep_cat_*
     // writes right BEHIND the staged columns: found from dYt, B and Ncp, which the producers hold anyway.  The triangle arithmetic
     // inside this kernel -- a square root and two correction loops per look-up, inlined four times -- sat in the scalar registers of
@@ -363,8 +362,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             const int *tab = reinterpret_cast<const int *>(prm.dYt + prm.B * (int64_t)FD * prm.Ncp);
             return (int64_t)tab[2 * p + (want_b ? 1 : 0)];
         }
-        if (want_b) return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P in a Gram launch -- the 64-bit division sequence is ~150 scalar
+        // instructions, and it used to be inlined here twice for a case that cannot occur)
+        if (want_b) return (int64_t)((uint32_t)p % (uint32_t)prm.B);
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
     auto split_b = [&](int64_t p) -> int64_t { return split_ab(p, true); };
     auto split_a = [&](int64_t p) -> int64_t { return split_ab(p, false); };

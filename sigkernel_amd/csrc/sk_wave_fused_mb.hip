@@ -312,14 +312,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     const unsigned my_x = lds0 + X_BASE + (unsigned)((lam & 7) * RC * XROW);
     int tband = 0;   // split mode: the true band of this lane's path-read cursor (`band` itself stays 0: nb = 1)
 
-    const bool small = prm.P <= 0x7fffffffLL && prm.B <= 0x7fffffffLL;
     auto split_b = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p % (uint32_t)prm.B) : p % prm.B;
+        return (int64_t)((uint32_t)p % (uint32_t)prm.B);   // (32-bit: the launcher refuses P >= 2^31 - 2^20, and B <= P)
     };
     auto split_a = [&](int64_t p) -> int64_t {
         if (prm.B <= 0) return p;
-        return small ? (int64_t)((uint32_t)p / (uint32_t)prm.B) : p / prm.B;
+        return (int64_t)((uint32_t)p / (uint32_t)prm.B);
     };
 
     // the wave's boundary row in global memory: [NUp][E] doubles, position = the producing / consuming lane's unit u
