@@ -302,7 +302,10 @@ class _SigKernel(torch.autograd.Function):
             return torch.ones(A, dtype=X.dtype, device=X.device)   # an empty batch: an empty result, like the CPU reference
         Xd, Yd = X.detach(), Y.detach()
         ctx.kept_edges = None
-        if X.requires_grad and hasattr(be, "solve_fwd_keep_edges"):
+        # (whether a gradient can be ASKED for -- not X.requires_grad: under torch.no_grad() a leaf X must not make the forward keep edges,
+        # take the adjoint's kernel family or up-cast fp32 paths)
+        need = bool(ctx.needs_input_grad[0])
+        if need and hasattr(be, "solve_fwd_keep_edges"):
             # a gradient is pending: the forward keeps the terminal edges of every pair (8 (MM + NN) bytes each; a paired batch is
             # small), so that backward is ONE adjoint launch instead of a second forward sweep + the adjoint
             edge_bytes = 8.0 * A * (((M - 1) << dyadic_order) + ((N - 1) << dyadic_order) + 32)
@@ -319,7 +322,7 @@ class _SigKernel(torch.autograd.Function):
                     return K
         K = _fused_forward(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, gram=False)
         if K is not None:
-            ctx.K = K.detach() if X.requires_grad else None     # forward values: what arms the fused adjoint's device-side rescue
+            ctx.K = K.detach() if need else None     # forward values: what arms the fused adjoint's device-side rescue
             return K
         K = torch.empty(A, dtype=X.dtype, device=X.device)
         per_row = 2 * M * N * X.element_size()
@@ -588,17 +591,18 @@ class _SigKernelGram(torch.autograd.Function):
         if M < 2 or N < 2 or A == 0 or B == 0:   # single points: k = 1; an empty batch: an empty matrix
             return torch.ones(A, B, dtype=X.dtype, device=X.device)
         Xd, Yd = X.detach(), Y.detach()
+        need, need_y = bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1])      # (not need: see _SigKernel.forward)
         # `sym`: the reference's GPU path ignores it (sigkernel.py:366-382) and its CPU path silently assumes X is Y.
         # Here it halves the work when that assumption can be checked (same storage) and no gradient is needed.
         ctx.sym_blocks = None
         if sym and _same_storage(Xd, Yd):
-            if not X.requires_grad and not Y.requires_grad:
+            if not need and not need_y:
                 return _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes)
             # with a gradient: the triangular forward AND a triangular adjoint (a pair above the diagonal also stands for
             # its mirror image, through the second-argument contraction of the same W) -- fused static kernels only
             # (the fused linear adjoint is faster on all pairs than the unfused one on the triangle: 14 vs 20 ms at the C3 shape)
             # (long / wide RBF paths: the multi-band fused adjoint on ALL pairs beats the unfused triangle -- C5's shape 0.29 s against 0.46 s)
-            if X.requires_grad and Y.requires_grad and _sym_triangle_ok(be, static_kernel, Xd, dyadic_order, _naive_solver):
+            if need and need_y and _sym_triangle_ok(be, static_kernel, Xd, dyadic_order, _naive_solver):
                 ctx.sym_blocks = []
                 K = _gram_symmetric(be, static_kernel, Xd.contiguous(), dyadic_order, _naive_solver, workspace_bytes,
                                     ctx.sym_blocks)
@@ -606,13 +610,13 @@ class _SigKernelGram(torch.autograd.Function):
                 return K
         fused = _fused_static(static_kernel, True) is not None
         # with a gradient pending, tile like backward will, so that the caching allocator can reuse the same blocks
-        rows_factor = (3 if fused else 8) if X.requires_grad else None
-        ctx.kept_edges = [] if X.requires_grad else None
+        rows_factor = (3 if fused else 8) if need else None
+        ctx.kept_edges = [] if need else None
         K = _gram_block(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, workspace_bytes, rows_factor, ctx.kept_edges)
         if sym and _same_storage(Xd, Yd):   # all pairs were solved (fused adjoint ahead): still hand back an exactly symmetric matrix
             iu = torch.triu_indices(A, A, offset=1, device=K.device)
             K[iu[1], iu[0]] = K[iu[0], iu[1]]
-        ctx.K = K.detach() if X.requires_grad else None     # forward values: what arms the fused adjoints' device-side rescue
+        ctx.K = K.detach() if need else None     # forward values: what arms the fused adjoints' device-side rescue
         return K
 
     @staticmethod
