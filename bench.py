@@ -19,6 +19,9 @@ split over the ranks, every rank solves its block with no data-path collective, 
 full matrix on every rank.  --scaling weak (default for gram configs): X has N x rows_per_gpu rows; --scaling strong
 (default and only choice for c4, the config BASELINE names for 8 GPUs): the batch is fixed and divided.
 
+With N > 1 (or --force-dist) the line's `configs` holds BASELINE configs[3] (the config BASELINE.json names for 8 GPUs) and configs[4]
+STRONG-scaled under the same process group (dist_configs); at N = 1 without it, `configs` holds c2, two training-sized MMD steps, c5, c4.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : the kernel that dominates the step against the ceiling that binds it (fp64 vector issue for the fused
                  kernels, with the HBM-equivalent rate of the increments they never materialise as a second figure;

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         // lane 63's stream unit at macro-step t is t - 63; its first whole chunk [0, 8) is complete at t = 70
         f_pos = 0;
     }
+    bool gave_up = false;        // split mode: a producer's counter did not move for seconds: this wave's results are NaN from here on
     int f_i = 0;                 // split mode: the stream position of the bottom lane's row unit
     unsigned *pub_ptr = nullptr; // ... the progress counter a flush has yet to publish (after the wait for its stores), and the count
     unsigned pub_cnt = 0;
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (lam < CHUNK / 16) {
             d2_t v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + BO_BASE + (unsigned)(lam * 16)) : "memory");
+            if (SPLIT && gave_up) v = d2_t{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};   // poison the bands below
             store_through(frow + (int64_t)f_pos * E + lam * 2, v);
         }
         f_pos += 8;
@@ -454,11 +456,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (seen >= need) return;
         const unsigned want = need + (unsigned)prm.lead < total ? need + (unsigned)prm.lead : total;
         const unsigned *pp = prm.prog + ((int64_t)(xb - 1) * prm.Pn + sp);
-        for (;;) {
+        // (bounded: the ticket order rules out a deadlock, but a counter that never moves -- a corrupted workspace, a fault in another
+        // wave -- must cost a wrong result, which the NaN below makes visible, not a hung device: ~2^22 polls of >= 0.5 us)
+        for (unsigned spins = 0;; ++spins) {
             unsigned v;
             asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pp) : "memory");
             seen = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
             if (seen >= want) break;
+            if (spins >= (1u << 22)) { gave_up = true; seen = total; break; }
             __builtin_amdgcn_s_sleep(16);
         }
     };
@@ -750,6 +755,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
+                if (SPLIT && gave_up) v = __longlong_as_double(0x7ff8000000000000LL);
                 static_cast<TO *>(prm.out)[pair_v] = (TO)v;
             }
         }
