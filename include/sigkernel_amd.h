@@ -81,11 +81,13 @@ const char *sk_build_info(void);
  *                           sk_rbf_adjoint_fused_f64 -- nothing of size pairs x M x N exists
  *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
  *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
- *   SK_ROUTE_FUSED_SWAP     (forward only) the one-band kernels on (Y, X): the second paths fit one band (rows <= 64 RC), the first do not
+ *   SK_ROUTE_FUSED_SWAP     the one-band kernels on (Y, X): the second paths fit one band (rows <= 64 RC), the first do not; for the ADJOINT
+ *                           (rbf, dim <= 4, fp64, Gram): sk_rbf_adjoint_fused_f64 on (Y, X) with the second-argument sums
  *                           (128 x 128 pairs of 700 x 20 points: 0.41 ms against 1.56 ms streamed); Gram callers transpose the result
  * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never
  * SK_ROUTE_STREAM: every such call CAN run with nothing of size pairs x M x N in HBM. */
 #define SK_ROUTE_NO_STREAM 1
+#define SK_ROUTE_NO_SWAP 2      /* never answer a swapped ADJOINT route (paired batches: the second-argument sums exist for Gram calls) */
 /* The COST table: every measured crossover the library (sk_route_query, the launchers) and the host layer (symmetric blocks, merged
  * loss, paired merge) decide by, with the same-box A/B measurement each came from -- entries 0 .. n-1 (sk_cost_name returns NULL past
  * the end).  Scope rules say what a kernel CAN do; these say when it is the faster choice.  tools/crossovers.py re-measures them on

@@ -18,6 +18,7 @@ SK_OK = 0
 OP_FORWARD, OP_ADJOINT, OP_ADJOINT_SYM = 0, 1, 2
 ROUTE_STREAM, ROUTE_FUSED, ROUTE_FUSED_MB, ROUTE_FUSED_MB_SWAP, ROUTE_FUSED_SWAP = 0, 1, 2, 3, 4
 ROUTE_NO_STREAM = 1
+ROUTE_NO_SWAP = 2
 SCHEME_DEFAULT = 0
 SCHEME_NAIVE = 1
 FLAG_EXACT = 1
@@ -321,12 +322,12 @@ class HipBackend:
     name = "hip"
 
     @staticmethod
-    def route(op, kind, D, M, N, dyadic, naive, elem_size, no_stream=False):
+    def route(op, kind, D, M, N, dyadic, naive, elem_size, no_stream=False, no_swap=False):
         """Which kernel family serves the call (sk_route_query, csrc/sk_route.hip): ROUTE_STREAM / _FUSED / _FUSED_MB / _FUSED_MB_SWAP / _FUSED_SWAP.
         no_stream: never STREAM where a fused kernel exists (by default short paths, on which the multi-band kernels would mostly
         sweep padding, take the faster streaming route)."""
         return int(load().sk_route_query(int(op), int(kind), int(D), int(M), int(N), int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT,
-                                         int(elem_size), ROUTE_NO_STREAM if no_stream else 0))
+                                         int(elem_size), (ROUTE_NO_STREAM if no_stream else 0) | (ROUTE_NO_SWAP if no_swap else 0)))
 
     def increments(self, G):
         """G [..., M, N] -> inc_c [..., M-1, N-1] (sigkernel.py:217, :363)."""

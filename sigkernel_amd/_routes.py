@@ -13,6 +13,8 @@ the same with its SK_* knobs, sk_abi.hip):
                          training-sized step -- up to 128 x 128 pairs each -- on three streams = parallel branches of the graph)
     SK_NO_MERGED_LOSS    compute_mmd / compute_scoring_rule / compute_expected_scoring_rule of training-sized batches as the reference's
                          composition of compute_Gram calls (default: one Gram block K(X, [X; Y]), sigkernel._SigKernelLoss)
+    SK_NO_ADJOINT_SWAP   gradients for long first paths against short second ones never through the one-band rbf adjoint on (y, x) with the
+                         second-argument sums (default: rbf, dim <= 4, fp64 Gram calls whose second paths fit its lanes)
     SK_NO_LOSS_LAUNCH    the merged loss route without the one-launch glue of csrc/sk_loss.hip (staging of [X; Y], K(X, [X; Y]) + the
                          triangle of K(Y, Y) in ONE forward launch, value / weights / gradient fold as single kernels): torch ops instead
     SK_NO_STREAM         memory first: LinearKernel / RBFKernel calls of path dim <= 16, dyadic <= 2 NEVER hold increments in HBM, also
@@ -25,7 +27,7 @@ import os
 
 _ENV = {"no_fused_rbf": "SK_NO_FUSED_RBF", "no_fused_mb": "SK_NO_FUSED_MB", "no_fused_adjoint": "SK_NO_FUSED_ADJOINT",
         "no_fused_deriv": "SK_NO_FUSED_DERIV", "no_y32": "SK_FUSEDMB_NO_Y32", "no_stream": "SK_NO_STREAM", "no_mmd_streams": "SK_NO_MMD_STREAMS",
-        "no_merged_loss": "SK_NO_MERGED_LOSS", "no_loss_launch": "SK_NO_LOSS_LAUNCH"}
+        "no_merged_loss": "SK_NO_MERGED_LOSS", "no_loss_launch": "SK_NO_LOSS_LAUNCH", "no_adjoint_swap": "SK_NO_ADJOINT_SWAP"}
 
 
 class Routes:

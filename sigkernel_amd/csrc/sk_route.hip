@@ -21,8 +21,9 @@
 //     FUSED      linear: dim <= 8, M - 1 <= 128 (64 at d = 2) (csrc/sk_wave_adj_fused.hip);
 //                rbf: dim <= 4, d = 1..2, M <= 128 / 64; dim 5..8 at d = 1: M <= 64 (one row per lane); d = 0: dim <= 8, default stencil, M <= 128, two rows per lane (csrc/sk_wave_adj_fused_rbf.hip;
 //                its 8-dim variants spill and lose)
+//     FUSED_SWAP rbf, dim <= 4, fp64, Gram calls: the one-band adjoint on (y, x) with the second-argument sums when only the SECOND paths
+//                fit its lanes (64 points at d = 1..2, 128 at d = 0): d k(x, y) / dx = d2 k(y, x)
 //     FUSED_MB   dim <= 16, d = 0..2, any M, N (csrc/sk_wave_adj_fused_mb.hip; rbf at d = 0: two coarse rows per lane); never swapped
-//                (the gradient is the first argument's)
 //   STREAM       everything else (dim > 16, d > 2, other static kernels): static kernel -> increments in HBM -> sk_solve_fwd_* /
 //                sk_static_increments -> sk_solve_adj -> sk_static_adjoint (or the generic vector-Jacobian route)
 //
@@ -156,6 +157,11 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d)) return SK_ROUTE_FUSED;
         if (kind == 1 && D <= 8 && d == 0 && !naive && M <= 128) return SK_ROUTE_FUSED;   // two coarse rows per lane
         if (kind == 1 && D <= 8 && d == 1 && M <= 64) return SK_ROUTE_FUSED;               // dim 5..8: one coarse row per lane
+        // long first paths against short second ones (rbf, dim <= 4, fp64 paths; Gram calls -- the host passes SK_ROUTE_NO_SWAP for
+        // paired batches): the one-band adjoint on (y, x) with the SECOND-argument sums, d k(x, y) / dx = d2 k(y, x) (k and the static
+        // kernel are symmetric), where the second paths fit its lanes -- 0.55-0.65x the streamed time, profiles/r05_asym.txt
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= 64))
+            return SK_ROUTE_FUSED_SWAP;
         if (may_stream && prefer_stream(Mc, Nc, mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)))) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }

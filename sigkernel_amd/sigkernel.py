@@ -75,7 +75,9 @@ def _route(be, op, static_kernel, Xd, Yd, dyadic, naive, gram):
         return STREAM
     if (fused[0] == 1 and routes.no_fused_rbf) or (op == OP_ADJOINT and routes.no_fused_adjoint):
         return STREAM
-    r = _route_query(be.route, op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), Xd.element_size(), routes.no_stream)
+    # (a swapped ADJOINT -- second-argument sums of the one-band rbf adjoint on (y, x) -- exists for Gram calls only)
+    no_swap = op == OP_ADJOINT and (not gram or routes.no_adjoint_swap or not hasattr(be, "second_argument_gradient"))
+    r = _route_query(be.route, op, fused[0], Xd.shape[2], Xd.shape[1], Yd.shape[1], dyadic, bool(naive), Xd.element_size(), routes.no_stream, no_swap)
     if r in (FUSED_MB, FUSED_MB_SWAP) and routes.no_fused_mb:
         return STREAM
     return r
@@ -107,6 +109,11 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
             res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
         elif ra == FUSED_MB:
             res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, keep_edges=True)
+        elif ra == FUSED_SWAP and gram and not f32:
+            # long first paths, short second ones: forward AND adjoint on (y, x) -- the edges are those of the pairs (b, a)
+            res = one_band(Yd, Xd, param, dyadic, naive, True, keep_edges=True)
+            if res is not None:
+                res = (res[0].t().contiguous(), res[1])
         if res is not None:
             return res
     rf = _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, gram)
@@ -255,6 +262,35 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
     return grad
 
 
+def _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget, Kvals=None):
+    """dL/dX of a Gram block whose FIRST paths are long and whose second paths fit the one-band RBF adjoint's lanes (route FUSED_SWAP):
+    the adjoint runs on the pairs (y_b, x_a) -- k and the static kernel are symmetric -- with the SECOND-argument sums of that sweep
+    (sk_rbf_adjoint_fused_f64 with ypart), folded with the transposed upstream gradient: d k(x_a, y_b) / d x_a = d2 k(y_b, x_a).
+    Tiled over the rows of Y by the memory of the sums (48 bytes per pair and node column).  kept: the edges the forward kept for the
+    swapped pairs, else they are formed here.  None where the kernel declines (the caller streams)."""
+    A, B = Xd.shape[0], Yd.shape[0]
+    sigma = float(static_kernel.sigma)
+    edges = kept[0][2] if (kept and len(kept) == 1 and kept[0][:2] == (0, A) and kept[0][2] is not None) else None
+    KT = None if Kvals is None else Kvals.t().contiguous()
+    if edges is None:
+        res = be.solve_fwd_fused_rbf(Yd, Xd, sigma, dyadic, naive, True, keep_edges=True)
+        if res is None or res[1] is None:
+            return None
+        KT, edges = res
+    per = edges.numel() // B
+    goT = go.t().contiguous()                     # upstream gradient of the pair (b, a)
+    grad = None
+    for b0, b1 in _tiles(B, 64 * A * (Xd.shape[1] + 16), budget):
+        res = be.rbf_adjoint_fused(Yd[b0:b1].contiguous(), Xd, sigma, dyadic, edges[b0 * per:b1 * per], None, gram=True, yside=True,
+                                   kfinal=None if KT is None else KT[b0:b1], naive=naive)
+        if res is None:
+            return None
+        g = be.second_argument_gradient(res[2], Xd, sigma, goT[b0:b1], 0)
+        grad = g if grad is None else grad + g
+        del res
+    return grad
+
+
 def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, workspace_bytes, Kvals=None):
     """dL/dX (A,M,D) of a Gram block (gram=True: go (A,B)) or a paired batch (go (A,)): the fused linear / RBF adjoint when it
     applies, else the unfused routes tiled over rows by their transient memory (3 (Linear/RBF) or 8 (generic) arrays of the
@@ -266,6 +302,11 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
         g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals, route)
         if g is not None:
             return g
+    if route == FUSED_SWAP and gram and Xd.dtype == torch.float64:
+        g = _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget, Kvals)
+        if g is not None:
+            return g
+        kept = None       # (edges of the swapped pairs are of no use to the streaming route below)
     fused = _fused_static(static_kernel, gram) is not None
     esize = 8 if (fused and _upcast_tile(Xd, dyadic)) else Xd.element_size()
     per_row = (3 if fused else 8) * (Yd.shape[0] if gram else 1) * M * N * esize

@@ -461,6 +461,39 @@ def test_loss_launch_route_on_the_gpu(kind, D, d, A, B, M, naive, monkeypatch):
         assert rel_err(out[False][1], gw) <= 1e-9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,d,A,B,M,N,naive", [(3, 1, 9, 7, 300, 64, False), (4, 2, 5, 11, 129, 33, False), (2, 0, 6, 6, 500, 128, False), (1, 1, 17, 3, 140, 20, True),
+                                               (4, 0, 4, 9, 129, 128, False), (3, 2, 12, 12, 700, 64, True)])
+def test_long_first_paths_take_the_swapped_adjoint(D, d, A, B, M, N, naive, monkeypatch):
+    """Gradients of a Gram block whose first paths are long and whose second paths fit the one-band RBF adjoint (route FUSED_SWAP: the
+    sweep runs on (y, x), the gradient comes from its second-argument sums; sigkernel.py:404-502 has no such asymmetry) against the
+    default routes without the swap (routes.no_adjoint_swap) and the oracle's closed form; values unchanged; mmd through the same route."""
+    gen = torch.Generator().manual_seed(D * 100 + M)
+    k = sigkernel_amd.RBFKernel(0.9)
+    sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    X, Y = Xc.to(DEV), Yc.to(DEV)
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    be = _lib.get_backend()
+    assert be.route(_lib.OP_ADJOINT, 1, D, M, N, d, naive, 8) == _lib.ROUTE_FUSED_SWAP
+    out = {}
+    for off in (False, True):
+        monkeypatch.setattr(sigkernel_amd.routes, "no_adjoint_swap", off)
+        skmod._route_query.cache_clear()
+        Xg = X.clone().requires_grad_(True)
+        K = sk.compute_Gram(Xg, Y)
+        (g1,) = torch.autograd.grad((K * w.to(DEV)).sum(), Xg, retain_graph=True)
+        (g2,) = torch.autograd.grad((K * w.to(DEV)).sum(), Xg)
+        assert torch.equal(g1, g2)
+        out[off] = (K.detach().cpu().numpy(), g1.cpu().numpy())
+    monkeypatch.setattr(sigkernel_amd.routes, "no_adjoint_swap", False)
+    skmod._route_query.cache_clear()
+    assert rel_err(out[False][0], out[True][0]) <= 1e-12 and rel_err(out[False][1], out[True][1]) <= 1e-9
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, d, naive=naive, nthreads=NT)
+    assert rel_err(out[False][1], want) <= 1e-9
+    assert rel_err(out[False][0], O.gram_forward(Xc, Yc, k, d, naive=naive, nthreads=NT)) <= 1e-11
+
+
 def _mb_split_knob(on):
     os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
     _lib.load().sk_reload_knobs()
