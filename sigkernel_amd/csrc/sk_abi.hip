@@ -152,13 +152,13 @@ RankW knob_shares(const char *name) {
 }
 Knobs parse_knobs() {
     Knobs k{};
-    k.wave_pf = knob_int("SK_WAVE_PF"); k.wave_wpc = knob_int("SK_WAVE_WPC"); k.wave_wpb = knob_int("SK_WAVE_WPB");
+    k.wave_wpc = knob_int("SK_WAVE_WPC"); k.wave_wpb = knob_int("SK_WAVE_WPB");
     k.adj_wpc = knob_int("SK_ADJ_WPC"); k.adj_wpb = knob_int("SK_ADJ_WPB");
     k.adjf_wpc = knob_int("SK_ADJF_WPC"); k.adjf_wpb = knob_int("SK_ADJF_WPB");
     k.adjr_wpc = knob_int("SK_ADJR_WPC"); k.adjr_wpb = knob_int("SK_ADJR_WPB");
     k.adjmb_wpc = knob_int("SK_ADJMB_WPC"); k.adjmb_wpb = knob_int("SK_ADJMB_WPB"); k.adjmb_q_static = knob_int("SK_ADJMB_Q_STATIC");
     k.derivf_wpc = knob_int("SK_DERIVF_WPC"); k.derivf_wpb = knob_int("SK_DERIVF_WPB"); k.derivf_noshift = knob_int("SK_DERIVF_NOSHIFT");
-    k.deriv_pf = knob_int("SK_DERIV_PF"); k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
+    k.deriv_wpc = knob_int("SK_DERIV_WPC"); k.deriv_wpb = knob_int("SK_DERIV_WPB");
     k.fused_wpc = knob_int("SK_FUSED_WPC"); k.fused_wpb = knob_int("SK_FUSED_WPB"); k.fused_q_static = knob_int("SK_FUSED_Q_STATIC");
     k.fused_mid = getenv("SK_FUSED_MID") ? knob_int("SK_FUSED_MID") : 1;
     k.fusedmb_wpc = knob_int("SK_FUSEDMB_WPC"); k.fusedmb_wpb = knob_int("SK_FUSEDMB_WPB"); k.fusedmb_q_static = knob_int("SK_FUSEDMB_Q_STATIC");

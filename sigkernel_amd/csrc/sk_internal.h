@@ -11,13 +11,13 @@ namespace sk {
 // 0 / n = 0 mean "the built-in default".  Tools that sweep a knob inside one process call sk_reload_knobs() after changing it.
 struct RankW { int n; double w[4]; };      // shares of the pairs by wave age rank, per cent; n = number of ranks given
 struct Knobs {
-    int wave_pf, wave_wpc, wave_wpb;
+    int wave_wpc, wave_wpb;
     int adj_wpc, adj_wpb;
     int adjf_wpc, adjf_wpb;
     int adjr_wpc, adjr_wpb;
     int adjmb_wpc, adjmb_wpb, adjmb_q_static;     // sk_wave_adj_fused_mb.hip
     int derivf_wpc, derivf_wpb, derivf_noshift;   // sk_wave_deriv_fused.hip
-    int deriv_pf, deriv_wpc, deriv_wpb;
+    int deriv_wpc, deriv_wpb;
     int fused_wpc, fused_wpb, fused_q_static, fused_mid;
     int fusedmb_wpc, fusedmb_wpb, fusedmb_q_static, fusedmb_split, fusedmb_lead;
     RankW rank_w, wave_rank_w, adj_rank_w, adjf_rank_w, adjr_rank_w, deriv_rank_w, fused_rank_w, fusedmb_rank_w;

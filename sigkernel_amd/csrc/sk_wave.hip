@@ -349,16 +349,20 @@ int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t 
     return check_launch();
 }
 
-// Tuning knobs (environment, read at launch): SK_WAVE_PF = prefetch distance in macro-steps (2 (default), 3 or 4),
-// SK_WAVE_WPC = cap on resident waves per CU.  Defaults are what measured best on MI355X.
+// Tuning knob: SK_WAVE_WPC = cap on resident waves per CU.  The prefetch distance is 2 macro-steps (3 and 4 were built as variants of
+// their own until round 5 -- 128 kernel instances only an environment knob could reach; 2 measured best, DESIGN 4.1 of round 1).
 
 template <typename T, int DY, bool NAIVE, int PF>
 int launch_nv(const WaveParams &prm, bool multiband, int blocks, size_t lds_bytes, hipStream_t s) {
     const bool full = prm.logL == 6;
-    if (prm.edges) {   // the adjoint's forward pass: one prefetch depth is enough variants
-        if (multiband) return launch_one<T, DY, NAIVE, true, false, true, 2>(prm, blocks, lds_bytes, s);
-        return full ? launch_one<T, DY, NAIVE, false, true, true, 2>(prm, blocks, lds_bytes, s)
-                    : launch_one<T, DY, NAIVE, false, false, true, 2>(prm, blocks, lds_bytes, s);
+    if (prm.edges) {   // the adjoint's forward pass (strip edges exist up to dyadic 2 in fp64, 1 in fp32: sk_strip_edges_bytes)
+        if constexpr (DY <= (sizeof(T) == 8 ? 2 : 1)) {
+            if (multiband) return launch_one<T, DY, NAIVE, true, false, true, 2>(prm, blocks, lds_bytes, s);
+            return full ? launch_one<T, DY, NAIVE, false, true, true, 2>(prm, blocks, lds_bytes, s)
+                        : launch_one<T, DY, NAIVE, false, false, true, 2>(prm, blocks, lds_bytes, s);
+        } else {
+            return SK_ERR_UNSUPPORTED;
+        }
     }
     if (multiband) return launch_one<T, DY, NAIVE, true, false, false, PF>(prm, blocks, lds_bytes, s);
     return full ? launch_one<T, DY, NAIVE, false, true, false, PF>(prm, blocks, lds_bytes, s)
@@ -367,14 +371,9 @@ int launch_nv(const WaveParams &prm, bool multiband, int blocks, size_t lds_byte
 
 template <typename T, int DY>
 int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t lds_bytes, hipStream_t s) {
-    switch (pf) {
-        case 2: return prm.naive ? launch_nv<T, DY, true, 2>(prm, multiband, blocks, lds_bytes, s)
-                                 : launch_nv<T, DY, false, 2>(prm, multiband, blocks, lds_bytes, s);
-        case 4: return prm.naive ? launch_nv<T, DY, true, 4>(prm, multiband, blocks, lds_bytes, s)
-                                 : launch_nv<T, DY, false, 4>(prm, multiband, blocks, lds_bytes, s);
-        default: return prm.naive ? launch_nv<T, DY, true, 3>(prm, multiband, blocks, lds_bytes, s)
-                                  : launch_nv<T, DY, false, 3>(prm, multiband, blocks, lds_bytes, s);
-    }
+    (void)pf;
+    return prm.naive ? launch_nv<T, DY, true, 2>(prm, multiband, blocks, lds_bytes, s)
+                     : launch_nv<T, DY, false, 2>(prm, multiband, blocks, lds_bytes, s);
 }
 
 }  // namespace
@@ -384,8 +383,7 @@ int launch_dy(const WaveParams &prm, bool multiband, int pf, int blocks, size_t 
 template <typename T>
 int launch_fwd_wave(const T *inc_c, int64_t ld, const Geom &g, T *out_final, double *strip_edges, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    int PF = knobs().wave_pf > 0 ? knobs().wave_pf : 2;
-    if ((PF != 3 && PF != 4) || strip_edges) PF = 2;
+    const int PF = 2;
     const int DY = g.dyadic;
     if (DY > 3) return SK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(inc_c) & 15) || ((ld * sizeof(T)) & 15)) return SK_ERR_UNSUPPORTED;

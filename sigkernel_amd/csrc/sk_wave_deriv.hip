@@ -419,8 +419,7 @@ int launch_pf(const DerivParams &prm, int blocks, size_t lds_bytes, hipStream_t 
 
 template <typename T, int DY, bool MULTIBAND, bool FULLWAVE>
 int launch_one(const DerivParams &prm, int blocks, size_t lds_bytes, hipStream_t s) {
-    if (prm.pf == 5) return launch_pf<T, DY, MULTIBAND, FULLWAVE, 5>(prm, blocks, lds_bytes, s);
-    return launch_pf<T, DY, MULTIBAND, FULLWAVE, 3>(prm, blocks, lds_bytes, s);
+    return launch_pf<T, DY, MULTIBAND, FULLWAVE, 3>(prm, blocks, lds_bytes, s);   // (a distance of 5 was a knob-only variant until round 5)
 }
 
 template <typename T, int DY>
@@ -439,7 +438,7 @@ template <typename T>
 int launch_deriv_wave(const T *inc, const T *inc_d, const T *inc_dd, int64_t ld, const Geom &g, T *out_k, T *out_kd,
                       T *out_kdd, hipStream_t s) {
     constexpr int CW = Unit<T>::CW;
-    const int PF = knobs().deriv_pf == 5 ? 5 : 3;   // prefetch distance (macro-steps)
+    const int PF = 3;   // prefetch distance (macro-steps)
     const int DY = g.dyadic;
     if (DY > (sizeof(T) == 8 ? 2 : 1)) return SK_ERR_UNSUPPORTED;   // register budget: S = CW << DY columns x 3 states
     if (((reinterpret_cast<uintptr_t>(inc) | reinterpret_cast<uintptr_t>(inc_d) | reinterpret_cast<uintptr_t>(inc_dd)) & 15) ||

@@ -262,5 +262,5 @@ def test_kernel_variants_stay_within_their_budget():
     assert r.returncode == 0, r.stdout
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py")], capture_output=True, text=True)
     n = len([ln for ln in r.stdout.splitlines()[1:] if ln.strip()])
-    assert 0 < n <= 660, n
-    assert os.path.getsize(os.path.join(ROOT, "sigkernel_amd", "libsigkernel_amd.so")) <= 10 * (1 << 20)
+    assert 0 < n <= 530, n
+    assert os.path.getsize(os.path.join(ROOT, "sigkernel_amd", "libsigkernel_amd.so")) <= 9 * (1 << 20)

@@ -38,6 +38,5 @@ def run(label, **env):
         os.environ.pop(k)
 
 
-for pf in (2, 3):
-    for wpc in (4, 8):
-        run("PF=%d WPC=%d" % (pf, wpc), SK_WAVE_PF=pf, SK_WAVE_WPC=wpc)
+for wpc in (4, 8, 12):      # (the prefetch distance is fixed at 2 macro-steps since round 5: its other values were knob-only variants)
+    run("WPC=%d" % wpc, SK_WAVE_WPC=wpc)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """(CPU) Every kernel instance of the build: VGPRs (arch + accum), SGPRs, scratch bytes, static LDS -- from the gfx950 ISA that
 csrc/Makefile keeps in csrc/obj (-save-temps).  usage: variants.py [--csv] [substring ...]
-With --check <file>: fails when an instance's scratch bytes grew against the committed table (profiles/r05_variants.txt)."""
+With --reached <rocprofv3 kernel_stats.csv | dir of them | the HIP runtime's launch log reduced to "<count> ShaderName : <name>" lines>: a
+column of launches per instance (tools/reach_sweep.py is the workload).  With --check <file>: fails when an instance's scratch bytes grew against the committed table (profiles/r05_variants.txt)."""
 import glob, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJ = os.path.join(ROOT, "sigkernel_amd", "csrc", "obj")
@@ -57,9 +58,16 @@ def main():
         args = [a for a in args if a != f]
         reached = {}
         for ff in sorted(glob.glob(os.path.join(f, "**", "*kernel_stats.csv"), recursive=True)) if os.path.isdir(f) else [f]:
-            for r in csv.DictReader(open(ff)):
-                n = norm(r["Name"])
-                reached[n] = reached.get(n, 0) + int(r["Calls"])
+            if ff.endswith(".csv"):
+                for r in csv.DictReader(open(ff)):
+                    n = norm(r["Name"])
+                    reached[n] = reached.get(n, 0) + int(r["Calls"])
+            else:        # `AMD_LOG_LEVEL=3 python tools/reach_sweep.py 2>&1 | grep -o "ShaderName : .*" | sort | uniq -c`: "<count> ShaderName : <name>"
+                for ln in open(ff):
+                    m = re.match(r"\s*(\d+) ShaderName : (.*)", ln)
+                    if m:
+                        n = norm(m.group(2).strip())
+                        reached[n] = reached.get(n, 0) + int(m.group(1))
     if args:
         rows = [r for r in rows if all(a in r["pretty"] or a in r["unit"] for a in args)]
     print("unit\tvgpr\taccum_off\tsgpr\tscratch\tlds\t%sinstance\tmangled" % ("launches\t" if reached is not None else ""))
