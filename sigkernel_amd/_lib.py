@@ -909,8 +909,8 @@ class HipBackend:
         with _device(X.device):
             fn = getattr(load(), "sk_static_adjoint_" + _suffix(X))
             if kind == 0:
-                T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
                 if D <= 8:      # pre-differenced, dimension-major y: every load of the contraction is coalesced
+                    T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
                     ldy = _padded_ld(N - 1, 8)
                     dYt = _prep_paths(Y, True, True, 1.0, ldy)
                     fl = getattr(load(), "sk_linear_adjoint_" + _suffix(X))
@@ -923,9 +923,16 @@ class HipBackend:
                     dY = Y[:, 1:] - Y[:, :-1]
                     Wv = W[..., :N - 1]
                     if gram:
-                        Tm = torch.matmul(Wv, dY)                                   # (A, B, Mc, D)
-                        T = (Tm * scale[:, :, None, None]).sum(1) if scale is not None else Tm.sum(1)
-                        del Tm
+                        # in column blocks of Y, so that the (A, b, Mc, D) products stay below ~256 MB whatever B is (for D
+                        # close to N the un-blocked product was up to twice the size of W, outside the caller's tile accounting)
+                        step = max(1, int((256 << 20) // max(1, A * (M - 1) * D * X.element_size())))
+                        T = None
+                        for b0 in range(0, B, step):
+                            Tm = torch.matmul(Wv[:, b0:b0 + step], dY[b0:b0 + step])    # (A, b, Mc, D)
+                            if scale is not None:
+                                Tm = Tm.mul_(scale[:, b0:b0 + step, None, None])
+                            T = Tm.sum(1) if T is None else T.add_(Tm.sum(1))
+                            del Tm
                     else:
                         T = torch.matmul(Wv, dY)                                    # (A, Mc, D)
                         if scale is not None:
