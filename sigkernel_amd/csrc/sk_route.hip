@@ -97,6 +97,12 @@ const CostEntry COSTS[] = {
     {"fused_mid_min_pairs_per_rank", 4,
      "pairs per lane group and rank from which a no-queue fused forward that fills the chip deals out shares by wave age rank: 64-row shard of the "
      "headline Gram 0.695 -> 0.640 ms, 128 + 128 path mmd step 1.237 -> 1.171 ms (r05, same box)"},
+    {"fused_static_share_linear", 35,
+     "per cent of a lane group's equal share the one-band fused forward deals out before its work queue (SK_FUSED_Q_STATIC overrides): the headline "
+     "Gram 4.06 ms at 35, 4.09 at 20, 4.10 at 3, 4.42 at 65, 4.80 at 92 -- waves of a SIMD run at different speeds, the queue evens them out"},
+    {"fused_static_share_rbf", 20,
+     "... the RBF variants (longer macro-steps, a draw costs less of one): 2048 x 2048 pairs, dyadic 2: 52.0 ms at 35, 50.9 at 20, 50.6 at 3; "
+     "512 / 1024 paths: 3.41 -> 3.34, 13.0 -> 12.8 ms; C4 335.6 -> 334.5 (profiles/r05_qstatic.txt)"},
     {"mb_split_max_resident_share", 0.5,
      "few pairs of long paths: bands of a pair on several waves when the pairs fill at most this share of the resident waves (r05: 16 x 16 pairs "
      "of 4096 points 18.7 -> 4.7 ms; 32 x 32 pairs of 700 points 2.18 -> 1.96 ms)"},

@@ -877,7 +877,8 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     const int span = (pl.L - 1 + pl.lag + 24) / pl.NUp + 2;
     int logC = 0;
     while ((span >> logC) + 1 > 3) ++logC;
-    const int pct = knobs().fused_q_static > 0 ? (knobs().fused_q_static > 100 ? 100 : knobs().fused_q_static) : 35;
+    const int pct = knobs().fused_q_static > 0 ? (knobs().fused_q_static > 100 ? 100 : knobs().fused_q_static)
+                                                : (int)cost_by_name(KIND == 1 ? "fused_static_share_rbf" : "fused_static_share_linear");
     // ... and not smaller than needed either: ~24 draws per lane group balance a launch to a per cent or two, while every
     // chunk costs each lane one look-up of its first pair (the variants that keep edges do that in the macro-step path)
     while ((per * (100 - pct) / 100) >> (logC + 1) >= 24 && logC < 8) ++logC;
