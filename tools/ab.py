@@ -21,8 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         X, Y = walk(512, 64, 3), walk(512, 64, 3); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1); fn = lambda: sk.compute_Gram(X, Y)
     elif cfg == "c5":
         X, Y = walk(256, 512, 16, torch.float32), walk(256, 512, 16, torch.float32); sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 2); fn = lambda: sk.compute_Gram(X, Y)
-    elif cfg.startswith("g:") or cfg.startswith("f:"):
-        # g:kind:A:M:N:D:d[:naive]  compute_Gram(X, Y) with a weighted-sum backward (f: forward only) on a free shape -- what the
+    elif cfg.startswith("g:") or cfg.startswith("f:") or cfg.startswith("e:"):
+        # g:kind:A:M:N:D:d[:naive]  compute_Gram(X, Y) with a weighted-sum backward (f: forward only, e: forward that keeps edges) on a free shape -- what the
         # round-4 route changes are checked with (shapes that streamed increments before)
         _, kind, A, M, N, D, d = cfg.split(":")[:7]
         naive = cfg.endswith(":naive")
@@ -33,6 +33,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
         sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
         if cfg.startswith("f:"):
             fn = lambda: sk.compute_Gram(X, Y)
+        elif cfg.startswith("e:"):      # the forward of a call with a gradient pending (keeps the terminal edges), no backward
+            Xg = X.detach().requires_grad_(True)
+            fn = lambda: sk.compute_Gram(Xg, Y).detach()
         else:
             def fn():
                 Xg = X.detach().requires_grad_(True); (sk.compute_Gram(Xg, Y) * w).sum().backward(); return Xg.grad
