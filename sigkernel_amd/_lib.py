@@ -1230,11 +1230,11 @@ class HipBackend:
             out = torch.empty(3, flat.shape[1], dtype=inc3.dtype, device=inc3.device)
             f = 1 << (int(dyadic) - 2)
             ldr = _padded_ld(Nc * f, 8)
-            step = max(1, int(self.UPCAST_CHUNK_BYTES // (3 * Mc * f * ldr * 8)))
+            step = max(1, int(self._refined_chunk_bytes(flat) // (3 * Mc * f * ldr * 8)))
             for p0 in range(0, flat.shape[1], step):
                 p1 = min(flat.shape[1], p0 + step)
                 buf = torch.zeros(3, p1 - p0, Mc * f, ldr, dtype=torch.float64, device=inc3.device)
-                buf[..., :Nc * f] = (flat[:, p0:p1].double() * (1.0 / (f * f))).repeat_interleave(f, dim=2).repeat_interleave(f, dim=3)
+                self._fill_refined(buf, flat[:, p0:p1], f)
                 k, kd, kdd = self.solve_deriv(buf[..., :Nc * f], 2, flags)
                 out[0, p0:p1], out[1, p0:p1], out[2, p0:p1] = k, kd, kdd
                 del buf
@@ -1294,17 +1294,37 @@ class HipBackend:
         return res + (err.reshape(batch),) if return_residual else res
 
 
+    def _refined_chunk_bytes(self, src, chunk_bytes=None):
+        """Bytes of refined increments handled at a time: UPCAST_CHUNK_BYTES at most, and no more than twice what the caller holds
+        already (its tile of coarse increments, which it sized to ITS budget -- SigKernel(workspace_bytes=...)), 256 MiB at least."""
+        cap = max(256 << 20, 2 * src.numel() * src.element_size())
+        return min(int(chunk_bytes or self.UPCAST_CHUNK_BYTES), cap)
+
+    @staticmethod
+    def _fill_refined(buf, src, f):
+        """buf [..., Mc f, ldr] (fp64, zeroed) <- src [..., Mc, Nc] replicated f x f and scaled by 1 / f^2, written through a strided view:
+        no replicated temporary (repeat_interleave made two of the chunk's size)."""
+        Mc, Nc = src.shape[-2:]
+        lead = tuple(src.shape[:-2])
+        ldr = buf.shape[-1]
+        strides, acc = [], Mc * f * ldr
+        for n in reversed(lead):
+            strides.append(acc)
+            acc *= n
+        view = buf.as_strided(lead + (Mc, f, Nc, f), tuple(reversed(strides)) + (f * ldr, ldr, f, 1))
+        view.copy_((src.double() * (1.0 / (f * f)))[..., :, None, :, None])
+
     def _refined(self, flat, f, chunk_bytes=None):
         """Chunks (p0, p1, refined) of flat [P, Mc, Nc]: every increment replicated f x f and scaled by 1 / f^2 (powers of two: exact), in
         fp64, rows zero-padded to whole 128-byte lines -- dyadic order d on flat is dyadic order d - log2 f on these, the same fine grid
         bit for bit (the reference's own tile(), sigkernel.py:218, :364)."""
         P, Mc, Nc = flat.shape
         ldr = _padded_ld(Nc * f, 8)
-        step = max(1, int((chunk_bytes or self.UPCAST_CHUNK_BYTES) // (Mc * f * ldr * 8)))
+        step = max(1, int(self._refined_chunk_bytes(flat, chunk_bytes) // (Mc * f * ldr * 8)))
         for p0 in range(0, P, step):
             p1 = min(P, p0 + step)
             buf = torch.zeros(p1 - p0, Mc * f, ldr, dtype=torch.float64, device=flat.device)
-            buf[..., :Nc * f] = (flat[p0:p1].double() * (1.0 / (f * f))).repeat_interleave(f, dim=1).repeat_interleave(f, dim=2)
+            self._fill_refined(buf, flat[p0:p1], f)
             yield p0, p1, buf[..., :Nc * f]
 
     def _solve_adj_refined(self, inc_c, dyadic, naive, flags, return_residual):
