@@ -142,6 +142,14 @@ __global__ __launch_bounds__(256) void k_loss_weights(int64_t A, int64_t B, cons
 }
 
 constexpr int FIN_BATCH = 8;
+constexpr int FIN_SPLIT = 4;      // lanes per output of the finish kernels (a power of two: the lanes of an output are adjacent)
+
+// v of the FIN_SPLIT adjacent lanes of an output -> (v0 + v1) + (v2 + v3) on the first of them (every lane of the wave takes part: the
+// loops below run whole groups, `t < n * FIN_SPLIT` with blockDim a multiple of FIN_SPLIT -- a group is inside the bound or outside it)
+__device__ __forceinline__ void fin_combine(double &v) {
+    v += __shfl_down(v, 1, FIN_SPLIT);
+    v += __shfl_down(v, 2, FIN_SPLIT);
+}
 
 // gpart [A][chunks][rows][outw]: node row r < M of x_a: cs = sum_c [a][c][r][0], accd[j] = sum_c [a][c][r][2 + j];
 // dL/dx_a[r][j] = gscale (-2 / sigma) (x_a[r][j] cs - accd[j]); gscale: a device scalar (nullable = 1) -- the adjoint is linear in the
@@ -152,24 +160,32 @@ __global__ __launch_bounds__(256) void k_rbf_adjoint_finish(const double *__rest
     const int64_t n = A * (int64_t)M * D;
     const double gs = gscale ? *gscale : 1.0;
     const int64_t step = (int64_t)rows * outw;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // FIN_SPLIT adjacent lanes share an output: lane s adds the s-th quarter of the chunks in ascending order, the quarters are combined
+    // as (q0 + q1) + (q2 + q3) -- a fixed tree; a training-sized batch has too few outputs to hide 8 dependent rounds of loads otherwise
+    const int64_t quarter = (chunks + FIN_SPLIT - 1) / FIN_SPLIT;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * FIN_SPLIT; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / FIN_SPLIT;
+        const int sub = (int)(t - i * FIN_SPLIT);
         const int64_t a = i / ((int64_t)M * D);
         const int rem = (int)(i - a * (int64_t)M * D);
         const int r = rem / D, j = rem - r * D;
         const double *src = gpart + (a * chunks * rows + r) * (int64_t)outw;
+        const int64_t c_lo = sub * quarter, c_hi = c_lo + quarter < chunks ? c_lo + quarter : chunks;
         double cs = 0.0, acc = 0.0;
-        for (int64_t ch0 = 0; ch0 < chunks; ch0 += FIN_BATCH) {     // chunks in ascending order, eight loads in flight at a time
+        for (int64_t ch0 = c_lo; ch0 < c_hi; ch0 += FIN_BATCH) {     // chunks in ascending order, eight loads in flight at a time
             double u[FIN_BATCH], v[FIN_BATCH];
 #pragma unroll
             for (int k = 0; k < FIN_BATCH; ++k) {
-                const bool in = ch0 + k < chunks;
+                const bool in = ch0 + k < c_hi;
                 u[k] = in ? src[(ch0 + k) * step] : 0.0;
                 v[k] = in ? src[(ch0 + k) * step + 2 + j] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < FIN_BATCH; ++k) { cs += u[k]; acc += v[k]; }
         }
-        grad[i] = gs * (c * (X[i] * cs - acc));
+        fin_combine(cs);
+        fin_combine(acc);
+        if (sub == 0) grad[i] = gs * (c * (X[i] * cs - acc));
     }
 }
 
@@ -180,24 +196,30 @@ __global__ __launch_bounds__(256) void k_linear_adjoint_finish(const double *__r
     const int64_t n = A * (int64_t)M * D;
     const int Mc = M - 1;
     const double gs = gscale ? *gscale : 1.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t quarter = (chunks + FIN_SPLIT - 1) / FIN_SPLIT;      // (as k_rbf_adjoint_finish)
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * FIN_SPLIT; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / FIN_SPLIT;
+        const int sub = (int)(t - i * FIN_SPLIT);
         const int64_t a = i / ((int64_t)M * D);
         const int rem = (int)(i - a * (int64_t)M * D);
         const int r = rem / D, j = rem - r * D;
         const double *src = tpart + a * chunks * rows * (int64_t)8 + j;
+        const int64_t c_lo = sub * quarter, c_hi = c_lo + quarter < chunks ? c_lo + quarter : chunks;
         double up = 0.0, dn = 0.0;     // T[r - 1], T[r]
-        for (int64_t ch0 = 0; ch0 < chunks; ch0 += FIN_BATCH) {
+        for (int64_t ch0 = c_lo; ch0 < c_hi; ch0 += FIN_BATCH) {
             double u[FIN_BATCH], v[FIN_BATCH];
 #pragma unroll
             for (int k = 0; k < FIN_BATCH; ++k) {
-                const bool in = ch0 + k < chunks;
+                const bool in = ch0 + k < c_hi;
                 u[k] = in && r >= 1 ? src[((ch0 + k) * rows + (rows - r)) * (int64_t)8] : 0.0;
                 v[k] = in && r < Mc ? src[((ch0 + k) * rows + (rows - 1 - r)) * (int64_t)8] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < FIN_BATCH; ++k) { up += u[k]; dn += v[k]; }
         }
-        grad[i] = gs * (scale2 * (up - dn));
+        fin_combine(up);
+        fin_combine(dn);
+        if (sub == 0) grad[i] = gs * (scale2 * (up - dn));
     }
 }
 
@@ -236,14 +258,14 @@ int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go
 
 int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
                               const double *gscale, double *grad, hipStream_t s) {
-    hipLaunchKernelGGL(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
+    hipLaunchKernelGGL(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
                        -2.0 / sigma, gscale, grad);
     return check_launch();
 }
 
 int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
                                  double *grad, hipStream_t s) {
-    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
+    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
     return check_launch();
 }
 
