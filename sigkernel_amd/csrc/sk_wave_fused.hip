@@ -460,22 +460,52 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     int ecol_uf = EDGES && lam < prm.e_L ? prm.u_f : -1;               // the unit whose block holds the terminal column
     int ecol_off = EDGES ? prm.e_NUp * S + lam * R : 0;
     asm volatile("" : "+v"(erow_lim), "+v"(ecol_uf), "+v"(ecol_off));
-    double *ep_cur = nullptr;   // EDGES: edge block of the pair the sweep is in (null: no such pair), set where psk changes
-    int ep_left = 0;            // ... and how many more pairs of this lane's chunk follow it: consecutive stream positions of a
-                                // chunk are consecutive pairs, so the pointer just advances; only a chunk's first pair is looked
-                                // up (with chunks of CQ pairs and L skewed lanes that is L / (CQ NUp) lookups per macro-step)
-    unsigned ep_p = NOPAIR;     // ... its index
+    // EDGES: edge block of the pair this lane's sweep is in (nullptr: no such pair / a pair that keeps no edges), moved where psk changes.
+    // Consecutive stream positions of a chunk are consecutive pairs, so inside a chunk the pointer just advances; the FIRST pair of a
+    // chunk has to be looked up (chunk bases are whatever the queue handed out).  That look-up used to sit in the macro-step path
+    // (sweep_pair_is, taken by some lane 0.4-0.8 times per step under the queue), and although it is only ~50 instructions it cost the
+    // edge-keeping forward 15-18 % (profiles/r05_edges_ablation.txt): everything it reads -- the chunk ring, C0, CQ, P, the layout --
+    // stayed in scalar registers across the step loop, and the loop's own values came back through v_readlane instead.  Now every lane
+    // keeps the block of its NEXT chunk's first pair ready (nx_*), refreshed once per 8 macro-steps in the producers' block (where those
+    // scalars are at home), and entering a chunk is three moves.  A chunk lasts >= NUp >= 8 steps and is drawn >= 9 steps before lane 0
+    // enters it, so the refresh between two entries of a lane always finds the chunk known.
+    double *ep_cur = nullptr, *nx_ptr = nullptr;
+    int ep_left = 0, nx_left = 0;         // pairs of the lane's chunk after the current one / of the next chunk after its first
+    int ep_ok = 0, nx_ok = 0;             // ... how many of those keep edges (the loss layout's triangle keeps none)
+    int ep_k = 0;                         // chunks this lane's sweep has entered = index of its next chunk
+    auto refresh_next = [&]() __attribute__((always_inline)) {
+        if (EDGES) {
+            if (ep_k < have) {
+                asm volatile("");
+                const int size = ep_k == 0 ? C0 : CQ;
+                const unsigned b = ring_at(ep_k & 3);
+                const unsigned p = b + (unsigned)(grp * size);
+                const unsigned ne = edge_pairs();
+                const bool ok = b < P32 && p < P32 && p < ne;
+                nx_ptr = ok ? prm.edges + (uint64_t)p * (uint64_t)(unsigned)EP : nullptr;
+                nx_left = size - 1;
+                const unsigned room = ok ? ne - 1u - p : 0u;
+                nx_ok = (int)(room < (unsigned)(size - 1) ? room : (unsigned)(size - 1));
+            }
+        }
+    };
     auto sweep_pair_is = [&](int pk) __attribute__((always_inline)) {
         if (EDGES) {
             if (ep_left > 0) {
                 ep_left -= 1;
-                ep_p = (ep_p != NOPAIR && ep_p + 1u < edge_pairs()) ? ep_p + 1u : NOPAIR;
-                ep_cur += EP;
+                if (ep_ok > 0) {
+                    ep_ok -= 1;
+                    ep_cur += EP;
+                } else {
+                    ep_cur = nullptr;
+                }
+            } else if (pk >= 0) {
+                ep_cur = nx_ptr;
+                ep_left = nx_left;
+                ep_ok = nx_ok;
+                ep_k += 1;
             } else {
-                asm volatile("");
-                ep_p = stream_pair_left(grp, pk, ep_left);
-                if (ep_p >= edge_pairs()) ep_p = NOPAIR;
-                ep_cur = prm.edges + (int64_t)(ep_p != NOPAIR ? ep_p : 0u) * EP;
+                ep_cur = nullptr;
             }
         }
     };
@@ -503,7 +533,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_y();
     issue_x();
+    refresh_next();
     sweep_pair_is(psk);
+    refresh_next();
     if constexpr (!CUR) {
         if (c_u0 == 0) {   // lanes that start a pair in macro-step 0 (their K state is 1.0 already)
             load_x_rows(my_x);
@@ -718,7 +750,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         if (!FULLWAVE) corner = top[S - 1];
 
         if (EDGES) {
-            const bool pair_ok = ep_p != NOPAIR;
+            const bool pair_ok = ep_cur != nullptr;
             e_ptr = ep_cur;
             erow_at = (pair_ok && uk < erow_lim) ? uk * S : -1;
             ecol_at = (pair_ok && uk == ecol_uf) ? ecol_off : -1;
@@ -791,6 +823,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             issue_y();       // slab ((t + 1) >> 3) + 1
             issue_x();       // window t + 9 .. t + 16
             x_rd_off ^= (unsigned)(JMAX * XSLAB);
+            refresh_next();
         }
         if (AHEAD && CUR) read_y();   // for macro-step t + 1
     }
