@@ -464,7 +464,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
     // Consecutive stream positions of a chunk are consecutive pairs, so inside a chunk the pointer just advances; the FIRST pair of a
     // chunk has to be looked up (chunk bases are whatever the queue handed out).  That look-up used to sit in the macro-step path
     // (sweep_pair_is, taken by some lane 0.4-0.8 times per step under the queue), and although it is only ~50 instructions it cost the
-    // edge-keeping forward 15-18 % (profiles/r05_edges_ablation.txt): everything it reads -- the chunk ring, C0, CQ, P, the layout --
+    // edge-keeping forward ~5 % (profiles/r05_edges_ablation.txt): everything it reads -- the chunk ring, C0, CQ, P, the layout --
     // stayed in scalar registers across the step loop, and the loop's own values came back through v_readlane instead.  Now every lane
     // keeps the block of its NEXT chunk's first pair ready (nx_*), refreshed once per 8 macro-steps in the producers' block (where those
     // scalars are at home), and entering a chunk is three moves.  A chunk lasts >= NUp >= 8 steps and is drawn >= 9 steps before lane 0
