@@ -414,7 +414,10 @@ def test_merged_loss_route_on_the_gpu(kind, D, d, dt, A, B, M, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,d,A,B,M,naive", [("rbf", 3, 1, 32, 32, 64, False), ("rbf", 3, 1, 64, 64, 64, False), ("linear", 8, 1, 24, 40, 50, False),
                                                   ("rbf", 4, 2, 40, 17, 30, False), ("rbf", 2, 0, 9, 2, 20, False), ("linear", 5, 0, 2, 3, 120, True),
-                                                  ("rbf", 8, 1, 7, 5, 33, True), ("linear", 3, 2, 130, 3, 12, False), ("rbf", 1, 2, 3, 130, 9, False)])
+                                                  ("rbf", 8, 1, 7, 5, 33, True), ("linear", 3, 2, 130, 3, 12, False), ("rbf", 1, 2, 3, 130, 9, False),
+                                                  # big enough for the work queue: lanes enter drawn chunks, and the pairs that keep no edges
+                                                  # (the triangle of K(Y, Y)) start in the middle of one
+                                                  ("rbf", 3, 1, 320, 320, 33, False), ("linear", 6, 1, 300, 420, 40, False)])
 def test_loss_launch_route_on_the_gpu(kind, D, d, A, B, M, naive, monkeypatch):
     """The one-launch glue of the loss wrappers (csrc/sk_loss.hip: sk_prep_cat, sk_solve_fwd_loss_f64 -- the rectangle K(X, [X; Y]) and
     the strict triangle of K(Y, Y) as ONE launch --, sk_loss_value, sk_loss_weights, sk_*_adjoint_finish) against the same merged
