@@ -74,9 +74,29 @@ import sigkernel_amd  # noqa: E402
 from sigkernel_amd import _lib  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-# MI355X fp64 VECTOR peak (FMA = 2 flop): SURVEY 8(d)'s figure = half of the part's 157.3 TFLOP/s fp64 matrix peak
-# (256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz); the microarch guide carries no fp64-vector row
+# MI355X fp64 VECTOR peak (FMA = 2 flop): SURVEY 8(d)'s figure, AMD's public 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk
+# x 2 flop x 2.4 GHz -- half of the 157.3 TFLOP/s the microarchitecture guide lists for FP32 (vector and matrix); the guide has no
+# fp64 row of its own
 FP64_VECTOR_PEAK_TF = 78.6
+PEAK_SOURCE = ("SURVEY 8(d): AMD's public MI355X fp64 VECTOR figure, 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes/clk x 2 flop x "
+               "2.4 GHz -- half of the 157.3 TFLOP/s FP32 vector / matrix rows of /opt/skills/guides/MI355X_MICROARCH.md, which has no "
+               "fp64 row; tools/ubench/fma_rate measures 63 TFLOP/s of independent v_fma_f64 at the ~2.1 GHz the chip sustains")
+
+
+def fwd_ops_per_pair(kname, D, Mc, Nc, dyadic):
+    """FMA-class fp64 lane operations of one forward PDE with the static kernel inside: 3 per fine cell (the stencil) + per coarse
+    cell 3 (linear, on the pre-scaled increment) or 4 (rbf) coefficient operations + the static kernel (linear: D FMAs; rbf: 2 D for
+    the distance, 19 for the exponential, 4 for the 4-corner difference)."""
+    per_coarse = (3 + D) if kname == "linear" else (4 + 2 * D + 23)
+    return ((Mc << dyadic) * (Nc << dyadic)) * 3 + Mc * Nc * per_coarse
+
+
+def adj_ops_per_pair(kname, D, Mc, Nc, dyadic):
+    """... of one fused adjoint: 7 per fine cell (the reverse stencil 3, K recomputed backwards 3, their product 1) + per coarse cell
+    10 coefficient operations (a, b, 1/b by Newton, a/b) + the static kernel's chain rule (rbf: the node 2 D + 21, the 4-corner
+    difference 3, the weights' 4-corner sums and products 12, the 2 D accumulators; linear: D for the increment, D + 1 for W dy)."""
+    per_coarse = (11 + 2 * D) if kname == "linear" else (46 + 4 * D)
+    return ((Mc << dyadic) * (Nc << dyadic)) * 7 + Mc * Nc * per_coarse
 
 CONFIGS = {
     # name: rows of X (per GPU under weak scaling), B, M, N, D, static kernel, dyadic, dtype, mode, description
@@ -472,8 +492,12 @@ def main():
         result[other.scaling + "_scaling"] = {
             "value": other.entries_per_step * args.steps / el2, "unit": "entries/s", "ms_per_step": 1e3 * el2 / args.steps,
             "batch_x": other.A_total, "rows_per_gpu": -(-other.A_total // world), "batch_y": other.B,
+            "collectives": collectives_per_step(other.step, min(args.steps, 5), dist, dev),
             "note": "same config, same steps / warmup / barriers, timed right after the headline region"}
         del other
+    if use_dist:
+        # per-step time inside RCCL (all ranks take part; after the timed regions): what a shortfall of the scaling curve is made of
+        result["collectives"] = collectives_per_step(wl.step, min(args.steps, 5), dist, dev)
 
     t_ex = time.perf_counter()
     if rank == 0 and not args.no_extras:
@@ -601,13 +625,116 @@ def other_configs(dev, args):
                     gms, same = graph_replay_ms(wl, 50)
                     ent["hip_graph"] = {"ms_per_step": gms, "value": wl.entries_per_step / (gms * 1e-3), "gradient_bit_identical_to_eager": same}
             res[name] = ent
-            del wl, out
+            del out
+            try:
+                blocks = config_roofline(wl, ent["ms_per_step"])
+                if blocks:
+                    ent.update(blocks)
+            except Exception as e:      # noqa: BLE001 -- the ceiling is an extra: its failure must not cost the config its number
+                ent["roofline_error"] = "%s: %s" % (type(e).__name__, e)
+            del wl
             torch.cuda.empty_cache()
             torch.cuda.synchronize()
             ent["wall_s"] = time.perf_counter() - t_cfg
         except Exception as e:      # noqa: BLE001 -- a failing secondary config must not cost the headline its line
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
+
+
+def config_roofline(wl, step_ms):
+    """A `roofline` block for one of the secondary configs, by the headline's method: the algorithmic fp64 lane operations of the
+    config's DOMINANT solver launch (x 2 flop) over that launch's duration, measured by HIP events on the launch stream around the
+    host call that issues it (the staging launch of a few microseconds and -- for the adjoints -- the screen / rescue / fold launches
+    are inside the bracket), against the fp64 vector peak; `step_frac`: the same for ALL solver launches of a step over the timed
+    step.  Every config here runs fused kernels that never read the increment matrix: the binding ceiling is fp64 issue, not HBM."""
+    from sigkernel_amd.sigkernel import _fused_forward
+    be = _lib.get_backend()
+    A, B, Mc, Nc, D, d, kn = wl.A_total, wl.B, wl.M - 1, wl.N - 1, wl.D, wl.dyadic, wl.kname
+    sk = wl.sk1
+    f_ops, a_ops = fwd_ops_per_pair(kn, D, Mc, Nc, d), adj_ops_per_pair(kn, D, Mc, Nc, d)
+    blocks = {}
+
+    def block(kernel, pairs, ops_per_pair, ms):
+        avg = float(np.mean(ms))
+        tf = 2.0 * pairs * ops_per_pair / (avg * 1e-3) / 1e12
+        return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TF,
+                "kernel": kernel, "pairs_per_launch": int(pairs), "fp64_lane_ops_per_launch": int(pairs * ops_per_pair),
+                "avg_launch_ms": avg, "min_launch_ms": float(np.min(ms)), "traffic": None}
+
+    if wl.mode == "gram":
+        if wl.sym:
+            pairs, fn = A * (A + 1) // 2, (lambda: sk.compute_Gram(wl.X, wl.X, sym=True))
+            kernel = "sk_solve_fwd_%s_sym_f64 (k_fwd_fused: the pairs on and above the diagonal, one launch)" % kn
+        else:
+            pairs, fn = A * B, (lambda: _fused_forward(be, sk.static_kernel, wl.X, wl.Y, d, False, gram=True))
+            kernel = "sk_solve_fwd_static_* (k_fwd_fused_mb: several bands per pair)" if Mc > 128 else "sk_solve_fwd_%s_* (k_fwd_fused)" % kn
+        if fn() is None:
+            return None
+        blocks["roofline"] = block(kernel, pairs, f_ops, time_launches(fn, 5))
+        step_ops = pairs * f_ops
+    elif A + B <= 256:
+        # training-sized step (the one-launch loss route): K(X, [X; Y]) + the strict triangle of K(Y, Y) in ONE forward launch, the
+        # rectangle's adjoint in one
+        kind, param = (0, 1.0) if kn == "linear" else (1, 1.0)
+        p_f, p_a = A * (A + B) + B * (B - 1) // 2, A * (A + B)
+        Xd, Yd = wl.X.detach(), wl.Y.detach()
+        res = be.loss_forward(kind, param, Xd, Yd, d, False, True, True)
+        if res is None:
+            return None
+        ms_f = time_launches(lambda: be.loss_forward(kind, param, Xd, Yd, d, False, True, True), 10)
+        blocks["roofline"] = block("sk_prep_cat_f64 + sk_solve_fwd_loss_f64 (k_fwd_fused, keeps the rectangle's edges) + sk_loss_value_f64",
+                                   p_f, f_ops, ms_f)
+        _, out, edges, (Zr, Zt, Zr_adj), wb = res
+        adj = be.linear_adjoint_fused if kind == 0 else be.rbf_adjoint_fused
+        run_a = lambda: adj(Xd, None, param, d, edges, wb, gram=True, kfinal=out[:p_a], naive=False, staged=(Zr_adj, Zt, A + B, wl.M))   # noqa: E731
+        if run_a() is not None:
+            blocks["roofline_adjoint"] = block("sk_%s_adjoint_fused_f64 (screen + k_adj_fused_* + rescue + fold)" % kn, p_a, a_ops,
+                                               time_launches(run_a, 10))
+        step_ops = p_f * f_ops + p_a * a_ops
+    else:
+        # BASELINE configs[3]: the dominant launch is the adjoint of K_XY (all A x B pairs, one launch); the step's solver work is
+        # the triangle of K_XX and K_XY forward with edges, the triangle of K_YY, and the two adjoints
+        Xd, Yd = wl.X.detach(), wl.Y.detach()
+        res = _fused_forward(be, sk.static_kernel, Xd, Yd, d, False, gram=True, keep_edges=True)
+        if res is None or res[1] is None:
+            return None
+        K, edges = res
+        gen = torch.Generator().manual_seed(11)
+        w = torch.randn(A, B, generator=gen, dtype=torch.float64).to(Xd.device)
+        adj = be.linear_adjoint_fused if kn == "linear" else be.rbf_adjoint_fused
+        run_a = lambda: adj(Xd, Yd, 1.0, d, edges, w, gram=True, kfinal=K)   # noqa: E731
+        if run_a() is None:
+            return None
+        blocks["roofline"] = block("sk_%s_adjoint_fused_f64 on K_XY (k_adj_fused_*: reverse PDE + K recomputed + chain rule, one launch)" % kn,
+                                   A * B, a_ops, time_launches(run_a, 3))
+        del K, edges, res, w
+        tri_x, tri_y = A * (A + 1) // 2, B * (B + 1) // 2
+        step_ops = (tri_x + A * B + tri_y) * f_ops + (A * B + tri_x) * a_ops
+    tf_step = 2.0 * step_ops / (step_ms * 1e-3) / 1e12
+    blocks["step_frac"] = {"fp64_lane_ops_per_step": int(step_ops), "achieved": tf_step, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": tf_step / FP64_VECTOR_PEAK_TF,
+                           "note": "every solver launch of one timed step (glue launches and host time included in the time, not in the operations)"}
+    return blocks
+
+
+def collectives_per_step(step, steps, dist, dev):
+    """What a step spends in this package's collectives: `steps` extra steps AFTER the timed region with every all-gather / all-reduce
+    bracketed by events (sigkernel_amd.distributed.record_collectives) -- per step: calls, milliseconds, bytes received."""
+    from sigkernel_amd import distributed as skd
+    skd.record_collectives(True)
+    try:
+        for _ in range(steps):
+            step()
+        summ = skd.collective_summary()
+    finally:
+        skd.record_collectives(False)
+    if dist is not None:
+        dist.barrier()
+    res = {k: {"calls_per_step": v["calls"] / steps, "ms_per_step": v["ms"] / steps, "bytes_per_step": v["bytes"] / steps} for k, v in summ.items()}
+    return {"all_gather_ms": res.get("all_gather", {}).get("ms_per_step", 0.0), "all_reduce_ms": res.get("all_reduce", {}).get("ms_per_step", 0.0),
+            "detail": res, "steps": steps,
+            "note": "HIP events on the caller's stream around each collective of sigkernel_amd.distributed, %d steps after the timed region "
+                    "(rank 0's view: it includes the wait for the slowest rank to arrive)" % steps}
 
 
 DIST_CONFIGS = (("c4", 3, 2), ("c5", 2, 1))     # (name, timed steps, warm-ups) of the N > 1 line
@@ -633,6 +760,7 @@ def dist_configs(world, rank, dev, group, dist, plan=DIST_CONFIGS, shapes=None):
                    "rows_per_gpu": cfg["rows_per_gpu"], "parallelism": cfg["parallelism"],
                    "dtype": "f64" if wl.dtype == torch.float64 else "f32",
                    "grid_cells_per_s": wl.entries_per_step * steps / elapsed * wl.cells_per_entry}
+            ent["collectives"] = collectives_per_step(wl.step, 2, dist, dev)      # (every rank takes part; after the timed region)
             if rank == 0:
                 if wl.mode == "gram":
                     ent["parity"] = gram_parity(wl, out, 64 if wl.cells_per_entry < 1e6 else 8)
@@ -693,8 +821,7 @@ def extras(result, args, cfg, sk, be, X, Y, Xc, Yc, out, A_total, world, value):
         live = None if (args.no_live_traffic or sym or world > 1) else live_traffic(args.config, "k_fwd_fused")
         result["roofline"] = {
             "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TF,
-            "peak_source": "SURVEY 8(d): half of the 157.3 TFLOP/s fp64 MATRIX peak of /opt/skills/guides/MI355X_MICROARCH.md (256 CUs x 4 SIMDs x "
-                           "16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz); the guide itself carries no fp64-vector row",
+            "peak_source": PEAK_SOURCE,
             "traffic": live["hbm_bytes_per_launch"] if live else traffic_entry(args.config + "_fused", pairs_f),
             "traffic_source": ("measured in this run: rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum "
                                "TCC_EA0_WRREQ_64B_sum on a child bench.py --config %s --steps 3 --no-extras, %d dispatches of k_fwd_fused*, "

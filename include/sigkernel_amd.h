@@ -59,6 +59,9 @@ typedef enum sk_status {
 #define SK_FLAG_FAST_ONLY 4 /* never fall back: SK_ERR_UNSUPPORTED if the tiled kernels do not
                                cover the shape/layout (used by tests and benchmarks)            */
 
+/* 320.  The number moves whenever an exported signature changes incompatibly: 310 -> 320 gave sk_solve_fwd_{linear,rbf}_sym_* their
+ * pair_tab argument (position 3) and added the sk_prep_cat_* / sk_solve_fwd_loss_f64 / sk_loss_* / sk_*_adjoint_finish_f64 family; a
+ * binding written against 310 must not load a 320 library silently (sigkernel_amd/_lib.py checks it at load). */
 int sk_version(void);
 /* "sigkernel_amd gfx950; sources <hash>; <hipcc --version>; ISA hazard lint passed at build": the sources and the toolchain this
  * binary was built from (static string).  The hand-scheduled kernels are linted at build time against the register allocator of
@@ -399,7 +402,10 @@ size_t sk_solve_fwd_static_workspace_bytes(int kind, int64_t P, int Mc, int Nc, 
  * counter, work handed out band-major by one ticket counter (an item only waits for a smaller ticket: no deadlock whatever is
  * resident) -- instead of one wave sweeping the bands of its pair one after the other; the same arithmetic in the same order, bit
  * for bit.  The workspace above includes its rows.  Returns the bands per pair when a launch of P pairs takes that mode, else 0
- * (cython_backend.pyx:64-119 has no length limit; its one thread per pair is what this replaces).  SK_FUSEDMB_SPLIT=0 disables. */
+ * (cython_backend.pyx:64-119 has no length limit; its one thread per pair is what this replaces).  SK_FUSEDMB_SPLIT=0 disables.
+ * Status: a wave's wait for the band above is bounded (~2^22 polls: a stall -- queue preemption, a fault in another wave -- must
+ * not hang the device); an item that gives up poisons ITS pair with NaN (the wave's other items are untouched) and counts in the
+ * launch's status word, the LAST 8 bytes (uint64) of the workspace as passed: 0 after every normal launch. */
 int sk_solve_fwd_static_split(int kind, int64_t P, int Mc, int Nc, int dyadic, int D);
 int sk_solve_fwd_static_rows(int kind, int Mc, int dyadic);
 /* Ncp = 2 NUp: columns per dimension row of Yt (zero-padded), the same for sk_rbf_adjoint_fused_mb_f64 / sk_linear_adjoint_fused_mb_f64. */

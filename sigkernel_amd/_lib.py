@@ -130,6 +130,9 @@ class SigKernelLibraryError(RuntimeError):
     pass
 
 
+ABI_VERSION = 320      # include/sigkernel_amd.h: sk_version()
+
+
 def load():
     """Load the shared library (once). Raises if it has not been built."""
     global _lib
@@ -143,6 +146,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.sk_version() != ABI_VERSION:      # (a stale in-tree build: the signatures above would bind the wrong arguments)
+            raise SigKernelLibraryError("%s exports ABI %d, this binding is written against %d: rebuild it (python -m sigkernel_amd.build)"
+                                        % (LIB_PATH, lib.sk_version(), ABI_VERSION))
         _lib = lib
     return _lib
 
@@ -168,6 +174,18 @@ def costs():
 
 def cost(name):
     return costs()[name][0]
+
+
+class _SplitStatus:
+    """The status word of a split-mode sk_solve_fwd_static_* launch, reduced on demand (`int(s)` synchronises): how many (band, pair)
+    items gave up waiting for the band above (their pairs are NaN); 0 after every normal launch."""
+
+    def __init__(self, ws):
+        self._ws = ws
+
+    def __int__(self):
+        n8 = self._ws.numel() & ~7
+        return int(self._ws[n8 - 8:n8].view(torch.int64).item())
 
 
 def _check(status, what):
@@ -320,6 +338,7 @@ class HipBackend:
     """The product back-end: every method enqueues HIP kernels on the current stream."""
 
     name = "hip"
+    last_split_status = None      # _SplitStatus of the last split-mode sk_solve_fwd_static_* launch (None: the last one was not)
 
     @staticmethod
     def route(op, kind, D, M, N, dyadic, naive, elem_size, no_stream=False, no_swap=False):
@@ -500,7 +519,10 @@ class HipBackend:
             _check(rc, "sk_solve_fwd_loss")
             value = torch.empty((), dtype=torch.float64, device=dev)
             wb = torch.empty(P_rect, dtype=torch.float64, device=dev) if keep_edges else None   # d value / dK: the adjoint's weights
-            _check(lib.sk_loss_value_f64(_ptr(out), A, B, int(bool(with_yy)), _ptr(value), _ptr(wb), _stream(X)), "sk_loss_value")
+            rc = lib.sk_loss_value_f64(_ptr(out), A, B, int(bool(with_yy)), _ptr(value), _ptr(wb), _stream(X))
+            if rc == 2:          # (a decline, like the forward's: the caller's torch glue serves the call)
+                return None
+            _check(rc, "sk_loss_value")
         return value, out, edges, (Zr, Zt, Zr2 if two_rows else Zr), wb
 
     @staticmethod
@@ -628,6 +650,8 @@ class HipBackend:
         if rc == 2:
             return None
         _check(rc, "sk_solve_fwd_static")
+        # split mode's status word (the last 8 bytes of the workspace: items whose bounded wait gave up -> NaN pairs), read on demand
+        self.last_split_status = _SplitStatus(ws) if int(lib.sk_solve_fwd_static_split(int(kind), P, Mc, Nc, int(dyadic), D)) and not keep_edges and not y32 else None
         return (out, edges) if keep_edges else out
 
     FUSED_RESCUE_BLOCKS_MB = 8   # (a stored pair of 2044 x 2044 grids is 67 MB)

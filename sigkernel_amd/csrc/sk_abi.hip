@@ -189,7 +189,10 @@ int device_cu_count() {
 
 extern "C" {
 
-int sk_version(void) { return 310; }   // 310: edges argument of sk_solve_fwd_static_*, the multi-band adjoints, the fused derivative solver
+// 320 (round 5/6): sk_solve_fwd_{linear,rbf}_sym_* take the pair table (argument 3), sk_prep_cat_*, sk_solve_fwd_loss_f64, sk_loss_*,
+// sk_*_adjoint_finish_f64, sk_cost_query; the SK_WAVE_PF / SK_DERIV_PF / SK_ADJR_ALL knobs are gone; split mode's status word
+// (310: edges argument of sk_solve_fwd_static_*, the multi-band adjoints, the fused derivative solver)
+int sk_version(void) { return 320; }
 
 /* Development hook: parse the SK_* environment variables again (tools that sweep a knob inside one process).  Not
  * thread-safe against concurrent launches; product code never calls it. */

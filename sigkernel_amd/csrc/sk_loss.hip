@@ -246,7 +246,8 @@ template int launch_prep_cat<float>(const float *, int64_t, const float *, int64
                                     int, int, int *, int64_t, hipStream_t);
 
 int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, hipStream_t s) {
-    if ((A + B) * A + B * B >= 0x7fffffffLL) return SK_ERR_UNSUPPORTED;     // (32-bit indices; the loss wrappers' merged route ends far below)
+    // (32-bit indices; the loss wrappers' merged route ends far below.  The triangle of K(Y, Y) only counts when it is there.)
+    if (A < 0 || B < 0 || (A + B) * A + (with_yy ? B * (B - 1) / 2 : 0) >= 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, (int)A, (int)B, with_yy, value, wb);
     return check_launch();
 }

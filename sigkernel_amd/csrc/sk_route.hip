@@ -94,6 +94,10 @@ const CostEntry COSTS[] = {
     {"mmd_streams_max_pairs", 16384,
      "pairs per Gram matrix up to which a CAPTURED composed compute_mmd forks its three matrices onto three streams (replays 10-15 % faster at 16..64 paths)"},
     {"keep_edges_fraction", 0.5, "share of the transient budget the edges kept between forward and backward may take"},
+    {"loss_launch_free_bytes", 268435456.0,
+     "bytes the one-launch loss route (sk_solve_fwd_loss_f64: values, weights, pair table and the rectangle's edges, allocated in one piece and held until "
+     "backward) may take without asking the device for its free memory -- hipMemGetInfo costs 20-30 us, a tenth of a 32 + 32-path step; above it the "
+     "call is held to keep_edges_fraction of the budget like every other route (ADVICE r5)"},
     {"fused_mid_min_pairs_per_rank", 4,
      "pairs per lane group and rank from which a no-queue fused forward that fills the chip deals out shares by wave age rank: 64-row shard of the "
      "headline Gram 0.695 -> 0.640 ms, 128 + 128 path mmd step 1.237 -> 1.171 ms (r05, same box)"},

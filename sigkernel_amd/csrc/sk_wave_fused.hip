@@ -853,6 +853,7 @@ struct FusedPlan {
     int G, NUp, L, lag;
     size_t lds_bytes;   // per wave
     int waves_per_cu;   // from LDS and the measured optimum; still to be capped by the variant's VGPR use
+    int rcx;            // coarse rows per lane when not the strip kernels' own (0: Tile<DY>::RC)
 };
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND, int RCX = 0>
@@ -881,7 +882,12 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
         // 0.65 for q = 1 / 2 / 3, from per-wave timestamps of the 128 x 128 symmetric RBF launch (1.13 / 0.83 / 0.73 us,
         // tools/experiments/r03_c2_wave_times.py) -- there 8256 pairs are 4096 lane groups x 2 + 64, and q = 2 (0.193 ms)
         // beats q = 3 (6144 lane groups, a third of them with two pairs: 0.220 ms).
-        static const double rate[4] = {1.0, 1.0, 0.735, 0.65};
+        // (round 6, per-wave time of a macro-step against a lone wave's, from launches of exactly k pairs per lane group at q waves per
+        // SIMD, profiles/r06_rc4_steps.txt: two rows per lane 1 / 0.70 / 0.62 without edges, 1 / 0.69 / 0.56 with; four rows per lane
+        // 1 / 0.69 without, 1 / 0.79 with -- and a SIMD whose waves are of unequal length carries fewer of them once the short ones
+        // are done: two phases, not one rate over the sum of the steps)
+        static const double rate_std[4] = {1.0, 1.0, 0.70, 0.60}, rate_dbl[4] = {1.0, 1.0, EDGES ? 0.79 : 0.69, 0.62};
+        const double *rate = (RCX != 0 && RCX == 2 * Tile<DY>::RC) ? rate_dbl : rate_std;
         const int64_t nsimd = (int64_t)device_cu_count() * 4;
         const int fill = pl.L - 1 + pl.lag;
         double best = 0;
@@ -892,7 +898,9 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
             const int64_t base = pl.P / (W * pl.G), rem = pl.P - base * W * pl.G, nbig = (rem + pl.G - 1) / pl.G;
             if (base == 0) W = nbig;
             const int64_t on_simd = (W + nsimd - 1) / nsimd, big_on_simd = std::min(on_simd, (nbig + nsimd - 1) / nsimd);
-            const double cost = (double)(big_on_simd * ((base + 1) * pl.NUp + fill) + (on_simd - big_on_simd) * (base * pl.NUp + fill)) * rate[on_simd];
+            const double longest = (double)((base + (big_on_simd > 0 ? 1 : 0)) * pl.NUp + fill), shortest = (double)(base * pl.NUp + fill);
+            const double all = (on_simd > big_on_simd && base > 0) ? shortest : longest;      // steps every wave of the SIMD runs
+            const double cost = all * (double)on_simd * rate[on_simd] + (longest - all) * (double)big_on_simd * rate[big_on_simd > 0 ? big_on_simd : 1];
             if (best_q == 0 || cost < best * 0.98) { best = cost; best_q = q; }
         }
         if (best_q && knobs().fused_wpc <= 0) {
@@ -977,19 +985,45 @@ int launch_fused_nd(FusedParams prm, const FusedPlan &pl, hipStream_t s) {
     return check_launch();
 }
 
+// Coarse rows per lane of the one-band forward (0: the strip kernels' own, Tile<DY>::RC).  TWICE the strip kernels' rows wherever the
+// registers hold them (round 6): a pair then takes half the lanes -- half the skew's fill, twice as many pairs per wave -- and a
+// macro-step does twice the cells for 1.4-1.6x the time, because what a macro-step costs is to a good part independent of the rows
+// (the neighbour exchange, the pair-start block some lane runs in every step, cursors, ring addresses, the scalar stream:
+// profiles/r06_small_launch_pmc.txt).  Same arithmetic per cell in the same order: bit-identical results (104 arrays,
+// tools/experiments/r06_rc4.py).  Same-box A/B (profiles/r06_rc4_ab.txt): headline 4.13 -> 3.85 ms, 64-row shard 0.641 -> 0.606,
+// linear with edges 5.39 -> 4.78, rbf with edges 9.88 -> 8.94 (1024 x 1024 pairs of 64 points), a 32 + 32-path MMD step 0.303 -> 0.270.
+//   dyadic 1: linear (every variant) and rbf of dim <= 4: FOUR rows (pairs of up to 129 points on <= 32 lanes: no full-wave variant);
+//             rbf of dim 5..8: two (the four-row form would not fit 256 registers);
+//   dyadic 2: the variants that keep edges (linear, rbf of dim <= 4; fp64, default stencil): TWO rows (-6 %; without edges: no gain);
+//   dyadic 0: rbf with 8 staged dims: two instead of four (the four-row form spills), everything else the strip kernels' four.
+constexpr int fused_rcx(int kind, int dy, int nd, bool edges, bool plain /* fp64 output, default stencil */) {
+    return dy == 1 ? ((kind == 0 || nd == 4) ? 4 : 0)
+         : dy == 2 ? ((edges && plain && (kind == 0 || nd == 4)) ? 2 : 0)
+         : ((kind == 1 && nd == 8) ? 2 : 0);
+}
+constexpr int fused_nd(int dims, bool plain) { return plain && dims <= 4 ? 4 : 8; }   // the four-dimension variants: fp64, default stencil
+
+template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND, int ND>
+int launch_fused_v(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
+    constexpr bool PLAIN = !NAIVE && sizeof(TO) == 8;
+    constexpr int RCX = fused_rcx(KIND, DY, ND, EDGES, PLAIN);
+    if (pl.rcx != RCX) return SK_ERR_UNSUPPORTED;      // (the plan was sized for another row count: host and device rules disagree)
+    // the doubled forms serve a pair on at most 32 lanes: their full-wave instances would be dead code
+    if constexpr (FULLWAVE && RCX != 0 && RCX == 2 * Tile<DY>::RC) return SK_ERR_UNSUPPORTED;
+    // RBF at dyadic 0 with 8 staged dims: the edges' reader exists for the default stencil in fp64 only
+    else if constexpr (KIND == 1 && DY == 0 && ND == 8 && EDGES && !PLAIN) return SK_ERR_UNSUPPORTED;
+    else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, ND, RCX>(prm, pl, s);
+}
+
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, bool EDGES, int KIND>
 int launch_fused_e(const FusedParams &prm, const FusedPlan &pl, hipStream_t s) {
     // paths of dimension <= 4 skip the four zero dimensions (fp64, default scheme: the variants that are worth their build time)
     if constexpr (!NAIVE && sizeof(TO) == 8) {
-        if (prm.dims <= 4) return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, pl, s);
+        if (prm.dims <= 4) return launch_fused_v<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 4>(prm, pl, s);
     }
-    // RBF at dyadic 0 with 8 staged dims in fp64 compiles to 280-290 registers with spills: no variant for it (reads left in flight
-    // are unsafe there, tools/check_async_hazards.py: scan_pressure) -- such calls take sk_solve_fwd_static_* or the unfused route
-    // -- with TWO rows per lane it fits (pairs of up to 128 points; no edges: launch_fwd_fused sized the plan for it)
-    if constexpr (KIND == 1 && DY == 0) {
-        if constexpr (EDGES && (NAIVE || sizeof(TO) != 8)) return SK_ERR_UNSUPPORTED;   // (the adjoint that reads them: default stencil)
-        else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8, 2>(prm, pl, s);
-    } else return launch_fused_nd<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
+    // (RBF at dyadic 0 with 8 staged dims in fp64 compiles to 280-290 registers with spills in the four-row form: no variant for it --
+    // reads left in flight are unsafe there, tools/check_async_hazards.py: scan_pressure -- with TWO rows per lane it fits: fused_rcx)
+    return launch_fused_v<TO, DY, NAIVE, FULLWAVE, EDGES, KIND, 8>(prm, pl, s);
 }
 
 template <typename TO, int DY, bool NAIVE, bool FULLWAVE, int KIND>
@@ -1027,7 +1061,6 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     const bool four_dim = !g.naive && sizeof(TO) == 8 && D <= 4;
     const bool rbf0_two_rows = KIND == 1 && DY == 0 && !four_dim;
     if (rbf0_two_rows && strip_edges && (g.naive || sizeof(TO) != 8)) return SK_ERR_UNSUPPORTED;
-    const int RC = DY == 0 ? (rbf0_two_rows ? 2 : 4) : DY == 1 ? 2 : 1;
     // linear: one unit = two increment columns.  RBF: one unit = two NODE columns, and the sweep of a pair's last unit
     // reads one node column of the following unit, which therefore has to exist as padding inside the pair's stream;
     // likewise the lanes of a pair must cover M node rows, not M - 1 increment rows
@@ -1035,6 +1068,11 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     const int rows = KIND == 1 ? g.Mc + 1 : g.Mc;
     const int NUp = (NU + LINE_UNITS - 1) / LINE_UNITS * LINE_UNITS;
     if (Ncp < NUp * 2 || (Ncp & 1)) return SK_ERR_UNSUPPORTED;
+    // rows per lane: the strip kernels' own or twice that (fused_rcx, above -- the same rule the variant dispatch applies)
+    const int nd_v = fused_nd(D, !g.naive && sizeof(TO) == 8);
+    const int rcx = fused_rcx(KIND, DY, nd_v, strip_edges != nullptr, !g.naive && sizeof(TO) == 8);
+    const int RC = rcx ? rcx : (DY == 0 ? 4 : DY == 1 ? 2 : 1);
+    const bool doubled = rcx == 2 * (DY == 0 ? 4 : DY == 1 ? 2 : 1);
     int logL = 3;
     while (logL < 6 && (RC << logL) < rows) ++logL;
     if (rbf0_two_rows && strip_edges) {
@@ -1066,7 +1104,7 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     if (wpc_env > 0) waves_per_cu = waves_per_cu < wpc_env ? waves_per_cu : wpc_env;
     else if (waves_per_cu > 4) waves_per_cu &= ~3;   // whole four-wave workgroups
     if (waves_per_cu < 1) waves_per_cu = 1;
-    const FusedPlan pl{g.P, G, NUp, L, KIND == 1 ? 2 : 0, lds_bytes, waves_per_cu};
+    const FusedPlan pl{g.P, G, NUp, L, KIND == 1 ? 2 : 0, lds_bytes, waves_per_cu, rcx};
 
     FusedParams prm;
     prm.dXr = dXr; prm.dYt = dYt; prm.out = out; prm.edges = strip_edges; prm.P = g.P; prm.B = B;
@@ -1080,9 +1118,10 @@ int launch_fwd_fused(const double *dXr, const double *dYt, int64_t A, int64_t B,
     prm.e_L = L;
     if (strip_edges) {   // the layout sk_solve_adj_* reads (for the linear kernel it is this kernel's own)
         const Strip st = strip_geom(KIND == 1 ? rbf_edge_geom(g) : g, 8);
-        if (!st.ok || st.nb != 1 || (st.RC != RC && !rbf0_two_rows)) return SK_ERR_UNSUPPORTED;
+        if (!st.ok || st.nb != 1 || (st.RC != RC && !rbf0_two_rows && !doubled) || ((1 << st.logL) * st.RC) % RC) return SK_ERR_UNSUPPORTED;
         prm.e_NUp = st.NUp;
-        prm.e_L = (1 << st.logL) * (st.RC / RC);      // e_L x (this kernel's rows per lane) = the strip layout's padded rows
+        prm.e_L = ((1 << st.logL) * st.RC) / RC;      // e_L x (this kernel's rows per lane) = the strip layout's padded rows
+        if (prm.e_L > L) return SK_ERR_UNSUPPORTED;   // (every padded row of the strip layout must be some lane's)
     }
     prm.u_f = (g.Nc - 1) / 2;
     prm.lam_f = ((g.Mc - 1) / RC) % L;

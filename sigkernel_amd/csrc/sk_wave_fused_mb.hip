@@ -71,6 +71,7 @@ struct FusedMbParams {
     double *rows;        // [items][row_stride]
     int64_t row_stride;  // doubles per item row (NUp E)
     unsigned *prog;      // [items] chunks flushed, zeroed by the launcher
+    unsigned long long *status;   // the LAST 8 bytes of the caller's workspace: items whose wait for the band above gave up (zeroed by the launcher)
     int lead;            // chunks a band must be ahead of the band below it before that band's next window is fetched (the counter
                          // is then polled once per `lead` windows, not once per window); <= MB_LEAD
 };
@@ -410,7 +411,10 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         // lane 63's stream unit at macro-step t is t - 63; its first whole chunk [0, 8) is complete at t = 70
         f_pos = 0;
     }
-    bool gave_up = false;        // split mode: a producer's counter did not move for seconds: this wave's results are NaN from here on
+    // split mode: stream positions [bad_lo, bad_hi] of this wave whose producer's counter did not move for seconds -- THEIR results
+    // (and, through the poisoned boundary rows, those of the bands below them) are NaN; the wave's other items are not touched, and
+    // the launch's status word counts the give-ups (a stall must not show up as unexplained NaNs of unrelated pairs)
+    int bad_lo = 0x7fffffff, bad_hi = -1;
     int f_i = 0;                 // split mode: the stream position of the bottom lane's row unit
     unsigned *pub_ptr = nullptr; // ... the progress counter a flush has yet to publish (after the wait for its stores), and the count
     unsigned pub_cnt = 0;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
         if (lam < CHUNK / 16) {
             d2_t v;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(lds0 + BO_BASE + (unsigned)(lam * 16)) : "memory");
-            if (SPLIT && gave_up) v = d2_t{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};   // poison the bands below
+            if (SPLIT && f_i >= bad_lo && f_i <= bad_hi) v = d2_t{__longlong_as_double(0x7ff8000000000000LL), __longlong_as_double(0x7ff8000000000000LL)};   // poison the bands below
             store_through(frow + (int64_t)f_pos * E + lam * 2, v);
         }
         f_pos += 8;
@@ -463,7 +467,13 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
             asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(pp) : "memory");
             seen = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
             if (seen >= want) break;
-            if (spins >= (1u << 22)) { gave_up = true; seen = total; break; }
+            if (spins >= (1u << 22)) {
+                bad_lo = x_pi < bad_lo ? x_pi : bad_lo;
+                bad_hi = x_pi > bad_hi ? x_pi : bad_hi;
+                if (lam == 0 && prm.status) atomicAdd(prm.status, 1ULL);
+                seen = total;
+                break;
+            }
             __builtin_amdgcn_s_sleep(16);
         }
     };
@@ -755,7 +765,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                         asm volatile("" : "+v"(cv));
                         if (k * CW + q == prm.sel_f) v = cv;
                     }
-                if (SPLIT && gave_up) v = __longlong_as_double(0x7ff8000000000000LL);
+                if (SPLIT && pv >= bad_lo && pv <= bad_hi) v = __longlong_as_double(0x7ff8000000000000LL);
                 static_cast<TO *>(prm.out)[pair_v] = (TO)v;
             }
         }
@@ -843,6 +853,10 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
         prm.C0 = 0;
         prm.q_first = 0;
         if (hipMemsetAsync(prm.prog, 0, prog_bytes + sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
+        // the status word: the last 8 bytes of the workspace AS PASSED (inside the 64 bytes of slack behind the counter whatever the
+        // resident waves turn out to be, so that the caller finds it without knowing the layout)
+        prm.status = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ws) + (ws_bytes & ~(size_t)7)) - 1;
+        if (hipMemsetAsync(prm.status, 0, sizeof(unsigned long long), s) != hipSuccess) return SK_ERR_LAUNCH;
     } else if (!ws || ws_bytes < (size_t)waves * (size_t)prm.ws_stride * sizeof(double) + 64) {
         return SK_ERR_WORKSPACE;
     } else if (waves == max_waves && per >= 8 && pct < 100) {
@@ -1010,7 +1024,7 @@ int launch_fwd_fused_mb(int kind, const double *Xr, const void *Yt_any, int yt_f
     prm.Xr = Xr; prm.Yt = Yt; prm.out = out; prm.edges = edges; prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp;
     prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = pl.NUp; prm.nb = pl.nb; prm.inv_sigma = inv_sigma; prm.ws_stride = pl.ws_stride;
     prm.naive = g.naive;
-    prm.split = 0; prm.Pn = g.P; prm.nb_true = pl.nb; prm.rows = nullptr; prm.row_stride = 0; prm.prog = nullptr;
+    prm.split = 0; prm.Pn = g.P; prm.nb_true = pl.nb; prm.rows = nullptr; prm.row_stride = 0; prm.prog = nullptr; prm.status = nullptr;
     int64_t P_launch = g.P;
     const size_t split_rows = mb_split_rows_bytes(kind, g.P, g.Mc, g.Nc, g.dyadic, D, y32, edges != nullptr);
     if (split_rows) {

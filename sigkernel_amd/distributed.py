@@ -18,7 +18,63 @@ from . import _lib
 from .sigkernel import (_SigKernel, _SigKernelGram, _budget, _fused_static, _gram_block, _sym_fused_gradient, _sym_triangle_ok,
                         _sym_unfused_gradient, k_kgrad)
 
-__all__ = ["row_range", "sharded_gram", "sharded_kernel", "ShardedGram", "ShardedPaired", "ShardedSymGram", "sharded_kgrad"]
+__all__ = ["row_range", "sharded_gram", "sharded_kernel", "ShardedGram", "ShardedPaired", "ShardedSymGram", "sharded_kgrad",
+           "record_collectives", "collective_summary"]
+
+# Per-collective timings, on request (bench.py's N > 1 line: what a step spends in RCCL as opposed to its kernels).  While a list
+# hangs here every collective of this module is bracketed by two events on the caller's stream (HIP events on a GPU -- a
+# torch.distributed collective makes the caller's stream wait for it, so the second event completes when the collective has --,
+# the wall clock on the CPU / gloo test configuration).  Off (None) by default: nothing is recorded, nothing synchronises.
+_COLLECTIVE_LOG = None
+
+
+def record_collectives(on=True):
+    """Start (or stop and drop) the log of this module's collectives; collective_summary() reads it."""
+    global _COLLECTIVE_LOG
+    _COLLECTIVE_LOG = [] if on else None
+
+
+def collective_summary():
+    """{"all_gather": {"calls", "ms", "bytes"}, "all_reduce": {...}} of the collectives logged since record_collectives(); synchronises
+    the device.  bytes: what this rank RECEIVES (all-gather: the gathered tensor; all-reduce: the reduced tensor)."""
+    log = _COLLECTIVE_LOG or []
+    if any(e[2] is not None and not isinstance(e[2], float) for e in log):
+        torch.cuda.synchronize()
+    out = {}
+    for kind, nbytes, t0, t1 in log:
+        ms = (t1 - t0) * 1e3 if isinstance(t0, float) else t0.elapsed_time(t1)
+        ent = out.setdefault(kind, {"calls": 0, "ms": 0.0, "bytes": 0})
+        ent["calls"] += 1
+        ent["ms"] += float(ms)
+        ent["bytes"] += int(nbytes)
+    return out
+
+
+class _timed_collective:
+    def __init__(self, kind, tensor):
+        self.on = _COLLECTIVE_LOG is not None
+        self.kind, self.tensor = kind, tensor
+
+    def __enter__(self):
+        if self.on:
+            import time as _t
+            if self.tensor.is_cuda:
+                self.t0 = torch.cuda.Event(enable_timing=True)
+                self.t0.record()
+            else:
+                self.t0 = _t.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on and exc[0] is None and _COLLECTIVE_LOG is not None:
+            import time as _t
+            if self.tensor.is_cuda:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+            else:
+                t1 = _t.perf_counter()
+            _COLLECTIVE_LOG.append((self.kind, self.tensor.numel() * self.tensor.element_size(), self.t0, t1))
+        return False
 
 
 def row_range(n_rows, rank, world):
@@ -31,12 +87,13 @@ def row_range(n_rows, rank, world):
 def _gather(out, inp, group):
     """all_gather_into_tensor; a gloo group is given host copies of device tensors (gloo moves no HIP memory: this is the
     test configuration -- several ranks sharing one GPU -- not a production path, which is RCCL)."""
-    if out.is_cuda and dist.get_backend(group) == "gloo":
-        host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, inp.cpu(), group=group)
-        out.copy_(host)
-    else:
-        dist.all_gather_into_tensor(out, inp, group=group)
+    with _timed_collective("all_gather", out):
+        if out.is_cuda and dist.get_backend(group) == "gloo":
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, inp.cpu(), group=group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=group)
 
 
 def _all_gather_rows(block, n_rows, chunk, group):
@@ -189,12 +246,13 @@ def _assemble_folded(strips, A, bs, world, group):
 
 
 def _all_reduce_sum(t, group):
-    if t.is_cuda and dist.get_backend(group) == "gloo":      # (test configuration: several ranks sharing one GPU)
-        host = t.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        t.copy_(host)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    with _timed_collective("all_reduce", t):
+        if t.is_cuda and dist.get_backend(group) == "gloo":      # (test configuration: several ranks sharing one GPU)
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 

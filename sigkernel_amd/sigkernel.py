@@ -758,31 +758,39 @@ def routes_allow_streams():
     return not routes.no_mmd_streams
 
 
-def _loss_weights(A, B, dtype, device):
+def _loss_weights(A, B, dtype, device, max_cached=16):
     """Constant weight matrices of the loss wrappers, built once per (A, B, dtype, device):
        wf (A, A+B)  value:    [ (1 - I) / (A (A-1)) | -2 / (A B) ]   -- K_XX_m - 2 mean(K_XY) = sum(K(X, [X; Y]) * wf)
        wb (A, A+B)  gradient: [ 2 (1 - I) / (A (A-1)) | -2 / (A B) ] -- d loss / dK with the reference's 2x rule on the K_XX part
                               (_SigKernelGram.backward doubles when both arguments require grad, sigkernel.py:410-412)
        wy (B, B)    value:    (1 - I) / (B (B-1))                     -- K_YY_m = sum(K_YY * wy); None for B < 2"""
     key = (A, B, dtype, device)
-    w = _LOSS_WEIGHTS.get(key)
-    if w is None:
-        # (built inside a hipGraph capture -- a capture without a warm-up call -- the fills are nodes of that graph and the memory
-        # belongs to its pool: such weights serve the captured call only and are not cached)
-        # NEVER evicted: a captured hipGraph holds the cached tensors by address (an eviction would let the allocator hand their
-        # blocks out again under an already captured training step); A (A + B) elements per distinct batch shape
-        capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        wf = torch.empty(A, A + B, dtype=dtype, device=device)
-        wf[:, :A] = (1.0 - torch.eye(A, dtype=dtype, device=device)) / (A * (A - 1.0))
-        wf[:, A:] = -2.0 / (A * float(B))
-        wb = wf.clone()
-        wb[:, :A] *= 2.0
-        wy = (1.0 - torch.eye(B, dtype=dtype, device=device)) / (B * (B - 1.0)) if B > 1 else None
-        w = (wf, wb, wy)
-        if not capturing:
-            if device.type == "cuda":
-                torch.cuda.current_stream(device).synchronize()    # once per shape: later calls may read them from any stream
-            _LOSS_WEIGHTS[key] = w
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    ent = _LOSS_WEIGHTS.get(key)
+    if ent is not None:
+        # a captured hipGraph holds the cached tensors BY ADDRESS: an entry a capture has used is pinned for good (an eviction would
+        # let the allocator hand its blocks out again under an already captured training step); everything else is least-recently-used
+        _LOSS_WEIGHTS[key] = _LOSS_WEIGHTS.pop(key)[:3] + (ent[3] or capturing,)
+        return ent[:3]
+    # (built inside a hipGraph capture -- a capture without a warm-up call -- the fills are nodes of that graph and the memory
+    # belongs to its pool: such weights serve the captured call only and are not cached)
+    wf = torch.empty(A, A + B, dtype=dtype, device=device)
+    wf[:, :A] = (1.0 - torch.eye(A, dtype=dtype, device=device)) / (A * (A - 1.0))
+    wf[:, A:] = -2.0 / (A * float(B))
+    wb = wf.clone()
+    wb[:, :A] *= 2.0
+    wy = (1.0 - torch.eye(B, dtype=dtype, device=device)) / (B * (B - 1.0)) if B > 1 else None
+    w = (wf, wb, wy)
+    if not capturing:
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()    # once per shape: later calls may read them from any stream
+        _LOSS_WEIGHTS[key] = w + (False,)
+        # bounded: workloads whose batch sizes vary would otherwise leak A (A + B) + B^2 elements per distinct shape; the oldest
+        # UNPINNED entries go (dicts keep insertion order; a hit re-inserts its entry at the end)
+        # (max_cached: weight sets kept besides those a graph capture has pinned)
+        if len(_LOSS_WEIGHTS) > max_cached:
+            for k in [k for k, e in _LOSS_WEIGHTS.items() if not e[3]][:len(_LOSS_WEIGHTS) - max_cached]:
+                del _LOSS_WEIGHTS[k]
     return w
 
 
@@ -807,7 +815,7 @@ class _SigKernelLoss(torch.autograd.Function):
         ctx.static_kernel, ctx.dyadic_order, ctx._naive_solver, ctx.workspace_bytes = static_kernel, dyadic_order, _naive_solver, workspace_bytes
         ctx.kept_edges = ctx.K = ctx.launch = None
         need = ctx.needs_input_grad[0]
-        fast = _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, need)
+        fast = _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic_order, _naive_solver, need, with_yy, workspace_bytes)
         if fast is not None:
             # the one-launch glue (csrc/sk_loss.hip): staging of [X; Y] (no concatenated copy), K(X, [X; Y]) and the strict triangle of
             # K(Y, Y) in ONE forward launch, the scalar in one reduction -- three launches where the route below issues a dozen
@@ -816,7 +824,7 @@ class _SigKernelLoss(torch.autograd.Function):
                 val, out, edges, staged, wb = res
                 if need:
                     ctx.save_for_backward(X)
-                    ctx.launch = (fast, out, edges, staged, wb, A, B, Xd.shape[1])
+                    ctx.launch = (fast, out, edges, staged, wb, A, B, Xd.shape[1], Yd)
                 return val
         Z = torch.cat((Xd, Yd))
         wf, wb, wy = _loss_weights(A, B, X.dtype, X.device)
@@ -846,14 +854,20 @@ class _SigKernelLoss(torch.autograd.Function):
             # arrays the forward staged and the edges it kept; the upstream scalar stays on the device and multiplies the fold of the
             # partial sums into dL/dX (the adjoint is linear in it): screen + sweep + rescue + fold, four launches
             (X,) = ctx.saved_tensors
-            (kind, param), out, edges, (Zr, Zt, Zr_adj), wb, A, B, M = ctx.launch
+            (kind, param), out, edges, (Zr, Zt, Zr_adj), wb, A, B, M, Yd = ctx.launch
             Xd = X.detach().contiguous()
             gs = grad_output.detach().to(torch.float64).contiguous()
             adj = be.linear_adjoint_fused if kind == 0 else be.rbf_adjoint_fused
             res = adj(Xd, None, param, ctx.dyadic_order, edges, wb, gram=True, kfinal=out[:A * (A + B)], naive=ctx._naive_solver,
                       staged=(Zr_adj, Zt, A + B, M), gscale=gs)
-            if res is None:      # (sk_route_query named the one-band adjoint for this shape: its launcher must not decline)
-                raise RuntimeError("sigkernel_amd: the fused adjoint declined a shape sk_route_query routed to it")
+            if res is None:
+                # sk_route_query named the one-band adjoint for this shape and its launcher declined all the same (a scope or workspace
+                # check the query does not mirror): like every other gradient route, fall back -- the rows' gradient from the paths
+                # (its own forward sweep; the kept edges are of no use to the streaming kernels) with the same weights
+                go = (wb.view(A, A + B) * gs).contiguous()
+                g = _rows_gradient(be, ctx.static_kernel, Xd, torch.cat((Xd, Yd)), go, ctx.dyadic_order, ctx._naive_solver, True, None,
+                                   ctx.workspace_bytes, None)
+                return g, None, None, None, None, None, None
             return res[0], None, None, None, None, None, None
         X, Z = ctx.saved_tensors
         go = (ctx.wb * grad_output.to(X.dtype)).contiguous()
@@ -864,20 +878,38 @@ class _SigKernelLoss(torch.autograd.Function):
         return grad_X, None, None, None, None, None, None
 
 
-def _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic, naive, need_grad):
+def _loss_launch_ok(be, static_kernel, Xd, Yd, dyadic, naive, need_grad, with_yy=True, workspace_bytes=None):
     """(kind, param) when a loss wrapper's call can take the one-launch glue of csrc/sk_loss.hip: exactly LinearKernel / RBFKernel,
     fp64 paths of one length, the ONE-BAND fused kernels for the forward and -- with a gradient pending -- for the adjoint too
-    (sk_route_query on the rectangle's shape); None otherwise (the merged route's torch glue serves everything else)."""
+    (sk_route_query on the rectangle's shape), pair counts inside the 32-bit / 15-bit fields of sk_solve_fwd_loss_f64 and
+    sk_loss_value_f64 (checked HERE, before any launch), and -- with a gradient pending -- edges of the whole rectangle that fit the
+    share of the transient budget a call may keep until backward (`keep_edges_fraction` of workspace_bytes, as _gram_block); None
+    otherwise (the merged route's torch glue serves everything else: it tiles the rows and drops the edges where they do not fit)."""
     if routes.no_loss_launch or not hasattr(be, "loss_forward") or Xd.dtype != torch.float64 or Xd.shape[1:] != Yd.shape[1:]:
         return None
     fused = _fused_static(static_kernel, True)
     if fused is None:
         return None
+    A, B, M = Xd.shape[0], Yd.shape[0], Xd.shape[1]
+    tri_n = B if with_yy else 0
+    p_rect, p_tri = A * (A + B), (tri_n * (tri_n - 1) // 2 if tri_n > 1 else 0)
+    # sk_solve_fwd_loss_f64 packs A and tri_n into 15 bits each and indexes pairs with 31 bits; sk_loss_value_f64 indexes with 32
+    if A > 0x7fff or tri_n > 0x7fff or p_rect >= 0x7ff00000 or p_rect + p_tri >= 0x7ff00000:
+        return None
     if _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, True) != FUSED:
         return None
     if need_grad and _route(be, OP_ADJOINT, static_kernel, Xd, Yd, dyadic, naive, True) != FUSED:
         return None
+    # what the call allocates in one piece and (the edges, the weights, the staged paths) holds until backward: 8 (MM + NN + 32)
+    # bytes of edges per rectangle pair, values + weights + pair table 8 bytes per pair each
+    held = 8.0 * p_rect * ((2 * ((M - 1) << int(dyadic)) + 32) if need_grad else 0) + 8.0 * (3 * p_rect + 2 * p_tri)
+    if (workspace_bytes is not None or held > _cost("loss_launch_free_bytes")) and \
+            held > _cost("keep_edges_fraction") * _budget(Xd.device, workspace_bytes):
+        return None
     return fused
+
+
+_LOSS_LAUNCH_FREE_BYTES = None    # "loss_launch_free_bytes": below this the one-launch loss route does not ask the device for its free memory
 
 
 class _NoGradCtx:
