@@ -113,6 +113,15 @@ int sk_route_query(int op, int kind, int D, int M, int N, int dyadic, int scheme
  * knob inside one process call this after changing it.  Not for product code (not thread-safe against concurrent launches). */
 void sk_reload_knobs(void);
 
+/* Diagnostics: which kernel instances does a workload launch?  Every launch of the library is counted per kernel instance while
+ * tracing is on (enable: 1 on, 0 off, anything else: query; returns the previous state; SK_TRACE_LAUNCHES=1 in the environment
+ * switches it on at load).  sk_launch_trace_dump writes "count<TAB>device symbol<NL>" per instance launched since the last reset into
+ * buf (NUL-terminated, truncated to n bytes; buf may be NULL) and returns the bytes the whole list needs; reset != 0 clears the counts.
+ * tools/reach_sweep.py + tests check the list of instances the build contains against it: no unreachable instance.  No counterpart in
+ * the reference (its back-ends are JIT-compiled per call signature, cuda_backend.py:5). */
+int sk_launch_trace(int enable);
+size_t sk_launch_trace_dump(char *buf, size_t n, int reset);
+
 /* kappa_d = 4^-d / sqrt(12), see sk_solve_fwd_linear_*. */
 double sk_linear_prescale(int dyadic);
 const char *sk_status_string(int status);
@@ -143,9 +152,10 @@ int sk_static_increments_f32(int kind, double param, const float *X, const float
  * nor dL/dG_static materialised.  Replaces the finite-difference contraction (sigkernel.py:313-341, :472-500) and the
  * `grad_output * grad_points` reduction over the second batch index (:343, :410-416) for these two static kernels.
  *   W [P,M-1,ldw]; scale [P] = upstream gradient per pair (NULL = 1); pairs as in sk_static_increments_*.
- *   kind 0 (linear): out = T [A,M-1,D], T[a][p] = sum_b scale_ab sum_q W[a,b,p,q] (y[b,q+1]-y[b,q]); the caller forms
- *                    dL/dx[a][m] = param^2 (T[a][m-1] - T[a][m]).
- *   kind 1 (rbf):    out = dL/dX [A,M,D]. */
+ *   kind 1 (rbf):    out = dL/dX [A,M,D].
+ *   kind 0 (linear): SK_ERR_UNSUPPORTED -- T[a][p] = sum_b scale_ab sum_q W[a,b,p,q] (y[b,q+1]-y[b,q]) runs from pre-differenced paths in
+ *                    sk_linear_adjoint_* (dim <= 8) and is a plain batched GEMM beyond; the generic kernel that served it here was
+ *                    reached by no route (removed in round 6). */
 int sk_static_adjoint_f64(int kind, double param, const double *X, const double *Y, const double *W, int64_t ldw,
                           const double *scale, int64_t A, int64_t B, int M, int N, int D, double *out, void *stream);
 int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y, const float *W, int64_t ldw,
@@ -418,7 +428,8 @@ int sk_solve_fwd_static_f64(int kind, double param, const double *Xr, const doub
                             int Ncp, int D, int fd, int dyadic, int scheme, double *out_final, double *edges, void *workspace,
                             size_t workspace_bytes, void *stream);
 /* f32: yt_f32 = 1 (kind 1, fd = 16 only): Yt holds the fp32 points packed as sk_prep_paths_f32 layout 2 writes them -- half
- * the LDS ring, twice the resident waves at 16 dimensions; arithmetic stays fp64.  yt_f32 = 0: Yt is the fp64 array above. */
+ * the LDS ring, twice the resident waves at 16 dimensions; arithmetic stays fp64 (dyadic >= 1).  yt_f32 = 0: Yt is the fp64 array above --
+ * except for kind 1, fd = 16, dyadic >= 1, which this entry point serves in the packed form only (SK_ERR_UNSUPPORTED otherwise). */
 int sk_solve_fwd_static_f32(int kind, double param, const double *Xr, const void *Yt, int yt_f32, int64_t A, int64_t B, int Mrows,
                             int Mc, int Nc, int Ncp, int D, int fd, int dyadic, int scheme, float *out_final, double *edges,
                             void *workspace, size_t workspace_bytes, void *stream);

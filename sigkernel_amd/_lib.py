@@ -43,6 +43,8 @@ SIGNATURES = {
     "sk_cost_note": (ctypes.c_char_p, [_int]),
     "sk_solve_fwd_static_cols": (_int, [_int, _int]),
     "sk_reload_knobs": (None, []),
+    "sk_launch_trace": (_int, [_int]),
+    "sk_launch_trace_dump": (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t, _int]),
     "sk_linear_prescale": (ctypes.c_double, [_int]),
     "sk_status_string": (ctypes.c_char_p, [_int]),
     "sk_device_count": (_int, []),
@@ -174,6 +176,25 @@ def costs():
 
 def cost(name):
     return costs()[name][0]
+
+
+def launch_trace(enable=True):
+    """Count every kernel launch of the library per kernel instance from now on (sk_launch_trace); returns the previous state."""
+    return bool(load().sk_launch_trace(1 if enable else 0))
+
+
+def launch_counts(reset=False):
+    """{device symbol (mangled): launches} since the last reset (sk_launch_trace_dump)."""
+    lib = load()
+    n = int(lib.sk_launch_trace_dump(None, 0, 0))
+    buf = ctypes.create_string_buffer(n + 16)
+    lib.sk_launch_trace_dump(buf, n + 16, 1 if reset else 0)
+    out = {}
+    for ln in buf.value.decode().split("\n"):
+        if "\t" in ln:
+            c, name = ln.split("\t", 1)
+            out[name] = out.get(name, 0) + int(c)
+    return out
 
 
 class _SplitStatus:
@@ -628,7 +649,7 @@ class HipBackend:
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         with _device(dev):
-            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and not routes.no_y32 and dyadic >= 1
+            y32 = kind == 1 and fd == 16 and X.dtype == torch.float32 and dyadic >= 1
             if kind == 0:
                 Xr = _prep_paths(X, True, False, float(param) ** 2, Mrows, fd)
                 Yt = _prep_paths(Y, True, True, 1.0, Ncp, fd)
@@ -723,7 +744,7 @@ class HipBackend:
             scale = scale.double().contiguous()
         with _device(dev):
             Xr = _prep_paths(X, False, False, 1.0, mrows, fd)
-            y32 = fd == 16 and X.dtype == torch.float32 and not routes.no_y32 and dyadic >= 1
+            y32 = fd == 16 and X.dtype == torch.float32 and dyadic >= 1
             if y32:      # fp32 points, two dimensions per 16-byte unit + a row of fp64 norms: half the LDS ring (as the forward)
                 Yt = torch.empty(B, fd // 2 + 1, Ncp, 2, dtype=torch.float32, device=dev)
                 _check(load().sk_prep_paths_f32(_ptr(Y), B, N, D, 0, 2, 1.0, _ptr(Yt), Ncp, fd, _stream(X)), "sk_prep_paths (packed fp32)")

@@ -26,7 +26,7 @@ A running process flips them through the attributes of `sigkernel_amd.routes` (t
 import os
 
 _ENV = {"no_fused_rbf": "SK_NO_FUSED_RBF", "no_fused_mb": "SK_NO_FUSED_MB", "no_fused_adjoint": "SK_NO_FUSED_ADJOINT",
-        "no_fused_deriv": "SK_NO_FUSED_DERIV", "no_y32": "SK_FUSEDMB_NO_Y32", "no_stream": "SK_NO_STREAM", "no_mmd_streams": "SK_NO_MMD_STREAMS",
+        "no_fused_deriv": "SK_NO_FUSED_DERIV", "no_stream": "SK_NO_STREAM", "no_mmd_streams": "SK_NO_MMD_STREAMS",
         "no_merged_loss": "SK_NO_MERGED_LOSS", "no_loss_launch": "SK_NO_LOSS_LAUNCH", "no_adjoint_swap": "SK_NO_ADJOINT_SWAP"}
 
 

@@ -1,7 +1,14 @@
 // sk_abi.hip -- the extern "C" surface declared in include/sigkernel_amd.h.
 // Argument checking and kernel selection only; no torch types, no allocation, no synchronisation.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 #include "sk_internal.h"
 #include "sk_wave_common.h"
@@ -172,8 +179,17 @@ Knobs parse_knobs() {
 }
 Knobs g_knobs = parse_knobs();          // dynamic initialisation = library load
 std::atomic<int> g_cu_count[16];        // 0: not asked yet
+// launch trace (sk_internal.h: SK_LAUNCH): counts per host stub, guarded by a mutex (diagnostics: the cost only exists while tracing)
+std::atomic<int> g_trace{knob_int("SK_TRACE_LAUNCHES") != 0 ? 1 : 0};
+std::mutex g_trace_mu;
+std::unordered_map<const void *, unsigned long long> g_trace_counts;
 }  // namespace
 const Knobs &knobs() { return g_knobs; }
+bool trace_on() { return g_trace.load(std::memory_order_relaxed) != 0; }
+void trace_launch(const void *host_stub) {
+    std::lock_guard<std::mutex> lock(g_trace_mu);
+    g_trace_counts[host_stub] += 1;
+}
 int device_cu_count() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
@@ -193,6 +209,33 @@ extern "C" {
 // sk_*_adjoint_finish_f64, sk_cost_query; the SK_WAVE_PF / SK_DERIV_PF / SK_ADJR_ALL knobs are gone; split mode's status word
 // (310: edges argument of sk_solve_fwd_static_*, the multi-band adjoints, the fused derivative solver)
 int sk_version(void) { return 320; }
+
+int sk_launch_trace(int enable) {
+    const int prev = sk::g_trace.load(std::memory_order_relaxed);
+    if (enable == 0 || enable == 1) sk::g_trace.store(enable, std::memory_order_relaxed);
+    return prev;
+}
+
+size_t sk_launch_trace_dump(char *buf, size_t n, int reset) {
+    std::string out;
+    {
+        std::lock_guard<std::mutex> lock(sk::g_trace_mu);
+        std::vector<std::pair<std::string, unsigned long long>> rows;
+        for (const auto &kv : sk::g_trace_counts) {
+            const char *name = hipKernelNameRefByPtr(kv.first, nullptr);
+            rows.emplace_back(name ? name : "?", kv.second);
+        }
+        std::sort(rows.begin(), rows.end());
+        for (const auto &r : rows) out += std::to_string(r.second) + "\t" + r.first + "\n";
+        if (reset) sk::g_trace_counts.clear();
+    }
+    if (buf && n) {
+        const size_t c = out.size() < n - 1 ? out.size() : n - 1;
+        memcpy(buf, out.data(), c);
+        buf[c] = 0;
+    }
+    return out.size() + 1;
+}
 
 /* Development hook: parse the SK_* environment variables again (tools that sweep a knob inside one process).  Not
  * thread-safe against concurrent launches; product code never calls it. */

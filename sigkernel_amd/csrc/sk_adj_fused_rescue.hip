@@ -245,7 +245,7 @@ size_t fused_rescue_workspace_bytes(int kind, int64_t P, int Mc, int Nc, int dya
 }
 
 int launch_fused_screen(const double *kfinal, const double *scale, int64_t P, double screen, double *scale_eff, double *err, hipStream_t s) {
-    hipLaunchKernelGGL(k_screen, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, kfinal, scale, P, screen, scale_eff, err);
+    SK_LAUNCH(k_screen, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, kfinal, scale, P, screen, scale_eff, err);
     return check_launch();
 }
 
@@ -269,7 +269,7 @@ int launch_fused_rescue(int kind, const double *Xs, const double *Ys, const doub
     prm.ws = (double *)ws; prm.ws_block = (int64_t)(per_block / sizeof(double));
     prm.fd = fd; prm.N0 = n0; prm.n0cols = n0cols;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_fused_rescue, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_fused_rescue, dim3((unsigned)blocks), dim3(WAVE), lds, s, prm);
+    SK_LAUNCH(k_fused_rescue, dim3((unsigned)blocks), dim3(WAVE), lds, s, prm);
     return check_launch();
 }
 

@@ -118,7 +118,7 @@ int launch_increments(const T *G, int64_t P, int M, int N, T *inc_c, int64_t ld,
     const int strips = (M - 1 + ROWS - 1) / ROWS;
     const int64_t blocks = P * strips;
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G, M, N, strips, inc_c, ld);
+    SK_LAUNCH(k_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G, M, N, strips, inc_c, ld);
     return check_launch();
 }
 
@@ -127,7 +127,7 @@ int launch_increments_adjoint(const T *W, int64_t ldw, const T *scale, int64_t P
     const int strips = (M + ROWS - 1) / ROWS;
     const int64_t blocks = P * strips;
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_increments_adjoint<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, W, ldw, scale, M, N, strips, dG);
+    SK_LAUNCH(k_increments_adjoint<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, W, ldw, scale, M, N, strips, dG);
     return check_launch();
 }
 
@@ -145,7 +145,7 @@ int launch_deriv_increments(const T *G0, const T *G1, const T *G2, double eps, i
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
     // the python scalars of sigkernel.py:529-539, rounded to T when they meet the tensor like torch does
     const T c1 = (T)(1. / eps), c2 = (T)(2. / eps), c3 = (T)(1. / (eps * eps));
-    hipLaunchKernelGGL(k_deriv_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G0, G1, G2, c1, c2, c3, M, N, strips,
+    SK_LAUNCH(k_deriv_increments<T>, dim3((unsigned)blocks), dim3(TPB), 0, s, G0, G1, G2, c1, c2, c3, M, N, strips,
                        inc, inc_d, inc_dd, ld);
     return check_launch();
 }

@@ -30,6 +30,19 @@ const char *cost_note(int which);
 double cost_by_name(const char *name);
 int device_cu_count();                     // sk_abi.hip: compute units of the current device (256 on MI355X), cached per device
 
+// ---- launch trace (diagnostics, sk_abi.hip) -------------------------------------------------------------------------------------------
+// EVERY kernel launch of the library goes through SK_LAUNCH.  With tracing on (sk_launch_trace(1), or SK_TRACE_LAUNCHES=1 in the
+// environment at load) the launches are counted per kernel instance -- by the instance's host stub, named by its device symbol when the
+// counts are dumped (sk_launch_trace_dump) -- so that a sweep of the public API can be checked against the list of instances the build
+// contains without a profiler (tools/reach_sweep.py, tests/test_abi.py: no unreachable instance).  Off: one relaxed load per launch.
+bool trace_on();
+void trace_launch(const void *host_stub);
+#define SK_LAUNCH(kern, ...)                                                   \
+    do {                                                                        \
+        if (::sk::trace_on()) ::sk::trace_launch((const void *)(kern));         \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                                  \
+    } while (0)
+
 // The fused adjoints' decomposition (sk_wave_common.h: chunk_split / chunk_share): a lane group sweeps one CHUNK of the B pairs
 // of one path x_a and leaves a partial sum in slot a * nch + c; chunks swept by the oldest waves are longer.
 struct ChunkSplit {

@@ -236,8 +236,8 @@ template <typename T>
 int launch_prep_cat(const T *X, int64_t A, const T *Y, int64_t B, int M, int D, int diff, double scale_rows, double scale_rows2, double *out_rows,
                     double *out_rows2, int rows, double *out_cols, int cols, int FDp, int *pair_tab, int64_t tri_n, hipStream_t s) {
     const int64_t n = (A + B) * (int64_t)(rows + cols) * FDp;
-    if (diff) hipLaunchKernelGGL((k_prep_cat<T, true>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
-    else hipLaunchKernelGGL((k_prep_cat<T, false>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
+    if (diff) SK_LAUNCH((k_prep_cat<T, true>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
+    else SK_LAUNCH((k_prep_cat<T, false>), dim3(grid_for(n)), dim3(256), 0, s, X, A, Y, B, M, D, scale_rows, scale_rows2, out_rows, out_rows2, rows, out_cols, cols, FDp, pair_tab, tri_n);
     return check_launch();
 }
 template int launch_prep_cat<double>(const double *, int64_t, const double *, int64_t, int, int, int, double, double, double *, double *, int, double *,
@@ -248,25 +248,25 @@ template int launch_prep_cat<float>(const float *, int64_t, const float *, int64
 int launch_loss_value(const double *out, int64_t A, int64_t B, int with_yy, double *value, double *wb, hipStream_t s) {
     // (32-bit indices; the loss wrappers' merged route ends far below.  The triangle of K(Y, Y) only counts when it is there.)
     if (A < 0 || B < 0 || (A + B) * A + (with_yy ? B * (B - 1) / 2 : 0) >= 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, (int)A, (int)B, with_yy, value, wb);
+    SK_LAUNCH(k_loss_value, dim3(1), dim3(LV_THREADS), 0, s, out, (int)A, (int)B, with_yy, value, wb);
     return check_launch();
 }
 
 int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go, hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_weights, dim3(grid_for(A * (A + B))), dim3(256), 0, s, A, B, grad_out, go);
+    SK_LAUNCH(k_loss_weights, dim3(grid_for(A * (A + B))), dim3(256), 0, s, A, B, grad_out, go);
     return check_launch();
 }
 
 int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
                               const double *gscale, double *grad, hipStream_t s) {
-    hipLaunchKernelGGL(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
+    SK_LAUNCH(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
                        -2.0 / sigma, gscale, grad);
     return check_launch();
 }
 
 int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
                                  double *grad, hipStream_t s) {
-    hipLaunchKernelGGL(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
+    SK_LAUNCH(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
     return check_launch();
 }
 

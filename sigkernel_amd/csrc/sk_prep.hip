@@ -120,8 +120,8 @@ int launch_prep_pair(const T *X, int64_t A, int M, const T *Y, int64_t B, int N,
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks < 1) blocks = 1;
-    if (diff) hipLaunchKernelGGL((k_prep_pair<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
-    else hipLaunchKernelGGL((k_prep_pair<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
+    if (diff) SK_LAUNCH((k_prep_pair<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
+    else SK_LAUNCH((k_prep_pair<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, X, A, M, Y, B, N, D, scale_x, scale_y, out_x, rows_x, out_y, rows_y, FDp);
     return check_launch();
 }
 template int launch_prep_pair<double>(const double *, int64_t, int, const double *, int64_t, int, int, int, double, double, double *, int, double *, int,
@@ -141,15 +141,18 @@ int launch_prep_paths(const T *X, int64_t A, int M, int D, int diff, int dim_maj
         if (diff) return SK_ERR_UNSUPPORTED;
         blocks = (A * (int64_t)rows * (FDp + 2) + 255) / 256;
         if (blocks > 256 * 32) blocks = 256 * 32;
-        hipLaunchKernelGGL((k_prep_paths_packed32<T>), dim3((unsigned)blocks), b, 0, s, X, A, M, D, scale, reinterpret_cast<float *>(out), rows, FDp);
-        return check_launch();
+        if constexpr (sizeof(T) != 4) return SK_ERR_UNSUPPORTED;      // (the packed layout is fp32 paths as they are: no fp64 source)
+        else {
+            SK_LAUNCH((k_prep_paths_packed32<T>), dim3((unsigned)blocks), b, 0, s, X, A, M, D, scale, reinterpret_cast<float *>(out), rows, FDp);
+            return check_launch();
+        }
     }
     if (diff) {
-        if (dim_major) hipLaunchKernelGGL((k_prep_paths<T, true, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
-        else hipLaunchKernelGGL((k_prep_paths<T, true, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        if (dim_major) SK_LAUNCH((k_prep_paths<T, true, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        else SK_LAUNCH((k_prep_paths<T, true, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
     } else {
-        if (dim_major) hipLaunchKernelGGL((k_prep_paths<T, false, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
-        else hipLaunchKernelGGL((k_prep_paths<T, false, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        if (dim_major) SK_LAUNCH((k_prep_paths<T, false, true>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
+        else SK_LAUNCH((k_prep_paths<T, false, false>), g, b, 0, s, X, A, M, D, scale, out, rows, FDp);
     }
     return check_launch();
 }

@@ -167,7 +167,7 @@ int launch_fwd_simple(const T *inc_c, const Geom &g, T *out_final, T *out_grid, 
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_fwd_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_fwd_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc,
+    SK_LAUNCH(k_fwd_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc,
                        g.dyadic, g.naive, out_final, out_grid, out_edges);
     return check_launch();
 }
@@ -185,7 +185,7 @@ int launch_adj_simple(const T *inc_c, const Geom &g, T *out_final, T *W, int64_t
     if (blocks > 1024) blocks = 1024;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_adj_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_adj_simple<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic,
+    SK_LAUNCH(k_adj_simple<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic,
                        g.naive, out_final, W, ldw, (double *)ws);
     return check_launch();
 }
@@ -206,7 +206,7 @@ int launch_adj_rescue(const T *inc_c, const Geom &g, const double *err, double t
     if (blocks > 1024) blocks = 1024;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_adj_rescue<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_adj_rescue<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic, g.naive,
+    SK_LAUNCH(k_adj_rescue<T>, dim3((int)blocks), dim3(WAVE), lds, s, inc_c, g.ld, g.P, g.Mc, g.Nc, g.dyadic, g.naive,
                        err, tol, out_final, W, ldw, (double *)ws);
     return check_launch();
 }
@@ -228,7 +228,7 @@ int launch_deriv_simple(const T *inc, const T *inc_d, const T *inc_dd, const Geo
     if (lds > 160 * 1024) return SK_ERR_UNSUPPORTED;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)k_deriv_simple<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_deriv_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc, inc_d, inc_dd, g.ld, g.P, g.Mc,
+    SK_LAUNCH(k_deriv_simple<T>, dim3(pick_blocks(g.P)), dim3(WAVE), lds, s, inc, inc_d, inc_dd, g.ld, g.P, g.Mc,
                        g.Nc, g.dyadic, out_k, out_kd, out_kdd);
     return check_launch();
 }

@@ -252,52 +252,6 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return v;
 }
 
-// linear: T[a][p][k] = sum_b s_ab sum_q W[a,b,p,q] * (y[b,q+1,k] - y[b,q,k]);  dL/dx[a,m] = s^2 (T[a][m-1] - T[a][m])
-template <typename T, int DMAX, int NT>
-__global__ __launch_bounds__(NT) void k_static_linear_adj(const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
-                                                          const T *__restrict__ scale, int64_t B, int M, int N, int D,
-                                                          int strips, T *__restrict__ Tout) {
-    constexpr int RS = 64 / DMAX;   // rows per block: RS * DMAX accumulators per thread
-    __shared__ double red[NT / 64 + 1];
-    const int Mc = M - 1, Nc = N - 1;
-    const int64_t a = blockIdx.x / strips;
-    const int p0 = (int)(blockIdx.x % strips) * RS;
-    double acc[RS][DMAX];
-#pragma unroll
-    for (int r = 0; r < RS; ++r)
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k) acc[r][k] = 0.0;
-    const int64_t nb = B > 0 ? B : 1;
-    for (int64_t bb = 0; bb < nb; ++bb) {
-        const int64_t b = B > 0 ? bb : a, p = B > 0 ? a * B + bb : a;
-        const double s = scale ? (double)scale[p] : 1.0;
-        const T *y = Y + b * (int64_t)N * D;
-        const T *w = W + p * (int64_t)Mc * ldw;
-        for (int q = threadIdx.x; q < Nc; q += NT) {
-            double dy[DMAX];
-#pragma unroll
-            for (int k = 0; k < DMAX; ++k)
-                dy[k] = k < D ? s * ((double)y[(int64_t)(q + 1) * D + k] - (double)y[(int64_t)q * D + k]) : 0.0;
-            double wv[RS];   // unconditional loads from clamped rows: a predicated load gets its own s_waitcnt
-#pragma unroll
-            for (int r = 0; r < RS; ++r) wv[r] = (double)w[(int64_t)min(p0 + r, Mc - 1) * ldw + q];
-#pragma unroll
-            for (int r = 0; r < RS; ++r) {
-                const double wz = p0 + r < Mc ? wv[r] : 0.0;
-#pragma unroll
-                for (int k = 0; k < DMAX; ++k) acc[r][k] = fma(wz, dy[k], acc[r][k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < RS; ++r)
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k) {
-            const double v = block_sum<NT>(acc[r][k], red);
-            if (threadIdx.x == 0 && p0 + r < Mc && k < D) Tout[(a * Mc + p0 + r) * (int64_t)D + k] = (T)v;
-        }
-}
-
 // linear, from pre-differenced paths: T[a][p][k] = sum_b s_ab sum_q W[a,b,p,q] * dYt[b][k][q], with dYt [Bn][DP][ldy]
 // dimension-major and zero-padded (the array sk_solve_fwd_linear_* takes, DP = 8).  Thread = column q: the 8 dy values
 // and the RS rows of W are 16 fully coalesced loads per pair, no per-element predicates; two pairs are in flight per
@@ -607,19 +561,17 @@ __global__ __launch_bounds__(NT *NW) void k_rbf_adj2(const T *__restrict__ X, co
 template <typename T, int DMAX, int NT>
 int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
+    // (kind 0, the LINEAR static kernel, has no kernel here any more: its contraction T[a] = sum_b W[a, b] dY[b] runs from pre-differenced,
+    // dimension-major paths in sk_linear_adjoint_* for dim <= 8, and is a plain batched GEMM beyond -- the generic form that lived here
+    // was reached by no route of the host layer, round 6)
     if (kind == 0) {
-        constexpr int RS = 64 / DMAX;
-        const int strips = (M - 1 + RS - 1) / RS;
-        const int64_t blocks = A * strips;
-        if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_static_linear_adj<T, DMAX, NT>), dim3((unsigned)blocks), dim3(NT), 0, s, Y, W, ldw, scale, B,
-                           M, N, D, strips, out);
+        return SK_ERR_UNSUPPORTED;
     } else {
         constexpr int RM = DMAX <= 8 ? 4 : DMAX == 16 ? 2 : 1;   // node rows per block (RM * DMAX accumulators per thread)
         const int row_groups = (M + RM - 1) / RM;
         const int64_t blocks = A * row_groups;
         if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_static_rbf_adj<T, DMAX, NT, RM>), dim3((unsigned)blocks), dim3(NT), 0, s, X, Y, W, ldw, scale, B,
+        SK_LAUNCH((k_static_rbf_adj<T, DMAX, NT, RM>), dim3((unsigned)blocks), dim3(NT), 0, s, X, Y, W, ldw, scale, B,
                            M, N, D, 1.0 / param, row_groups, out);
     }
     return check_launch();
@@ -640,7 +592,7 @@ int launch_static_d(int kind, double param, const T *X, const T *Y, int64_t A, i
         const int col_tiles = (int)((ld + SK_TPB * LIN_CPT - 1) / (SK_TPB * LIN_CPT));
         const int64_t blocks = P * col_tiles;
         if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_static_linear<T, DMAX>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
+        SK_LAUNCH((k_static_linear<T, DMAX>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
                            param * param, inc, ld, col_tiles);
     } else {
         const T z = (T)0;
@@ -648,13 +600,13 @@ int launch_static_d(int kind, double param, const T *X, const T *Y, int64_t A, i
             const int col_tiles = 1;
             const int64_t blocks = P;
             if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL((k_static_nodes<T, DMAX, 1, 1, 1>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
+            SK_LAUNCH((k_static_nodes<T, DMAX, 1, 1, 1>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
                                N, D, 1.0 / param, z, z, z, inc, (T *)nullptr, (T *)nullptr, ld, col_tiles);
         } else {
             const int col_tiles = (int)((ld + 2 * SK_TPB - 1) / (2 * SK_TPB));
             const int64_t blocks = P * col_tiles;
             if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-            hipLaunchKernelGGL((k_static_nodes<T, DMAX, 1, 1, 2>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
+            SK_LAUNCH((k_static_nodes<T, DMAX, 1, 1, 2>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, X, X, Y, B, M,
                                N, D, 1.0 / param, z, z, z, inc, (T *)nullptr, (T *)nullptr, ld, col_tiles);
         }
     }
@@ -671,7 +623,7 @@ int launch_static_deriv_d(int kind, double param, const T *X0, const T *X1, cons
     const int64_t blocks = A * B * col_tiles;
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
 #define SK_LAUNCH_NODES(KIND, CPT)                                                                                      \
-    hipLaunchKernelGGL((k_static_nodes<T, DMAX, KIND, 3, CPT>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X0, X1, X2, Y, B, \
+    SK_LAUNCH((k_static_nodes<T, DMAX, KIND, 3, CPT>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X0, X1, X2, Y, B, \
                        M, N, D, inv_sigma, c1, c2, c3, inc, inc_d, inc_dd, ld, col_tiles)
     if (kind == 0) {
         if (narrow) SK_LAUNCH_NODES(0, 1); else SK_LAUNCH_NODES(0, 2);
@@ -731,10 +683,10 @@ int launch_linear_adjoint_dyt(const double *dYt, int64_t ldy, const T *W, int64_
     const int64_t blocks = A * strips;
     if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
     if (Nc <= 80)
-        hipLaunchKernelGGL((k_linear_adj_dyt<T, 64>), dim3((unsigned)blocks), dim3(64), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc, D,
+        SK_LAUNCH((k_linear_adj_dyt<T, 64>), dim3((unsigned)blocks), dim3(64), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc, D,
                            strips, out);
     else
-        hipLaunchKernelGGL((k_linear_adj_dyt<T, 128>), dim3((unsigned)blocks), dim3(128), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc,
+        SK_LAUNCH((k_linear_adj_dyt<T, 128>), dim3((unsigned)blocks), dim3(128), 0, s, dYt, ldy, W, ldw, scale, B, Mc, Nc,
                            D, strips, out);
     return check_launch();
 }
@@ -754,7 +706,7 @@ int launch_static_adjoint2(int kind, double param, const T *X, const T *Y, const
         const int Nc = N - 1;
         const int col_tiles = (Nc + 63) / 64;
         if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_linear_adj2<T, 64, 8>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * 8), 0, s, dXr, Mrows, W, ldw,
+        SK_LAUNCH((k_linear_adj2<T, 64, 8>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * 8), 0, s, dXr, Mrows, W, ldw,
                            scale, A, B, b0, M - 1, Nc, D, col_tiles, out);
         return check_launch();
     }
@@ -762,7 +714,7 @@ int launch_static_adjoint2(int kind, double param, const T *X, const T *Y, const
     if (nbk * col_tiles > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
     // 32 KB of LDS for the partial sums whatever the dimension: 8 waves up to dim 8, 4 at 16, 2 at 32
 #define SK_RBF2(DM, NW)                                                                                                  \
-    hipLaunchKernelGGL((k_rbf_adj2<T, DM, 64, NW>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * NW), 0, s, X, Y, W, ldw, scale, \
+    SK_LAUNCH((k_rbf_adj2<T, DM, 64, NW>), dim3((unsigned)(nbk * col_tiles)), dim3(64 * NW), 0, s, X, Y, W, ldw, scale, \
                        A, B, b0, M, N, D, 1.0 / param, col_tiles, out)
     if (D <= 4) SK_RBF2(4, 8);
     else if (D <= 8) SK_RBF2(8, 8);

@@ -345,7 +345,7 @@ int launch_one(const WaveParams &prm, int blocks, size_t lds_bytes, hipStream_t 
     auto kern = k_fwd_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE, EDGES, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
+    SK_LAUNCH(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 

@@ -485,7 +485,7 @@ int launch_adj_one(const AdjParams &prm, int blocks, size_t lds_bytes, hipStream
     auto kern = k_adj_wave<T, DY, NAIVE, MULTIBAND, FULLWAVE>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
+    SK_LAUNCH(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 

@@ -432,7 +432,7 @@ int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
     auto kern = k_adj_fused_linear<DY, RC, FULLWAVE>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
-    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
+    SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
     return check_launch();
 }
 

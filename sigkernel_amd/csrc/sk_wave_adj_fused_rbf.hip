@@ -105,6 +105,65 @@ __device__ __forceinline__ void lds_write_carry(unsigned a, const d2_t (&v)[5]) 
                  : : "v"(a), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory");
 }
 
+// the y points of a macro-step (four dims) AND the top lane's S terminal-row values, one wait instead of two
+template <int S>
+__device__ __forceinline__ void lds_read_ydims_trow(d2_t (&v)[4], double (&t)[S], unsigned a_even, unsigned a_odd, unsigned ta);
+template <>
+__device__ __forceinline__ void lds_read_ydims_trow<4>(d2_t (&v)[4], double (&t)[4], unsigned a_even, unsigned a_odd, unsigned ta) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:256\n\tds_read_b128 %3, %9 offset:256\n\t"
+                 "ds_read_b64 %4, %10\n\tds_read_b64 %5, %10 offset:8\n\tds_read_b64 %6, %10 offset:16\n\tds_read_b64 %7, %10 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                 : "v"(a_even), "v"(a_odd), "v"(ta) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_ydims_trow<2>(d2_t (&v)[4], double (&t)[2], unsigned a_even, unsigned a_odd, unsigned ta) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:256\n\tds_read_b128 %3, %7 offset:256\n\t"
+                 "ds_read_b64 %4, %8\n\tds_read_b64 %5, %8 offset:8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(t[0]), "=&v"(t[1])
+                 : "v"(a_even), "v"(a_odd), "v"(ta) : "memory");
+}
+
+// Everything a lane reads when it starts a pair (four-dimension variants), issued together and handed over by ONE wait: its NX / 2 node
+// rows (two 16-byte pieces each, 64-byte rows), NC pieces of the pair's terminal column and the upstream gradient.  Some lane starts a pair
+// in EVERY macro-step, so the wave pays for this block every step; as four reads with a wait each it cost a lone wave four LDS round
+// trips per step (profiles/r06_small_launch_pmc.txt: nothing hides them at one wave per SIMD).
+template <int NX, int NC>
+__device__ __forceinline__ void lds_read_pair_start(d2_t (&x)[NX], d2_t (&c)[NC], double &sv, unsigned xa, unsigned ca, unsigned sa);
+template <>
+__device__ __forceinline__ void lds_read_pair_start<4, 3>(d2_t (&x)[4], d2_t (&c)[3], double &sv, unsigned xa, unsigned ca, unsigned sa) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
+                 "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\tds_read_b128 %6, %9 offset:32\n\tds_read_b64 %7, %10\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(sv)
+                 : "v"(xa), "v"(ca), "v"(sa) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_pair_start<4, 2>(d2_t (&x)[4], d2_t (&c)[2], double &sv, unsigned xa, unsigned ca, unsigned sa) {
+    asm volatile("ds_read_b128 %0, %7\n\tds_read_b128 %1, %7 offset:16\n\tds_read_b128 %2, %7 offset:64\n\tds_read_b128 %3, %7 offset:80\n\t"
+                 "ds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:16\n\tds_read_b64 %6, %9\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(sv)
+                 : "v"(xa), "v"(ca), "v"(sa) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_pair_start<2, 3>(d2_t (&x)[2], d2_t (&c)[3], double &sv, unsigned xa, unsigned ca, unsigned sa) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\t"
+                 "ds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\tds_read_b128 %4, %7 offset:32\n\tds_read_b64 %5, %8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(sv)
+                 : "v"(xa), "v"(ca), "v"(sa) : "memory");
+}
+template <>
+__device__ __forceinline__ void lds_read_pair_start<2, 2>(d2_t (&x)[2], d2_t (&c)[2], double &sv, unsigned xa, unsigned ca, unsigned sa) {
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\t"
+                 "ds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:16\n\tds_read_b64 %4, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(sv)
+                 : "v"(xa), "v"(ca), "v"(sa) : "memory");
+}
+
 template <int DY, int RC, bool FULLWAVE, int ND, bool YSIDE>
 __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_adj_fused_rbf(const AdjRbfParams prm) {
     constexpr int CW = 2;
@@ -347,15 +406,19 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             asm volatile("");
             valid = (unsigned)ps < (unsigned)ps_end ? 1 : 0;
             const unsigned xa = my_x + x_rd;
-#pragma unroll
-            for (int k = 0; k < RC; ++k) lds_read_xpt<ND>(xr[k], xa + k * 64u);
-            if constexpr (YSIDE) {
-                lds_read_xpt<ND>(xup, my_xup + x_rd);
-                yp_prev = yp_cur;
-                yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YW) : nullptr;
-            }
             double col[R + 2];
-            {
+            double sv_rd = 1.0;
+            const unsigned sv_at = my_sc + x_rd + (((sc_par0 ^ (unsigned)ps) & 1u) << 3);
+            if constexpr (ND == 4) {     // one asm, one wait (lds_read_pair_start)
+                d2_t xq[2 * RC], cq[R == 4 ? 3 : 2];
+                lds_read_pair_start<2 * RC, (R == 4 ? 3 : 2)>(xq, cq, sv_rd, xa, my_col + x_rd, sv_at);
+#pragma unroll
+                for (int k = 0; k < RC; ++k) { xr[k][0] = xq[2 * k][0]; xr[k][1] = xq[2 * k][1]; xr[k][2] = xq[2 * k + 1][0]; xr[k][3] = xq[2 * k + 1][1]; }
+#pragma unroll
+                for (int i = 0; i < (R == 4 ? 3 : 2); ++i) { col[2 * i] = cq[i][0]; col[2 * i + 1] = cq[i][1]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RC; ++k) lds_read_xpt<ND>(xr[k], xa + k * 64u);
                 const unsigned ca_ = my_col + x_rd;
                 if constexpr (R == 4) {
                     d2_t c3[3];
@@ -368,6 +431,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
                                  : "=&v"(c2[0]), "=&v"(c2[1]) : "v"(ca_) : "memory");
                     col[0] = c2[0][0]; col[1] = c2[0][1]; col[2] = c2[1][0]; col[3] = c2[1][1];
                 }
+                if (prm.scale) sv_rd = lds_read_f64(sv_at);
+            }
+            if constexpr (YSIDE) {
+                lds_read_xpt<ND>(xup, my_xup + x_rd);
+                yp_prev = yp_cur;
+                yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YW) : nullptr;
             }
             // col[1 + m] = K[MMp - lam R - R + m][NN], m = 0..R: the lane's fine rows bottom to top; K[0][NN] = 1 is not stored
             cornerR = 1.0;
@@ -375,7 +444,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = col[R - i]; }
             if (lam * R + R == MMp) leftF[R - 1] = 1.0;
-            const double sv = prm.scale ? lds_read_f64(my_sc + x_rd + (((sc_par0 ^ (unsigned)ps) & 1u) << 3)) : 1.0;
+            const double sv = prm.scale ? sv_rd : 1.0;
             if (sv != sv) valid = 0;      // NaN: a pair the rescue's screen took out of the sweep (sk_adj_fused_rescue.hip)
             sx = valid ? sv : 0.0;
             if constexpr (YSIDE) { if (!valid) yp_cur = nullptr; }
@@ -384,9 +453,13 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // -- y points of the unit's two node columns
         d2_t yv[ND];
         const unsigned ya = my_y + (unsigned)(yslab * RY_SLAB + ((u & 7) << 4));
-        lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
-        if constexpr (TPEND) lds_take<S>(trow, trow_p);
-        else lds_read_f64_block<S>(trow, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        if constexpr (!TPEND && ND == 4 && S <= 4) {
+            lds_read_ydims_trow<S>(yv, trow, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7), ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        } else {
+            lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            if constexpr (TPEND) lds_take<S>(trow, trow_p);
+            else lds_read_f64_block<S>(trow, ec_rd + (unsigned)(((7 - (t & 7)) * S + 1) * 8));
+        }
 
         // -- top rows of the two states
         double topR[S], topF[S];
@@ -618,7 +691,7 @@ int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
     auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YSIDE>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
-    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
+    SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
     return check_launch();
 }
 

@@ -413,7 +413,7 @@ int launch_pf(const DerivParams &prm, int blocks, size_t lds_bytes, hipStream_t 
     auto kern = k_deriv_wave<T, DY, MULTIBAND, FULLWAVE, PF>;
     if (lds_bytes > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
+    SK_LAUNCH(kern, dim3(blocks), dim3(WAVE * prm.wg.wpb), lds_bytes, s, prm);
     return check_launch();
 }
 

@@ -878,7 +878,7 @@ int launch_mb_one(FusedMbParams prm, int64_t P, size_t lds_bytes, int waves_per_
     const size_t lds_block = wave_group_lds(prm.wg);
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
-    hipLaunchKernelGGL(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
+    SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
     return check_launch();
 }
 
@@ -943,18 +943,22 @@ int launch_mb_dy(const FusedMbParams &prm, const MbPlan &pl, bool naive, bool y3
                 return SK_ERR_UNSUPPORTED;
             }
             if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
-            return launch_mb_one<TO, DY, false, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+            // (fp32 RBF paths of 9..16 dims at dyadic >= 1 are staged as packed fp32 -- y32 -- by every caller: the fp64-ring form of that
+            // case was an A/B knob's instance, removed in round 6)
+            if constexpr (sizeof(TO) == 4) return SK_ERR_UNSUPPORTED;
+            else return launch_mb_one<TO, DY, false, KIND, 16, true>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
         }
         return SK_ERR_UNSUPPORTED;
     }
-    if (y32) {   // fp32 y ring: built where it pays (RBF points of fp32 inputs, 16 dims)
-        if constexpr (KIND == 1 && sizeof(TO) == 4) {
+    if (y32) {   // fp32 y ring: built where it pays (RBF points of fp32 inputs, 16 dims, dyadic >= 1: at dyadic 0 the four-row form has no registers for it)
+        if constexpr (KIND == 1 && sizeof(TO) == 4 && DY >= 1) {
             if (pl.fd == 16) return launch_mb_one<TO, DY, true, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
         }
         return SK_ERR_UNSUPPORTED;
     }
     if (pl.fd == 8) return launch_mb_one<TO, DY, false, KIND, 8>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
-    return launch_mb_one<TO, DY, false, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
+    if constexpr (KIND == 1 && sizeof(TO) == 4 && DY >= 1) return SK_ERR_UNSUPPORTED;     // (see above: y32 serves this case)
+    else return launch_mb_one<TO, DY, false, KIND, 16>(prm, P, pl.lds_bytes, pl.waves_per_cu, ws, ws_bytes, s);
 }
 
 }  // namespace

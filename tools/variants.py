@@ -62,8 +62,13 @@ def main():
                 for r in csv.DictReader(open(ff)):
                     n = norm(r["Name"])
                     reached[n] = reached.get(n, 0) + int(r["Calls"])
-            else:        # `AMD_LOG_LEVEL=3 python tools/reach_sweep.py 2>&1 | grep -o "ShaderName : .*" | sort | uniq -c`: "<count> ShaderName : <name>"
-                for ln in open(ff):
+            else:        # tools/reach_sweep.py --out: "<count><TAB><device symbol>" (sk_launch_trace_dump); older: "<count> ShaderName : <name>"
+                lines = open(ff).read().split("\n")
+                syms = [ln.split("\t", 1) for ln in lines if re.match(r"\d+\t\S", ln)]
+                for (c, _), d in zip(syms, demangle([sname.split(".kd")[0] for _, sname in syms])):
+                    n = norm(d)
+                    reached[n] = reached.get(n, 0) + int(c)
+                for ln in lines:
                     m = re.match(r"\s*(\d+) ShaderName : (.*)", ln)
                     if m:
                         n = norm(m.group(2).strip())
