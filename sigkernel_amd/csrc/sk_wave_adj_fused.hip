@@ -61,6 +61,14 @@ __device__ __forceinline__ void lds_read_run<4>(d2_t (&v)[4], unsigned a) {
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
 }
 
+template <>
+__device__ __forceinline__ void lds_read_run<8>(d2_t (&v)[8], unsigned a) {      // two consecutive 64-byte rows, one wait
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                 "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
+                 "ds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(a) : "memory");
+}
+
 // RC = coarse rows per lane: the forward kernels' choice at dyadic 1, 2; at dyadic 0 two instead of their four (register budget)
 template <int DY, int RC, bool FULLWAVE>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
@@ -269,12 +277,14 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             for (int i = 0; i < R; ++i) { leftR[i] = 1.0; leftF[i] = ncol[i + 1]; }
             s_pair = nscale;
             const unsigned xa = my_x + (unsigned)(((t >> 3) % X_SLOTS) * JMAX * XSLAB);
+            // (some lane starts a pair in every macro-step: the rows of a lane in ONE asm with one wait, profiles/r06_small_launch_pmc.txt)
+            {
+                d2_t xv[4 * RC];
+                lds_read_run<4 * RC>(xv, xa);
 #pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                d2_t xv[4];
-                lds_read_run<4>(xv, xa + k * 64u);
+                for (int k = 0; k < RC; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[j][0]; dxr[k][2 * j + 1] = xv[j][1]; }
+                    for (int j = 0; j < 4; ++j) { dxr[k][2 * j] = xv[4 * k + j][0]; dxr[k][2 * j + 1] = xv[4 * k + j][1]; }
             }
         }
 

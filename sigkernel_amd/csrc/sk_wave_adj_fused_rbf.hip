@@ -29,6 +29,9 @@
 namespace sk {
 namespace {
 
+#ifndef SK_ADJR_HOLD_Y
+#define SK_ADJR_HOLD_Y 1
+#endif
 constexpr int RFD = 8;                 // dims carried by the staged arrays
 constexpr int RY_SLAB = RFD * 128;
 constexpr int RX_SLOTS = 2;
@@ -92,12 +95,24 @@ __device__ __forceinline__ void lds_read_xpt(double (&x)[ND], unsigned a) {
     }
 }
 // the five 16-byte pieces of the second-argument carry (piece m = component m of node columns c1, c2): 65 slots of 16 bytes per
-// piece -- one per lane, and slot 64, which nobody writes: the zero a group's top lane starts from
+// piece.  Lane l READS slot l and WRITES slot l + 1 -- what it hands to the lane below -- except a group's bottom lane, which writes the
+// spare slot 64 (nobody reads it): slot g L, the one a group's top lane reads, is therefore never written and stays the zero the
+// kernel's LDS clear left there.  (Until round 6 lane l read slot l - 1 and the top lane slot 64: in the 16-lane phase of a b128 read
+// slot 64 sat on the banks of slot 0 -- every carry read a two-way bank conflict, SQ_LDS_BANK_CONFLICT 2.4e7 per launch of C4's y-side
+// adjoint; now 0.  The piece size is what keeps eight waves of that launch on a CU: 160,640 of 163,840 bytes.)
 constexpr int YC_PIECE = 65 * 16;
 __device__ __forceinline__ void lds_read_carry(d2_t (&v)[5], unsigned a) {
     asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1040\n\tds_read_b128 %2, %5 offset:2080\n\t"
                  "ds_read_b128 %3, %5 offset:3120\n\tds_read_b128 %4, %5 offset:4160\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
+}
+// the y points (four dims) and the carry of a macro-step's contraction, one wait instead of two
+__device__ __forceinline__ void lds_read_ydims_carry(d2_t (&y)[4], d2_t (&v)[5], unsigned a_even, unsigned a_odd, unsigned a) {
+    asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %9 offset:256\n\tds_read_b128 %3, %10 offset:256\n\t"
+                 "ds_read_b128 %4, %11\n\tds_read_b128 %5, %11 offset:1040\n\tds_read_b128 %6, %11 offset:2080\n\t"
+                 "ds_read_b128 %7, %11 offset:3120\n\tds_read_b128 %8, %11 offset:4160\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+                 : "v"(a_even), "v"(a_odd), "v"(a) : "memory");
 }
 __device__ __forceinline__ void lds_write_carry(unsigned a, const d2_t (&v)[5]) {
     asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1040\n\tds_write_b128 %0, %3 offset:2080\n\t"
@@ -225,7 +240,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     const unsigned ec_base = lds0 + x_base0 + (unsigned)(G * RX_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
     const unsigned ec_slot = (unsigned)(G * ECG);
     const unsigned yc_base = ec_base + 2u * ec_slot;                                     // YSIDE: the carry, 16 bytes per lane and piece
-    const unsigned yc_rd = yc_base + (unsigned)((is_top ? WAVE : lane - 1) << 4);        // what the lane above handed down (top lane: zero)
+    const unsigned yc_rd = yc_base + (unsigned)(lane << 4);                              // what the lane above handed down (top lane: zero)
+    const unsigned yc_wr = yc_base + (unsigned)((is_bot ? WAVE : lane + 1) << 4);        // what this lane hands down (a bottom lane: nowhere)
     bool row_ok[RC];   // this lane's coarse rows that exist (p_k < Mc)
 #pragma unroll
     for (int k = 0; k < RC; ++k) row_ok[k] = Mcp - 1 - (lam * RC + k) < prm.Mc;
@@ -388,6 +404,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // (left in flight only in the variants without spills -- dyadic 2, dims <= 4: C4's --; the others spill 16-127 registers and
         // read it blocking where it is needed: tools/check_async_hazards.py, scan_pressure)
         constexpr bool TPEND = DY == 2 && ND == 4;
+        constexpr bool HOLD_Y = SK_ADJR_HOLD_Y && ND == 4 && !YSIDE;
         double trow_p[S], trow[S];
         if constexpr (TPEND) {
 #pragma unroll
@@ -567,12 +584,15 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         }
         // -- contraction: node rows r_k = p_k + 1 at node columns c1 (this unit's second) and c2 (the previous unit's first).
         //    The y points are read from the ring a second time: holding them across the sweep costs 4 ND VGPRs
-        {
+        // (HOLD_Y: the variants with registers to spare keep them instead -- one LDS round trip less per macro-step)
+        d2_t car[5];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
+        if constexpr (YSIDE) {
+            asm volatile("" ::: "memory");
+            lds_read_ydims_carry(yv, car, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7), yc_rd);
+        } else if constexpr (!HOLD_Y) {
             asm volatile("" ::: "memory");
             lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
-        d2_t car[5];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
-        if constexpr (YSIDE) lds_read_carry(car, yc_rd);
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
             const double u0 = k == 0 ? wup0[0] : wk[(k + RC - 1) % RC][0];     // cells of coarse row p_k + 1
@@ -610,7 +630,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             }
             if constexpr (YSIDE) {
                 // what this lane hands down: the sums over the node rows r_k so far
-                lds_write_carry(yc_base + (unsigned)(lane << 4), car);
+                lds_write_carry(yc_wr, car);
                 if (is_bot) {   // the bottom lane completes them with node row 0 and stores the two columns of its pair
                     asm volatile("");
                     car[0][0] += cb1; car[0][1] += cb2;
