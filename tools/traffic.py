@@ -32,7 +32,7 @@ def main():
     c = counters(os.path.join(p3, "pmc_c3"), "k_fwd_fused")
     if c:
         out["c3_fused"] = entry(c, 262144, rnd + ": rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum on "
-                                "k_fwd_fused<double,1,false,true,false,0,8> (bench.py --config c3), tools/profile_round.sh -> profiles/" + tag + "p_rocprof_summary.txt")
+                                "k_fwd_fused<double,1,false,false,false,0,8,4> (bench.py --config c3), tools/profile_round.sh -> profiles/" + tag + "p_rocprof_summary.txt")
     c = counters(os.path.join(p3, "pmc_c5"), "k_fwd_fused_mb")
     if c:
         out["c5_fused"] = entry(c, 65536, rnd + ": the same counters on k_fwd_fused_mb<float,2,true,1,16> (bench.py --config c5), profiles/" + tag + "p_rocprof_summary.txt: "
