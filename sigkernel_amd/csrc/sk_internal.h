@@ -275,48 +275,54 @@ inline int check_launch() {
 }
 
 // ---- device math shared by the RBF kernels (sk_wave_fused.hip, sk_static.hip) ----------------------------------------
-// exp(x) for finite x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-term ln 2), Taylor polynomial of
-// degree 13 in |r| <= ln2 / 2 (truncation 4e-18), result scaled by 2^n; underflow goes through v_ldexp to 0.  Without the
-// range checks and special cases of the library exp this is 19 VALU instructions.
-// The 11 polynomial coefficients that are not inline constants live in VGPRs: as SGPR pairs they push the kernel's scalar
-// state into spills (v_readlane in the hot loop).
-struct ExpCoef {
-    double c[11];   // 1/13!, 1/12!, ..., 1/3!
+// exp(x) for finite x <= 0 (the RBF exponent): n = rint(x log2 e), r = x - n ln 2 (two-term ln 2), a polynomial in |r| <= ln2 / 2,
+// result scaled by 2^n; underflow goes through v_ldexp to 0.  Without the range checks and special cases of the library exp this is
+// 20 VALU instructions.  The polynomial is 1 + r + r^2 / 2 + sum_{k = 3 .. DEG} c_k r^k with the c_k of the MINIMAX fit of that form
+// (relative error; Remez in 80-digit arithmetic, tools/experiments/r06_exp_minimax.py; the three low terms are inline constants and
+// stay Taylor's): DEG = 11: 2.4e-17 -- a fifth of an ulp, below the rounding of its own Horner steps; rounds 1-5 ran the Taylor
+// polynomial of degree 13 (4e-18) for two more FMAs per node, and a node is 40 % of the fp64 work of a dyadic-1 RBF forward;
+// DEG = 9: 1.1e-13 -- for the fp32-ring kernel of sk_wave_fused_mb.hip, whose results are fp32 (rounds 3-5: Taylor degree 10, 2e-13).
+// The coefficients that are not inline constants live in VGPRs: as SGPR pairs they push the kernel's scalar state into spills
+// (v_readlane in the hot loop).
+// x below -800 -> a value in (-800.0000001, -800]: exp of it is already 0 in fp64, and n stays inside the int range for absurdly
+// distant points.  A select, not fmax: a NaN exponent (NaN / inf coordinates) must stay NaN, as in the reference -- and a select of the
+// HIGH word only (0xC0890000 = the high word of -800.0; whatever the low word holds, the value stays within 1e-7 of -800): one
+// v_cndmask instead of two.
+__device__ __forceinline__ double exp_clamp(double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    return __hiloint2double(x < -800.0 ? (int)0xC0890000u : hi, lo);
+}
+template <int DEG> struct ExpPoly;
+template <> struct ExpPoly<11> {
+    static constexpr int N = 9;      // r^11 .. r^3
+    static constexpr double k[N] = {2.297635202637367e-08, 2.7622226391501255e-07, 2.756385758315426e-06, 2.4801516346828486e-05, 0.00019841262672752407,
+                                    0.001388888892051129, 0.00833333333652807, 0.04166666666661997, 0.16666666666661958};
+};
+template <> struct ExpPoly<9> {
+    static constexpr int N = 7;      // r^9 .. r^3
+    static constexpr double k[N] = {2.4813607735638368e-06, 2.4869465890354224e-05, 0.00019848113928851274, 0.0013888836980909258, 0.008333328086765797,
+                                    0.041666666786023716, 0.1666666667871994};
+};
+template <int DEG> struct ExpCoefT {
+    double c[ExpPoly<DEG>::N];
     __device__ __forceinline__ void init() {
-        const double k[11] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
-                              1.0 / 5040.0,       1.0 / 720.0,       1.0 / 120.0,      1.0 / 24.0,      1.0 / 6.0};
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            c[i] = k[i];
+        for (int i = 0; i < ExpPoly<DEG>::N; ++i) {
+            c[i] = ExpPoly<DEG>::k[i];
             asm volatile("" : "+v"(c[i]));
         }
     }
 };
-__device__ __forceinline__ double exp_nonpos(double x, const ExpCoef &e) {
-    x = x < -800.0 ? -800.0 : x;   // exp(-800) is already 0 in fp64; keeps n inside int range for absurdly distant points.
-                                   // A select, not fmax: a NaN exponent (NaN / inf coordinates) must stay NaN, as in the reference
+typedef ExpCoefT<11> ExpCoef;
+template <int DEG>
+__device__ __forceinline__ double exp_nonpos(double x, const ExpCoefT<DEG> &e) {
+    x = exp_clamp(x);
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);
     double p = e.c[0];
 #pragma unroll
-    for (int i = 1; i < 11; ++i) p = fma(p, r, e.c[i]);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)n);
-}
-// the same polynomial started at coefficient I0 (degree 13 - I0): I0 = 3 is degree 10, truncation 0.3466^11 / 11! = 2e-13 --
-// below what fp32 results can resolve (the fp32-ring kernel of sk_wave_fused_mb.hip), three FMAs shorter
-template <int I0>
-__device__ __forceinline__ double exp_nonpos_from(double x, const ExpCoef &e) {
-    x = x < -800.0 ? -800.0 : x;
-    const double n = __builtin_rint(x * 1.4426950408889634074);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = e.c[I0];
-#pragma unroll
-    for (int i = I0 + 1; i < 11; ++i) p = fma(p, r, e.c[i]);
+    for (int i = 1; i < ExpPoly<DEG>::N; ++i) p = fma(p, r, e.c[i]);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -324,21 +330,13 @@ __device__ __forceinline__ double exp_nonpos_from(double x, const ExpCoef &e) {
 }
 // the same with the coefficients left to the compiler (kernels whose scalar register file has room for them)
 __device__ __forceinline__ double exp_nonpos(double x) {
-    x = x < -800.0 ? -800.0 : x;   // NaN-preserving clamp (see above)
+    x = exp_clamp(x);
     const double n = __builtin_rint(x * 1.4426950408889634074);
     double r = fma(n, -6.93147180369123816490e-01, x);
     r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double p = ExpPoly<11>::k[0];
+#pragma unroll
+    for (int i = 1; i < ExpPoly<11>::N; ++i) p = fma(p, r, ExpPoly<11>::k[i]);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
     for (int i = 0; i < R; ++i) left[i] = 1.0;
 #pragma unroll
     for (int i = 0; i < S; ++i) bot[i] = 1.0;
-    ExpCoef expc;   // the polynomial's coefficients in VGPRs: as SGPR pairs they spill the scalar state (v_readlane in the loop)
+    ExpCoefT<(Y32 ? 9 : 11)> expc;   // the polynomial's coefficients in VGPRs (the fp32 ring's results are fp32: degree 9): as SGPR pairs they spill the scalar state (v_readlane in the loop)
     if (RBF) expc.init();
     double *e_base = nullptr;   // EDGES: edge block of the pair the lane's sweep is in
 
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                         double xy = 0.0;
 #pragma unroll
                         for (int j = 0; j < FD; ++j) xy = fma(x0[j], yv[j][q], xy);
-                        abv[2 + q] = exp_nonpos_from<3>(fma(xy, two_inv_sigma, x0n + ysn[q]), expc);
+                        abv[2 + q] = exp_nonpos(fma(xy, two_inv_sigma, x0n + ysn[q]), expc);
                     }
                 } else {
 #pragma unroll
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused_mb(const FusedMbParams p
                         double xy = 0.0;
 #pragma unroll
                         for (int j = 0; j < FD; ++j) xy = fma(xr[k][j], yv[j][q], xy);
-                        own[k][2 + q] = exp_nonpos_from<3>(fma(xy, two_inv_sigma, xsn[k] + ysn[q]), expc);
+                        own[k][2 + q] = exp_nonpos(fma(xy, two_inv_sigma, xsn[k] + ysn[q]), expc);
                     } else {
                         double d2 = 0.0;
 #pragma unroll

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""(GPU box) Four coarse rows per lane at dyadic 1 (k_fwd_fused<..., RCX = 4>) against two: bit-identity and the per-macro-step
+"""(GPU box; ran on the round-6 EXPERIMENT build, which chose the rows per lane by SK_FUSED_RC4 -- the knob is gone, fused_rcx in
+csrc/sk_wave_fused.hip is the rule) Four coarse rows per lane at dyadic 1 (k_fwd_fused<..., RCX = 4>) against two: bit-identity and the per-macro-step
 costs the launcher's model (fused_small_cost, csrc/sk_wave_fused.hip) is calibrated by.
    r06_rc4.py                 drives itself: every part once per SK_FUSED_RC4 setting (a knob is read once per process)
    r06_rc4.py --dump f.npz    one process: values and gradients of the parity shapes -> f.npz

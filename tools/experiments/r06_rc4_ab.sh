@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: SK_FUSED_RC4 existed only in the experiment build of round 6 (it chose the rows per lane at run time); the rule is now fused_rcx in
+# csrc/sk_wave_fused.hip and the knob is gone -- this script documents how profiles/r06_rc4_ab.txt was produced.
 # (GPU box) four coarse rows per lane at dyadic 1 (SK_FUSED_RC4=2: wherever in scope) against two (=0), same box, alternating:
 # the BASELINE-derived shapes the forward kernel serves -> gpurun_out/r06_rc4_ab.txt
 R=gpurun_out/${1:-r06_rc4_ab}.txt; : > $R
