@@ -662,9 +662,16 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
 #pragma unroll
             for (int k = 0; k < RC; ++k)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) own[k][c] = own[k][c + 2];
+                for (int c = 0; c < 4; ++c) { own[k][c] = own[k][c + 2]; asm volatile("" : "+v"(own[k][c])); }
             bel[0] = bel[2];
             bel[1] = bel[3];
+            asm volatile("" : "+v"(bel[0]), "+v"(bel[1]));
+            // (the empty asm statements make every shifted value an opaque definition: left to itself the copy coalescer resolved the
+            // window's shift -- a chain of 2 RC + 1 overlapping copies -- through extra temporaries, 106 v_mov per macro-step of the
+            // four-row variant against 54 now, 197 -> 169 VGPRs; 512 x 512 RBF pairs 1.89 -> 1.81 ms, C2 0.161 -> 0.157,
+            // profiles/r06_exp_ab.txt.  Re-labelling the slots instead -- the loop unrolled by three -- was tried first: 181 -> 269
+            // VGPRs and 72 lint hazards, the allocator copies the pending y units around.  The same pins on the adjoint's and the
+            // multi-band forward's histories change nothing or add moves: not applied there.)
         } else {
 #pragma unroll
             for (int k = 0; k < RC; ++k)
