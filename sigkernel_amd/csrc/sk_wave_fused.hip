@@ -575,10 +575,20 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
                 top[i] = ktop[i];
             }
         } else {
+            // KTOP_KEPT: into the persistent ktop as well -- the DPP's `old` operand is then a register that is live anyway (a fresh 1.0
+            // per value is two moves per value and macro-step); the tops of the other lane groups are selected as before.  It costs 2 S
+            // VGPRs, so only the doubled-row variants take it: their LDS holds them to two waves per SIMD whatever the registers (one
+            // exception: linear with 8 dims and edges at dyadic 2 would drop from three waves to two)
+            constexpr bool KTOP_KEPT = RCX != 0 && RCX == 2 * Tile<DY>::RC && !(KIND == 0 && ND == 8 && DY == 2);
 #pragma unroll
             for (int i = 0; i < S; ++i) {
-                const double sh = dpp_shr1(bot[i], 1.0);
-                top[i] = is_top ? 1.0 : sh;
+                if constexpr (KTOP_KEPT) {
+                    ktop[i] = dpp_shr1(bot[i], ktop[i]);
+                    top[i] = is_top ? 1.0 : ktop[i];
+                } else {
+                    const double sh = dpp_shr1(bot[i], 1.0);
+                    top[i] = is_top ? 1.0 : sh;
+                }
             }
         }
 
