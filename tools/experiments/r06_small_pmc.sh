@@ -23,7 +23,7 @@ run() {   # name regex workload-args...
         python $REPO/tools/experiments/r05_small_steps.py "$@" 12 > /dev/null 2> "$OUT/$name.$i.err" || echo "  failed: $set" >> $R
   done
   python - "$OUT/$name" >> $R <<'PY'
-import csv, glob, sys, os
+import csv, glob, sys, os, re
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
@@ -31,7 +31,8 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
     for r in csv.DictReader(open(f)):
         per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"]); kn[r["Dispatch_Id"]] = r["Kernel_Name"]
     for (d, c), v in per.items():
-        acc[kn[d].split("(")[0][-70:]][c].append(v)
+        m = re.search(r"(k_\w+<[^>]*>)", kn[d])
+        acc[m.group(1) if m else kn[d][:60]][c].append(v)
 for k in sorted(acc):
     print("  kernel %s" % k)
     m = {c: sorted(v)[len(v) // 2] for c, v in acc[k].items()}
@@ -39,8 +40,8 @@ for k in sorted(acc):
     try:
         w, wc = m["SQ_WAVES"], m["SQ_WAVE_CYCLES"]
         tot = sum(m.get(c, 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD"))
-        print("    -> per wave: %.0f VALU, %.0f SALU, %.0f LDS, %.0f SMEM instructions; wave cycles (x4) per instruction of any kind: %.2f, per VALU: %.2f"
-              % (m["SQ_INSTS_VALU"] / w, m["SQ_INSTS_SALU"] / w, m["SQ_INSTS_LDS"] / w, m.get("SQ_INSTS_SMEM", 0) / w, 4 * wc / tot, 4 * wc / m["SQ_INSTS_VALU"]))
+        print("    -> per wave: %.0f VALU, %.0f SALU (of which %.0f branches), %.0f LDS, %.0f SMEM instructions; wave cycles (x4) per instruction of any kind: %.2f, per VALU: %.2f"
+              % (m["SQ_INSTS_VALU"] / w, m["SQ_INSTS_SALU"] / w, m.get("SQ_INSTS_BRANCH", 0) / w, m["SQ_INSTS_LDS"] / w, m.get("SQ_INSTS_SMEM", 0) / w, 4 * wc / tot, 4 * wc / m["SQ_INSTS_VALU"]))
     except Exception as e:
         print("    (no summary: %s)" % e)
 PY
