@@ -465,6 +465,64 @@ def test_loss_launch_route_on_the_gpu(kind, D, d, A, B, M, naive, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rbf", "linear"])
+def test_loss_launch_route_falls_back_when_the_fused_adjoint_declines(kind, monkeypatch):
+    """the one-launch loss route's backward must not raise when the fused adjoint declines a shape sk_route_query routed to it
+    (a scope or workspace check the query does not mirror): it falls back to the rows' gradient with the same weights -- the same
+    gradient as the undisturbed route, to rounding."""
+    gen = torch.Generator().manual_seed(17)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(0.8)
+    sk = sigkernel_amd.SigKernel(k, 1)
+    X, Y = walk(gen, 12, 30, 3).to(DEV), walk(gen, 9, 30, 3).to(DEV)
+    be = _lib.get_backend()
+    Xg = X.clone().requires_grad_(True)
+    sk.compute_mmd(Xg, Y).backward()
+    want = Xg.grad.clone()
+    name = "linear_adjoint_fused" if kind == "linear" else "rbf_adjoint_fused"
+    real = getattr(be, name)
+    calls = []
+
+    def declining(*a, **kw):
+        if kw.get("staged") is not None:      # the loss route's call (it hands over the arrays its forward staged)
+            calls.append(1)
+            return None
+        return real(*a, **kw)
+    monkeypatch.setattr(be, name, declining)
+    Xg = X.clone().requires_grad_(True)
+    sk.compute_mmd(Xg, Y).backward()
+    assert calls, "the one-launch route was not the one taken"
+    assert rel_err(Xg.grad.cpu().numpy(), want.cpu().numpy()) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_loss_launch_route_checks_its_limits_and_budget_before_launching(monkeypatch):
+    """pair fields of 15 / 31 bits are checked BEFORE any launch (the triangle of K(Y, Y) only where it is solved), and a call
+    whose edges + values + weights + pair table would exceed keep_edges_fraction of the transient budget is left to the tiled route."""
+    be = _lib.get_backend()
+    k = sigkernel_amd.RBFKernel(1.0)
+    gen = torch.Generator().manual_seed(3)
+    X, Y = walk(gen, 8, 17, 2).to(DEV), walk(gen, 6, 17, 2).to(DEV)
+    assert skmod._loss_launch_ok(be, k, X, Y, 1, False, True, True, None) is not None
+    # a budget the edges of 8 x 14 pairs (8 (2 x 32 + 32) bytes each) cannot fit into: declined with a gradient pending, taken without
+    assert skmod._loss_launch_ok(be, k, X, Y, 1, False, True, True, 4096) is None
+    assert skmod._loss_launch_ok(be, k, X, Y, 1, False, False, True, 1 << 20) is not None
+    # B = 47000 paths (sk_loss_value_f64 used to count B^2 >= 2^31 even without the triangle): too many for the 15-bit triangle field -> declined for the MMD, fine for the scoring rule
+    Ybig = torch.zeros(47000, 3, 2, dtype=torch.float64, device=DEV)
+    Xs = torch.zeros(4, 3, 2, dtype=torch.float64, device=DEV)
+    assert skmod._loss_launch_ok(be, k, Xs, Ybig, 0, False, False, True, None) is None
+    assert skmod._loss_launch_ok(be, k, Xs, Ybig, 0, False, False, False, None) is not None
+    sk = sigkernel_amd.SigKernel(k, 0)
+    v = sk.compute_expected_scoring_rule(Xs, Ybig)      # (ADVICE: B >= 46341 used to raise after the forward launch had run)
+    assert torch.isfinite(v)
+    # the constant weights of the torch-glue route: a bounded cache (least recently used first), pinned entries stay
+    skmod._LOSS_WEIGHTS.clear()
+    for a in range(2, 24):
+        skmod._loss_weights(a, 3, torch.float64, X.device, max_cached=8)
+    assert len(skmod._LOSS_WEIGHTS) == 8 and (23, 3, torch.float64, X.device) in skmod._LOSS_WEIGHTS and (2, 3, torch.float64, X.device) not in skmod._LOSS_WEIGHTS
+    skmod._LOSS_WEIGHTS.clear()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("D,d,A,B,M,N,naive", [(3, 1, 9, 7, 300, 64, False), (4, 2, 5, 11, 129, 33, False), (2, 0, 6, 6, 500, 128, False), (1, 1, 17, 3, 140, 20, True),
                                                (4, 0, 4, 9, 129, 128, False), (3, 2, 12, 12, 700, 64, True)])
 def test_long_first_paths_take_the_swapped_adjoint(D, d, A, B, M, N, naive, monkeypatch):
