@@ -286,6 +286,32 @@ def test_kernel_variants_stay_within_their_budget():
     assert os.path.getsize(os.path.join(ROOT, "sigkernel_amd", "libsigkernel_amd.so")) <= 9 * (1 << 20)
 
 
+def test_baseline_kernels_keep_their_waves_per_simd():
+    """The kernels the BASELINE configs spend their time in, and the resident waves per SIMD their VGPR count allows (512 registers per lane
+    and SIMD, allocated in eights): a compiler or source change that pushes one of them over its line -- C4's edge-keeping forward sits at
+    exactly 168 = three waves -- costs a wave per SIMD silently; here it fails a test.  (The headline variant is held to two waves by its
+    20 KB of LDS per wave, not by registers.)"""
+    import subprocess
+    obj = os.path.join(ROOT, "sigkernel_amd", "csrc", "obj")
+    if not glob.glob(os.path.join(obj, "*gfx950.s")):
+        pytest.skip("no ISA listings (the library was built elsewhere)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py")], capture_output=True, text=True)
+    vgpr = {ln.split("\t")[6]: int(ln.split("\t")[1]) for ln in r.stdout.splitlines()[1:] if ln.strip()}
+    need = {"k_fwd_fused<double, 1, false, false, false, 0, 8, 4>": 2,          # C3 (headline)
+            "k_fwd_fused<double, 1, false, false, false, 1, 4, 4>": 2,          # C2
+            "k_fwd_fused<double, 1, false, false, true, 1, 4, 4>": 2,           # the training-sized steps' forward
+            "k_adj_fused_rbf<1, 2, false, 4, false>": 2,                        # ... and adjoint
+            "k_fwd_fused<double, 2, false, false, true, 1, 4, 2>": 3,           # C4: forward with edges
+            "k_fwd_fused<double, 2, false, true, false, 1, 4, 0>": 3,           # C4: K_YY
+            "k_adj_fused_rbf<2, 1, true, 4, false>": 2,                         # C4: adjoint of K_XY
+            "k_adj_fused_rbf<2, 1, true, 4, true>": 2,                          # C4: triangle of K_XX with second-argument sums
+            "k_fwd_fused_mb<float, 2, true, 1, 16, false, 1, false>": 2}        # C5
+    for name, waves in need.items():
+        assert name in vgpr, name
+        have = 512 // ((vgpr[name] + 7) // 8 * 8)
+        assert have >= waves, "%s: %d VGPRs = %d waves per SIMD, needs %d" % (name, vgpr[name], have, waves)
+
+
 @pytest.mark.gpu
 def test_every_kernel_instance_is_launched_by_the_sweep():
     """The reach sweep itself, on the GPU (a minute): every route of the public API plus the batch-size- and length-gated calls, with the
