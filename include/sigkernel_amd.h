@@ -59,9 +59,10 @@ typedef enum sk_status {
 #define SK_FLAG_FAST_ONLY 4 /* never fall back: SK_ERR_UNSUPPORTED if the tiled kernels do not
                                cover the shape/layout (used by tests and benchmarks)            */
 
-/* 320.  The number moves whenever an exported signature changes incompatibly: 310 -> 320 gave sk_solve_fwd_{linear,rbf}_sym_* their
- * pair_tab argument (position 3) and added the sk_prep_cat_* / sk_solve_fwd_loss_f64 / sk_loss_* / sk_*_adjoint_finish_f64 family; a
- * binding written against 310 must not load a 320 library silently (sigkernel_amd/_lib.py checks it at load). */
+/* 330.  The number moves whenever an exported signature changes incompatibly: 310 -> 320 gave sk_solve_fwd_{linear,rbf}_sym_* their
+ * pair_tab argument (position 3) and added the sk_prep_cat_* / sk_solve_fwd_loss_f64 / sk_loss_* / sk_*_adjoint_finish_f64 family;
+ * 320 -> 330 gave sk_linear_adjoint_fused_f64 its ypart / ypart_doubles / ycols_out arguments (the second-argument sums).  A binding
+ * written against an older number must not load this library silently (sigkernel_amd/_lib.py checks it at load). */
 int sk_version(void);
 /* "sigkernel_amd gfx950; sources <hash>; <hipcc --version>; ISA hazard lint passed at build": the sources and the toolchain this
  * binary was built from (static string).  The hand-scheduled kernels are linted at build time against the register allocator of
@@ -85,8 +86,9 @@ const char *sk_build_info(void);
  *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
  *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
  *   SK_ROUTE_FUSED_SWAP     the one-band kernels on (Y, X): the second paths fit one band (rows <= 64 RC), the first do not; for the ADJOINT
- *                           (rbf, dim <= 4, fp64, Gram): sk_rbf_adjoint_fused_f64 on (Y, X) with the second-argument sums
- *                           (128 x 128 pairs of 700 x 20 points: 0.41 ms against 1.56 ms streamed); Gram callers transpose the result
+ *                           (fp64, Gram; rbf of dim <= 4, linear of dim <= 8): sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 on
+ *                           (Y, X) with the second-argument sums (rbf, 128 x 128 pairs of 700 x 20 points: 0.41 ms against 1.56 ms
+ *                           streamed); Gram callers transpose the result
  * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never
  * SK_ROUTE_STREAM: every such call CAN run with nothing of size pairs x M x N in HBM. */
 #define SK_ROUTE_NO_STREAM 1
@@ -182,11 +184,17 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
  *   then T[a][p][:] = that[a][*rows_out - 1 - p][:] for p < Mc is what sk_linear_adjoint_* returns.  tpart == NULL: only
  *   *ppg_out and *rows_out are set (size query: A * (B / ppg) * rows * 8 doubles).  err [P] zero-initialised: per-pair
  *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic <= 2, Mc <= 128 (64 at dyadic 2),
- *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED (sk_route_query(SK_OP_ADJOINT, 0, ...) == SK_ROUTE_FUSED says when it applies). */
+ *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED (sk_route_query(SK_OP_ADJOINT, 0, ...) == SK_ROUTE_FUSED says when it applies).
+ *   ypart / ycols_out (either non-NULL; Gram only, B > 0): the SECOND-argument sums INSTEAD of tpart (which is not touched) --
+ *   ypart viewed as [A][B][*ycols_out][8]: per pair and increment column q < Nc of y_b, sum_p W[a,b,p,q] dXr[a][p][:], WITHOUT the
+ *   upstream gradient (`scale` then only marks screened pairs): d k(x_a, y_b) / d (y_b[q+1] - y_b[q]); the caller weights the pairs of
+ *   a y_b, adds them and differences along the path.  Columns q >= Nc are padding and hold nothing meaningful.  ypart == NULL with
+ *   ycols_out set: size query (A B *ycols_out 8 doubles).  This is what SK_ROUTE_FUSED_SWAP runs on (Y, X) for LinearKernel. */
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
-                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, const double *kfinal, double screen,
-                                double tol, void *rescue_ws, size_t rescue_ws_bytes, void *stream);
+                                size_t tpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
+                                int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
+                                size_t rescue_ws_bytes, void *stream);
 
 /* Adjoint PDE AND RBFKernel chain rule in one kernel (csrc/sk_wave_adj_fused_rbf.hip): the reverse sweep evaluates the nodes
  * G = exp(-|x - y|^2 / sigma) itself, forms its increments as their 4-corner differences, recomputes K from the terminal edges a

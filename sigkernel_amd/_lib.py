@@ -92,8 +92,8 @@ SIGNATURES = {
     "sk_solve_fwd_rbf_sym_f32": (_int, [_vp, _vp, _vp, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp]),
     "sk_solve_fwd_rbf_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "sk_solve_fwd_linear_edges_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _vp,
-                                           _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
+    "sk_linear_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp,
+                                           _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
     "sk_rbf_adjoint_fused_f64": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _int, _int, _int, _int, ctypes.c_double, _vp, _vp, _vp,
                                         _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, _vp, _sz, _vp]),
     "sk_fused_rescue_workspace_bytes": (_sz, [_int, _i64, _int, _int, _int, _int]),
@@ -132,7 +132,7 @@ class SigKernelLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 320      # include/sigkernel_amd.h: sk_version()
+ABI_VERSION = 330      # include/sigkernel_amd.h: sk_version()
 
 
 def load():
@@ -777,14 +777,17 @@ class HipBackend:
         g = (-2.0 / float(sigma)) * (X.double() * cs - accd)               # sum_c V G (-2/sigma) (x_r - y_c)
         return g.to(X.dtype), _WorstResidual(err)
 
-    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False, staged=None, gscale=None):
+    def linear_adjoint_fused(self, X, Y, param, dyadic, edges, scale, gram=True, kfinal=None, naive=False, staged=None, gscale=None, yside=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the LINEAR static kernel straight from the paths
         and the forward's terminal edges: adjoint PDE and contraction in one kernel (sk_linear_adjoint_fused_f64; dim <= 8,
         dyadic <= 2, M - 1 <= 128 (64 at dyadic 2); computed in fp64 whatever the dtype of X).  None outside that scope.  The
         gradient is only valid when the residual is <= ADJ_RESIDUAL_TOL (not NaN) -- unless `kfinal` (the forward values, one
         per pair) is given: then the library's device-side rescue (sk_adj_fused_rescue.hip) takes exploding pairs out of the
         sweep, solves them with stored grids and adds their exact share, and the gradient is valid as returned -- nothing for the
-        host to check, no synchronisation.  gram=False: paired batch, Y [A,N,D], scale [A]."""
+        host to check, no synchronisation.  gram=False: paired batch, Y [A,N,D], scale [A].
+        yside (Gram): the SECOND-argument sums INSTEAD -- (None, residual, sums (A, B, N-1, D)): per pair and increment q of y_b,
+        sum_p W[a,b,p,q] s^2 (x_a[p+1] - x_a[p]) = d k(x_a, y_b) / d (y_b[q+1] - y_b[q]), WITHOUT the upstream gradient (`scale` is not
+        used; see second_argument_gradient)."""
         _dev(X, "X")
         A, M, D = X.shape
         if staged is not None:      # (dXr [>= A][256][8] with s^2, dYt [B][8][Ncp], B, N): staged by the caller (loss_forward)
@@ -795,36 +798,43 @@ class HipBackend:
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic not in (0, 1, 2) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or Mc > (64 if dyadic == 2 else 128):
             return None
+        if yside and not gram:
+            return None
         dev = X.device
         Mrows, Ncp = 256, (Nc + 15) // 16 * 16
         if scale is not None:
             scale = scale.double().contiguous()
         lib = load()
         P, Bk = (A * B, B) if gram else (A, 0)
-        ppg, rows = ctypes.c_int(0), ctypes.c_int(0)
+        ppg, rows, ycols = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        sizes = (ctypes.byref(ppg), ctypes.byref(rows), ctypes.byref(ycols) if yside else None)
         with _device(dev):
             if staged is None:
                 # fp32 paths: differences of the up-cast points, as the edge-keeping forward forms them (both arrays in one launch)
                 dXr, dYt = _prep_pair(X, Y, True, float(param) ** 2, Mrows, Ncp)
             args = (_ptr(dXr), _ptr(dYt), A, Bk, Mrows, Mc, Nc, Ncp, int(dyadic), SCHEME_NAIVE if naive else SCHEME_DEFAULT, _ptr(edges),
                     _ptr(scale))
-            rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, ctypes.byref(ppg), ctypes.byref(rows), None, 0.0, 0.0, None, 0,
-                                                 _stream(X))
+            rc = lib.sk_linear_adjoint_fused_f64(*args, None, 0, None, None, 0, *sizes, None, 0.0, 0.0, None, 0, _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
             self.last_fused_ppg = ppg.value      # (pairs per lane-group chunk of the last fused adjoint: what the tests look at)
-            tpart = torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
+            tpart = None if yside else torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
+            # every (pair, increment column < Nc) is written by the kernel; the padding columns up to ycols hold nothing meaningful
+            ypart = torch.empty(A, B, ycols.value, 8, dtype=torch.float64, device=dev) if yside else None
             kf, rws, rws_bytes = self._fused_rescue_args(0, kfinal, P, Mc, Nc, dyadic, dev)
             # (with the rescue armed, its screening pass writes every residual entry before the sweep)
             err = torch.empty(P, dtype=torch.float64, device=dev) if kf is not None else torch.zeros(P, dtype=torch.float64, device=dev)
-            rc = lib.sk_linear_adjoint_fused_f64(*args, _ptr(tpart), tpart.numel(), _ptr(err), ctypes.byref(ppg), ctypes.byref(rows),
-                                                 _ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes,
-                                                 _stream(X))
+            rc = lib.sk_linear_adjoint_fused_f64(*args, _ptr(tpart), 0 if yside else tpart.numel(), _ptr(err), _ptr(ypart),
+                                                 ypart.numel() if yside else 0, *sizes, _ptr(kf), float(self.FUSED_SCREEN),
+                                                 float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused")
+            if yside:
+                self.last_fused_err = err
+                return None, _WorstResidual(err), ypart[:, :, :Nc, :D]
         # worst self-check residual of the launch, NaN-propagating (torch.max does): stays on the device (diagnostics; with
         # `kfinal` the rescue has already dealt with exploding pairs: entries of -1 are pairs it took out of the sweep)
             # the chunks of an a added in ascending order, the flipped rows back to p, d inc[p,q] / d x[p+1] = +s^2 dy[q],
@@ -908,11 +918,18 @@ class HipBackend:
     def second_argument_gradient(ysums, Y, sigma, weight, b0=0):
         """dL/dY[b0:] (B-b0, N, D) from rbf_adjoint_fused(..., yside=True)'s sums (A, B, N, 2+D) and the per-pair upstream gradient
         `weight` (A, B): sum_a weight[a, b] (-2/sigma) (y_b[c] S0[a, b, c] - S1[a, b, c]).  The pairs are folded over a in a fixed
-        order (one matrix product per b), so the result is reproducible."""
+        order (one matrix product per b), so the result is reproducible.
+        sigma None: from linear_adjoint_fused(..., yside=True)'s sums (A, B, N-1, D) per INCREMENT of y_b -- folded the same way, then
+        differenced along the path (d inc[q] / d y[q+1] = +1, / d y[q] = -1)."""
         D = Y.shape[2]
         w = weight[:, b0:].double()
         ys = ysums[:, b0:]
-        folded = torch.einsum("ab,abck->bck", w, ys)              # (B-b0, N, 2+D)
+        folded = torch.einsum("ab,abck->bck", w, ys)              # (B-b0, N, 2+D) / linear: (B-b0, N-1, D)
+        if sigma is None:
+            g = torch.zeros(folded.shape[0], Y.shape[1], D, dtype=torch.float64, device=Y.device)
+            g[:, 1:] = folded
+            g[:, :-1] -= folded
+            return g.to(Y.dtype)
         g = (-2.0 / float(sigma)) * (Y[b0:].double() * folded[..., 0:1] - folded[..., 2:2 + D])
         return g.to(Y.dtype)
 

@@ -205,10 +205,11 @@ int device_cu_count() {
 
 extern "C" {
 
+// 330 (round 6): sk_linear_adjoint_fused_f64 takes ypart / ypart_doubles / ycols_out (the second-argument sums, route FUSED_SWAP)
 // 320 (round 5/6): sk_solve_fwd_{linear,rbf}_sym_* take the pair table (argument 3), sk_prep_cat_*, sk_solve_fwd_loss_f64, sk_loss_*,
 // sk_*_adjoint_finish_f64, sk_cost_query; the SK_WAVE_PF / SK_DERIV_PF / SK_ADJR_ALL knobs are gone; split mode's status word
 // (310: edges argument of sk_solve_fwd_static_*, the multi-band adjoints, the fused derivative solver)
-int sk_version(void) { return 320; }
+int sk_version(void) { return 330; }
 
 int sk_launch_trace(int enable) {
     const int prev = sk::g_trace.load(std::memory_order_relaxed);
@@ -486,16 +487,17 @@ int sk_solve_fwd_linear_edges_f64(const double *dXr, const double *dYt, int64_t 
 
 int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp,
                                 int dyadic, int scheme, const double *edges, const double *scale, double *tpart,
-                                size_t tpart_doubles, double *err, int *ppg_out, int *rows_out, const double *kfinal, double screen,
-                                double tol, void *rescue_ws, size_t rescue_ws_bytes, void *stream) {
+                                size_t tpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,
+                                int *ycols_out, const double *kfinal, double screen, double tol, void *rescue_ws,
+                                size_t rescue_ws_bytes, void *stream) {
     if (!dXr || !dYt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
-    if ((tpart && !err) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
+    if (((tpart || ypart) && !err) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
     const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};
-    return launch_adj_fused_linear(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, ppg_out, rows_out,
-                                   rescue_ws ? &fr : nullptr, (hipStream_t)stream);
+    return launch_adj_fused_linear(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, tpart, tpart_doubles, err, ypart, ypart_doubles, ppg_out,
+                                   rows_out, ycols_out, rescue_ws ? &fr : nullptr, (hipStream_t)stream);
 }
 
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,

@@ -38,7 +38,8 @@ struct FusedRescueParams {
     const double *err;         // residuals after the sweep: -1 marked by k_screen, > tol failed
     double tol;
     double *part;              // Tpart [groups][rows][8] (linear, coarse rows flipped) / Gpart [groups][rows][outw] (rbf, node rows)
-    double *Ypart;             // rbf, nullable: [P][ycols][6]
+    double *Ypart;             // nullable: rbf [P][ycols][6] per node column; linear [P][ycols][8] per increment column, and `part` null
+                               // (the second-argument form of sk_wave_adj_fused.hip has no first-argument sums to patch)
     int64_t A, B, P, n_groups;
     int Mrows, Ncp, Mc, Nc, D, dyadic, rows, outw, ycols;
     int naive;                 // _naive_solver stencil (cython_backend.pyx:114)
@@ -54,7 +55,7 @@ struct FusedRescueParams {
     int64_t ws_block;          // doubles per block
 };
 
-// exact contribution of pair p, added to the chunk's partial sums `slot` (and, rbf, written to Ypart)
+// exact contribution of pair p, added to the chunk's partial sums `slot` (null: none kept) and written to Ypart (if kept)
 __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slot, double *lds, double *wsb) {
     const int Mc = prm.Mc, Nc = prm.Nc, M = Mc + 1, N = Nc + 1, d = prm.dyadic;
     const int64_t a = prm.B > 0 ? p / prm.B : p, b = prm.B > 0 ? p % prm.B : p;
@@ -92,11 +93,18 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
     adj_pair<double>(inc, Nc, Mc, Nc, d, prm.naive, lds, Kf, Kr, nullptr, W, Nc);
     if (prm.kind == 0) {
         // T[a][pp][k] += s sum_q W[pp][q] dy[q][k], kept at flipped row rows - 1 - pp (sk_wave_adj_fused.hip)
-        for (int c = lane; c < Mc * fd; c += WAVE) {
+        for (int c = lane; slot && c < Mc * fd; c += WAVE) {
             const int pp = c / fd, k = c - pp * fd;
             double t = 0.0;
             for (int q = 0; q < Nc; ++q) t = fma(W[(int64_t)pp * Nc + q], ys[(int64_t)k * prm.Ncp + q], t);
             slot[(int64_t)(prm.rows - 1 - pp) * fd + k] += s * t;
+        }
+        // second argument: per increment column q, sum_pp W[pp][q] s^2 dx[pp][:], WITHOUT the upstream gradient
+        for (int c = lane; prm.Ypart && c < Nc * 8; c += WAVE) {
+            const int q = c >> 3, k = c & 7;
+            double t = 0.0;
+            for (int pp = 0; pp < Mc; ++pp) t = fma(W[(int64_t)pp * Nc + q], xs[pp * fd + k], t);
+            prm.Ypart[(p * prm.ycols + q) * 8 + k] = t;
         }
     } else {
         // V[r][c] = w[r-1][c-1] + w[r][c] - w[r-1][c] - w[r][c-1] (w = W inside the grid, 0 outside): d k / d G[r][c]
@@ -148,9 +156,9 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
                 todo &= todo - 1;
                 const int64_t pp = base + l;
                 const bool failed = prm.err[pp] > prm.tol;
-                double *slot = prm.part + pp * (int64_t)prm.rows * prm.outw;
+                double *slot = prm.part ? prm.part + pp * (int64_t)prm.rows * prm.outw : nullptr;
                 if (failed) {
-                    for (int c = threadIdx.x; c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
+                    for (int c = threadIdx.x; slot && c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
                     if (prm.N0)
                         for (int c = threadIdx.x; c < prm.n0cols; c += WAVE) prm.N0[pp * prm.n0cols + c] = 0.0;
                     __syncthreads();
@@ -189,9 +197,9 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
             const int64_t first_l = bcast64(first, l), slot_l = bcast64(slot_i, l);
             const int ppg_l = __shfl(ppg, l);
             const bool failed_l = __shfl((int)failed, l) != 0;
-            double *slot = prm.part + slot_l * (int64_t)prm.rows * prm.outw;
+            double *slot = prm.part ? prm.part + slot_l * (int64_t)prm.rows * prm.outw : nullptr;
             if (failed_l) {      // a pair the screen let through failed after the fact: the whole chunk again, exactly
-                for (int c = threadIdx.x; c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
+                for (int c = threadIdx.x; slot && c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
                 if (prm.N0)    // (one pair per chunk there)
                     for (int c = threadIdx.x; c < prm.n0cols; c += WAVE) prm.N0[first_l * prm.n0cols + c] = 0.0;
                 __syncthreads();
@@ -217,9 +225,9 @@ __global__ __launch_bounds__(WAVE) void k_fused_rescue(const FusedRescueParams p
         failed = __any(failed);
         marked = __any(marked);
         if (!failed && !marked) continue;
-        double *slot = prm.part + slot_i * (int64_t)prm.rows * prm.outw;
+        double *slot = prm.part ? prm.part + slot_i * (int64_t)prm.rows * prm.outw : nullptr;
         if (failed) {
-            for (int c = threadIdx.x; c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
+            for (int c = threadIdx.x; slot && c < prm.rows * prm.outw; c += WAVE) slot[c] = 0.0;
             if (prm.N0)
                 for (int c = threadIdx.x; c < prm.n0cols; c += WAVE) prm.N0[first * prm.n0cols + c] = 0.0;
             __syncthreads();

@@ -213,8 +213,8 @@ int launch_adj_fused_rbf_mb(const double *Xr, const void *Yt, int yt_f32, int64_
 
 // ---- sk_wave_adj_fused.hip: adjoint with the linear static kernel fused in (no increments, no W in HBM) ----
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                            int *ppg_out, int *rows_out, const FusedRescue *rescue, hipStream_t s);
+                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err, double *ypart,
+                            size_t ypart_doubles, int *ppg_out, int *rows_out, int *ycols_out, const FusedRescue *rescue, hipStream_t s);
 
 // ---- sk_prep.hip: fp64, zero-padded, row-major / dimension-major staging of the paths for the fused kernels ----
 template <typename T>

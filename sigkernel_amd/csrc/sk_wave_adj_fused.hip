@@ -28,6 +28,8 @@ struct AdjFusedParams {
     const double *edges;   // [P][NNp + MMp] strip layout (strip_geom)
     const double *scale;   // [P] upstream gradient per pair, nullable
     double *Tpart;         // [P / PPG][L*RC][8]  partial sums, flipped coarse rows
+    double *Ypart;         // YSIDE: [P][2 NUp][8] per pair and increment column q of y_b: sum_p W[p][q] s^2 (x[p+1]-x[p]), WITHOUT the
+                           // upstream gradient (the caller weights and adds the pairs of a second path)
     double *err;           // [P] zero-initialised: worst |Kf - 1| on the recomputed boundary
     int64_t P, B;          // B > 0: Gram, pair p = (p / B, p % B); B == 0: paired, pair p = (p, p) and PPG = 1
     int Mrows, Ncp, Mc, Nc, NUp, logL, PPG, n_steps;
@@ -69,8 +71,35 @@ __device__ __forceinline__ void lds_read_run<8>(d2_t (&v)[8], unsigned a) {     
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(a) : "memory");
 }
 
+// YSIDE: the carry of the second-argument sums, 16 bytes per lane and piece; piece i = dims (2 (i & 3), 2 (i & 3) + 1) of the unit's
+// column i >> 2.  Lane l reads slot l (what the lane above handed down; a group's top lane: never written, zero) and writes slot
+// l + 1, a bottom lane the spare slot 64 -- the slot numbering of sk_wave_adj_fused_rbf.hip (no bank conflicts, 65-slot pieces).
+constexpr int LYC_PIECE = 65 * 16;
+// the y differences of a macro-step (eight dims) AND the carry, one wait instead of three (a lone wave pays every LDS round trip in
+// full, profiles/r06_small_launch_pmc.txt)
+__device__ __forceinline__ void lds_read_dims8_carry8(d2_t (&v)[8], d2_t (&c)[8], unsigned a_even, unsigned a_odd, unsigned ca) {
+    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %16 offset:256\n\tds_read_b128 %3, %17 offset:256\n\t"
+                 "ds_read_b128 %4, %16 offset:512\n\tds_read_b128 %5, %17 offset:512\n\tds_read_b128 %6, %16 offset:768\n\t"
+                 "ds_read_b128 %7, %17 offset:768\n\t"
+                 "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:1040\n\tds_read_b128 %10, %18 offset:2080\n\t"
+                 "ds_read_b128 %11, %18 offset:3120\n\tds_read_b128 %12, %18 offset:4160\n\tds_read_b128 %13, %18 offset:5200\n\t"
+                 "ds_read_b128 %14, %18 offset:6240\n\tds_read_b128 %15, %18 offset:7280\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(c[0]), "=&v"(c[1]),
+                   "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                 : "v"(a_even), "v"(a_odd), "v"(ca)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_write_carry4(unsigned a, const d2_t (&v)[8], int h) {
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1040\n\tds_write_b128 %0, %3 offset:2080\n\t"
+                 "ds_write_b128 %0, %4 offset:3120"
+                 : : "v"(a), "v"(v[4 * h]), "v"(v[4 * h + 1]), "v"(v[4 * h + 2]), "v"(v[4 * h + 3]) : "memory");
+}
+
 // RC = coarse rows per lane: the forward kernels' choice at dyadic 1, 2; at dyadic 0 two instead of their four (register budget)
-template <int DY, int RC, bool FULLWAVE>
+// YSIDE: the SECOND-argument sums instead of the first-argument ones (route FUSED_SWAP: long first paths against short second ones are
+// swept as (y, x)): per unit the lanes hand the running sum over their rows down through LDS, the bottom lane stores it per pair
+template <int DY, int RC, bool FULLWAVE, bool YSIDE>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
@@ -121,6 +150,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
                           (unsigned)((lam & 7) * RC * 64);
     const unsigned ec_off = x_base0 + (unsigned)(G * X_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
     const unsigned ec_slot = (unsigned)(G * ECG);
+    const bool is_bot = lam == L - 1;
+    const unsigned yc_rd = lds0 + ec_off + 2u * ec_slot + (unsigned)(lane << 4);
+    const unsigned yc_wr = lds0 + ec_off + 2u * ec_slot + (unsigned)((is_bot ? WAVE : lane + 1) << 4);
 
     // ---- producers: the rings of sk_wave_fused.hip, filled in FLIPPED order ------------------------------------------------
     // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
@@ -212,11 +244,19 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         if (nu == 0 && lam * RC * r + R == MMp) pcol[R] = 1.0;
     };
 
-    double dxr[RC][FD], tacc[RC][FD];
+    // YSIDE: the upstream gradient only says which pairs are swept (NaN: screened out; the sums stay unweighted): 1 for a pair of the
+    // group that exists, NaN kept, 0 outside
+    auto pair_scale = [&](int ps_, double sv) -> double {
+        if (ps_ < 0 || ps_ >= PPG) return 0.0;
+        const double v = prm.scale ? sv : 1.0;
+        if constexpr (YSIDE) return pair0 + ps_ < prm.P ? (v != v ? v : 1.0) : 0.0;
+        return v;
+    };
+    double dxr[RC][FD], tacc[YSIDE ? 1 : RC][FD];
 #pragma unroll
     for (int k = 0; k < RC; ++k)
 #pragma unroll
-        for (int j = 0; j < FD; ++j) { dxr[k][j] = 0.0; tacc[k][j] = 0.0; }
+        for (int j = 0; j < FD; ++j) { dxr[k][j] = 0.0; if (!YSIDE || k == 0) tacc[YSIDE ? 0 : k][j] = 0.0; }
     double ktopR[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) ktopR[i] = 1.0;
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite (see the contraction below)
-        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB + 2 * G * ECG);
+        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB + 2 * G * ECG + (YSIDE ? 8 * LYC_PIECE : 0));
         const d2_t z = {0.0, 0.0};
         for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -251,7 +291,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         async_wait<0>(ncol, pcol);
         async_wait<0>(tsc, pscale);
         fix_edges(u, ncol);
-        nscale = (u == 0 && ps >= 0 && ps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+        nscale = u == 0 ? pair_scale(ps, tsc[0]) : 0.0;
     }
     issue_y();
     issue_x();
@@ -290,9 +330,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 
         // -- y differences of the unit (original column order inside the unit)
         d2_t dyv[FD];
+        d2_t car[YSIDE ? 8 : 1];     // YSIDE: what the lanes above summed for this unit's two columns one macro-step ago
         {
             const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
-            lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            if constexpr (YSIDE) lds_read_dims8_carry8(dyv, car, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7), yc_rd);
+            else lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
         lds_take<S>(trow, trow_p);
         if ((t & 7) == 0) issue_edge_chunk();
@@ -379,11 +421,35 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         {
             const bool live = s_pair != 0.0 && s_pair == s_pair;   // (NaN: a pair the rescue's screen took out of the sweep)
             const double wsc = sc * s_pair;
+            double wq[RC][CW];
 #pragma unroll
-            for (int k = 0; k < RC; ++k) {
-                const double w0 = live ? acc[k][1] * wsc : 0.0, w1 = live ? acc[k][0] * wsc : 0.0;   // original columns 0, 1
+            for (int k = 0; k < RC; ++k) { wq[k][0] = live ? acc[k][1] * wsc : 0.0; wq[k][1] = live ? acc[k][0] * wsc : 0.0; }   // original columns 0, 1
+            if constexpr (!YSIDE) {
 #pragma unroll
-                for (int j = 0; j < FD; ++j) tacc[k][j] = fma(w0, dyv[j][0], fma(w1, dyv[j][1], tacc[k][j]));
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) tacc[k][j] = fma(wq[k][0], dyv[j][0], fma(wq[k][1], dyv[j][1], tacc[k][j]));
+            } else {
+                // second argument: column q of the unit gets sum_k w[k][q] dxr[k][:], on top of what the lanes above summed for it one
+                // macro-step ago (read with the y differences at the top of the step: 32 VGPRs across the sweep, which these variants
+                // have -- no first-argument sums --, instead of two more LDS round trips here)
+                const int uo = NUp - 1 - u;
+                double *yp = prm.Ypart + ((pair0 + ps) * (int64_t)(2 * NUp) + 2 * uo) * FD;
+#pragma unroll
+                for (int q = 0; q < CW; ++q) {
+#pragma unroll
+                    for (int k = 0; k < RC; ++k)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            car[4 * q + j][0] = fma(wq[k][q], dxr[k][2 * j], car[4 * q + j][0]);
+                            car[4 * q + j][1] = fma(wq[k][q], dxr[k][2 * j + 1], car[4 * q + j][1]);
+                        }
+                    lds_write_carry4(yc_wr + (unsigned)(q * 4 * LYC_PIECE), car, q);
+                    if (is_bot && live) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<d2_t *>(yp + q * FD + 2 * j) = car[4 * q + j];
+                    }
+                }
             }
         }
 
@@ -402,7 +468,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             async_wait<0>(ncol, pcol);
             async_wait<0>(tsc, pscale);
             fix_edges(nu, ncol);
-            if (nu == 0) nscale = (nps >= 0 && nps < PPG) ? (prm.scale ? tsc[0] : 1.0) : 0.0;
+            if (nu == 0) nscale = pair_scale(nps, tsc[0]);
         }
 
         // -- advance; the next slab / window is requested right after the wait, so it has a whole macro-step before the
@@ -423,7 +489,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 
     // ---- the group's partial sums: Tpart[group][flipped coarse row][8] ------------------------------------------------------
     {
-        if (pair0 < prm.P) {
+        if (!YSIDE && pair0 < prm.P) {
             double *dst = prm.Tpart + (gslot * Mcp + (int64_t)lam * RC) * FD;
 #pragma unroll
             for (int k = 0; k < RC; ++k)
@@ -437,9 +503,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE>
+template <int DY, int RC, bool FULLWAVE, bool YSIDE>
 int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_linear<DY, RC, FULLWAVE>;
+    auto kern = k_adj_fused_linear<DY, RC, FULLWAVE, YSIDE>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -453,8 +519,9 @@ int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
 namespace {
 int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
                                  const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                                 int *ppg_out, int *rows_out, int64_t *rows_per_launch, int64_t *epair, int64_t force_nch,
-                                 const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes, hipStream_t s) {
+                                 double *ypart, bool yside, int *ppg_out, int *rows_out, int *ycols_out, int64_t *rows_per_launch,
+                                 int64_t *epair, int64_t force_nch, const FusedRescue *rescue, const double *scale_orig, void *rescue_ws,
+                                 size_t rescue_ws_bytes, hipStream_t s) {
     const int DY = g.dyadic;
     if (DY > 2 || B < 0 || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(g, 8);   // the layout of the edges
@@ -469,8 +536,10 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16;
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16 +
+                             (yside ? 8 * LYC_PIECE : 0);
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
+    if (yside && B <= 0) return SK_ERR_UNSUPPORTED;   // (paired batches have no use for it: both arguments fit or neither does)
 
     // pairs per lane group: the smallest divisor of B that keeps the launch within the resident waves (8 per CU: the
     // kernel holds ~230 VGPRs, two waves per SIMD)
@@ -498,12 +567,13 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     const int64_t groups = g.P / PPG;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC;
-    if (!tpart) return SK_OK;
-    if (tpart_doubles < (size_t)groups * L * RC * FD) return SK_ERR_WORKSPACE;
+    if (ycols_out) *ycols_out = 2 * NUp;
+    if (yside ? !ypart : !tpart) return SK_OK;
+    if (!yside && tpart_doubles < (size_t)groups * L * RC * FD) return SK_ERR_WORKSPACE;
     const int64_t waves = (groups + G - 1) / G;
 
     AdjFusedParams prm;
-    prm.dXr = dXr; prm.dYt = dYt; prm.edges = edges; prm.scale = scale; prm.Tpart = tpart; prm.err = err;
+    prm.dXr = dXr; prm.dYt = dYt; prm.edges = edges; prm.scale = scale; prm.Tpart = tpart; prm.err = err; prm.Ypart = ypart;
     prm.P = g.P; prm.B = B; prm.Mrows = Mrows; prm.Ncp = Ncp; prm.Mc = g.Mc; prm.Nc = g.Nc; prm.NUp = NUp; prm.logL = logL;
     prm.PPG = (int)PPG;
     prm.E = st.NNp + st.MMp;
@@ -514,28 +584,41 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     int rc;
-    switch (DY) {
-        case 0: rc = full ? launch_adjf<0, 2, true>(prm, lds_block, s) : launch_adjf<0, 2, false>(prm, lds_block, s); break;
-        case 1: rc = full ? launch_adjf<1, 2, true>(prm, lds_block, s) : launch_adjf<1, 2, false>(prm, lds_block, s); break;
-        default: rc = full ? launch_adjf<2, 1, true>(prm, lds_block, s) : launch_adjf<2, 1, false>(prm, lds_block, s); break;
-    }
+    if (yside)
+        switch (DY) {
+            case 0: rc = full ? launch_adjf<0, 2, true, true>(prm, lds_block, s) : launch_adjf<0, 2, false, true>(prm, lds_block, s); break;
+            case 1: rc = full ? launch_adjf<1, 2, true, true>(prm, lds_block, s) : launch_adjf<1, 2, false, true>(prm, lds_block, s); break;
+            default: rc = full ? launch_adjf<2, 1, true, true>(prm, lds_block, s) : launch_adjf<2, 1, false, true>(prm, lds_block, s); break;
+        }
+    else
+        switch (DY) {
+            case 0: rc = full ? launch_adjf<0, 2, true, false>(prm, lds_block, s) : launch_adjf<0, 2, false, false>(prm, lds_block, s); break;
+            case 1: rc = full ? launch_adjf<1, 2, true, false>(prm, lds_block, s) : launch_adjf<1, 2, false, false>(prm, lds_block, s); break;
+            default: rc = full ? launch_adjf<2, 1, true, false>(prm, lds_block, s) : launch_adjf<2, 1, false, false>(prm, lds_block, s); break;
+        }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
-    return launch_fused_rescue(0, dXr, dYt, scale_orig, err, rescue->tol, tpart, nullptr, A, B, Mrows, Ncp, 8, g, L * RC, FD, 0, 0.0, prm.cs,
-                               groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
+    // (second-argument sums: the rescue writes a rescued pair's block of ypart and has no partial sums to patch)
+    return launch_fused_rescue(0, dXr, dYt, scale_orig, err, rescue->tol, yside ? nullptr : tpart, ypart, A, B, Mrows, Ncp, 8, g, L * RC, FD,
+                               2 * NUp, 0.0, prm.cs, groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
 }
 }  // namespace
 
+// ypart / ycols_out (either non-null: Gram only): the SECOND-argument sums instead, [A B][*ycols_out][8] per pair and increment column
+// of y_b, without the upstream gradient; tpart is not touched then.  Query (sizes only): tpart == ypart == nullptr.
 int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int64_t B, int Mrows, int Ncp, const Geom &g,
-                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err,
-                            int *ppg_out, int *rows_out, const FusedRescue *rescue, hipStream_t s) {
-    int ppg = 0, rows = 0;
+                            const double *edges, const double *scale, double *tpart, size_t tpart_doubles, double *err, double *ypart,
+                            size_t ypart_doubles, int *ppg_out, int *rows_out, int *ycols_out, const FusedRescue *rescue, hipStream_t s) {
+    int ppg = 0, rows = 0, ycols = 0;
     int64_t per_launch = 0, epair = 0;
-    int rc = launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, nullptr, 0, err, &ppg, &rows, &per_launch, &epair, 0,
-                                          nullptr, nullptr, nullptr, 0, s);
+    const bool yside = ypart != nullptr || ycols_out != nullptr;
+    int rc = launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, scale, nullptr, 0, err, nullptr, yside, &ppg, &rows, &ycols,
+                                          &per_launch, &epair, 0, nullptr, nullptr, nullptr, 0, s);
     if (rc != SK_OK) return rc;
     if (ppg_out) *ppg_out = ppg;
     if (rows_out) *rows_out = rows;
-    if (!tpart) return SK_OK;
+    if (ycols_out) *ycols_out = ycols;
+    if (yside ? !ypart : !tpart) return SK_OK;
+    if (ypart && ypart_doubles < (size_t)g.P * ycols * FD) return SK_ERR_WORKSPACE;
     // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN)
     const double *sweep_scale = scale;
     void *rws = nullptr;
@@ -552,19 +635,20 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
         }
     }
     if (per_launch <= 0 || B <= 0)
-        return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, sweep_scale, tpart, tpart_doubles, err, nullptr, nullptr, nullptr,
-                                            nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
+        return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, sweep_scale, tpart, tpart_doubles, err, ypart, yside, nullptr,
+                                            nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that tpart keeps one layout)
     const int64_t nch = B / ppg, slot = (int64_t)rows * FD;
-    if (tpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
+    if (!yside && tpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
     for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
         const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;
         Geom gs = g;
         gs.P = An * B;
         rc = launch_adj_fused_linear_rows(dXr + a0 * Mrows * FD, dYt, An, B, Mrows, Ncp, gs, edges + a0 * B * epair,
-                                          sweep_scale ? sweep_scale + a0 * B : nullptr, tpart + a0 * nch * slot, (size_t)(An * nch * slot),
-                                          err ? err + a0 * B : nullptr, nullptr, nullptr, nullptr, nullptr, nch, rescue,
-                                          scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
+                                          sweep_scale ? sweep_scale + a0 * B : nullptr, yside ? nullptr : tpart + a0 * nch * slot,
+                                          (size_t)(An * nch * slot), err ? err + a0 * B : nullptr,
+                                          ypart ? ypart + a0 * B * (int64_t)ycols * FD : nullptr, yside, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, nch, rescue, scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
         if (rc != SK_OK) return rc;
     }
     return SK_OK;

@@ -263,17 +263,19 @@ def _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, bu
 
 
 def _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget, Kvals=None):
-    """dL/dX of a Gram block whose FIRST paths are long and whose second paths fit the one-band RBF adjoint's lanes (route FUSED_SWAP):
+    """dL/dX of a Gram block whose FIRST paths are long and whose second paths fit the one-band adjoints' lanes (route FUSED_SWAP):
     the adjoint runs on the pairs (y_b, x_a) -- k and the static kernel are symmetric -- with the SECOND-argument sums of that sweep
-    (sk_rbf_adjoint_fused_f64 with ypart), folded with the transposed upstream gradient: d k(x_a, y_b) / d x_a = d2 k(y_b, x_a).
-    Tiled over the rows of Y by the memory of the sums (48 bytes per pair and node column).  kept: the edges the forward kept for the
-    swapped pairs, else they are formed here.  None where the kernel declines (the caller streams)."""
+    (sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 with ypart), folded with the transposed upstream gradient:
+    d k(x_a, y_b) / d x_a = d2 k(y_b, x_a).  Tiled over the rows of Y by the memory of the sums (48 / 64 bytes per pair and column).
+    kept: the edges the forward kept for the swapped pairs, else they are formed here.  None where the kernel declines (the caller streams)."""
     A, B = Xd.shape[0], Yd.shape[0]
-    sigma = float(static_kernel.sigma)
+    kind, param = _fused_static(static_kernel, True)
+    linear = kind == 0
+    fwd, adj = (be.solve_fwd_fused_linear, be.linear_adjoint_fused) if linear else (be.solve_fwd_fused_rbf, be.rbf_adjoint_fused)
     edges = kept[0][2] if (kept and len(kept) == 1 and kept[0][:2] == (0, A) and kept[0][2] is not None) else None
     KT = None if Kvals is None else Kvals.t().contiguous()
     if edges is None:
-        res = be.solve_fwd_fused_rbf(Yd, Xd, sigma, dyadic, naive, True, keep_edges=True)
+        res = fwd(Yd, Xd, param, dyadic, naive, True, keep_edges=True)
         if res is None or res[1] is None:
             return None
         KT, edges = res
@@ -281,11 +283,11 @@ def _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget
     goT = go.t().contiguous()                     # upstream gradient of the pair (b, a)
     grad = None
     for b0, b1 in _tiles(B, 64 * A * (Xd.shape[1] + 16), budget):
-        res = be.rbf_adjoint_fused(Yd[b0:b1].contiguous(), Xd, sigma, dyadic, edges[b0 * per:b1 * per], None, gram=True, yside=True,
-                                   kfinal=None if KT is None else KT[b0:b1], naive=naive)
+        res = adj(Yd[b0:b1].contiguous(), Xd, param, dyadic, edges[b0 * per:b1 * per], None, gram=True, yside=True,
+                  kfinal=None if KT is None else KT[b0:b1], naive=naive)
         if res is None:
             return None
-        g = be.second_argument_gradient(res[2], Xd, sigma, goT[b0:b1], 0)
+        g = be.second_argument_gradient(res[2], Xd, None if linear else param, goT[b0:b1], 0)
         grad = g if grad is None else grad + g
         del res
     return grad

@@ -65,9 +65,10 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sk_solve_fwd_rbf_f32(p, p, 1, 1, 256, 4, 4, 16, 3, 3, 0, 1.0, p, None, None) == 2           # dyadic 3: not covered
     assert lib.sk_solve_fwd_rbf_f64(p, p, 1, 1, 256, 128, 4, 16, 3, 1, 0, 1.0, p, None, None) == 2      # 129 node rows: two bands
     assert lib.sk_solve_fwd_linear_f64(p, p, 1, 1, 256, 4, 4, 16, 0, 1, 0, p, None, None) == 1                 # path dimension 0
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, -1, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 1  # B < 0
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 3, 0, p, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 2   # dyadic 3
-    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 1, 0, p, None, p, 64, p, None, None, p, 1e3, 1e-8, None, 0, None) == 1   # forward values without a rescue workspace
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, -1, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 1  # B < 0
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 3, 0, p, None, None, 0, None, None, 0, None, None, None, None, 0.0, 0.0, None, 0, None) == 2   # dyadic 3
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 1, 0, p, None, p, 64, p, None, 0, None, None, None, p, 1e3, 1e-8, None, 0, None) == 1   # forward values without a rescue workspace
+    assert lib.sk_linear_adjoint_fused_f64(p, p, 1, 2, 256, 4, 4, 16, 1, 0, p, None, None, 0, None, p, 64, None, None, None, None, 0.0, 0.0, None, 0, None) == 1   # second-argument sums without a residual array
     assert lib.sk_fused_rescue_workspace_bytes(1, 100, 63, 63, 2, 4) > 0 and lib.sk_fused_rescue_workspace_bytes(2, 100, 63, 63, 2, 4) == 0
 
 

@@ -479,15 +479,16 @@ def test_loss_launch_route_falls_back_when_the_fused_adjoint_declines(kind, monk
     sk.compute_mmd(Xg, Y).backward()
     want = Xg.grad.clone()
     name = "linear_adjoint_fused" if kind == "linear" else "rbf_adjoint_fused"
-    real = getattr(be, name)
+    real = getattr(type(be), name)
     calls = []
 
-    def declining(*a, **kw):
+    def declining(self, *a, **kw):
         if kw.get("staged") is not None:      # the loss route's call (it hands over the arrays its forward staged)
             calls.append(1)
             return None
-        return real(*a, **kw)
-    monkeypatch.setattr(be, name, declining)
+        return real(self, *a, **kw)
+    # (on the TYPE: undoing a patch of the instance would leave the bound method in its __dict__, shadowing later patches of the type)
+    monkeypatch.setattr(type(be), name, declining)
     Xg = X.clone().requires_grad_(True)
     sk.compute_mmd(Xg, Y).backward()
     assert calls, "the one-launch route was not the one taken"
@@ -523,20 +524,24 @@ def test_loss_launch_route_checks_its_limits_and_budget_before_launching(monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,d,A,B,M,N,naive", [(3, 1, 9, 7, 300, 64, False), (4, 2, 5, 11, 129, 33, False), (2, 0, 6, 6, 500, 128, False), (1, 1, 17, 3, 140, 20, True),
-                                               (4, 0, 4, 9, 129, 128, False), (3, 2, 12, 12, 700, 64, True)])
-def test_long_first_paths_take_the_swapped_adjoint(D, d, A, B, M, N, naive, monkeypatch):
-    """Gradients of a Gram block whose first paths are long and whose second paths fit the one-band RBF adjoint (route FUSED_SWAP: the
+@pytest.mark.parametrize("kind,D,d,A,B,M,N,naive", [("rbf", 3, 1, 9, 7, 300, 64, False), ("rbf", 4, 2, 5, 11, 129, 33, False), ("rbf", 2, 0, 6, 6, 500, 128, False),
+                                                    ("rbf", 1, 1, 17, 3, 140, 20, True), ("rbf", 4, 0, 4, 9, 129, 128, False), ("rbf", 3, 2, 12, 12, 700, 64, True),
+                                                    ("linear", 3, 1, 9, 7, 300, 64, False), ("linear", 8, 2, 5, 11, 129, 65, False),
+                                                    ("linear", 2, 0, 6, 6, 500, 60, False), ("linear", 5, 1, 17, 3, 140, 20, True),
+                                                    ("linear", 8, 0, 4, 9, 300, 70, False), ("linear", 1, 2, 12, 12, 700, 40, True),
+                                                    ("linear", 4, 1, 40, 70, 200, 9, False)])
+def test_long_first_paths_take_the_swapped_adjoint(kind, D, d, A, B, M, N, naive, monkeypatch):
+    """Gradients of a Gram block whose first paths are long and whose second paths fit the one-band adjoints (route FUSED_SWAP: the
     sweep runs on (y, x), the gradient comes from its second-argument sums; sigkernel.py:404-502 has no such asymmetry) against the
     default routes without the swap (routes.no_adjoint_swap) and the oracle's closed form; values unchanged; mmd through the same route."""
     gen = torch.Generator().manual_seed(D * 100 + M)
-    k = sigkernel_amd.RBFKernel(0.9)
+    k = sigkernel_amd.RBFKernel(0.9) if kind == "rbf" else sigkernel_amd.LinearKernel()
     sk = sigkernel_amd.SigKernel(k, d, _naive_solver=naive)
     Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
     X, Y = Xc.to(DEV), Yc.to(DEV)
     w = torch.randn(A, B, generator=gen, dtype=torch.float64)
     be = _lib.get_backend()
-    assert be.route(_lib.OP_ADJOINT, 1, D, M, N, d, naive, 8) == _lib.ROUTE_FUSED_SWAP
+    assert be.route(_lib.OP_ADJOINT, 1 if kind == "rbf" else 0, D, M, N, d, naive, 8) == _lib.ROUTE_FUSED_SWAP
     out = {}
     for off in (False, True):
         monkeypatch.setattr(sigkernel_amd.routes, "no_adjoint_swap", off)
@@ -774,6 +779,44 @@ def test_fused_rescue_covers_the_second_argument_sums(monkeypatch):
     got = Xg.grad.cpu().numpy()
     for a in range(30):
         assert rel_err(got[a], want[a]) <= 2 * _lib.HipBackend.ADJ_RESIDUAL_TOL, (a, rel_err(got[a], want[a]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,N", [(1, 32), (0, 80), (2, 20)])
+@pytest.mark.parametrize("screen", [1e3, 1e300])
+def test_swapped_linear_adjoint_rescues_an_exploding_pair(d, N, screen, monkeypatch):
+    """Long first paths against short second ones, LinearKernel (route FUSED_SWAP: sk_linear_adjoint_fused_f64 on (y, x) with the
+    second-argument sums), one pair with |K| ~ 1e9: screened out of the sweep -- or, with the screen disabled, failing its self-check
+    after the fact -- its block of the sums comes from the stored-grid rescue; every row of the gradient matches the oracle."""
+    be = _lib.get_backend()
+    monkeypatch.setattr(type(be), "FUSED_SCREEN", screen)
+    gen = torch.Generator().manual_seed(47 + d)
+    A, B, M, D = 6, 40, 200, 4
+    Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
+    Xc[2] = torch.linspace(0, 12, M, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    Yc[5] = torch.linspace(0, 12, N, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    k = sigkernel_amd.LinearKernel()
+    assert be.route(_lib.OP_ADJOINT, 0, D, M, N, d, False, 8) == _lib.ROUTE_FUSED_SWAP
+    wc = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    Kc = O.gram_forward(Xc, Yc, k, d)
+    wild = np.abs(Kc) > 1e3
+    assert np.abs(Kc[2, 5]) > 1e5 and 1 <= wild.sum() <= 12
+    be.last_fused_err = None
+    calls = []
+    orig = type(be).linear_adjoint_fused
+    monkeypatch.setattr(type(be), "linear_adjoint_fused", lambda self, *a, **kw: (calls.append((kw.get("kfinal") is not None, kw.get("yside"))), orig(self, *a, **kw))[1])
+    Xg = Xc.to(DEV).requires_grad_(True)
+    (sigkernel_amd.SigKernel(k, d).compute_Gram(Xg, Yc.to(DEV)) * wc.to(DEV)).sum().backward()
+    assert calls and all(c == (True, True) for c in calls), "the swapped adjoint was not used, or not armed with the forward values"
+    err = be.last_fused_err.cpu().numpy().reshape(B, A)          # pairs (b, a)
+    if screen < 1e100:
+        assert np.array_equal(err < 0, wild.T) and np.all(err[wild.T] == -1.0)
+    else:
+        assert err[5, 2] > be.ADJ_RESIDUAL_TOL or np.isnan(err[5, 2])
+    want = O.gram_grad_weighted(Xc, Yc, wc.numpy(), k, d, nthreads=NT)
+    got = Xg.grad.cpu().numpy()
+    for a in range(A):
+        assert rel_err(got[a], want[a]) <= 2 * be.ADJ_RESIDUAL_TOL, (a, rel_err(got[a], want[a]))
 
 
 @pytest.mark.gpu

@@ -124,6 +124,12 @@ def gated(g, be):
         sk.compute_Gram(Xg, Xg, sym=True).sum().backward()
         del Xg
         torch.cuda.empty_cache()
+    # long first paths against short second ones with a gradient, LinearKernel: the one-band adjoint on (y, x) with second-argument sums,
+    # on the full wave and on fewer lanes at each dyadic order (the 3 x 4 sweep above has no second paths of <= 33 points at dyadic 2)
+    for d, (M, N) in itertools.product((0, 1, 2), ((200, 20), (300, 100), (400, 60))):
+        sk = sigkernel_amd.SigKernel(LIN(), d)
+        Xg = walk(g, 5, M, 6, f64).requires_grad_(True)
+        sk.compute_Gram(Xg, walk(g, 7, N, 6, f64)).sum().backward()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
     # and more; its in-LDS band boundary (two bands, 126..157-point second paths)
     for kname, d, (M, N) in itertools.product(("linear", "rbf"), (0, 1, 2), ((65, 130), (129, 140), (129, 200), (100, 140))):
