@@ -107,12 +107,6 @@ const CostEntry COSTS[] = {
     {"fused_static_share_rbf", 20,
      "... the RBF variants (longer macro-steps, a draw costs less of one): 2048 x 2048 pairs, dyadic 2: 52.0 ms at 35, 50.9 at 20, 50.6 at 3; "
      "512 / 1024 paths: 3.41 -> 3.34, 13.0 -> 12.8 ms; C4 335.6 -> 334.5 (profiles/r05_qstatic.txt)"},
-    {"adj_swap_linear_d0_max_mb_eff", 0.45,
-     "LinearKernel at dyadic 0, long first paths against second ones of <= 129 points, with a gradient: the one-band adjoint on (y, x) with "
-     "second-argument sums only while the multi-band adjoint's sweep efficiency is below this (r06_asym, 128 x 128 pairs, dim 8, forward + "
-     "backward: 512 x 64 points (0.40) 3.03 ms swapped vs 5.73 streamed; 700 x 80 (0.455) 7.31 vs 6.53 multi-band; 800 x 100 (0.49) 8.50 vs "
-     "8.58; 1000 x 100 (0.61) 10.6 vs 8.6; 2000 x 128 (0.78) 20.5 vs 16.8; at dyadic 1 the swapped route wins at every length: 1000 x 100 "
-     "12.5 vs 13.7, 512 x 64 3.6 vs 7.9)"},
     {"mb_split_max_resident_share", 0.5,
      "few pairs of long paths: bands of a pair on several waves when the pairs fill at most this share of the resident waves (r05: 16 x 16 pairs "
      "of 4096 points 18.7 -> 4.7 ms; 32 x 32 pairs of 700 points 2.18 -> 1.96 ms)"},
@@ -178,12 +172,10 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         // kernel are symmetric), where the second paths fit its lanes -- 0.55-0.65x the streamed time, profiles/r05_asym.txt
         if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= 64))
             return SK_ROUTE_FUSED_SWAP;
-        // ... and the linear one-band adjoint on (y, x) (dim <= 8, fp64 paths): its second-argument form carries the sums over a lane's
-        // rows through LDS instead of keeping first-argument sums in registers (sk_wave_adj_fused.hip, round 6) -- 0.4-0.8x the time of the
-        // routes below (profiles/r06_asym.txt), except at dyadic 0 where the multi-band adjoint sweeps long first paths at a good efficiency
-        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 0 && D <= 8 && elem_size == 8 && Nc <= (d == 2 ? 64 : 128) &&
-            (d > 0 || mb_efficiency(kind, Mc, Nc, d, rc_of(d)) < cost("adj_swap_linear_d0_max_mb_eff")))
-            return SK_ROUTE_FUSED_SWAP;
+        // ... and the linear one-band adjoint on (y, x) (dim <= 8, fp64 paths): its second-argument form hands the sums over a lane's rows
+        // down the wave by DPP instead of keeping first-argument sums in registers (sk_wave_adj_fused.hip, round 6) -- 0.40-0.87x the time
+        // of the routes below at 128 x 128 pairs, within 1.16-1.33x of the other orientation (profiles/r06_asym.txt, r06_asym_xy.txt)
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 0 && D <= 8 && elem_size == 8 && Nc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED_SWAP;
         if (may_stream && prefer_stream(Mc, Nc, mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)))) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }

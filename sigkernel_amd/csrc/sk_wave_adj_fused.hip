@@ -71,34 +71,13 @@ __device__ __forceinline__ void lds_read_run<8>(d2_t (&v)[8], unsigned a) {     
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]) : "v"(a) : "memory");
 }
 
-// YSIDE: the carry of the second-argument sums, 16 bytes per lane and piece; piece i = dims (2 (i & 3), 2 (i & 3) + 1) of the unit's
-// column i >> 2.  Lane l reads slot l (what the lane above handed down; a group's top lane: never written, zero) and writes slot
-// l + 1, a bottom lane the spare slot 64 -- the slot numbering of sk_wave_adj_fused_rbf.hip (no bank conflicts, 65-slot pieces).
-constexpr int LYC_PIECE = 65 * 16;
-// the y differences of a macro-step (eight dims) AND the carry, one wait instead of three (a lone wave pays every LDS round trip in
-// full, profiles/r06_small_launch_pmc.txt)
-__device__ __forceinline__ void lds_read_dims8_carry8(d2_t (&v)[8], d2_t (&c)[8], unsigned a_even, unsigned a_odd, unsigned ca) {
-    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\tds_read_b128 %2, %16 offset:256\n\tds_read_b128 %3, %17 offset:256\n\t"
-                 "ds_read_b128 %4, %16 offset:512\n\tds_read_b128 %5, %17 offset:512\n\tds_read_b128 %6, %16 offset:768\n\t"
-                 "ds_read_b128 %7, %17 offset:768\n\t"
-                 "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:1040\n\tds_read_b128 %10, %18 offset:2080\n\t"
-                 "ds_read_b128 %11, %18 offset:3120\n\tds_read_b128 %12, %18 offset:4160\n\tds_read_b128 %13, %18 offset:5200\n\t"
-                 "ds_read_b128 %14, %18 offset:6240\n\tds_read_b128 %15, %18 offset:7280\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(c[0]), "=&v"(c[1]),
-                   "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-                 : "v"(a_even), "v"(a_odd), "v"(ca)
-                 : "memory");
-}
-__device__ __forceinline__ void lds_write_carry4(unsigned a, const d2_t (&v)[8], int h) {
-    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1040\n\tds_write_b128 %0, %3 offset:2080\n\t"
-                 "ds_write_b128 %0, %4 offset:3120"
-                 : : "v"(a), "v"(v[4 * h]), "v"(v[4 * h + 1]), "v"(v[4 * h + 2]), "v"(v[4 * h + 3]) : "memory");
-}
-
 // RC = coarse rows per lane: the forward kernels' choice at dyadic 1, 2; at dyadic 0 two instead of their four (register budget)
 // YSIDE: the SECOND-argument sums instead of the first-argument ones (route FUSED_SWAP: long first paths against short second ones are
-// swept as (y, x)): per unit the lanes hand the running sum over their rows down through LDS, the bottom lane stores it per pair
+// swept as (y, x)): per unit the lanes hand the running sum over their rows DOWN THE WAVE -- lane l + 1 sweeps at macro-step t + 1 the
+// unit lane l swept at t, so one wave_shr:1 of the 16 sums per macro-step (32 DPP moves) carries them along; a group's top lane starts
+// from zero, its bottom lane stores the unit's sums of its pair.  (First built with the carry in LDS, eight 65-slot pieces read with
+// the y differences and written back: 24 KB of LDS traffic per wave and macro-step against 8 -- the dyadic-0 sweep, four cells per
+// step, ran 1.87x the time of the first-argument form on the same grid, profiles/r06_asym.txt; the DPP form costs issue slots only.)
 template <int DY, int RC, bool FULLWAVE, bool YSIDE>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
     constexpr int CW = 2;
@@ -151,8 +130,6 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     const unsigned ec_off = x_base0 + (unsigned)(G * X_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
     const unsigned ec_slot = (unsigned)(G * ECG);
     const bool is_bot = lam == L - 1;
-    const unsigned yc_rd = lds0 + ec_off + 2u * ec_slot + (unsigned)(lane << 4);
-    const unsigned yc_wr = lds0 + ec_off + 2u * ec_slot + (unsigned)((is_bot ? WAVE : lane + 1) << 4);
 
     // ---- producers: the rings of sk_wave_fused.hip, filled in FLIPPED order ------------------------------------------------
     // y slab s = flipped units [8s, 8s+8) of the group's stream; flipped unit u' of a pair is original unit NUp-1-u' (its two
@@ -257,6 +234,11 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     for (int k = 0; k < RC; ++k)
 #pragma unroll
         for (int j = 0; j < FD; ++j) { dxr[k][j] = 0.0; if (!YSIDE || k == 0) tacc[YSIDE ? 0 : k][j] = 0.0; }
+    double car[YSIDE ? CW : 1][FD];     // YSIDE: the second-argument sums of the unit being swept, over the rows of the lanes above
+#pragma unroll
+    for (int q = 0; q < (YSIDE ? CW : 1); ++q)
+#pragma unroll
+        for (int j = 0; j < FD; ++j) car[q][j] = 0.0;
     double ktopR[S];
 #pragma unroll
     for (int i = 0; i < S; ++i) ktopR[i] = 1.0;
@@ -274,7 +256,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     for (int i = 0; i <= R; ++i) ncol[i] = 1.0;
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite (see the contraction below)
-        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB + 2 * G * ECG + (YSIDE ? 8 * LYC_PIECE : 0));
+        const int total = (int)(G * y_bytes + G * X_SLOTS * JMAX * XSLAB + 2 * G * ECG);
         const d2_t z = {0.0, 0.0};
         for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -330,11 +312,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 
         // -- y differences of the unit (original column order inside the unit)
         d2_t dyv[FD];
-        d2_t car[YSIDE ? 8 : 1];     // YSIDE: what the lanes above summed for this unit's two columns one macro-step ago
         {
             const unsigned ya = my_y + (unsigned)(yslab * Y_SLAB_PITCH + ((u & 7) << 4));
-            if constexpr (YSIDE) lds_read_dims8_carry8(dyv, car, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7), yc_rd);
-            else lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
         lds_take<S>(trow, trow_p);
         if ((t & 7) == 0) issue_edge_chunk();
@@ -431,24 +411,31 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
                     for (int j = 0; j < FD; ++j) tacc[k][j] = fma(wq[k][0], dyv[j][0], fma(wq[k][1], dyv[j][1], tacc[k][j]));
             } else {
                 // second argument: column q of the unit gets sum_k w[k][q] dxr[k][:], on top of what the lanes above summed for it one
-                // macro-step ago (read with the y differences at the top of the step: 32 VGPRs across the sweep, which these variants
-                // have -- no first-argument sums --, instead of two more LDS round trips here)
-                const int uo = NUp - 1 - u;
-                double *yp = prm.Ypart + ((pair0 + ps) * (int64_t)(2 * NUp) + 2 * uo) * FD;
+                // macro-step ago: the sums move one lane down, a group's top lane starts from zero
 #pragma unroll
-                for (int q = 0; q < CW; ++q) {
+                for (int q = 0; q < CW; ++q)
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) car[q][j] = dpp_shr1_zero(car[q][j]);
+                if (!FULLWAVE && is_top) {
+                    asm volatile("");      // a real branch under the exec mask: sixteen moves, not thirty-two selects
+#pragma unroll
+                    for (int q = 0; q < CW; ++q)
+#pragma unroll
+                        for (int j = 0; j < FD; ++j) car[q][j] = 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < CW; ++q)
 #pragma unroll
                     for (int k = 0; k < RC; ++k)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            car[4 * q + j][0] = fma(wq[k][q], dxr[k][2 * j], car[4 * q + j][0]);
-                            car[4 * q + j][1] = fma(wq[k][q], dxr[k][2 * j + 1], car[4 * q + j][1]);
-                        }
-                    lds_write_carry4(yc_wr + (unsigned)(q * 4 * LYC_PIECE), car, q);
-                    if (is_bot && live) {
+                        for (int j = 0; j < FD; ++j) car[q][j] = fma(wq[k][q], dxr[k][j], car[q][j]);
+                if (is_bot && live) {
+                    const int uo = NUp - 1 - u;
+                    double *yp = prm.Ypart + ((pair0 + ps) * (int64_t)(2 * NUp) + 2 * uo) * FD;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) *reinterpret_cast<d2_t *>(yp + q * FD + 2 * j) = car[4 * q + j];
-                    }
+                    for (int q = 0; q < CW; ++q)
+#pragma unroll
+                        for (int j = 0; j < FD; j += 2) *reinterpret_cast<d2_t *>(yp + q * FD + j) = d2_t{car[q][j], car[q][j + 1]};
                 }
             }
         }
@@ -536,8 +523,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16 +
-                             (yside ? 8 * LYC_PIECE : 0);
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * Y_SLAB_PITCH + X_SLOTS * JMAX * RC * 512) + (size_t)2 * G * (4 * S + 1) * 16;
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
     if (yside && B <= 0) return SK_ERR_UNSUPPORTED;   // (paired batches have no use for it: both arguments fit or neither does)
 

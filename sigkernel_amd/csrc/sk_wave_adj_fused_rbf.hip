@@ -94,32 +94,13 @@ __device__ __forceinline__ void lds_read_xpt(double (&x)[ND], unsigned a) {
         lds_read_row1<4>(x, a);
     }
 }
-// the five 16-byte pieces of the second-argument carry (piece m = component m of node columns c1, c2): 65 slots of 16 bytes per
-// piece.  Lane l READS slot l and WRITES slot l + 1 -- what it hands to the lane below -- except a group's bottom lane, which writes the
-// spare slot 64 (nobody reads it): slot g L, the one a group's top lane reads, is therefore never written and stays the zero the
-// kernel's LDS clear left there.  (Until round 6 lane l read slot l - 1 and the top lane slot 64: in the 16-lane phase of a b128 read
-// slot 64 sat on the banks of slot 0 -- every carry read a two-way bank conflict, SQ_LDS_BANK_CONFLICT 2.4e7 per launch of C4's y-side
-// adjoint; now 0.  The piece size is what keeps eight waves of that launch on a CU: 160,640 of 163,840 bytes.)
-constexpr int YC_PIECE = 65 * 16;
-__device__ __forceinline__ void lds_read_carry(d2_t (&v)[5], unsigned a) {
-    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:1040\n\tds_read_b128 %2, %5 offset:2080\n\t"
-                 "ds_read_b128 %3, %5 offset:3120\n\tds_read_b128 %4, %5 offset:4160\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]) : "v"(a) : "memory");
-}
-// the y points (four dims) and the carry of a macro-step's contraction, one wait instead of two
-__device__ __forceinline__ void lds_read_ydims_carry(d2_t (&y)[4], d2_t (&v)[5], unsigned a_even, unsigned a_odd, unsigned a) {
-    asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %9 offset:256\n\tds_read_b128 %3, %10 offset:256\n\t"
-                 "ds_read_b128 %4, %11\n\tds_read_b128 %5, %11 offset:1040\n\tds_read_b128 %6, %11 offset:2080\n\t"
-                 "ds_read_b128 %7, %11 offset:3120\n\tds_read_b128 %8, %11 offset:4160\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
-                 : "v"(a_even), "v"(a_odd), "v"(a) : "memory");
-}
-__device__ __forceinline__ void lds_write_carry(unsigned a, const d2_t (&v)[5]) {
-    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1040\n\tds_write_b128 %0, %3 offset:2080\n\t"
-                 "ds_write_b128 %0, %4 offset:3120\n\tds_write_b128 %0, %5 offset:4160"
-                 : : "v"(a), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]) : "memory");
-}
-
+// The second-argument carry (YSIDE: S0 / S1[0..4) of node columns c1, c2 over the node rows of the lanes above) travels DOWN THE WAVE
+// in registers: lane l + 1 sweeps at macro-step t + 1 the unit lane l swept at t, so one wave_shr:1 of the ten sums per macro-step (20 DPP
+// moves, bound_ctrl zero for lane 0; the top lanes of the other lane groups are cleared under the exec mask) carries them along.  Until
+// late in round 6 it went through five 65-slot LDS pieces (read with the y points, written back): 10 KB of LDS traffic per wave and
+// macro-step and 5.2 KB of the CU's LDS per wave -- the piece size was what kept eight waves of C4's y-side launch on a CU (160,640 of
+// 163,840 bytes).  Same-box A/B (profiles/r06_yside_dpp_ab.txt): C4 314.4-315.6 -> 313.8-314.3 ms, swapped RBF gradients of 512 x 64
+// points 4.03 -> 3.87 (d = 0), 4.54 -> 4.32 ms (d = 1).
 // the y points of a macro-step (four dims) AND the top lane's S terminal-row values, one wait instead of two
 template <int S>
 __device__ __forceinline__ void lds_read_ydims_trow(d2_t (&v)[4], double (&t)[S], unsigned a_even, unsigned a_odd, unsigned ta);
@@ -239,9 +220,6 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     const unsigned my_sc = my_slab + (unsigned)XS::XR_SC;
     const unsigned ec_base = lds0 + x_base0 + (unsigned)(G * RX_SLOTS * JMAX * XSLAB);   // terminal-row chunks behind the rings
     const unsigned ec_slot = (unsigned)(G * ECG);
-    const unsigned yc_base = ec_base + 2u * ec_slot;                                     // YSIDE: the carry, 16 bytes per lane and piece
-    const unsigned yc_rd = yc_base + (unsigned)(lane << 4);                              // what the lane above handed down (top lane: zero)
-    const unsigned yc_wr = yc_base + (unsigned)((is_bot ? WAVE : lane + 1) << 4);        // what this lane hands down (a bottom lane: nowhere)
     bool row_ok[RC];   // this lane's coarse rows that exist (p_k < Mc)
 #pragma unroll
     for (int k = 0; k < RC; ++k) row_ok[k] = Mcp - 1 - (lam * RC + k) < prm.Mc;
@@ -367,6 +345,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     // second-argument sums are weighted by the caller) and are SELECTED to zero outside the group's pairs.
     double sx = 0.0, sx_d = 0.0;
     int valid = 0;
+    d2_t car[YSIDE ? 5 : 1];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
+#pragma unroll
+    for (int i = 0; i < (YSIDE ? 5 : 1); ++i) car[i] = d2_t{0.0, 0.0};
     double *yp_cur = nullptr, *yp_prev = nullptr;   // YSIDE: the Ypart blocks of this lane's pair and of the one before (null: none)
     // per-lane constants of the pair-start block below (some lane starts a pair in EVERY macro-step, so the wave pays for that block
     // every step: 32-bit compares and one multiply-add instead of 64-bit pair arithmetic): how many of the group's pairs exist,
@@ -381,7 +362,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     asm volatile("" : "+v"(ps_end));
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite
-        const int total = (int)(G * y_bytes + G * RX_SLOTS * JMAX * XSLAB + 2 * G * ECG + (YSIDE ? 5 * YC_PIECE : 0));
+        const int total = (int)(G * y_bytes + G * RX_SLOTS * JMAX * XSLAB + 2 * G * ECG);
         const d2_t z = {0.0, 0.0};
         for (int o = lane * 16; o < total; o += WAVE * 16) lds_write_b128(lds0 + (unsigned)o, z);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -403,7 +384,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // the top lane's terminal-row values of this macro-step (no wait: complete at the y read's lgkmcnt(0) below)
         // (left in flight only in the variants without spills -- dyadic 2, dims <= 4: C4's --; the others spill 16-127 registers and
         // read it blocking where it is needed: tools/check_async_hazards.py, scan_pressure)
-        constexpr bool TPEND = DY == 2 && ND == 4;
+        constexpr bool TPEND = DY == 2 && ND == 4 && !(YSIDE && !FULLWAVE);   // (that one: 16 VGPRs short since the carry lives in registers)
         constexpr bool HOLD_Y = SK_ADJR_HOLD_Y && ND == 4 && !YSIDE;
         double trow_p[S], trow[S];
         if constexpr (TPEND) {
@@ -585,10 +566,16 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         // -- contraction: node rows r_k = p_k + 1 at node columns c1 (this unit's second) and c2 (the previous unit's first).
         //    The y points are read from the ring a second time: holding them across the sweep costs 4 ND VGPRs
         // (HOLD_Y: the variants with registers to spare keep them instead -- one LDS round trip less per macro-step)
-        d2_t car[5];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
         if constexpr (YSIDE) {
             asm volatile("" ::: "memory");
-            lds_read_ydims_carry(yv, car, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7), yc_rd);
+            lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { car[i][0] = dpp_shr1_zero(car[i][0]); car[i][1] = dpp_shr1_zero(car[i][1]); }
+            if (!FULLWAVE && is_top) {
+                asm volatile("");
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { car[i][0] = 0.0; car[i][1] = 0.0; }
+            }
         } else if constexpr (!HOLD_Y) {
             asm volatile("" ::: "memory");
             lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
@@ -629,8 +616,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
                 for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
             }
             if constexpr (YSIDE) {
-                // what this lane hands down: the sums over the node rows r_k so far
-                lds_write_carry(yc_wr, car);
+                // what this lane hands down (next macro-step's wave_shr): the sums over the node rows r_k so far
                 if (is_bot) {   // the bottom lane completes them with node row 0 and stores the two columns of its pair
                     asm volatile("");
                     car[0][0] += cb1; car[0][1] += cb2;
@@ -757,8 +743,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
     const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? (half_rows ? XSlab<1, 2>::BYTES : XSlab<2, 4>::BYTES) : XSlab<1, 4>::BYTES;
-    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * xslab) + (size_t)2 * G * (4 * S + 1) * 16 +
-                             (ypart ? 5 * YC_PIECE : 0);
+    const size_t lds_bytes = (size_t)G * (((L >> 3) + 2) * RY_SLAB + RX_SLOTS * JMAX * xslab) + (size_t)2 * G * (4 * S + 1) * 16;
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
 
     const int n_cu = device_cu_count();

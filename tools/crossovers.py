@@ -52,21 +52,6 @@ for name, kern, D, d, M, grad in (("mb_min_eff", "linear", 12, 1, 140, True), ("
     report(name, "%s dim %d d=%d, %d x %d pairs of %d points%s" % (kern, D, d, A, A, M, ", with a gradient" if grad else ""),
            "multi-band fused", ta, "streamed", tb, "a" if route == _lib.ROUTE_FUSED_MB else "b")
 
-# --- adj_swap_linear_d0_max_mb_eff: LinearKernel at dyadic 0, long first paths against short second ones with a gradient: the one-band
-#     adjoint on (y, x) with second-argument sums against the multi-band adjoint, at a shape just above the threshold (0.455: the table
-#     picks the multi-band kernel) -- the swapped side is forced by answering the route query for it
-A, D, M, N = 128, 8, 700, 80
-X, Y, w = walk(A, M, D), walk(A, N, D), torch.randn(A, A, generator=g, dtype=torch.float64).cuda()
-sk = sigkernel_amd.SigKernel(sigkernel_amd.LinearKernel(), 0)
-f = grad_step(sk, X, Y, w)
-RQ = S._route_query
-def fa(): S._route_query = lambda fn, op, *key: _lib.ROUTE_FUSED_SWAP if op == _lib.OP_ADJOINT else RQ(fn, op, *key); f(); S._route_query = RQ
-def fb(): set_routes(no_adjoint_swap=True); f(); set_routes(no_adjoint_swap=False)
-ta, tb = ab(fa, fb)
-route = _lib.get_backend().route(_lib.OP_ADJOINT, 0, D, M, N, 0, False, 8)
-report("adj_swap_linear_d0_max_mb_eff", "linear dim %d d=0, %d x %d pairs of %d x %d points, with a gradient" % (D, A, A, M, N),
-       "one-band adjoint on (y, x)", ta, "multi-band adjoint", tb, "a" if route == _lib.ROUTE_FUSED_SWAP else "b")
-
 # --- sym_min_cells / sym_tiles: a symmetric Gram on the streaming route, one block against the blocked triangle, at the threshold
 D, M, d = 20, 48, 1
 cells_pair = ((M - 1) << d) ** 2

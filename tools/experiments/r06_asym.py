@@ -28,8 +28,8 @@ for kind in kinds:
             for d in (0, 1, 2):
                 for M, N in ((512, 64), (300, 40), (700, 80), (800, 100), (1500, 90), (1000, 100), (2000, 128), (200, 9), (66, 30), (140, 64), (130, 128)):
                     kk = 0 if kind == "linear" else 1
-                    # (shapes the route table leaves to the multi-band adjoint -- LinearKernel, dyadic 0, efficient bands -- run with the
-                    # swapped route forced, marked *: what the cost entry adj_swap_linear_d0_max_mb_eff decides)
+                    # (shapes the route table would leave to the multi-band adjoint are run with the swapped route forced, marked *: none
+                    # since the carry moved from LDS to DPP -- the first build kept LinearKernel at dyadic 0 with efficient bands there)
                     forced = be.route(_lib.OP_ADJOINT, kk, D, M, N, d, False, 8) != _lib.ROUTE_FUSED_SWAP
                     if forced and not (kind == "linear" and d == 0 and N <= 129 and be.route(_lib.OP_ADJOINT, kk, D, M, N, d, False, 8, True) == _lib.ROUTE_FUSED_MB): continue
                     X, Y = walk(A, M, D), walk(A, N, D)
