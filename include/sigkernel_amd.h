@@ -86,7 +86,7 @@ const char *sk_build_info(void);
  *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
  *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
  *   SK_ROUTE_FUSED_SWAP     the one-band kernels on (Y, X): the second paths fit one band (rows <= 64 RC), the first do not; for the ADJOINT
- *                           (fp64, Gram; rbf of dim <= 4, linear of dim <= 8): sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 on
+ *                           (fp64, Gram; dim <= 8 -- rbf of dim 5..8 at dyadic 0 and 1): sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 on
  *                           (Y, X) with the second-argument sums (rbf, 128 x 128 pairs of 700 x 20 points: 0.41 ms against 1.56 ms
  *                           streamed); Gram callers transpose the result
  * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never
@@ -210,11 +210,13 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  *   M <= lanes x rows per lane (edges: sk_strip_edges_bytes(P, Mc, Nc, ...) -- with Nc + 1 in place of Nc when Nc is a multiple
  *   of 16: the sweep needs a padding NODE column behind the last unit, as sk_solve_fwd_rbf_edges_f64 keeps them); otherwise SK_ERR_UNSUPPORTED
  *   (sk_route_query(SK_OP_ADJOINT, 1, ...) == SK_ROUTE_FUSED says when the host layer takes it: path dim <= 4).
- *   ypart (nullable; Gram, path dim <= 4): the SECOND-argument sums of the same sweep, for compute_Gram(X, X, sym=True) with a
+ *   ypart (nullable; Gram): the SECOND-argument sums of the same sweep, for compute_Gram(X, X, sym=True) with a
  *   gradient (compute_mmd's K_XX, sigkernel.py:190), where only the pairs on and above the diagonal are solved and a pair (a, b)
- *   also owes d1 k(x_b, x_a) = d2 k(x_a, x_b) to row b.  Viewed as [A*B][*ycols_out][6], node column c < N of pair (a, b) holds
- *   S0 = [..][0] and S1 = [..][2 .. 2+D), WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1);
- *   the caller weights the pairs and folds them over a.  ycols_out != NULL in the size query asks for that variant's sizes. */
+ *   also owes d1 k(x_b, x_a) = d2 k(x_a, x_b) to row b -- and for SK_ROUTE_FUSED_SWAP.  Viewed as [A*B][*ycols_out][W], W = 6 for
+ *   path dim <= 4 and 10 for dim 5..8, node column c < N of pair (a, b) holds S0 = [..][0] and S1 = [..][2 .. 2+D), WITHOUT the
+ *   upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1); the caller weights the pairs and folds them over a.
+ *   Path dim 5..8 (dyadic 0 and 1): the sums INSTEAD of gpart, which is not written then (the variant of that width has registers
+ *   for one of the two).  ycols_out != NULL in the size query asks for that variant's sizes. */
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
                              size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,

@@ -854,9 +854,10 @@ class HipBackend:
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
         linear_adjoint_fused the gradient is valid only when the residual is <= ADJ_RESIDUAL_TOL, unless `kfinal` (forward values per
         pair) arms the device-side rescue.
-        yside (Gram, dim <= 4): a third result, the second-argument sums of the same sweep as a (A, B, N, 2 + D) tensor [S0, 0, S1]
+        yside (Gram): a third result, the second-argument sums of the same sweep as a (A, B, N, 2 + D) tensor [S0, 0, S1]
         per node of y_b, WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1) (see
-        second_argument_gradient)."""
+        second_argument_gradient).  Paths of dim 5..8: the sums INSTEAD of the first-argument gradient (the first result is None) --
+        the kernel variant of that width has registers for one of the two."""
         _dev(X, "X")
         A, M, D = X.shape
         if staged is not None:      # (Xr [>= A][256][8], Yt [B][8][Ncp], B, N): staged by the caller (loss_forward)
@@ -867,8 +868,9 @@ class HipBackend:
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic not in (0, 1, 2) or (dyadic == 0 and (naive or M > 128)) or Mc < 1 or Nc < 1 or A == 0 or B == 0 or not float(sigma) > 0:
             return None
-        if yside and (not gram or D > 4):
+        if yside and not gram:
             return None
+        yonly = yside and D > 4
         dev = X.device
         Mrows, Ncp = 256, (N + 15) // 16 * 16
         if scale is not None:
@@ -891,7 +893,7 @@ class HipBackend:
             self.last_fused_ppg = ppg.value
             gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read
-            ypart = torch.empty(A, B, ycols.value, 6, dtype=torch.float64, device=dev) if yside else None
+            ypart = torch.empty(A, B, ycols.value, 6 if D <= 4 else 10, dtype=torch.float64, device=dev) if yside else None
             kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev)
             # (with the rescue armed, its screening pass writes every residual entry before the sweep)
             err = torch.empty(P, dtype=torch.float64, device=dev) if kf is not None else torch.zeros(P, dtype=torch.float64, device=dev)
@@ -901,6 +903,9 @@ class HipBackend:
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused")
+            if yonly:
+                self.last_fused_err = err
+                return None, _WorstResidual(err), ypart[:, :, :N, :2 + D]
             # chunks of an a added in ascending order, then sum_c V G (-2/sigma) (x_r - y_c): one launch (sk_rbf_adjoint_finish_f64)
             X64 = X if X.dtype == torch.float64 else X.double()
             g = torch.empty(A, M, D, dtype=torch.float64, device=dev)

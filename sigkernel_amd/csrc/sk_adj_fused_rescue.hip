@@ -38,7 +38,7 @@ struct FusedRescueParams {
     const double *err;         // residuals after the sweep: -1 marked by k_screen, > tol failed
     double tol;
     double *part;              // Tpart [groups][rows][8] (linear, coarse rows flipped) / Gpart [groups][rows][outw] (rbf, node rows)
-    double *Ypart;             // nullable: rbf [P][ycols][6] per node column; linear [P][ycols][8] per increment column, and `part` null
+    double *Ypart;             // nullable: rbf [P][ycols][outw] per node column (outw = 6 / 10 for dims <= 4 / 5..8); linear [P][ycols][8] per increment column, and `part` null
                                // (the second-argument form of sk_wave_adj_fused.hip has no first-argument sums to patch)
     int64_t A, B, P, n_groups;
     int Mrows, Ncp, Mc, Nc, D, dyadic, rows, outw, ycols;
@@ -124,16 +124,17 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
             for (int k = 0; k < prm.outw - 2; ++k) dst[2 + k] += s * acc[k];
         }
         if (prm.Ypart) {                             // second argument: per node column, WITHOUT the upstream gradient
+            const int yd = prm.outw - 2;             // (the stride of the sums is the partial sums': 2 + 4 or 2 + 8 doubles)
             for (int c = lane; c < N; c += WAVE) {
-                double s0 = 0.0, s1[4] = {0, 0, 0, 0};
+                double s0 = 0.0, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int r = 0; r < M; ++r) {
                     const double v = VG(r, c);
                     s0 += v;
-                    for (int k = 0; k < 4; ++k) s1[k] = fma(v, xs[r * fd + k], s1[k]);
+                    for (int k = 0; k < yd; ++k) s1[k] = fma(v, xs[r * fd + k], s1[k]);
                 }
-                double *dst = prm.Ypart + (p * prm.ycols + c) * 6;
+                double *dst = prm.Ypart + (p * prm.ycols + c) * prm.outw;
                 dst[0] = s0; dst[1] = 0.0;
-                for (int k = 0; k < 4; ++k) dst[2 + k] = s1[k];
+                for (int k = 0; k < yd; ++k) dst[2 + k] = s1[k];
             }
         }
     }

@@ -172,6 +172,10 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         // kernel are symmetric), where the second paths fit its lanes -- 0.55-0.65x the streamed time, profiles/r05_asym.txt
         if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= 64))
             return SK_ROUTE_FUSED_SWAP;
+        // dim 5..8 (dyadic 0 and 1: the one-band adjoint of that width exists there): the second-argument sums INSTEAD of the first-argument
+        // ones, which is all the swapped call needs (sk_wave_adj_fused_rbf.hip, YONLY; round 6)
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 8 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : (d == 1 && N <= 64)))
+            return SK_ROUTE_FUSED_SWAP;
         // ... and the linear one-band adjoint on (y, x) (dim <= 8, fp64 paths): its second-argument form hands the sums over a lane's rows
         // down the wave by DPP instead of keeping first-argument sums in registers (sk_wave_adj_fused.hip, round 6) -- 0.40-0.87x the time
         // of the routes below at 128 x 128 pairs, within 1.16-1.33x of the other orientation (profiles/r06_asym.txt, r06_asym_xy.txt)

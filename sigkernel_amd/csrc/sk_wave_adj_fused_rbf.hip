@@ -35,7 +35,8 @@ namespace {
 constexpr int RFD = 8;                 // dims carried by the staged arrays
 constexpr int RY_SLAB = RFD * 128;
 constexpr int RX_SLOTS = 2;
-constexpr int YW = 6;                  // doubles per (pair, node column) of the second-argument sums: S0, 0, S1[0..4)
+constexpr int YW = 6;                  // doubles per (pair, node column) of the second-argument sums: S0, 0, S1[0..4); 10 for dims 5..8
+constexpr int yw_of(int nd) { return nd + 2; }
 
 // One x window slab (per lane group, ring slot and lap): everything the 8 lanes that start a pair during the window need, in
 // ONE run of 16-byte DMA pieces:
@@ -170,7 +171,11 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     constexpr int ECG = (4 * S + 1) * 16;    // terminal-row chunk of one lane group (sk_wave_adj.hip)
     constexpr int NPC = 4 * S + 1;
     static_assert(R == 4 || R == 2, "the column-edge reads below take R + 2 doubles out of aligned 16-byte pieces");
-    static_assert(!YSIDE || ND == 4, "the second-argument sums are built for paths of dim <= 4");
+    // YSIDE with paths of dim 5..8 (ND = 8): the second-argument sums INSTEAD of the first-argument ones (route FUSED_SWAP only): the
+    // 9 (RC + 1) first-argument accumulators and the previous unit's y points make room for the 18 carried sums and the node row above
+    constexpr bool YONLY = YSIDE && ND == 8;
+    constexpr int NCAR = 1 + ND;           // S0, S1[0..ND) per node column
+    constexpr int YWK = yw_of(ND);
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
     char *lds;
     const int64_t wave_id = wave_slot(prm.wg, lds_block, lds);
@@ -315,9 +320,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
     for (int j = 0; j < (YSIDE ? ND : 1); ++j) xup[j] = 0.0;
     // accumulators per node row r_k = p_k + 1 (k < RC) and, [RC], node row p_{RC-1} (node row 0 on the bottom lane)
-    double cs[RC + 1], accd[RC + 1][ND];
+    double cs[YONLY ? 1 : RC + 1], accd[YONLY ? 1 : RC + 1][ND];
 #pragma unroll
-    for (int k = 0; k <= RC; ++k) {
+    for (int k = 0; k < (YONLY ? 1 : RC + 1); ++k) {
         cs[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < ND; ++j) accd[k][j] = 0.0;
@@ -345,9 +350,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     // second-argument sums are weighted by the caller) and are SELECTED to zero outside the group's pairs.
     double sx = 0.0, sx_d = 0.0;
     int valid = 0;
-    d2_t car[YSIDE ? 5 : 1];    // YSIDE: S0 / S1[0..4) of node columns (c1, c2), summed over the node rows of the lanes above
+    d2_t car[YSIDE ? NCAR : 1];    // YSIDE: S0 / S1[0..ND) of node columns (c1, c2), summed over the node rows of the lanes above
 #pragma unroll
-    for (int i = 0; i < (YSIDE ? 5 : 1); ++i) car[i] = d2_t{0.0, 0.0};
+    for (int i = 0; i < (YSIDE ? NCAR : 1); ++i) car[i] = d2_t{0.0, 0.0};
     double *yp_cur = nullptr, *yp_prev = nullptr;   // YSIDE: the Ypart blocks of this lane's pair and of the one before (null: none)
     // per-lane constants of the pair-start block below (some lane starts a pair in EVERY macro-step, so the wave pays for that block
     // every step: 32-bit compares and one multiply-add instead of 64-bit pair arithmetic): how many of the group's pairs exist,
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         ps_end = rem <= 0 ? 0 : (rem < (int64_t)PPG ? (int)rem : PPG);
     }
     const unsigned sc_par0 = (unsigned)(((reinterpret_cast<uintptr_t>(prm.scale) >> 3) ^ (uintptr_t)pair0) & 1u);
-    double *const yp_base = YSIDE ? prm.Ypart + pair0 * (int64_t)(2 * NUp * YW) : nullptr;
+    double *const yp_base = YSIDE ? prm.Ypart + pair0 * (int64_t)(2 * NUp * YWK) : nullptr;
     asm volatile("" : "+v"(ps_end));
 
     {   // lanes ahead of their first pair read slabs no DMA has written yet: make those finite
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             if constexpr (YSIDE) {
                 lds_read_xpt<ND>(xup, my_xup + x_rd);
                 yp_prev = yp_cur;
-                yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YW) : nullptr;
+                yp_cur = valid ? yp_base + (uint64_t)(unsigned)ps * (uint64_t)(unsigned)(2 * NUp * YWK) : nullptr;
             }
             // col[1 + m] = K[MMp - lam R - R + m][NN], m = 0..R: the lane's fine rows bottom to top; K[0][NN] = 1 is not stored
             cornerR = 1.0;
@@ -567,14 +572,16 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         //    The y points are read from the ring a second time: holding them across the sweep costs 4 ND VGPRs
         // (HOLD_Y: the variants with registers to spare keep them instead -- one LDS round trip less per macro-step)
         if constexpr (YSIDE) {
-            asm volatile("" ::: "memory");
-            lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            if constexpr (!YONLY) {      // (the second-argument sums alone need no y point)
+                asm volatile("" ::: "memory");
+                lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
+            }
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { car[i][0] = dpp_shr1_zero(car[i][0]); car[i][1] = dpp_shr1_zero(car[i][1]); }
+            for (int i = 0; i < NCAR; ++i) { car[i][0] = dpp_shr1_zero(car[i][0]); car[i][1] = dpp_shr1_zero(car[i][1]); }
             if (!FULLWAVE && is_top) {
                 asm volatile("");
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { car[i][0] = 0.0; car[i][1] = 0.0; }
+                for (int i = 0; i < NCAR; ++i) { car[i][0] = 0.0; car[i][1] = 0.0; }
             }
         } else if constexpr (!HOLD_Y) {
             asm volatile("" ::: "memory");
@@ -590,10 +597,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double V1 = ((wk[k][0] + u1) - wk[k][1]) - u0;
             const double V2 = ((wk[k][1] + u2) - wkP[k]) - u1;
             const double cb1 = V1 * g1, cb2 = V2 * g2;
-            const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
-            cs[k] += cv1 + cv2;
+            if constexpr (!YONLY) {
+                const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
+                cs[k] += cv1 + cv2;
 #pragma unroll
-            for (int j = 0; j < ND; ++j) accd[k][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[k][j]));
+                for (int j = 0; j < ND; ++j) accd[k][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[k][j]));
+            }
             if constexpr (YSIDE) {     // x of node row r_k: the lane above's last row (k = 0) or this lane's row k - 1
                 car[0][0] += cb1; car[0][1] += cb2;
 #pragma unroll
@@ -608,12 +617,14 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double V1 = wk[RC - 1][1] - wk[RC - 1][0];
             const double V2 = wkP[RC - 1] - wk[RC - 1][1];
             const double cb1 = V1 * Gown[RC - 1][1], cb2 = V2 * GownP[RC - 1];
-            const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
-            if (is_bot) {
-                asm volatile("");
-                cs[RC] += cv1 + cv2;
+            if constexpr (!YONLY) {
+                const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
+                if (is_bot) {
+                    asm volatile("");
+                    cs[RC] += cv1 + cv2;
 #pragma unroll
-                for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+                    for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+                }
             }
             if constexpr (YSIDE) {
                 // what this lane hands down (next macro-step's wave_shr): the sums over the node rows r_k so far
@@ -627,17 +638,17 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
                     }
                     // node column c1 = 2uo + 1 of this pair; c2 = 2uo + 2, which at the pair's first step (uo = NUp - 1) is
                     // node column 0 of the pair BEFORE
-                    double *d1 = yp_cur ? yp_cur + (2 * uo + 1) * YW : nullptr;
-                    double *d2p = u == 0 ? yp_prev : (yp_cur ? yp_cur + (2 * uo + 2) * YW : nullptr);
+                    double *d1 = yp_cur ? yp_cur + (2 * uo + 1) * YWK : nullptr;
+                    double *d2p = u == 0 ? yp_prev : (yp_cur ? yp_cur + (2 * uo + 2) * YWK : nullptr);
                     if (d1) {
                         *reinterpret_cast<d2_t *>(d1) = d2_t{car[0][0], 0.0};
-                        *reinterpret_cast<d2_t *>(d1 + 2) = d2_t{car[1][0], car[2][0]};
-                        *reinterpret_cast<d2_t *>(d1 + 4) = d2_t{car[3][0], car[4][0]};
+#pragma unroll
+                        for (int j = 0; j < ND; j += 2) *reinterpret_cast<d2_t *>(d1 + 2 + j) = d2_t{car[1 + j][0], car[2 + j][0]};
                     }
                     if (d2p) {
                         *reinterpret_cast<d2_t *>(d2p) = d2_t{car[0][1], 0.0};
-                        *reinterpret_cast<d2_t *>(d2p + 2) = d2_t{car[1][1], car[2][1]};
-                        *reinterpret_cast<d2_t *>(d2p + 4) = d2_t{car[3][1], car[4][1]};
+#pragma unroll
+                        for (int j = 0; j < ND; j += 2) *reinterpret_cast<d2_t *>(d2p + 2 + j) = d2_t{car[1 + j][1], car[2 + j][1]};
                     }
                 }
             }
@@ -647,8 +658,10 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         GabvP = Gabv[0];
 #pragma unroll
         for (int k = 0; k < RC; ++k) { wkP[k] = wk[k][0]; GownP[k] = Gown[k][0]; }
+        if constexpr (!YONLY) {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) yP[j] = yv[j][0];
+            for (int j = 0; j < ND; ++j) yP[j] = yv[j][0];
+        }
         lastOwn[0] = Gown[RC - 1][0]; lastOwn[1] = Gown[RC - 1][1];
         lastW[0] = wk[RC - 1][0]; lastW[1] = wk[RC - 1][1];
         sx_d = sx;
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
 
     // ---- the group's partial sums: Gpart[group][node row][OUTW], node row r_k = Mcp - lam RC - k; node row 0 from the bottom lane
-    {
+    if constexpr (!YONLY) {
         if (pair0 < prm.P) {
             double *base = prm.Gpart + gslot * (int64_t)(Mcp + 1) * OUTW;
 #pragma unroll
@@ -739,7 +752,7 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC + 1) return SK_ERR_UNSUPPORTED;   // (+ 1: the node row above the first lane's)
     const int ND = D <= 4 ? 4 : 8;
     const bool yside = ypart != nullptr || ycols_out != nullptr;
-    if (yside && (ND != 4 || B <= 0)) return SK_ERR_UNSUPPORTED;
+    if (yside && B <= 0) return SK_ERR_UNSUPPORTED;   // (dims 5..8: the second-argument sums INSTEAD of the first-argument ones, YONLY)
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
     const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? (half_rows ? XSlab<1, 2>::BYTES : XSlab<2, 4>::BYTES) : XSlab<1, 4>::BYTES;
@@ -792,11 +805,13 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const bool full = logL == 6;
     int rc;
     if (DY == 0) {
-        if (ypart) rc = full ? launch_adjr<0, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, true>(prm, lds_block, s);
+        if (ypart && ND == 8) rc = full ? launch_adjr<0, 2, true, 8, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, true>(prm, lds_block, s);
+        else if (ypart) rc = full ? launch_adjr<0, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, true>(prm, lds_block, s);
         else if (ND == 8) rc = full ? launch_adjr<0, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, false>(prm, lds_block, s);
         else rc = full ? launch_adjr<0, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, false>(prm, lds_block, s);
     } else if (ypart) {
-        if (DY == 1) rc = full ? launch_adjr<1, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 4, true>(prm, lds_block, s);
+        if (DY == 1 && ND == 8) rc = full ? launch_adjr<1, 1, true, 8, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, true>(prm, lds_block, s);
+        else if (DY == 1) rc = full ? launch_adjr<1, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 4, true>(prm, lds_block, s);
         else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
     } else if (DY == 1) {
         if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
@@ -825,7 +840,8 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     if (outw_out) *outw_out = outw;
     if (ycols_out) *ycols_out = ycols;
     if (!gpart) return SK_OK;
-    if (ypart && ypart_doubles < (size_t)g.P * ycols * YW) return SK_ERR_WORKSPACE;
+    const int yw = yw_of(D <= 4 ? 4 : 8);
+    if (ypart && ypart_doubles < (size_t)g.P * ycols * yw) return SK_ERR_WORKSPACE;
     // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN)
     const double *sweep_scale = scale;
     void *rws = nullptr;
@@ -856,7 +872,7 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
         gs.P = An * B;
         rc = launch_adj_fused_rbf_rows(Xr + a0 * Mrows * RFD, Yt, An, B, Mrows, Ncp, D, gs, inv_sigma, edges + a0 * B * Epair,
                                        sweep_scale ? sweep_scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
-                                       err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * YW : nullptr, nullptr, nullptr,
+                                       err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * yw : nullptr, nullptr, nullptr,
                                        nullptr, nullptr, nullptr, nch, rescue, scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
         if (rc != SK_OK) return rc;
     }

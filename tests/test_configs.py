@@ -529,7 +529,9 @@ def test_loss_launch_route_checks_its_limits_and_budget_before_launching(monkeyp
                                                     ("linear", 3, 1, 9, 7, 300, 64, False), ("linear", 8, 2, 5, 11, 129, 65, False),
                                                     ("linear", 2, 0, 6, 6, 500, 60, False), ("linear", 5, 1, 17, 3, 140, 20, True),
                                                     ("linear", 8, 0, 4, 9, 300, 70, False), ("linear", 1, 2, 12, 12, 700, 40, True),
-                                                    ("linear", 4, 1, 40, 70, 200, 9, False)])
+                                                    ("linear", 4, 1, 40, 70, 200, 9, False), ("rbf", 6, 0, 6, 6, 300, 100, False),
+                                                    ("rbf", 8, 1, 5, 9, 200, 64, False), ("rbf", 5, 1, 7, 4, 140, 20, True), ("rbf", 7, 0, 4, 5, 129, 128, False),
+                                                    ("rbf", 8, 0, 30, 40, 150, 24, False)])
 def test_long_first_paths_take_the_swapped_adjoint(kind, D, d, A, B, M, N, naive, monkeypatch):
     """Gradients of a Gram block whose first paths are long and whose second paths fit the one-band adjoints (route FUSED_SWAP: the
     sweep runs on (y, x), the gradient comes from its second-argument sums; sigkernel.py:404-502 has no such asymmetry) against the
@@ -782,29 +784,32 @@ def test_fused_rescue_covers_the_second_argument_sums(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("d,N", [(1, 32), (0, 80), (2, 20)])
+@pytest.mark.parametrize("kind,D,d,N", [("linear", 4, 1, 32), ("linear", 4, 0, 80), ("linear", 4, 2, 20), ("rbf", 6, 0, 80), ("rbf", 6, 1, 32)])
 @pytest.mark.parametrize("screen", [1e3, 1e300])
-def test_swapped_linear_adjoint_rescues_an_exploding_pair(d, N, screen, monkeypatch):
-    """Long first paths against short second ones, LinearKernel (route FUSED_SWAP: sk_linear_adjoint_fused_f64 on (y, x) with the
-    second-argument sums), one pair with |K| ~ 1e9: screened out of the sweep -- or, with the screen disabled, failing its self-check
-    after the fact -- its block of the sums comes from the stored-grid rescue; every row of the gradient matches the oracle."""
+def test_swapped_adjoint_rescues_an_exploding_pair(kind, D, d, N, screen, monkeypatch):
+    """Long first paths against short second ones (route FUSED_SWAP on (y, x) with the second-argument sums: sk_linear_adjoint_fused_f64,
+    and sk_rbf_adjoint_fused_f64 on paths of dim 5..8, where the sums replace the first-argument ones), one pair with |K| ~ 1e5 .. 1e9:
+    screened out of the sweep -- or, with the screen disabled, failing its self-check after the fact -- its block of the sums comes
+    from the stored-grid rescue; every row of the gradient matches the oracle."""
     be = _lib.get_backend()
     monkeypatch.setattr(type(be), "FUSED_SCREEN", screen)
     gen = torch.Generator().manual_seed(47 + d)
-    A, B, M, D = 6, 40, 200, 4
+    A, B, M = 6, 40, 200
     Xc, Yc = walk(gen, A, M, D) * 2, walk(gen, B, N, D) * 2
-    Xc[2] = torch.linspace(0, 12, M, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
-    Yc[5] = torch.linspace(0, 12, N, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
-    k = sigkernel_amd.LinearKernel()
-    assert be.route(_lib.OP_ADJOINT, 0, D, M, N, d, False, 8) == _lib.ROUTE_FUSED_SWAP
+    reach = 12.0 if kind == "linear" else 20.0
+    Xc[2] = torch.linspace(0, reach, M, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    Yc[5] = torch.linspace(0, reach, N, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(1.0)
+    assert be.route(_lib.OP_ADJOINT, 0 if kind == "linear" else 1, D, M, N, d, False, 8) == _lib.ROUTE_FUSED_SWAP
     wc = torch.randn(A, B, generator=gen, dtype=torch.float64)
     Kc = O.gram_forward(Xc, Yc, k, d)
     wild = np.abs(Kc) > 1e3
     assert np.abs(Kc[2, 5]) > 1e5 and 1 <= wild.sum() <= 12
     be.last_fused_err = None
     calls = []
-    orig = type(be).linear_adjoint_fused
-    monkeypatch.setattr(type(be), "linear_adjoint_fused", lambda self, *a, **kw: (calls.append((kw.get("kfinal") is not None, kw.get("yside"))), orig(self, *a, **kw))[1])
+    name = "linear_adjoint_fused" if kind == "linear" else "rbf_adjoint_fused"
+    orig = getattr(type(be), name)
+    monkeypatch.setattr(type(be), name, lambda self, *a, **kw: (calls.append((kw.get("kfinal") is not None, kw.get("yside"))), orig(self, *a, **kw))[1])
     Xg = Xc.to(DEV).requires_grad_(True)
     (sigkernel_amd.SigKernel(k, d).compute_Gram(Xg, Yc.to(DEV)) * wc.to(DEV)).sum().backward()
     assert calls and all(c == (True, True) for c in calls), "the swapped adjoint was not used, or not armed with the forward values"

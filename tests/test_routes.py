@@ -56,15 +56,15 @@ TABLE = [
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), FSWAP, FSWAP), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 140, 140, 1, False, 8), MB, MB),
     # rbf one band: dim <= 4, dyadic 1..2, M <= 128 / 64; dyadic 0: dim <= 8, default stencil, M <= 128 (two rows per lane)
-    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 65, 64, 1, True, 8), STREAM, MB), ((ADJ, 1, 7, 40, 300, 1, True, 4), FUSED, FUSED),
+    ((ADJ, 1, 4, 128, 100, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 129, 170, 1, False, 8), MB, MB), ((ADJ, 1, 5, 64, 64, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 65, 64, 1, True, 8), FSWAP, FSWAP), ((ADJ, 1, 8, 65, 64, 2, False, 8), STREAM, MB), ((ADJ, 1, 8, 200, 65, 1, False, 8), STREAM, MB), ((ADJ, 1, 7, 40, 300, 1, True, 4), FUSED, FUSED),
     ((ADJ, 1, 7, 128, 128, 1, False, 8), STREAM, MB), ((ADJ, 1, 7, 140, 140, 1, False, 8), MB, MB), ((ADJ, 1, 4, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 128, 128, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 3, 129, 128, 0, False, 8), FSWAP, FSWAP),
     ((ADJ, 1, 4, 40, 40, 0, True, 8), STREAM, MB), ((ADJ, 1, 5, 40, 40, 0, False, 8), FUSED, FUSED), ((ADJ, 1, 8, 128, 300, 0, False, 4), FUSED, FUSED), ((ADJ, 1, 9, 40, 40, 0, False, 8), STREAM, MB),
-    ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), MB, MB),
+    ((ADJ, 1, 4, 40, 33, 1, False, 8), FUSED, FUSED), ((ADJ, 1, 4, 40, 34, 1, True, 8), FUSED, FUSED), ((ADJ, 1, 6, 200, 120, 0, False, 8), FSWAP, FSWAP), ((ADJ, 1, 6, 200, 120, 0, True, 8), MB, MB),
     # the multi-band adjoint is never swapped (the gradient is the first argument's); the ONE-BAND rbf adjoint is, through its
     # second-argument sums, where only the second paths fit its lanes (dim <= 4, fp64; 64 points at dyadic 1..2, 128 at dyadic 0)
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
     ((ADJ, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 4, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 65, 1, False, 8), STREAM, MB),
-    ((ADJ, 1, 5, 512, 64, 1, False, 8), STREAM, MB), ((ADJ, 1, 3, 512, 64, 1, False, 4), STREAM, MB), ((ADJ, 0, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 1, False, 8), FSWAP, FSWAP),
+    ((ADJ, 1, 5, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 64, 1, False, 4), STREAM, MB), ((ADJ, 0, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 1, False, 8), FSWAP, FSWAP),
     # compute_Gram(X, X, sym=True) with a gradient (SK_OP_ADJOINT_SYM): the triangle with the second-argument sums for rbf, fp64, dim <= 4,
     # 64 points at dyadic 1..2 / 128 at dyadic 0; all pairs otherwise (profiles/r05_yside_ab.txt)
     ((2, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED), ((2, 1, 3, 65, 65, 1, False, 8), STREAM, STREAM), ((2, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED),
@@ -95,8 +95,8 @@ def test_linear_and_rbf_up_to_16_dims_can_always_run_fused():
         r = be.route(op, kind, D, M, N, d, naive, es, no_stream=True)
         assert r != STREAM, (op, kind, D, M, N, d, naive, es)
         assert op == FWD or r != SWAP
-        # the adjoint on (y, x): the kernels with second-argument sums only (rbf dim <= 4, linear dim <= 8; fp64 paths)
-        assert op == FWD or r != FSWAP or (es == 8 and ((kind == 1 and D <= 4 and N <= 128) or (kind == 0 and D <= 8 and N <= 129)))
+        # the adjoint on (y, x): the kernels with second-argument sums only (dim <= 8; rbf of dim 5..8 at dyadic 0 and 1; fp64 paths)
+        assert op == FWD or r != FSWAP or (es == 8 and D <= 8 and ((kind == 1 and N <= 128 and (D <= 4 or d <= 1)) or (kind == 0 and N <= 129)))
         r0 = be.route(op, kind, D, M, N, d, naive, es)
         assert r0 in (STREAM, r)                              # the default only ever falls back to streaming
         if r0 == STREAM:
