@@ -215,8 +215,9 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  *   also owes d1 k(x_b, x_a) = d2 k(x_a, x_b) to row b -- and for SK_ROUTE_FUSED_SWAP.  Viewed as [A*B][*ycols_out][W], W = 6 for
  *   path dim <= 4 and 10 for dim 5..8, node column c < N of pair (a, b) holds S0 = [..][0] and S1 = [..][2 .. 2+D), WITHOUT the
  *   upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1); the caller weights the pairs and folds them over a.
- *   Path dim 5..8 (dyadic 0 and 1): the sums INSTEAD of gpart, which is not written then (the variant of that width has registers
- *   for one of the two).  ycols_out != NULL in the size query asks for that variant's sizes. */
+ *   gpart == NULL with ypart given, and always for path dim 5..8 (dyadic 0 and 1): the sums INSTEAD of gpart, which is not written
+ *   then (all a swapped call needs -- fewer instructions per macro-step; the variant of dims 5..8 has registers for one of the two).
+ *   ycols_out != NULL in the size query asks for that variant's sizes. */
 int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Mc, int Nc, int Ncp, int D,
                              int dyadic, int scheme, double sigma, const double *edges, const double *scale, double *gpart,
                              size_t gpart_doubles, double *err, double *ypart, size_t ypart_doubles, int *ppg_out, int *rows_out,

@@ -848,7 +848,8 @@ class HipBackend:
             g = g.to(X.dtype)
         return g, res
 
-    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False, staged=None, gscale=None):
+    def rbf_adjoint_fused(self, X, Y, sigma, dyadic, edges, scale, gram=True, yside=False, kfinal=None, naive=False, staged=None, gscale=None,
+                          yonly=False):
         """(dL/dX (A,M,D), worst self-check residual, reduced on demand: `float(r)`) for the RBF static kernel straight from the paths and
         the forward's terminal edges: adjoint PDE, node evaluation and chain rule in one kernel (sk_rbf_adjoint_fused_f64; fp64
         sweep whatever the dtype of X; dim <= 8, dyadic 1..2, one band per pair).  None outside that scope.  As for
@@ -856,8 +857,8 @@ class HipBackend:
         pair) arms the device-side rescue.
         yside (Gram): a third result, the second-argument sums of the same sweep as a (A, B, N, 2 + D) tensor [S0, 0, S1]
         per node of y_b, WITHOUT the upstream gradient: d k(x_a, y_b) / d y_b[c] = (-2 / sigma) (y_b[c] S0 - S1) (see
-        second_argument_gradient).  Paths of dim 5..8: the sums INSTEAD of the first-argument gradient (the first result is None) --
-        the kernel variant of that width has registers for one of the two."""
+        second_argument_gradient).  yonly, and always for paths of dim 5..8: the sums INSTEAD of the first-argument gradient (the first
+        result is None) -- all a swapped call needs, and the kernel variant of dims 5..8 has registers for one of the two."""
         _dev(X, "X")
         A, M, D = X.shape
         if staged is not None:      # (Xr [>= A][256][8], Yt [B][8][Ncp], B, N): staged by the caller (loss_forward)
@@ -870,7 +871,7 @@ class HipBackend:
             return None
         if yside and not gram:
             return None
-        yonly = yside and D > 4
+        yonly = yside and (yonly or D > 4)
         dev = X.device
         Mrows, Ncp = 256, (N + 15) // 16 * 16
         if scale is not None:
@@ -891,14 +892,14 @@ class HipBackend:
             _check(rc, "sk_rbf_adjoint_fused (query)")
             chunks = B // ppg.value if gram else 1
             self.last_fused_ppg = ppg.value
-            gpart = torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
+            gpart = None if yonly else torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read
             ypart = torch.empty(A, B, ycols.value, 6 if D <= 4 else 10, dtype=torch.float64, device=dev) if yside else None
             kf, rws, rws_bytes = self._fused_rescue_args(1, kfinal, P, Mc, Nc, dyadic, dev)
             # (with the rescue armed, its screening pass writes every residual entry before the sweep)
             err = torch.empty(P, dtype=torch.float64, device=dev) if kf is not None else torch.zeros(P, dtype=torch.float64, device=dev)
             tail = head + (_ptr(kf), float(self.FUSED_SCREEN), float(self.ADJ_RESIDUAL_TOL), _ptr(rws), rws_bytes, _stream(X))
-            rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), gpart.numel(), _ptr(err), _ptr(ypart),
+            rc = lib.sk_rbf_adjoint_fused_f64(*args, _ptr(gpart), 0 if yonly else gpart.numel(), _ptr(err), _ptr(ypart),
                                               ypart.numel() if yside else 0, *tail)
             if rc == 2:
                 return None

@@ -507,7 +507,7 @@ int sk_rbf_adjoint_fused_f64(const double *Xr, const double *Yt, int64_t A, int6
                              size_t rescue_ws_bytes, void *stream) {
     if (!Xr || !Yt || !edges || A < 0 || B < 0 || Mc < 1 || Nc < 1 || D < 1 || dyadic < 0 || dyadic > 16) return SK_ERR_BAD_ARG;
     if (scheme != SK_SCHEME_DEFAULT && scheme != SK_SCHEME_NAIVE) return SK_ERR_BAD_ARG;
-    if (!(sigma > 0.0) || !(sigma < 1e300) || (gpart && !err) || (ypart && !gpart) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
+    if (!(sigma > 0.0) || !(sigma < 1e300) || ((gpart || ypart) && !err) || (kfinal && !rescue_ws)) return SK_ERR_BAD_ARG;
     if (A == 0) return SK_OK;
     const Geom g = make_geom(B > 0 ? A * B : A, Mc, Nc, dyadic, scheme);
     const FusedRescue fr{kfinal, screen, tol, rescue_ws, rescue_ws_bytes};

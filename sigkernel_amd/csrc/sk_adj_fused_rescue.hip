@@ -112,7 +112,7 @@ __device__ void rescue_pair(const FusedRescueParams &prm, int64_t p, double *slo
         auto VG = [&](int r, int c) -> double {
             return (((w_at(r - 1, c - 1) + w_at(r, c)) - w_at(r - 1, c)) - w_at(r, c - 1)) * G[r * N + c];
         };
-        for (int r = lane; r < M; r += WAVE) {      // first argument: per node row, cs = sum_c V G, accd = sum_c V G y_c
+        for (int r = lane; slot && r < M; r += WAVE) {      // first argument: per node row, cs = sum_c V G, accd = sum_c V G y_c
             double cs = 0.0, acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = 0; c < N; ++c) {
                 const double v = VG(r, c);

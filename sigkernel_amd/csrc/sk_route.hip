@@ -170,7 +170,8 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         // long first paths against short second ones (rbf, dim <= 4, fp64 paths; Gram calls -- the host passes SK_ROUTE_NO_SWAP for
         // paired batches): the one-band adjoint on (y, x) with the SECOND-argument sums, d k(x, y) / dx = d2 k(y, x) (k and the static
         // kernel are symmetric), where the second paths fit its lanes -- 0.55-0.65x the streamed time, profiles/r05_asym.txt
-        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= 64))
+        // (the second-argument sums ALONE -- no first-argument accumulators -- fit with two rows per lane at dyadic 1: 128 points)
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= (d == 1 ? 128 : 64)))
             return SK_ROUTE_FUSED_SWAP;
         // dim 5..8 (dyadic 0 and 1: the one-band adjoint of that width exists there): the second-argument sums INSTEAD of the first-argument
         // ones, which is all the swapped call needs (sk_wave_adj_fused_rbf.hip, YONLY; round 6)

@@ -161,8 +161,12 @@ __device__ __forceinline__ void lds_read_pair_start<2, 2>(d2_t (&x)[2], d2_t (&c
                  : "v"(xa), "v"(ca), "v"(sa) : "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE, int ND, bool YSIDE>
+// YS: 0 = first-argument sums; 1 = both (the triangular K_XX; dims <= 4); 2 = the SECOND-argument sums only (route FUSED_SWAP: all the
+// swapped call needs -- no first-argument accumulators, no second read of the y points; the only second-argument form of dims 5..8)
+template <int DY, int RC, bool FULLWAVE, int ND, int YS>
 __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_adj_fused_rbf(const AdjRbfParams prm) {
+    constexpr bool YSIDE = YS != 0;
+    static_assert(YS != 1 || ND == 4, "both sets of sums fit for paths of dim <= 4 only");
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
     typedef XSlab<RC, R> XS;
@@ -171,9 +175,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     constexpr int ECG = (4 * S + 1) * 16;    // terminal-row chunk of one lane group (sk_wave_adj.hip)
     constexpr int NPC = 4 * S + 1;
     static_assert(R == 4 || R == 2, "the column-edge reads below take R + 2 doubles out of aligned 16-byte pieces");
-    // YSIDE with paths of dim 5..8 (ND = 8): the second-argument sums INSTEAD of the first-argument ones (route FUSED_SWAP only): the
-    // 9 (RC + 1) first-argument accumulators and the previous unit's y points make room for the 18 carried sums and the node row above
-    constexpr bool YONLY = YSIDE && ND == 8;
+    // YONLY at ND = 8: the 9 (RC + 1) first-argument accumulators and the previous unit's y points make room for the 18 carried sums
+    // and the node row above
+    constexpr bool YONLY = YS == 2;
     constexpr int NCAR = 1 + ND;           // S0, S1[0..ND) per node column
     constexpr int YWK = yw_of(ND);
     extern __shared__ __attribute__((aligned(16))) char lds_block[];
@@ -705,9 +709,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE, int ND, bool YSIDE>
+template <int DY, int RC, bool FULLWAVE, int ND, int YS>
 int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YSIDE>;
+    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YS>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -723,9 +727,10 @@ int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
 namespace {
 int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int64_t B, int Mrows, int Ncp, int D, const Geom &g,
                               double inv_sigma, const double *edges, const double *scale, double *gpart, size_t gpart_doubles, double *err,
-                              double *ypart, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out, int64_t *rows_per_launch,
+                              double *ypart, int ys, int *ppg_out, int *rows_out, int *outw_out, int *ycols_out, int64_t *rows_per_launch,
                               int64_t force_nch, const FusedRescue *rescue, const double *scale_orig, void *rescue_ws, size_t rescue_ws_bytes,
                               hipStream_t s) {
+    // ys: 0 first-argument sums, 1 both, 2 the second-argument sums only (the kernel's YS)
     const int DY = g.dyadic;
     if (DY < 0 || DY > 2 || B < 0 || D < 1 || D > RFD || g.P != (B > 0 ? A * B : A)) return SK_ERR_UNSUPPORTED;
     const Strip st = strip_geom(rbf_edge_geom(g), 8);   // the layout of the edges; the sweep uses the same lanes and units
@@ -743,16 +748,16 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     // ... and so do the second-argument sums at dyadic 1: with two rows per lane that variant spilled 168-176 bytes and ran 2.5x
     // slower per pair than the plain one (the triangle it serves lost to all pairs: 42 against 27 ms on 1024 paths of 64 points,
     // profiles/r05_yside_ab.txt); one row per lane fits -- pairs of up to 64 points; longer paths take all pairs (sigkernel.py)
-    const bool yside_req = ypart != nullptr || ycols_out != nullptr;
-    const bool half_rows = DY == 0 || (DY == 1 && (D > 4 || yside_req));
+    // (the second-argument sums ALONE fit with two rows per lane: 174-181 VGPRs at one row)
+    const bool half_rows = DY == 0 || (DY == 1 && (D > 4 || ys == 1));
     if (half_rows && st.logL > 5) return SK_ERR_UNSUPPORTED;
     const int RC = half_rows ? st.RC / 2 : st.RC, NUp = st.NUp, logL = half_rows ? st.logL + 1 : st.logL, L = 1 << logL, G = WAVE / L;
     if (g.Mc + 1 > L * RC) return SK_ERR_UNSUPPORTED;          // the node rows must fit the lanes (the last lane-row is padding)
     if (g.Nc > 2 * NUp - 1) return SK_ERR_UNSUPPORTED;         // node column 2 NUp must be padding
     if (Ncp < NUp * 2 || (Ncp & 1) || Mrows < L * RC + 1) return SK_ERR_UNSUPPORTED;   // (+ 1: the node row above the first lane's)
     const int ND = D <= 4 ? 4 : 8;
-    const bool yside = ypart != nullptr || ycols_out != nullptr;
-    if (yside && B <= 0) return SK_ERR_UNSUPPORTED;   // (dims 5..8: the second-argument sums INSTEAD of the first-argument ones, YONLY)
+    if (ys == 1 && ND != 4) return SK_ERR_UNSUPPORTED;   // (dims 5..8: the second-argument sums INSTEAD of the first-argument ones)
+    if (ys && B <= 0) return SK_ERR_UNSUPPORTED;
     const int JMAX = (L + NUp - 1) / NUp;
     const int S = 2 << DY;
     const int xslab = DY == 0 ? XSlab<2, 2>::BYTES : DY == 1 ? (half_rows ? XSlab<1, 2>::BYTES : XSlab<2, 4>::BYTES) : XSlab<1, 4>::BYTES;
@@ -788,8 +793,8 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     if (rows_out) *rows_out = L * RC + 1;
     if (outw_out) *outw_out = OUTW;
     if (ycols_out) *ycols_out = 2 * NUp;
-    if (!gpart) return SK_OK;
-    if (gpart_doubles < (size_t)groups * (L * RC + 1) * OUTW) return SK_ERR_WORKSPACE;
+    if (!gpart && !ypart) return SK_OK;
+    if (gpart && gpart_doubles < (size_t)groups * (L * RC + 1) * OUTW) return SK_ERR_WORKSPACE;
     const int64_t waves = (groups + G - 1) / G;
 
     AdjRbfParams prm;
@@ -804,20 +809,24 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     int rc;
+    const bool yonly = ys == 2;
     if (DY == 0) {
-        if (ypart && ND == 8) rc = full ? launch_adjr<0, 2, true, 8, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, true>(prm, lds_block, s);
-        else if (ypart) rc = full ? launch_adjr<0, 2, true, 4, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, true>(prm, lds_block, s);
-        else if (ND == 8) rc = full ? launch_adjr<0, 2, true, 8, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, false>(prm, lds_block, s);
-        else rc = full ? launch_adjr<0, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, false>(prm, lds_block, s);
+        if (yonly && ND == 8) rc = full ? launch_adjr<0, 2, true, 8, 2>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, 2>(prm, lds_block, s);
+        else if (yonly) rc = full ? launch_adjr<0, 2, true, 4, 2>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 2>(prm, lds_block, s);
+        else if (ypart) rc = full ? launch_adjr<0, 2, true, 4, 1>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 1>(prm, lds_block, s);
+        else if (ND == 8) rc = full ? launch_adjr<0, 2, true, 8, 0>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, 0>(prm, lds_block, s);
+        else rc = full ? launch_adjr<0, 2, true, 4, 0>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 0>(prm, lds_block, s);
     } else if (ypart) {
-        if (DY == 1 && ND == 8) rc = full ? launch_adjr<1, 1, true, 8, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, true>(prm, lds_block, s);
-        else if (DY == 1) rc = full ? launch_adjr<1, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<1, 1, false, 4, true>(prm, lds_block, s);
-        else rc = full ? launch_adjr<2, 1, true, 4, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, true>(prm, lds_block, s);
+        if (DY == 1 && ND == 8) rc = full ? launch_adjr<1, 1, true, 8, 2>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, 2>(prm, lds_block, s);
+        else if (DY == 1 && yonly) rc = full ? launch_adjr<1, 2, true, 4, 2>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, 2>(prm, lds_block, s);
+        else if (DY == 1) rc = full ? launch_adjr<1, 1, true, 4, 1>(prm, lds_block, s) : launch_adjr<1, 1, false, 4, 1>(prm, lds_block, s);
+        else if (yonly) rc = full ? launch_adjr<2, 1, true, 4, 2>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, 2>(prm, lds_block, s);
+        else rc = full ? launch_adjr<2, 1, true, 4, 1>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, 1>(prm, lds_block, s);
     } else if (DY == 1) {
-        if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, false>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, false>(prm, lds_block, s);
-        else rc = full ? launch_adjr<1, 1, true, 8, false>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, false>(prm, lds_block, s);
+        if (ND == 4) rc = full ? launch_adjr<1, 2, true, 4, 0>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, 0>(prm, lds_block, s);
+        else rc = full ? launch_adjr<1, 1, true, 8, 0>(prm, lds_block, s) : launch_adjr<1, 1, false, 8, 0>(prm, lds_block, s);
     } else {
-        rc = full ? launch_adjr<2, 1, true, 4, false>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, false>(prm, lds_block, s);
+        rc = full ? launch_adjr<2, 1, true, 4, 0>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, 0>(prm, lds_block, s);
     }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
     return launch_fused_rescue(1, Xr, Yt, scale_orig, err, rescue->tol, gpart, ypart, A, B, Mrows, Ncp, D, g, L * RC + 1, OUTW, 2 * NUp, inv_sigma,
@@ -832,14 +841,22 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     int ppg = 0, rows = 0, outw = 0, ycols = 0;
     int64_t per_launch = 0;
     const bool yside = want_yside || ypart;
-    int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, nullptr, &ppg, &rows, &outw,
+    // the form of the sweep: both sets of sums (dims <= 4) unless the caller hands over no gpart; a pure size query (neither array)
+    // answers for the form that exists -- the sizes it returns for the second-argument sums (*ycols_out) are the same in both
+    int ys = !yside ? 0 : ((D > 4 || (ypart && !gpart)) ? 2 : 1);
+    int rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, nullptr, ys, &ppg, &rows, &outw,
                                        yside ? &ycols : nullptr, &per_launch, 0, nullptr, nullptr, nullptr, 0, s);
+    if (rc == SK_ERR_UNSUPPORTED && ys == 1 && !gpart && !ypart) {
+        ys = 2;
+        rc = launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, scale, nullptr, 0, err, nullptr, ys, &ppg, &rows, &outw,
+                                       &ycols, &per_launch, 0, nullptr, nullptr, nullptr, 0, s);
+    }
     if (rc != SK_OK) return rc;
     if (ppg_out) *ppg_out = ppg;
     if (rows_out) *rows_out = rows;
     if (outw_out) *outw_out = outw;
     if (ycols_out) *ycols_out = ycols;
-    if (!gpart) return SK_OK;
+    if (!gpart && !ypart) return SK_OK;      // (gpart NULL with ypart: the second-argument sums only)
     const int yw = yw_of(D <= 4 ? 4 : 8);
     if (ypart && ypart_doubles < (size_t)g.P * ycols * yw) return SK_ERR_WORKSPACE;
     // device-side rescue (sk_adj_fused_rescue.hip): the workspace starts with the swept upstream gradient (screened pairs NaN)
@@ -858,12 +875,12 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
         }
     }
     if (per_launch <= 0 || B <= 0)
-        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, sweep_scale, gpart, gpart_doubles, err, ypart, nullptr,
+        return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, sweep_scale, gpart, gpart_doubles, err, ypart, ys, nullptr,
                                          nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that gpart keeps one layout)
     const int64_t nch = B / ppg;
     const int64_t slot = (int64_t)rows * outw;
-    if (gpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
+    if (gpart && gpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
     const Strip st = strip_geom(rbf_edge_geom(g), 8);
     const int64_t Epair = (int64_t)st.NUp * (2 << g.dyadic) + (int64_t)(1 << st.logL) * st.RC * (1 << g.dyadic);   // edge doubles per pair
     for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
@@ -871,8 +888,8 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
         Geom gs = g;
         gs.P = An * B;
         rc = launch_adj_fused_rbf_rows(Xr + a0 * Mrows * RFD, Yt, An, B, Mrows, Ncp, D, gs, inv_sigma, edges + a0 * B * Epair,
-                                       sweep_scale ? sweep_scale + a0 * B : nullptr, gpart + a0 * nch * slot, (size_t)(An * nch * slot),
-                                       err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * yw : nullptr, nullptr, nullptr,
+                                       sweep_scale ? sweep_scale + a0 * B : nullptr, gpart ? gpart + a0 * nch * slot : nullptr, (size_t)(An * nch * slot),
+                                       err ? err + a0 * B : nullptr, ypart ? ypart + a0 * B * (int64_t)ycols * yw : nullptr, ys, nullptr, nullptr,
                                        nullptr, nullptr, nullptr, nch, rescue, scale ? scale + a0 * B : nullptr, rws, rws_bytes, s);
         if (rc != SK_OK) return rc;
     }

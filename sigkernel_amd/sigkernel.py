@@ -284,7 +284,7 @@ def _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget
     grad = None
     for b0, b1 in _tiles(B, 64 * A * (Xd.shape[1] + 16), budget):
         res = adj(Yd[b0:b1].contiguous(), Xd, param, dyadic, edges[b0 * per:b1 * per], None, gram=True, yside=True,
-                  kfinal=None if KT is None else KT[b0:b1], naive=naive)
+                  kfinal=None if KT is None else KT[b0:b1], naive=naive, **({} if linear else {"yonly": True}))
         if res is None:
             return None
         g = be.second_argument_gradient(res[2], Xd, None if linear else param, goT[b0:b1], 0)

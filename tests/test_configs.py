@@ -531,7 +531,7 @@ def test_loss_launch_route_checks_its_limits_and_budget_before_launching(monkeyp
                                                     ("linear", 8, 0, 4, 9, 300, 70, False), ("linear", 1, 2, 12, 12, 700, 40, True),
                                                     ("linear", 4, 1, 40, 70, 200, 9, False), ("rbf", 6, 0, 6, 6, 300, 100, False),
                                                     ("rbf", 8, 1, 5, 9, 200, 64, False), ("rbf", 5, 1, 7, 4, 140, 20, True), ("rbf", 7, 0, 4, 5, 129, 128, False),
-                                                    ("rbf", 8, 0, 30, 40, 150, 24, False)])
+                                                    ("rbf", 8, 0, 30, 40, 150, 24, False), ("rbf", 3, 1, 6, 5, 300, 128, False), ("rbf", 4, 1, 9, 4, 200, 90, True)])
 def test_long_first_paths_take_the_swapped_adjoint(kind, D, d, A, B, M, N, naive, monkeypatch):
     """Gradients of a Gram block whose first paths are long and whose second paths fit the one-band adjoints (route FUSED_SWAP: the
     sweep runs on (y, x), the gradient comes from its second-argument sums; sigkernel.py:404-502 has no such asymmetry) against the

@@ -63,7 +63,7 @@ TABLE = [
     # the multi-band adjoint is never swapped (the gradient is the first argument's); the ONE-BAND rbf adjoint is, through its
     # second-argument sums, where only the second paths fit its lanes (dim <= 4, fp64; 64 points at dyadic 1..2, 128 at dyadic 0)
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
-    ((ADJ, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 4, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 65, 1, False, 8), STREAM, MB),
+    ((ADJ, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 4, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 65, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 129, 1, False, 8), MB, MB), ((ADJ, 1, 3, 512, 65, 2, False, 8), STREAM, MB),
     ((ADJ, 1, 5, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 64, 1, False, 4), STREAM, MB), ((ADJ, 0, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 1, False, 8), FSWAP, FSWAP),
     # compute_Gram(X, X, sym=True) with a gradient (SK_OP_ADJOINT_SYM): the triangle with the second-argument sums for rbf, fp64, dim <= 4,
     # 64 points at dyadic 1..2 / 128 at dyadic 0; all pairs otherwise (profiles/r05_yside_ab.txt)

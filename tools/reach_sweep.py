@@ -130,12 +130,13 @@ def gated(g, be):
         sk = sigkernel_amd.SigKernel(LIN(), d)
         Xg = walk(g, 5, M, 6, f64).requires_grad_(True)
         sk.compute_Gram(Xg, walk(g, 7, N, 6, f64)).sum().backward()
-    # ... and RBFKernel on paths of dim 5..8: the one-band adjoint's second-argument sums INSTEAD of the first-argument ones (dyadic 0, 1)
-    for d, (M, N) in itertools.product((0, 1), ((200, 20), (300, 100), (400, 60))):
-        if d == 1 and N > 64: continue
+    # ... and RBFKernel: the one-band adjoint's second-argument sums INSTEAD of the first-argument ones (dim 3: every dyadic order, two
+    # rows per lane at dyadic 1; dim 6: dyadic 0 and 1)
+    for D, d, (M, N) in itertools.product((3, 6), (0, 1, 2), ((200, 20), (300, 100), (400, 60))):
+        if (D == 6 and (d == 2 or (d == 1 and N > 64))) or (d == 2 and N > 64): continue
         sk = sigkernel_amd.SigKernel(RBF(0.9), d)
-        Xg = walk(g, 5, M, 6, f64).requires_grad_(True)
-        sk.compute_Gram(Xg, walk(g, 7, N, 6, f64)).sum().backward()
+        Xg = walk(g, 5, M, D, f64).requires_grad_(True)
+        sk.compute_Gram(Xg, walk(g, 7, N, D, f64)).sum().backward()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
     # and more; its in-LDS band boundary (two bands, 126..157-point second paths)
     for kname, d, (M, N) in itertools.product(("linear", "rbf"), (0, 1, 2), ((65, 130), (129, 140), (129, 200), (100, 140))):
