@@ -317,7 +317,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             lds_read_dims8(dyv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
         lds_take<S>(trow, trow_p);
-        if ((t & 7) == 0) issue_edge_chunk();
+        if (__builtin_expect((t & 7) == 0, 0)) issue_edge_chunk();
 
         // -- top rows
         double topR[S], topF[S];
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             yslab = yslab + 1 == NSLAB ? 0 : yslab + 1;
             ypar ^= 1;
         }
-        if (((t + 1) & 7) == 0) {
+        if (__builtin_expect(((t + 1) & 7) == 0, 0)) {
             issue_y();
             issue_x();
         }

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         // step, under the sweep, was tried (MID): no faster, and the compiler copies the destination registers around.
         auto fetch_next = [&]() {
             const bool turn = ((t + 1) & 7) == 0;   // the next step opens a y slab (for lane 0) and an x window: their DMA
-            if (turn) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // was issued 8 steps ago
+            if (__builtin_expect(turn, 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // was issued 8 steps ago
             a_e += 16;
             if (((t + 1) & 7) == lam7) {   // next slab: the other parity, one slab less one row on, wrapping at the end of the ring
                 asm volatile("");          // (a real branch: if-converted, the update costs two more VALU instructions per step)
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
         }
 
         // -- K[MM][NN] of a pair
-        if (CUR ? uk == my_uf : tm == c_out) {
+        if (__builtin_expect(CUR ? uk == my_uf : tm == c_out, 0)) {
             int pv = CUR ? psk : tq + c_kq + (tm + c_kr >= NUp ? 1 : 0);
             asm volatile("" : "+v"(pv));   // keeps the pair tests inside this (rarely taken) branch instead of in every step
             const unsigned pair_u = lane_pair(pv);
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_fwd_fused(const FusedParams prm) {
             }
         }
         if (CUR && !RBF) { uk = u; psk = ps; }
-        if (((t + 1) & 7) == 0) {
+        if (__builtin_expect(((t + 1) & 7) == 0, 0)) {
             // everything issued 8 macro-steps ago has had a whole slab period to land (leaving this step's edge stores in
             // flight with a counted wait was measured: no gain, their cost is issue slots, not latency)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
