@@ -86,7 +86,7 @@ const char *sk_build_info(void);
  *   SK_ROUTE_FUSED_MB       several bands / wide paths: sk_solve_fwd_static_*, sk_linear_adjoint_fused_mb_f64, sk_rbf_adjoint_fused_mb_f64
  *   SK_ROUTE_FUSED_MB_SWAP  (forward only) sk_solve_fwd_static_* on (Y, X): k is symmetric and that orientation is cheaper
  *   SK_ROUTE_FUSED_SWAP     the one-band kernels on (Y, X): the second paths fit one band (rows <= 64 RC), the first do not; for the ADJOINT
- *                           (fp64, Gram; dim <= 8 -- rbf of dim 5..8 at dyadic 0 and 1): sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 on
+ *                           (Gram; dim <= 8 -- rbf of dim 5..8 at dyadic 0 and 1; fp32 paths up-cast by the caller): sk_rbf_adjoint_fused_f64 / sk_linear_adjoint_fused_f64 on
  *                           (Y, X) with the second-argument sums (rbf, 128 x 128 pairs of 700 x 20 points: 0.41 ms against 1.56 ms
  *                           streamed); Gram callers transpose the result
  * For exactly LinearKernel / RBFKernel, D <= 16, dyadic <= 2, either scheme, the answer with SK_ROUTE_NO_STREAM is never

@@ -167,20 +167,21 @@ int route_query(int op, int kind, int D, int M, int N, int d, int naive, int ele
         if (kind == 1 && D <= 4 && d >= 1 && M <= 64 * rc_of(d)) return SK_ROUTE_FUSED;
         if (kind == 1 && D <= 8 && d == 0 && !naive && M <= 128) return SK_ROUTE_FUSED;   // two coarse rows per lane
         if (kind == 1 && D <= 8 && d == 1 && M <= 64) return SK_ROUTE_FUSED;               // dim 5..8: one coarse row per lane
-        // long first paths against short second ones (rbf, dim <= 4, fp64 paths; Gram calls -- the host passes SK_ROUTE_NO_SWAP for
+        // (fp32 paths: the host layer up-casts them, as it does for SK_ROUTE_FUSED -- the one-band kernels sweep in fp64 whatever the dtype)
+        // long first paths against short second ones (rbf, dim <= 4; Gram calls -- the host passes SK_ROUTE_NO_SWAP for
         // paired batches): the one-band adjoint on (y, x) with the SECOND-argument sums, d k(x, y) / dx = d2 k(y, x) (k and the static
         // kernel are symmetric), where the second paths fit its lanes -- 0.55-0.65x the streamed time, profiles/r05_asym.txt
         // (the second-argument sums ALONE -- no first-argument accumulators -- fit with two rows per lane at dyadic 1: 128 points)
-        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : N <= (d == 1 ? 128 : 64)))
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 4 && (d == 0 ? (!naive && N <= 128) : N <= (d == 1 ? 128 : 64)))
             return SK_ROUTE_FUSED_SWAP;
         // dim 5..8 (dyadic 0 and 1: the one-band adjoint of that width exists there): the second-argument sums INSTEAD of the first-argument
         // ones, which is all the swapped call needs (sk_wave_adj_fused_rbf.hip, YONLY; round 6)
-        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 8 && elem_size == 8 && (d == 0 ? (!naive && N <= 128) : (d == 1 && N <= 64)))
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 1 && D <= 8 && (d == 0 ? (!naive && N <= 128) : (d == 1 && N <= 64)))
             return SK_ROUTE_FUSED_SWAP;
         // ... and the linear one-band adjoint on (y, x) (dim <= 8, fp64 paths): its second-argument form hands the sums over a lane's rows
         // down the wave by DPP instead of keeping first-argument sums in registers (sk_wave_adj_fused.hip, round 6) -- 0.40-0.87x the time
         // of the routes below at 128 x 128 pairs, within 1.16-1.33x of the other orientation (profiles/r06_asym.txt, r06_asym_xy.txt)
-        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 0 && D <= 8 && elem_size == 8 && Nc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED_SWAP;
+        if (!(flags & SK_ROUTE_NO_SWAP) && kind == 0 && D <= 8 && Nc <= (d == 2 ? 64 : 128)) return SK_ROUTE_FUSED_SWAP;
         if (may_stream && prefer_stream(Mc, Nc, mb_efficiency(kind, Mc, Nc, d, kind == 1 && d == 0 ? 2 : rc_of(d)))) return SK_ROUTE_STREAM;
         return SK_ROUTE_FUSED_MB;
     }

@@ -109,11 +109,13 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
             res = one_band(Xd, Yd, param, dyadic, naive, gram, keep_edges=True)
         elif ra == FUSED_MB:
             res = be.solve_fwd_fused_static(kind, param, Xd, Yd, dyadic, naive, gram, keep_edges=True)
-        elif ra == FUSED_SWAP and gram and not f32:
-            # long first paths, short second ones: forward AND adjoint on (y, x) -- the edges are those of the pairs (b, a)
-            res = one_band(Yd, Xd, param, dyadic, naive, True, keep_edges=True)
+        elif ra == FUSED_SWAP and gram:
+            # long first paths, short second ones: forward AND adjoint on (y, x) -- the edges are those of the pairs (b, a); fp32 paths
+            # up-cast as for FUSED above
+            res = one_band(Yd.double(), Xd.double(), param, dyadic, naive, True, keep_edges=True) if f32 else \
+                one_band(Yd, Xd, param, dyadic, naive, True, keep_edges=True)
             if res is not None:
-                res = (res[0].t().contiguous(), res[1])
+                res = (res[0].t().contiguous().to(Xd.dtype), res[1])
         if res is not None:
             return res
     rf = _route(be, OP_FORWARD, static_kernel, Xd, Yd, dyadic, naive, gram)
@@ -304,10 +306,12 @@ def _rows_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, wor
         g = _fused_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, gram, kept, budget, Kvals, route)
         if g is not None:
             return g
-    if route == FUSED_SWAP and gram and Xd.dtype == torch.float64:
-        g = _swapped_gradient(be, static_kernel, Xd, Yd, go, dyadic, naive, kept, budget, Kvals)
+    if route == FUSED_SWAP and gram:
+        # (fp32 paths: swept in fp64 like every one-band call -- the edges their forward kept are those of the up-cast paths)
+        g = _swapped_gradient(be, static_kernel, Xd.double(), Yd.double(), go.double(), dyadic, naive, kept, budget,
+                              None if Kvals is None else Kvals.double())
         if g is not None:
-            return g
+            return g.to(Xd.dtype)
         kept = None       # (edges of the swapped pairs are of no use to the streaming route below)
     fused = _fused_static(static_kernel, gram) is not None
     esize = 8 if (fused and _upcast_tile(Xd, dyadic)) else Xd.element_size()

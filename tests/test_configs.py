@@ -562,6 +562,34 @@ def test_long_first_paths_take_the_swapped_adjoint(kind, D, d, A, B, M, N, naive
     assert rel_err(out[False][0], O.gram_forward(Xc, Yc, k, d, naive=naive, nthreads=NT)) <= 1e-11
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,M,N", [("linear", 6, 1, 300, 64), ("rbf", 3, 0, 200, 100), ("rbf", 7, 1, 150, 40), ("linear", 2, 2, 140, 33)])
+def test_fp32_paths_take_the_swapped_adjoint_up_cast(kind, D, d, M, N, monkeypatch):
+    """fp32 paths with long first / short second paths and a gradient: the swapped one-band route on the up-cast paths (as SK_ROUTE_FUSED does
+    for fp32 paths: the one-band kernels sweep in fp64 whatever the dtype) -- values and gradients in fp32, within fp32 rounding of the
+    oracle on the same fp32 inputs."""
+    gen = torch.Generator().manual_seed(7 * D + M)
+    k = sigkernel_amd.RBFKernel(0.9) if kind == "rbf" else sigkernel_amd.LinearKernel()
+    sk = sigkernel_amd.SigKernel(k, d)
+    A, B = 7, 5
+    Xc, Yc = walk(gen, A, M, D, torch.float32), walk(gen, B, N, D, torch.float32)
+    be = _lib.get_backend()
+    assert be.route(_lib.OP_ADJOINT, 1 if kind == "rbf" else 0, D, M, N, d, False, 4) == _lib.ROUTE_FUSED_SWAP
+    calls = []
+    name = "linear_adjoint_fused" if kind == "linear" else "rbf_adjoint_fused"
+    orig = getattr(type(be), name)
+    monkeypatch.setattr(type(be), name, lambda self, *a, **kw: (calls.append(kw.get("yside")), orig(self, *a, **kw))[1])
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    Xg = Xc.to(DEV).requires_grad_(True)
+    K = sk.compute_Gram(Xg, Yc.to(DEV))
+    (K * w.to(DEV).float()).sum().backward()
+    assert calls and all(calls), "the swapped adjoint was not used"
+    assert K.dtype == torch.float32 and Xg.grad.dtype == torch.float32
+    assert rel_err(K.detach().double().cpu().numpy(), O.gram_forward(Xc.double(), Yc.double(), k, d, nthreads=NT)) <= 1e-5
+    want = O.gram_grad_weighted(Xc.double(), Yc.double(), w.float().double().numpy(), k, d, nthreads=NT)
+    assert rel_err(Xg.grad.double().cpu().numpy(), want) <= 2e-5
+
+
 def _mb_split_knob(on):
     os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
     _lib.load().sk_reload_knobs()

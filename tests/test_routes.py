@@ -51,7 +51,7 @@ TABLE = [
     # long first paths, short second ones: the one-band forward on (y, x) (k is symmetric); never for a gradient, never beyond dim 8
     ((FWD, 0, 3, 700, 20, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((FWD, 0, 8, 1000, 129, 1, False, 4), FSWAP, FSWAP),
     ((FWD, 1, 4, 1000, 256, 0, False, 8), FSWAP, FSWAP), ((FWD, 1, 5, 1000, 256, 0, False, 8), MB, MB), ((ADJ, 0, 3, 700, 20, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 700, 66, 2, False, 8), STREAM, MB), ((ADJ, 0, 8, 700, 65, 2, True, 8), FSWAP, FSWAP),
-    ((ADJ, 0, 9, 700, 20, 0, False, 8), STREAM, MB), ((ADJ, 0, 3, 700, 20, 0, False, 4), STREAM, MB),
+    ((ADJ, 0, 9, 700, 20, 0, False, 8), STREAM, MB), ((ADJ, 0, 3, 700, 20, 0, False, 4), FSWAP, FSWAP),
     # adjoints: linear one band up to 128 increments (64 at dyadic 2), dim <= 8
     ((ADJ, 0, 8, 129, 500, 0, False, 8), FUSED, FUSED), ((ADJ, 0, 8, 130, 500, 0, False, 8), MB, MB), ((ADJ, 0, 8, 65, 30, 2, True, 8), FUSED, FUSED),
     ((ADJ, 0, 8, 66, 30, 2, False, 8), FSWAP, FSWAP), ((ADJ, 0, 9, 20, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 100, 100, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 140, 140, 1, False, 8), MB, MB),
@@ -64,7 +64,7 @@ TABLE = [
     # second-argument sums, where only the second paths fit its lanes (dim <= 4, fp64; 64 points at dyadic 1..2, 128 at dyadic 0)
     ((ADJ, 0, 12, 700, 20, 1, False, 8), STREAM, MB), ((ADJ, 0, 12, 700, 150, 1, False, 8), MB, MB),
     ((ADJ, 1, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 4, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 65, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 129, 1, False, 8), MB, MB), ((ADJ, 1, 3, 512, 65, 2, False, 8), STREAM, MB),
-    ((ADJ, 1, 5, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 64, 1, False, 4), STREAM, MB), ((ADJ, 0, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 1, False, 8), FSWAP, FSWAP),
+    ((ADJ, 1, 5, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 1, 3, 512, 64, 1, False, 4), FSWAP, FSWAP), ((ADJ, 0, 3, 512, 64, 1, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 0, False, 8), FSWAP, FSWAP), ((ADJ, 0, 8, 1000, 100, 1, False, 8), FSWAP, FSWAP),
     # compute_Gram(X, X, sym=True) with a gradient (SK_OP_ADJOINT_SYM): the triangle with the second-argument sums for rbf, fp64, dim <= 4,
     # 64 points at dyadic 1..2 / 128 at dyadic 0; all pairs otherwise (profiles/r05_yside_ab.txt)
     ((2, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED), ((2, 1, 3, 65, 65, 1, False, 8), STREAM, STREAM), ((2, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED),
@@ -95,8 +95,8 @@ def test_linear_and_rbf_up_to_16_dims_can_always_run_fused():
         r = be.route(op, kind, D, M, N, d, naive, es, no_stream=True)
         assert r != STREAM, (op, kind, D, M, N, d, naive, es)
         assert op == FWD or r != SWAP
-        # the adjoint on (y, x): the kernels with second-argument sums only (dim <= 8; rbf of dim 5..8 at dyadic 0 and 1; fp64 paths)
-        assert op == FWD or r != FSWAP or (es == 8 and D <= 8 and ((kind == 1 and N <= 128 and (D <= 4 or d <= 1)) or (kind == 0 and N <= 129)))
+        # the adjoint on (y, x): the kernels with second-argument sums only (dim <= 8; rbf of dim 5..8 at dyadic 0 and 1; fp32 paths up-cast by the host)
+        assert op == FWD or r != FSWAP or (D <= 8 and ((kind == 1 and N <= 128 and (D <= 4 or d <= 1)) or (kind == 0 and N <= 129)))
         r0 = be.route(op, kind, D, M, N, d, naive, es)
         assert r0 in (STREAM, r)                              # the default only ever falls back to streaming
         if r0 == STREAM:
