@@ -180,9 +180,10 @@ int sk_linear_adjoint_f32(const double *dYt, int64_t ldy, const float *W, int64_
  *   factor (this kernel forms inc = <dXr, dYt> itself, and so does its rescue: a forward's pre-scaled staging would give gradients
  *   wrong by kappa);  dYt [Bn][8][Ncp] = y[q+1]-y[q], Mrows, Ncp: as sk_solve_fwd_linear_* takes them;
  *   edges: sk_strip_edges_bytes layout;  scale [A*B] nullable;  either scheme.
- *   tpart [tpart_doubles] receives partial sums over b: viewed as [A][B / *ppg_out][*rows_out][8], sum over the chunk axis,
+ *   tpart [tpart_doubles] receives partial sums over b: viewed as [A][ceil(B / *ppg_out)][*rows_out][8] (the B pairs of an x_a are split
+ *   into that many chunks, lengths differing by one where the number does not divide B; *ppg_out is the longest), sum over the chunk axis,
  *   then T[a][p][:] = that[a][*rows_out - 1 - p][:] for p < Mc is what sk_linear_adjoint_* returns.  tpart == NULL: only
- *   *ppg_out and *rows_out are set (size query: A * (B / ppg) * rows * 8 doubles).  err [P] zero-initialised: per-pair
+ *   *ppg_out and *rows_out are set (size query: A * ceil(B / ppg) * rows * 8 doubles).  err [P] zero-initialised: per-pair
  *   self-check residual as for sk_solve_adj_*.  B == 0: paired batch (P = A, Bn = A, one chunk).  fp64, dyadic <= 2, Mc <= 128 (64 at dyadic 2),
  *   path dim <= 8; otherwise SK_ERR_UNSUPPORTED (sk_route_query(SK_OP_ADJOINT, 0, ...) == SK_ROUTE_FUSED says when it applies).
  *   ypart / ycols_out (either non-NULL; Gram only, B > 0): the SECOND-argument sums INSTEAD of tpart (which is not touched) --
@@ -203,7 +204,7 @@ int sk_linear_adjoint_fused_f64(const double *dXr, const double *dYt, int64_t A,
  * i.e. sk_static_increments + sk_solve_adj(EDGES_GIVEN) + sk_static_adjoint.
  *   Xr [A][Mrows][8], Yt [Bn][8][Ncp]: the POINT arrays sk_solve_fwd_rbf_* takes;  edges: sk_strip_edges_bytes layout;
  *   scale [P] nullable (upstream gradient per pair).  gpart [gpart_doubles] receives partial sums over b, viewed as
- *   [A][B / *ppg_out][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
+ *   [A][ceil(B / *ppg_out)][*rows_out][*outw_out]: summed over the chunk axis, row r < M holds cs = [..][0] and accd = [..][2 .. 2+D), and
  *   dL/dx_a[r] = (-2 / sigma) (x_a[r] cs - accd).  gpart == NULL: size query only.  err [P] zero-initialised: self-check residual
  *   as for sk_solve_adj_*.  B == 0: paired batch.  fp64, dyadic 1..2 (either scheme, path dim <= 8; dim 5..8 at dyadic 1: one coarse row per lane, M <= 64) and dyadic 0 (default scheme, path
  *   dim <= 8, M <= 128: two coarse rows per lane on the strip kernels' edge layout), one band per pair with

@@ -818,7 +818,7 @@ class HipBackend:
             if rc == 2:
                 return None
             _check(rc, "sk_linear_adjoint_fused (query)")
-            chunks = B // ppg.value if gram else 1
+            chunks = -(-B // ppg.value) if gram else 1     # (chunk c of an a: [c B / chunks, (c + 1) B / chunks): ppg is the longest)
             self.last_fused_ppg = ppg.value      # (pairs per lane-group chunk of the last fused adjoint: what the tests look at)
             tpart = None if yside else torch.empty(A, chunks, rows.value, 8, dtype=torch.float64, device=dev)
             # every (pair, increment column < Nc) is written by the kernel; the padding columns up to ycols hold nothing meaningful
@@ -890,7 +890,7 @@ class HipBackend:
             if rc == 2:
                 return None
             _check(rc, "sk_rbf_adjoint_fused (query)")
-            chunks = B // ppg.value if gram else 1
+            chunks = -(-B // ppg.value) if gram else 1
             self.last_fused_ppg = ppg.value
             gpart = None if yonly else torch.empty(A, chunks, rows.value, outw.value, dtype=torch.float64, device=dev)
             # every (pair, node column < N) is written by the kernel; the padding columns up to ycols are not, and are never read

@@ -46,11 +46,14 @@ void trace_launch(const void *host_stub);
 // The fused adjoints' decomposition (sk_wave_common.h: chunk_split / chunk_share): a lane group sweeps one CHUNK of the B pairs
 // of one path x_a and leaves a partial sum in slot a * nch + c; chunks swept by the oldest waves are longer.
 struct ChunkSplit {
-    int nr;              // 1: nch equal chunks of size[0] pairs, group gi = a * nch + c
+    int nr;              // 1: nch chunks of (at most) size[0] pairs, group gi = a * nch + c
     int cpr, nch;        // chunks of one a per rank; chunks of one a
     int64_t gpr;         // lane groups per rank (= waves per rank * G)
     int size[4];         // pairs in a chunk of rank r
     int off[4];          // first pair (within the B of an a) of rank r's chunks
+    int uneven;          // nr == 1 and nch does not divide B: chunk c of an a is [c B / nch, (c + 1) B / nch) -- lengths differ by one.
+    int B;               // (round 6: until then the chunk length had to DIVIDE B, and a batch without a suitable divisor -- a prime
+                         //  number of paths, 640, 768, 1536 -- left most lane groups idle: 127 x 127 pairs 10x slower than 128 x 128)
 };
 
 // Device-side rescue of the fused adjoints (sk_adj_fused_rescue.hip).

@@ -8,9 +8,10 @@
 // The two-state sweep itself (reverse PDE + backward recompute of K from the edges, self-check) is the one of
 // sk_wave_adj.hip; see there for the mathematics and for the edge prefetch.
 //
-// Decomposition: a lane group sweeps PPG consecutive pairs (a, b0 .. b0 + PPG - 1) of ONE path x_a -- the launcher picks
-// PPG as a divisor of B -- so its registers hold a partial sum over b for that a; it is stored (plain stores, no atomics:
-// the result does not depend on scheduling) to Tpart[group][flipped row][8], and the host adds the B / PPG chunks of an a.
+// Decomposition: a lane group sweeps PPG consecutive pairs (a, b0 .. b0 + PPG - 1) of ONE path x_a -- the launcher splits the B pairs
+// of an a into as many chunks as the resident lane groups take (pick_chunk; lengths differ by one where that number does not divide
+// B) -- so its registers hold a partial sum over b for that a; it is stored (plain stores, no atomics: the result does not depend on
+// scheduling) to Tpart[group][flipped row][8], and the host adds the ceil(B / PPG) chunks of an a.
 // Paired batches (B = 0) run with PPG = 1: one lane group per pair.
 // Scope: fp64, path dim <= 8, one band per pair (dyadic 0: up to 128 increment rows), dyadic <= 2, default scheme.
 #include "sk_wave_common.h"
@@ -119,7 +120,12 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     int64_t pair0, gslot;
     int PPG;
     chunk_share(prm.cs, wave_id * G + grp, prm.B > 0 ? prm.P / prm.B : prm.P, prm.B, prm.P, pair0, gslot, PPG);
-    PPG = __builtin_amdgcn_readfirstlane(PPG);   // (one rank per wave)
+    // the lane group's OWN pairs (what is summed); the wave sweeps as many as its longest group has (one rank per wave; uneven chunks
+    // differ by one pair: a shorter group's last pair position is swept unweighted)
+    const int ppg_own = PPG;
+    PPG = __builtin_amdgcn_readfirstlane(PPG);
+    if (prm.cs.uneven)
+        for (int gq = 1; gq < G; ++gq) PPG = max(PPG, __builtin_amdgcn_readlane(ppg_own, gq << prm.logL));
     const int n_steps = PPG * NUp + (L - 1);
     auto group_first = [&](int g) -> int64_t { return readlane64(pair0, g << prm.logL); };
     const bool is_top = lam == 0;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     // YSIDE: the upstream gradient only says which pairs are swept (NaN: screened out; the sums stay unweighted): 1 for a pair of the
     // group that exists, NaN kept, 0 outside
     auto pair_scale = [&](int ps_, double sv) -> double {
-        if (ps_ < 0 || ps_ >= PPG) return 0.0;
+        if (ps_ < 0 || ps_ >= ppg_own) return 0.0;
         const double v = prm.scale ? sv : 1.0;
         if constexpr (YSIDE) return pair0 + ps_ < prm.P ? (v != v ? v : 1.0) : 0.0;
         return v;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
         }
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
-        if (u == NUp - 1 && prm.err && ps >= 0 && ps < PPG && pair0 + ps < prm.P && s_pair == s_pair) {
+        if (u == NUp - 1 && prm.err && ps >= 0 && ps < ppg_own && pair0 + ps < prm.P && s_pair == s_pair) {
             double e = 0.0;
 #pragma unroll
             for (int rr = 0; rr < R; ++rr) e = fmax(e, fabs(leftF[rr] - 1.0));
@@ -527,30 +533,34 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     if (lds_bytes > 160 * 1024) return SK_ERR_UNSUPPORTED;
     if (yside && B <= 0) return SK_ERR_UNSUPPORTED;   // (paired batches have no use for it: both arguments fit or neither does)
 
-    // pairs per lane group: the smallest divisor of B that keeps the launch within the resident waves (8 per CU: the
-    // kernel holds ~230 VGPRs, two waves per SIMD)
+    // the resident lane groups: 8 waves per CU (the kernel holds ~230 VGPRs, two waves per SIMD)
     const int wpc = knobs().adjf_wpc > 0 ? knobs().adjf_wpc : 8;
     const int64_t max_groups = (int64_t)device_cu_count() * wpc * G;
-    int64_t PPG = B > 0 ? B : 1;   // paired: every pair has its own x, one pair per lane group.  Gram with more paths than
-    for (int64_t d = 1; d <= B; ++d)   // resident lane groups: one whole row of the Gram per group, launched in several rounds
-        if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
+    // pairs per lane group: see pick_chunk (paired batches: every pair has its own x, one pair per lane group)
+    int64_t PPG = pick_chunk(A, B, max_groups);
     if (epair) *epair = st.NNp + st.MMp;
-    if (force_nch > 0) PPG = B / force_nch;
+    if (force_nch > 0) PPG = (B + force_nch - 1) / force_nch;
     else if (rows_per_launch) {   // see launch_adj_fused_rbf_rows (sk_wave_adj_fused_rbf.hip)
         *rows_per_launch = 0;
         const int wpb = wave_group(lds_bytes, max_groups / G, knobs().adjf_wpb).wpb;
         const int64_t gpr = (int64_t)device_cu_count() * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
-        const int64_t nch = B > 0 ? B / PPG : 1;
-        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
+        const int64_t nch = chunks_of(B, PPG);
+        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0 && B % nch == 0)) {
+            // several exactly-filling launches of max_groups / m rows with m chunks per a, shares by wave age rank (~0.9 of the equal
+            // split's time each), against the one launch above: rounds x chunk length; the best m, the smallest among equals
+            const int64_t single_rounds = (A * nch + max_groups - 1) / max_groups;
+            double best = (double)single_rounds * (double)PPG;
             for (int64_t m = nr; m <= B && m <= max_groups; m += nr)
                 if (m >= nch && B % m == 0 && max_groups % m == 0 && B / m >= 4 * nr) {
-                    if (A >= max_groups / m) { *rows_per_launch = max_groups / m; PPG = B / m; }
-                    break;
+                    const int64_t rpl = max_groups / m, launches = (A + rpl - 1) / rpl;
+                    const double t = 0.9 * (double)launches * (double)(B / m);
+                    if (A >= rpl && t < best * 0.97) { best = t; *rows_per_launch = rpl; PPG = B / m; }
                 }
+        }
     }
     if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
-    const int64_t groups = g.P / PPG;
+    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : g.P;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC;
     if (ycols_out) *ycols_out = 2 * NUp;
@@ -622,9 +632,9 @@ int launch_adj_fused_linear(const double *dXr, const double *dYt, int64_t A, int
     }
     if (per_launch <= 0 || B <= 0)
         return launch_adj_fused_linear_rows(dXr, dYt, A, B, Mrows, Ncp, g, edges, sweep_scale, tpart, tpart_doubles, err, ypart, yside, nullptr,
-                                            nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
+                                            nullptr, nullptr, nullptr, nullptr, B > 0 ? chunks_of(B, ppg) : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that tpart keeps one layout)
-    const int64_t nch = B / ppg, slot = (int64_t)rows * FD;
+    const int64_t nch = chunks_of(B, ppg), slot = (int64_t)rows * FD;
     if (!yside && tpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
     for (int64_t a0 = 0; a0 < A; a0 += per_launch) {
         const int64_t An = A - a0 < per_launch ? A - a0 : per_launch;

@@ -215,7 +215,12 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     int64_t pair0, gslot;
     int PPG;
     chunk_share(prm.cs, wave_id * G + grp, prm.B > 0 ? prm.P / prm.B : prm.P, prm.B, prm.P, pair0, gslot, PPG);
-    PPG = __builtin_amdgcn_readfirstlane(PPG);   // (one rank per wave)
+    // the lane group's OWN pairs (what is summed); the wave sweeps as many as its longest group has (one rank per wave; uneven chunks
+    // differ by one pair, sk_wave_adj_fused.hip)
+    const int ppg_own = PPG;
+    PPG = __builtin_amdgcn_readfirstlane(PPG);
+    if (prm.cs.uneven)
+        for (int gq = 1; gq < G; ++gq) PPG = max(PPG, __builtin_amdgcn_readlane(ppg_own, gq << prm.logL));
     const int n_steps = PPG * NUp + (L - 1) + 1;   // + 1: node column 0 of the last pair completes one step later
     auto group_first = [&](int g) -> int64_t { return readlane64(pair0, g << prm.logL); };
     const bool is_top = lam == 0;
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     int ps_end;
     {
         const int64_t rem = prm.P - pair0;
-        ps_end = rem <= 0 ? 0 : (rem < (int64_t)PPG ? (int)rem : PPG);
+        ps_end = rem <= 0 ? 0 : (rem < (int64_t)ppg_own ? (int)rem : ppg_own);
     }
     const unsigned sc_par0 = (unsigned)(((reinterpret_cast<uintptr_t>(prm.scale) >> 3) ^ (uintptr_t)pair0) & 1u);
     double *const yp_base = YSIDE ? prm.Ypart + pair0 * (int64_t)(2 * NUp * YWK) : nullptr;
@@ -767,10 +772,9 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const int n_cu = device_cu_count();
     const int wpc = knobs().adjr_wpc > 0 ? knobs().adjr_wpc : 8;
     const int64_t max_groups = (int64_t)n_cu * wpc * G;
-    int64_t PPG = B > 0 ? B : 1;
-    for (int64_t d = 1; d <= B; ++d)
-        if (B % d == 0 && A * (B / d) <= max_groups) { PPG = d; break; }
-    if (force_nch > 0) PPG = B / force_nch;
+    // pairs per lane group: see pick_chunk (paired batches: every pair has its own x, one pair per lane group)
+    int64_t PPG = pick_chunk(A, B, max_groups);
+    if (force_nch > 0) PPG = (B + force_nch - 1) / force_nch;
     else if (rows_per_launch) {
         // Shares by wave age rank (ChunkSplit) need a launch that fills the chip exactly, with the chunks of an a a multiple of
         // the ranks: when the equal split does not give that, the caller sweeps the rows in several such launches.
@@ -778,16 +782,22 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         const int wpb = wave_group(lds_bytes, max_groups / G, knobs().adjr_wpb).wpb;
         const int64_t gpr = (int64_t)n_cu * wpb * G;
         const int64_t nr = gpr > 0 && max_groups % gpr == 0 ? max_groups / gpr : 0;
-        const int64_t nch = B > 0 ? B / PPG : 1;
-        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0))
+        const int64_t nch = chunks_of(B, PPG);
+        if (B > 0 && nr >= 2 && !(A * nch == max_groups && nch % nr == 0 && B % nch == 0)) {
+            // several exactly-filling launches of max_groups / m rows with m chunks per a, shares by wave age rank (~0.9 of the equal
+            // split's time each), against the one launch above: rounds x chunk length; the best m, the smallest among equals
+            const int64_t single_rounds = (A * nch + max_groups - 1) / max_groups;
+            double best = (double)single_rounds * (double)PPG;
             for (int64_t m = nr; m <= B && m <= max_groups; m += nr)
                 if (m >= nch && B % m == 0 && max_groups % m == 0 && B / m >= 4 * nr) {
-                    if (A >= max_groups / m) { *rows_per_launch = max_groups / m; PPG = B / m; }
-                    break;
+                    const int64_t rpl = max_groups / m, launches = (A + rpl - 1) / rpl;
+                    const double t = 0.9 * (double)launches * (double)(B / m);
+                    if (A >= rpl && t < best * 0.97) { best = t; *rows_per_launch = rpl; PPG = B / m; }
                 }
+        }
     }
     if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
-    const int64_t groups = g.P / PPG;
+    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : g.P;
     const int OUTW = ND + 2;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC + 1;
@@ -876,9 +886,9 @@ int launch_adj_fused_rbf(const double *Xr, const double *Yt, int64_t A, int64_t 
     }
     if (per_launch <= 0 || B <= 0)
         return launch_adj_fused_rbf_rows(Xr, Yt, A, B, Mrows, Ncp, D, g, inv_sigma, edges, sweep_scale, gpart, gpart_doubles, err, ypart, ys, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr, B > 0 ? B / ppg : 0, rescue, scale, rws, rws_bytes, s);
+                                         nullptr, nullptr, nullptr, nullptr, B > 0 ? chunks_of(B, ppg) : 0, rescue, scale, rws, rws_bytes, s);
     // several launches of per_launch rows each, all with the same chunks per a (so that gpart keeps one layout)
-    const int64_t nch = B / ppg;
+    const int64_t nch = chunks_of(B, ppg);
     const int64_t slot = (int64_t)rows * outw;
     if (gpart && gpart_doubles < (size_t)(A * nch * slot)) return SK_ERR_WORKSPACE;
     const Strip st = strip_geom(rbf_edge_geom(g), 8);

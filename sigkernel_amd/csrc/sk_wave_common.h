@@ -492,12 +492,29 @@ __host__ __device__ __forceinline__ void rank_share(const RankSplit &rs, int64_t
 // oldest waves are made longer: chunk c of every a belongs to rank c / cpr, and rank r's chunks hold size[r] pairs.
 // (struct ChunkSplit: sk_internal.h)
 
+// Pairs per lane-group chunk of a fused adjoint's Gram launch (B > 0): the smallest divisor of B that keeps A B / d lane groups within
+// the resident ones -- or, when that leaves more of them idle, the uneven split into as many chunks per a as they take (ChunkSplit::uneven).
+inline int64_t pick_chunk(int64_t A, int64_t B, int64_t max_groups) {
+    if (B <= 0) return 1;
+    int64_t ppg = B;
+    for (int64_t d = 1; d <= B; ++d)
+        if (B % d == 0 && A * (B / d) <= max_groups) { ppg = d; break; }
+    int64_t nch = max_groups / (A > 0 ? A : 1);
+    if (nch < 1) nch = 1;
+    if (nch > B) nch = B;
+    const int64_t ppg_u = (B + nch - 1) / nch;
+    return ppg_u < ppg ? ppg_u : ppg;      // (shorter chunks = more lane groups at work; equal when a divisor does as well)
+}
+inline int64_t chunks_of(int64_t B, int64_t ppg) { return B > 0 ? (B + ppg - 1) / ppg : 1; }
+
 inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_groups, int G, int wpb, int n_cu, const RankW &family) {
     ChunkSplit cs{};
-    const int64_t nch = B > 0 ? B / PPG : 1;
-    cs.nr = 1; cs.cpr = (int)nch; cs.nch = (int)nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = (int)PPG; cs.off[0] = 0;
+    // PPG: the LONGEST chunk; nch = ceil(B / PPG) chunks per a, of B / nch pairs each, rounded down or up
+    const int64_t nch = B > 0 ? (B + PPG - 1) / PPG : 1;
+    cs.nr = 1; cs.cpr = (int)nch; cs.nch = (int)nch; cs.gpr = (int64_t)1 << 62; cs.size[0] = (int)(B > 0 ? (B + nch - 1) / nch : PPG); cs.off[0] = 0;
+    cs.B = (int)B; cs.uneven = B > 0 && B % nch != 0;
     const int64_t gpr = (int64_t)n_cu * wpb * G;
-    if (B <= 0 || gpr <= 0 || A * nch != max_groups || max_groups % gpr) return cs;
+    if (B <= 0 || gpr <= 0 || cs.uneven || A * nch != max_groups || max_groups % gpr) return cs;
     const int nr = (int)(max_groups / gpr);
     if (nr < 2 || nr > 4 || nch % nr || PPG < 4 * nr) return cs;
     static constexpr double dflt[5][4] = {{1, 0, 0, 0}, {1, 0, 0, 0}, {0.66, 0.34, 0, 0}, {0.53, 0.30, 0.17, 0}, {0.40, 0.27, 0.19, 0.14}};
@@ -521,6 +538,15 @@ inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_gro
 // device (per lane): lane group gi -> its first pair, its slot in the partial-sum array, and the pairs it sweeps
 __host__ __device__ __forceinline__ void chunk_share(const ChunkSplit &cs, int64_t gi, int64_t A, int64_t B, int64_t P, int64_t &first, int64_t &slot, int &ppg) {
     if (B <= 0) { first = gi < P ? gi : P; slot = gi; ppg = 1; return; }   // paired batch: one pair per lane group
+    if (cs.uneven) {     // nch does not divide B: chunk c of an a is [c B / nch, (c + 1) B / nch)
+        const int64_t a = gi / cs.nch;
+        const int64_t cl = gi - a * cs.nch;
+        const int64_t lo = cl * cs.B / cs.nch, hi = (cl + 1) * cs.B / cs.nch;
+        ppg = (int)(hi - lo);
+        slot = gi;
+        first = a < A ? a * B + lo : P;
+        return;
+    }
     int r = (int)(gi / cs.gpr);
     if (r >= cs.nr) r = cs.nr - 1;
     int sz = cs.size[0], of = cs.off[0];

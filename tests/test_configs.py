@@ -590,6 +590,35 @@ def test_fp32_paths_take_the_swapped_adjoint_up_cast(kind, D, d, M, N, monkeypat
     assert rel_err(Xg.grad.double().cpu().numpy(), want) <= 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,A,B,M,N", [("linear", 4, 1, 127, 127, 40, 40), ("rbf", 3, 1, 101, 53, 33, 64), ("linear", 8, 0, 61, 131, 100, 30),
+                                              ("rbf", 4, 2, 37, 251, 20, 20), ("rbf", 6, 0, 43, 97, 50, 70), ("linear", 3, 2, 640, 77, 16, 16),
+                                              ("rbf", 3, 1, 7, 1009, 24, 24)])
+def test_batches_without_a_suitable_divisor_fill_the_lane_groups(kind, D, d, A, B, M, N):
+    """The fused adjoints split the B pairs of an x_a into as many chunks as the resident lane groups take; where that number does not
+    divide B the chunks differ by one pair (ChunkSplit::uneven, round 6: until then the chunk length had to divide B -- 127 x 127 pairs
+    ran 10x slower than 128 x 128).  Gradients against the oracle; the chunks are short (the lane groups are at work)."""
+    gen = torch.Generator().manual_seed(A + 3 * B)
+    k = sigkernel_amd.RBFKernel(0.9) if kind == "rbf" else sigkernel_amd.LinearKernel()
+    sk = sigkernel_amd.SigKernel(k, d)
+    Xc, Yc = walk(gen, A, M, D), walk(gen, B, N, D)
+    w = torch.randn(A, B, generator=gen, dtype=torch.float64)
+    be = _lib.get_backend()
+    assert be.route(_lib.OP_ADJOINT, 1 if kind == "rbf" else 0, D, M, N, d, False, 8) == _lib.ROUTE_FUSED
+    be.last_fused_ppg = None
+    Xg = Xc.to(DEV).requires_grad_(True)
+    (sk.compute_Gram(Xg, Yc.to(DEV)) * w.to(DEV)).sum().backward()
+    assert be.last_fused_ppg is not None and A * -(-B // be.last_fused_ppg) >= min(A * B, 1024), be.last_fused_ppg      # lane groups at work
+    want = O.gram_grad_weighted(Xc, Yc, w.numpy(), k, d, nthreads=NT)
+    assert rel_err(Xg.grad.cpu().numpy(), want) <= 1e-9
+    # the swapped call (the second-argument sums per pair) over the same uneven chunks
+    if B > A:
+        Yg = Yc.to(DEV).requires_grad_(True)
+        (sk.compute_Gram(Yg, Xc.to(DEV)) * w.t().to(DEV)).sum().backward()
+        want_y = O.gram_grad_weighted(Yc, Xc, w.t().contiguous().numpy(), k, d, nthreads=NT)
+        assert rel_err(Yg.grad.cpu().numpy(), want_y) <= 1e-9
+
+
 def _mb_split_knob(on):
     os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
     _lib.load().sk_reload_knobs()

@@ -178,7 +178,7 @@ def test_fused_linear_forward_keeps_usable_edges(be, A, B, M, N, D, d):
     assert float(r1.max()) <= 1e-9 and rel_err(W1.cpu().numpy(), W0.cpu().numpy()) <= ADJ_TOL
 
 
-@pytest.mark.parametrize("kind,D,d", [("rbf", 3, 1), ("linear", 8, 1), ("rbf", 4, 2), ("linear", 2, 2)])
+@pytest.mark.parametrize("kind,D,d", [("rbf", 3, 1), ("linear", 8, 1), ("rbf", 4, 2), ("linear", 2, 2), ("linear", 5, 0), ("rbf", 2, 0)])
 def test_symmetric_gram_with_gradient_uses_the_triangle(be, kind, D, d, monkeypatch):
     """compute_Gram(X, X, sym=True) with a gradient solves only the blocks on and above the diagonal; values, gradient of a
     non-symmetric loss and the reference's 2x rule must match the full (sym=False) computation."""
