@@ -122,7 +122,13 @@ inline double cost(const char *name) {
 // whether the streaming route is the default over the multi-band kernels at this shape
 inline bool prefer_stream(int Mc, int Nc, double eff, bool rbf16_forward = false) {
     const int strip = (int)cost("stream_one_strip_cells");
-    return (Mc <= strip && Nc <= strip) || eff < cost(rbf16_forward ? "mb_min_eff_rbf16_forward" : "mb_min_eff");
+    if (Mc <= strip && Nc <= strip) return true;
+    // the streaming kernels sweep the rows in strips of `strip` too: first paths just over a multiple of it (129 .. ~145 increments) pad
+    // THEIR last strip as the multi-band kernels pad their last band, so the multi-band efficiency is held against the streamed one
+    // (round 6, profiles/r06_mb_threshold.txt: 128 x 128 pairs of 130 points, linear dim 8 d = 1 -- efficiency 0.41 -- forward 2.38 ms
+    // streamed against 1.07 multi-band, with a gradient 7.30 against 3.75; every measurement behind mb_min_eff had one-strip paths)
+    const double eff_stream = Mc > strip ? (double)Mc / (double)(((Mc + strip - 1) / strip) * strip) : 1.0;   // (one strip: as measured before)
+    return eff < cost(rbf16_forward ? "mb_min_eff_rbf16_forward" : "mb_min_eff") * (rbf16_forward ? 1.0 : eff_stream);
 }
 }  // namespace
 

@@ -70,6 +70,10 @@ TABLE = [
     ((2, 1, 3, 64, 64, 1, False, 8), FUSED, FUSED), ((2, 1, 3, 65, 65, 1, False, 8), STREAM, STREAM), ((2, 1, 4, 64, 64, 2, False, 8), FUSED, FUSED),
     ((2, 1, 4, 128, 128, 0, False, 8), FUSED, FUSED), ((2, 1, 5, 64, 64, 1, False, 8), STREAM, STREAM), ((2, 0, 3, 64, 64, 1, False, 8), STREAM, STREAM),
     ((2, 1, 3, 64, 64, 1, False, 4), STREAM, STREAM),
+    # first paths just over one strip / band (129 .. ~145 increments): the streamed route pads its second strip as the multi-band kernels pad
+    # their second band -- the multi-band efficiency is held against the streamed one (round 6, profiles/r06_mb_threshold.txt)
+    ((FWD, 0, 8, 130, 130, 1, False, 8), MB, MB), ((ADJ, 0, 8, 130, 130, 1, False, 8), MB, MB), ((ADJ, 1, 8, 130, 130, 0, False, 8), MB, MB),
+    ((ADJ, 1, 3, 129, 129, 1, False, 8), STREAM, MB), ((FWD, 0, 12, 129, 129, 0, False, 8), STREAM, MB), ((ADJ, 0, 12, 130, 20, 1, False, 8), STREAM, MB),
     # outside: other kernels, dim > 16, dyadic > 2, single points
     ((FWD, 2, 3, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 17, 30, 30, 1, False, 8), STREAM, STREAM),
     ((ADJ, 1, 17, 30, 30, 1, False, 8), STREAM, STREAM), ((FWD, 0, 3, 30, 30, 3, False, 8), STREAM, STREAM),
