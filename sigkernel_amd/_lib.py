@@ -132,6 +132,17 @@ class SigKernelLibraryError(RuntimeError):
     pass
 
 
+def _stage_rows(kind, M, gram):
+    """Rows per staged first path of the one-band kernels ([A][rows][8] fp64).  A Gram call stages A + B paths -- nothing -- and keeps the
+    256 every variant accepts; a PAIRED batch stages every pair's x, and the padding was most of its HBM traffic (262 144 pairs of 64
+    points: 16 KB per path, three staging launches of 1.6 ms in a 18 ms training step): the smallest of 64 / 128 / 256 rows that holds
+    lanes x rows per lane of every variant (linear: M - 1 increments; rbf: M nodes and the node row above)."""
+    if gram:
+        return 256
+    need = (M - 1) if kind == 0 else 2 * M
+    return 64 if need <= 64 else (128 if need <= 128 else 256)
+
+
 ABI_VERSION = 330      # include/sigkernel_amd.h: sk_version()
 
 
@@ -416,7 +427,7 @@ class HipBackend:
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic > 2 or Mc < 1 or Nc < 1 or Mc > 64 * (4 >> min(dyadic, 2)):
             return None
-        Mrows, Ncp = 256, (Nc + 15) // 16 * 16
+        Mrows, Ncp = _stage_rows(0, M, gram), (Nc + 15) // 16 * 16
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
@@ -454,7 +465,7 @@ class HipBackend:
         Mc, Nc = M - 1, N - 1
         if D > 8 or dyadic > 2 or Mc < 1 or Nc < 1 or M > 64 * (4 >> min(dyadic, 2)) or not float(sigma) > 0:
             return None
-        Mrows, Ncp = 256, (N + 15) // 16 * 16
+        Mrows, Ncp = _stage_rows(1, M, gram), (N + 15) // 16 * 16
         dev = X.device
         out = torch.empty((A, B) if gram else (A,), dtype=X.dtype, device=dev)
         scheme = SCHEME_NAIVE if naive else SCHEME_DEFAULT
@@ -801,7 +812,7 @@ class HipBackend:
         if yside and not gram:
             return None
         dev = X.device
-        Mrows, Ncp = 256, (Nc + 15) // 16 * 16
+        Mrows, Ncp = _stage_rows(0, M, gram), (Nc + 15) // 16 * 16
         if scale is not None:
             scale = scale.double().contiguous()
         lib = load()
@@ -873,7 +884,7 @@ class HipBackend:
             return None
         yonly = yside and (yonly or D > 4)
         dev = X.device
-        Mrows, Ncp = 256, (N + 15) // 16 * 16
+        Mrows, Ncp = _stage_rows(1, M, gram), (N + 15) // 16 * 16
         if scale is not None:
             scale = scale.double().contiguous()
         lib = load()

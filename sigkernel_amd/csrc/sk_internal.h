@@ -52,6 +52,7 @@ struct ChunkSplit {
     int size[4];         // pairs in a chunk of rank r
     int off[4];          // first pair (within the B of an a) of rank r's chunks
     int uneven;          // nr == 1 and nch does not divide B: chunk c of an a is [c B / nch, (c + 1) B / nch) -- lengths differ by one.
+    int ppp;             // paired batches (B == 0): pairs per lane group (0 / 1: one); every pair keeps its own slot
     int B;               // (round 6: until then the chunk length had to DIVIDE B, and a batch without a suitable divisor -- a prime
                          //  number of paths, 640, 768, 1536 -- left most lane groups idle: 127 x 127 pairs 10x slower than 128 x 128)
 };

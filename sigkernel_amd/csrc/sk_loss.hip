@@ -223,6 +223,35 @@ __global__ __launch_bounds__(256) void k_linear_adjoint_finish(const double *__r
     }
 }
 
+// ONE chunk per a (paired batches: a slot per pair; small Gram rows): one lane per output, nothing to add up -- the FIN_SPLIT form above
+// leaves three of four lanes idle there and ran at 0.5 TB/s on the 262 144 pairs of a big paired batch (2.0 ms of an 18 ms step)
+__global__ __launch_bounds__(256) void k_rbf_adjoint_finish1(const double *__restrict__ gpart, int64_t A, int rows, int outw, const double *__restrict__ X,
+                                                             int M, int D, double c, const double *__restrict__ gscale, double *__restrict__ grad) {
+    const int64_t n = A * (int64_t)M * D;
+    const double gs = gscale ? *gscale : 1.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = i / ((int64_t)M * D);
+        const int rem = (int)(i - a * (int64_t)M * D);
+        const int r = rem / D, j = rem - r * D;
+        const double *src = gpart + (a * rows + r) * (int64_t)outw;
+        grad[i] = gs * (c * (X[i] * src[0] - src[2 + j]));
+    }
+}
+__global__ __launch_bounds__(256) void k_linear_adjoint_finish1(const double *__restrict__ tpart, int64_t A, int rows, int M, int D, double scale2,
+                                                                const double *__restrict__ gscale, double *__restrict__ grad) {
+    const int64_t n = A * (int64_t)M * D;
+    const int Mc = M - 1;
+    const double gs = gscale ? *gscale : 1.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = i / ((int64_t)M * D);
+        const int rem = (int)(i - a * (int64_t)M * D);
+        const int r = rem / D, j = rem - r * D;
+        const double *src = tpart + a * rows * (int64_t)8 + j;
+        const double up = r >= 1 ? src[(rows - r) * (int64_t)8] : 0.0, dn = r < Mc ? src[(rows - 1 - r) * (int64_t)8] : 0.0;
+        grad[i] = gs * (scale2 * (up - dn));
+    }
+}
+
 inline unsigned grid_for(int64_t n) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
@@ -259,6 +288,10 @@ int launch_loss_weights(int64_t A, int64_t B, const double *grad_out, double *go
 
 int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, int rows, int outw, const double *X, int M, int D, double sigma,
                               const double *gscale, double *grad, hipStream_t s) {
+    if (chunks == 1) {
+        SK_LAUNCH(k_rbf_adjoint_finish1, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, gpart, A, rows, outw, X, M, D, -2.0 / sigma, gscale, grad);
+        return check_launch();
+    }
     SK_LAUNCH(k_rbf_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, gpart, A, chunks, rows, outw, X, M, D,
                        -2.0 / sigma, gscale, grad);
     return check_launch();
@@ -266,6 +299,10 @@ int launch_rbf_adjoint_finish(const double *gpart, int64_t A, int64_t chunks, in
 
 int launch_linear_adjoint_finish(const double *tpart, int64_t A, int64_t chunks, int rows, int M, int D, double scale2, const double *gscale,
                                  double *grad, hipStream_t s) {
+    if (chunks == 1) {
+        SK_LAUNCH(k_linear_adjoint_finish1, dim3(grid_for(A * (int64_t)M * D)), dim3(256), 0, s, tpart, A, rows, M, D, scale2, gscale, grad);
+        return check_launch();
+    }
     SK_LAUNCH(k_linear_adjoint_finish, dim3(grid_for(A * (int64_t)M * D * FIN_SPLIT)), dim3(256), 0, s, tpart, A, chunks, rows, M, D, scale2, gscale, grad);
     return check_launch();
 }

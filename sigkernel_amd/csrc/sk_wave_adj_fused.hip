@@ -79,7 +79,10 @@ __device__ __forceinline__ void lds_read_run<8>(d2_t (&v)[8], unsigned a) {     
 // from zero, its bottom lane stores the unit's sums of its pair.  (First built with the carry in LDS, eight 65-slot pieces read with
 // the y differences and written back: 24 KB of LDS traffic per wave and macro-step against 8 -- the dyadic-0 sweep, four cells per
 // step, ran 1.87x the time of the first-argument form on the same grid, profiles/r06_asym.txt; the DPP form costs issue slots only.)
-template <int DY, int RC, bool FULLWAVE, bool YSIDE>
+// PAIRED: a paired batch (B == 0) with SEVERAL pairs per lane group: every pair has its own x, so a lane stores and clears its sums when
+// it finishes a pair (one pair per lane group, the form until round 6, pays the skew's fill and the wave's prologue for every pair:
+// 262 144 pairs of 64 points 68 ns per pair with a gradient against 20 for a Gram pair, profiles/r06_aspect.txt)
+template <int DY, int RC, bool FULLWAVE, bool YSIDE, bool PAIRED = false>
 __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedParams prm) {
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
@@ -446,6 +449,23 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
             }
         }
 
+        // -- PAIRED: this lane's rows of the pair are complete with its last flipped unit: out they go (slot = pair), the sums start over
+        if constexpr (PAIRED) {
+            if (u == NUp - 1) {
+                if (ps >= 0 && ps < ppg_own && pair0 + ps < prm.P) {
+                    double *dst = prm.Tpart + ((pair0 + ps) * Mcp + (int64_t)lam * RC) * FD;
+#pragma unroll
+                    for (int k = 0; k < RC; ++k)
+#pragma unroll
+                        for (int j = 0; j < FD; j += 2) *reinterpret_cast<d2_t *>(dst + k * FD + j) = d2_t{tacc[k][j], tacc[k][j + 1]};
+                }
+#pragma unroll
+                for (int k = 0; k < RC; ++k)
+#pragma unroll
+                    for (int j = 0; j < FD; ++j) tacc[k][j] = 0.0;
+            }
+        }
+
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
         if (u == NUp - 1 && prm.err && ps >= 0 && ps < ppg_own && pair0 + ps < prm.P && s_pair == s_pair) {
             double e = 0.0;
@@ -482,7 +502,7 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
 
     // ---- the group's partial sums: Tpart[group][flipped coarse row][8] ------------------------------------------------------
     {
-        if (!YSIDE && pair0 < prm.P) {
+        if (!YSIDE && !PAIRED && pair0 < prm.P) {
             double *dst = prm.Tpart + (gslot * Mcp + (int64_t)lam * RC) * FD;
 #pragma unroll
             for (int k = 0; k < RC; ++k)
@@ -496,9 +516,9 @@ __global__ __launch_bounds__(4 * WAVE) void k_adj_fused_linear(const AdjFusedPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE, bool YSIDE>
+template <int DY, int RC, bool FULLWAVE, bool YSIDE, bool PAIRED = false>
 int launch_adjf(const AdjFusedParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_linear<DY, RC, FULLWAVE, YSIDE>;
+    auto kern = k_adj_fused_linear<DY, RC, FULLWAVE, YSIDE, PAIRED>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -538,6 +558,14 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     const int64_t max_groups = (int64_t)device_cu_count() * wpc * G;
     // pairs per lane group: see pick_chunk (paired batches: every pair has its own x, one pair per lane group)
     int64_t PPG = pick_chunk(A, B, max_groups);
+    // paired batches of more pairs than resident lane groups: several consecutive pairs per lane group (the kernel stores and clears its
+    // sums at every pair end: PAIRED), up to 64 -- the skew's fill and the wave's prologue are then paid once per group, not per pair
+    int64_t ppp = 1;
+    if (B <= 0 && !yside) {
+        ppp = g.P / max_groups;
+        ppp = ppp < 1 ? 1 : (ppp > 64 ? 64 : ppp);
+        PPG = ppp;
+    }
     if (epair) *epair = st.NNp + st.MMp;
     if (force_nch > 0) PPG = (B + force_nch - 1) / force_nch;
     else if (rows_per_launch) {   // see launch_adj_fused_rbf_rows (sk_wave_adj_fused_rbf.hip)
@@ -560,12 +588,12 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
         }
     }
     if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
-    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : g.P;
+    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : (g.P + ppp - 1) / ppp;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC;
     if (ycols_out) *ycols_out = 2 * NUp;
     if (yside ? !ypart : !tpart) return SK_OK;
-    if (!yside && tpart_doubles < (size_t)groups * L * RC * FD) return SK_ERR_WORKSPACE;
+    if (!yside && tpart_doubles < (size_t)(B > 0 ? groups : g.P) * L * RC * FD) return SK_ERR_WORKSPACE;   // (paired: a slot per pair)
     const int64_t waves = (groups + G - 1) / G;
 
     AdjFusedParams prm;
@@ -577,6 +605,7 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
     prm.n_steps = (int)(PPG * NUp + (L - 1));
     prm.wg = wave_group(lds_bytes, waves, knobs().adjf_wpb);
     prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, device_cu_count(), knobs().adjf_rank_w);
+    prm.cs.ppp = (int)ppp;
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     int rc;
@@ -586,6 +615,12 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
             case 1: rc = full ? launch_adjf<1, 2, true, true>(prm, lds_block, s) : launch_adjf<1, 2, false, true>(prm, lds_block, s); break;
             default: rc = full ? launch_adjf<2, 1, true, true>(prm, lds_block, s) : launch_adjf<2, 1, false, true>(prm, lds_block, s); break;
         }
+    else if (ppp > 1)
+        switch (DY) {
+            case 0: rc = full ? launch_adjf<0, 2, true, false, true>(prm, lds_block, s) : launch_adjf<0, 2, false, false, true>(prm, lds_block, s); break;
+            case 1: rc = full ? launch_adjf<1, 2, true, false, true>(prm, lds_block, s) : launch_adjf<1, 2, false, false, true>(prm, lds_block, s); break;
+            default: rc = full ? launch_adjf<2, 1, true, false, true>(prm, lds_block, s) : launch_adjf<2, 1, false, false, true>(prm, lds_block, s); break;
+        }
     else
         switch (DY) {
             case 0: rc = full ? launch_adjf<0, 2, true, false>(prm, lds_block, s) : launch_adjf<0, 2, false, false>(prm, lds_block, s); break;
@@ -594,8 +629,11 @@ int launch_adj_fused_linear_rows(const double *dXr, const double *dYt, int64_t A
         }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
     // (second-argument sums: the rescue writes a rescued pair's block of ypart and has no partial sums to patch)
+    ChunkSplit rcs = prm.cs;      // (paired: every pair has its slot whatever the lane groups swept -- the rescue walks pairs)
+    rcs.ppp = 1;
+    if (B <= 0) rcs.size[0] = 1;
     return launch_fused_rescue(0, dXr, dYt, scale_orig, err, rescue->tol, yside ? nullptr : tpart, ypart, A, B, Mrows, Ncp, 8, g, L * RC, FD,
-                               2 * NUp, 0.0, prm.cs, groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
+                               2 * NUp, 0.0, rcs, B > 0 ? groups : g.P, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
 }
 }  // namespace
 

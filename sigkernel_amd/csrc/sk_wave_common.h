@@ -537,7 +537,13 @@ inline ChunkSplit chunk_split(int64_t A, int64_t B, int64_t PPG, int64_t max_gro
 
 // device (per lane): lane group gi -> its first pair, its slot in the partial-sum array, and the pairs it sweeps
 __host__ __device__ __forceinline__ void chunk_share(const ChunkSplit &cs, int64_t gi, int64_t A, int64_t B, int64_t P, int64_t &first, int64_t &slot, int &ppg) {
-    if (B <= 0) { first = gi < P ? gi : P; slot = gi; ppg = 1; return; }   // paired batch: one pair per lane group
+    if (B <= 0) {      // paired batch: ppp consecutive pairs per lane group (one until round 6), every pair with a slot of its own
+        const int64_t ppp = cs.ppp > 1 ? cs.ppp : 1;
+        first = gi * ppp < P ? gi * ppp : P;
+        slot = first;
+        ppg = (int)(P - first < ppp ? P - first : ppp);
+        return;
+    }
     if (cs.uneven) {     // nch does not divide B: chunk c of an a is [c B / nch, (c + 1) B / nch)
         const int64_t a = gi / cs.nch;
         const int64_t cl = gi - a * cs.nch;

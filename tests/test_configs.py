@@ -619,6 +619,42 @@ def test_batches_without_a_suitable_divisor_fill_the_lane_groups(kind, D, d, A, 
         assert rel_err(Yg.grad.cpu().numpy(), want_y) <= 1e-9
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d,P,M,N", [("linear", 5, 1, 9001, 64, 50), ("linear", 8, 0, 20011, 100, 128), ("linear", 3, 2, 12345, 40, 64)])
+def test_big_paired_batches_sweep_several_pairs_per_lane_group(kind, D, d, P, M, N, monkeypatch):
+    """compute_kernel(X, Y) with a gradient on more pairs than resident lane groups: a lane group of the fused adjoint sweeps several
+    consecutive pairs and stores / clears its sums at every pair end (PAIRED; until round 6 one pair per lane group).  Against the
+    streaming route on every pair, against the oracle on a sample; one exploding pair in the middle of a lane group's run is rescued."""
+    gen = torch.Generator().manual_seed(P)
+    k = sigkernel_amd.LinearKernel()
+    sk = sigkernel_amd.SigKernel(k, d)
+    Xc, Yc = walk(gen, P, M, D), walk(gen, P, N, D)
+    wild = P // 2 + 3
+    Xc[wild] = torch.linspace(0, 12, M, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    Yc[wild] = torch.linspace(0, 12, N, dtype=torch.float64)[:, None] * torch.ones(1, D, dtype=torch.float64) / np.sqrt(D)
+    go = torch.randn(P, generator=gen, dtype=torch.float64)
+    be = _lib.get_backend()
+    res = []
+    for off in (False, True):
+        monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", off)
+        skmod._route_query.cache_clear()
+        be.last_fused_ppg = None
+        Xg = Xc.to(DEV).requires_grad_(True)
+        K = sk.compute_kernel(Xg, Yc.to(DEV))
+        (K * go.to(DEV)).sum().backward()
+        res.append((K.detach().cpu().numpy(), Xg.grad.cpu().numpy(), be.last_fused_ppg))
+    monkeypatch.setattr(sigkernel_amd.routes, "no_fused_adjoint", False)
+    skmod._route_query.cache_clear()
+    assert res[0][2] is not None and res[0][2] > 1, res[0][2]          # several pairs per lane group
+    assert abs(res[0][0][wild]) > 1e5
+    assert rel_err(res[0][0], res[1][0]) <= 1e-12
+    for p in range(P):      # row by row: the wild pair's gradient is 1e6 times the others'
+        if rel_err(res[0][1][p], res[1][1][p]) > 1e-8: raise AssertionError((p, rel_err(res[0][1][p], res[1][1][p])))
+    for p in (0, 1, wild - 1, wild, wild + 1, P - 1):
+        want = O.gram_grad_weighted(Xc[p:p + 1], Yc[p:p + 1], go[p:p + 1].reshape(1, 1).numpy(), k, d)
+        assert rel_err(res[0][1][p], want[0]) <= 2 * be.ADJ_RESIDUAL_TOL, p
+
+
 def _mb_split_knob(on):
     os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
     _lib.load().sk_reload_knobs()

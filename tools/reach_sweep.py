@@ -137,6 +137,14 @@ def gated(g, be):
         sk = sigkernel_amd.SigKernel(RBF(0.9), d)
         Xg = walk(g, 5, M, D, f64).requires_grad_(True)
         sk.compute_Gram(Xg, walk(g, 7, N, D, f64)).sum().backward()
+    # paired batches of more pairs than resident lane groups, with a gradient: several pairs per lane group in the linear one-band
+    # adjoint (PAIRED), on the full wave and on fewer lanes
+    for d, M, Pn in ((0, 128, 5000), (0, 40, 9000), (1, 128, 5000), (1, 40, 9000), (2, 64, 5000), (2, 30, 9000)):
+        sk = sigkernel_amd.SigKernel(LIN(), d)
+        Xg = walk(g, Pn, M, 4, f64).requires_grad_(True)
+        sk.compute_kernel(Xg, walk(g, Pn, M, 4, f64)).sum().backward()
+        del Xg
+        torch.cuda.empty_cache()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
     # and more; its in-LDS band boundary (two bands, 126..157-point second paths)
     for kname, d, (M, N) in itertools.product(("linear", "rbf"), (0, 1, 2), ((65, 130), (129, 140), (129, 200), (100, 140))):
