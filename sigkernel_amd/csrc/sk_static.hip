@@ -161,7 +161,7 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
         // the x rows of this block, lanes = rows: they serve the extra node column, and (narrow paths) every row of the
         // sweep below reads its x through v_readlane from here -- a scalar load per row and dimension would put one
         // scalar-cache round trip on the critical path of every iteration
-        constexpr bool XREG = DMAX <= 8;
+        constexpr bool XREG = DMAX <= 8 || (NV == 1 && DMAX <= 32);
         double xr[NV][XREG ? DMAX : 1], xsq[NV];   // xsq: |x_row|^2, computed once per row here instead of once per node
         TA E[NV];
         {
@@ -324,6 +324,8 @@ __global__ __launch_bounds__(NT) void k_linear_adj_dyt(const double *__restrict_
 // once for the RM rows, and RM + 1 rows of W (t_r = W[r][n] - W[r][n-1], dG[m,n] = t_m - t_{m-1}) instead of 4 W values
 // per node -- the first version (one row per block) re-read every W row twice and every y node RM times more often.
 template <typename T, int DMAX, int NT, int RM>
+// (fp64, 17..32 dims: 260 VGPRs, one wave per SIMD.  Held to 256 -- two waves -- it is SLOWER, 12.1 -> 13.0 ms per 256 x 256 pairs of 64
+// points at dim 20, profiles/r06_wide_dims.txt: the kernel is bound by what it re-reads from L2 -- every block streams all of Y -- not by latency)
 __global__ __launch_bounds__(NT) void k_static_rbf_adj(const T *__restrict__ X, const T *__restrict__ Y,
                                                        const T *__restrict__ W, int64_t ldw, const T *__restrict__ scale,
                                                        int64_t B, int M, int N, int D, double inv_sigma, int row_groups,
