@@ -560,6 +560,93 @@ __global__ __launch_bounds__(NT *NW) void k_rbf_adj2(const T *__restrict__ X, co
     }
 }
 
+// The same for paths of 17..32 dims (one node row per wave: RM = 1 there), with the y points of a pair shared by the FOUR waves of a block
+// through LDS: in k_static_rbf_adj every (a, row) block streams all of Y from L2 -- 43 GB per launch at 256 x 256 pairs of 64 points and
+// 20 dims, 7.3 ms, 54 % of that gradient step (profiles/r06_api_profile.txt); holding the kernel to two waves per SIMD made it slower: it is
+// bound by that traffic.  Here a block owns four consecutive node rows of x_a; per pair its 256 threads copy y_b to LDS once (coalesced,
+// double-buffered, one barrier per pair) and every wave reads its column's point from there -- rows of DMAX + 1 doubles, so the 64 lanes
+// of a wave fall on different banks.  The arithmetic per (pair, node) is that of k_static_rbf_adj, operand for operand.
+constexpr int ADJT_NW = 4;
+constexpr int ADJT_NMAX = 128;
+template <typename T, int DMAX>
+__global__ __launch_bounds__(64 * ADJT_NW) void k_static_rbf_adj_tiled(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
+                                                                       const T *__restrict__ scale, int64_t B, int M, int N, int D, double inv_sigma,
+                                                                       int row_groups, T *__restrict__ gX) {
+    constexpr int DS = DMAX + 1;
+    extern __shared__ __attribute__((aligned(16))) double ysh[];      // [2][N][DS]
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t a = blockIdx.x / row_groups;
+    const int wv_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = (int)(blockIdx.x % row_groups) * ADJT_NW + wv_id;      // this wave's node row (>= M: it only keeps the barriers)
+    const bool row_ok = m < M;
+    const int mr = min(m, M - 1);
+    double xm[DMAX], acc[DMAX], xs = 0.0;
+    {
+        const T *x = X + (a * M + mr) * (int64_t)D;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            xm[k] = k < D ? (double)x[k] : 0.0;
+            xs = fma(xm[k], xm[k], xs);
+            acc[k] = 0.0;
+        }
+    }
+    const int64_t nb = B > 0 ? B : 1;
+    const int nd = N * D;
+    auto stage = [&](int64_t bb, int buf) {      // y_bb -> LDS buffer `buf` (all threads of the block)
+        const int64_t b = B > 0 ? bb : a;
+        const T *y = Y + b * (int64_t)N * D;
+        double *dst = ysh + (size_t)buf * N * DS;
+        for (int i = threadIdx.x; i < nd; i += 64 * ADJT_NW) {
+            const int n = i / D, k = i - n * D;
+            dst[n * DS + k] = (double)y[i];
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int64_t bb = 0; bb < nb; ++bb) {
+        if (bb + 1 < nb) stage(bb + 1, (int)((bb + 1) & 1));
+        const int64_t p = B > 0 ? a * B + bb : a;
+        const double sc = scale ? (double)scale[p] : 1.0;
+        const T *w = W + p * (int64_t)Mc * ldw;
+        const double *yb = ysh + (size_t)(bb & 1) * N * DS;
+        if (row_ok)
+            for (int n = lane; n < N; n += 64) {
+                const int nl = max(n - 1, 0), nr = min(n, Nc - 1);
+                const bool lf = n >= 1, rt = n < Nc;
+                double t[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {      // W rows m - 1 + r (zero outside the matrix)
+                    const int wr = m - 1 + r;
+                    const bool ok = wr >= 0 && wr < Mc;
+                    const int64_t ro = (int64_t)min(max(wr, 0), Mc - 1) * ldw;
+                    const double wl = (double)w[ro + nl], wr_ = (double)w[ro + nr];
+                    t[r] = ((ok && rt) ? wr_ : 0.0) - ((ok && lf) ? wl : 0.0);
+                }
+                double ys = 0.0, xy = 0.0, dk[DMAX];
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) {
+                    const double yk = k < D ? yb[n * DS + k] : 0.0;
+                    ys = fma(yk, yk, ys);
+                    dk[k] = yk - xm[k];
+                    xy = fma(xm[k], yk, xy);
+                }
+                const double g = exp_nonpos(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+                const double c = sc * (t[1] - t[0]) * g;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, dk[k], acc[k]);
+            }
+        __syncthreads();
+    }
+    // sum c (x_m - y) = - sum c d  (d = y - x_m): the lanes' sums added up, dL/dx = (-2 / sigma) of it
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        double v = -acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && k < D && row_ok) gX[(a * M + m) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
+    }
+}
+
 template <typename T, int DMAX, int NT>
 int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
@@ -582,8 +669,22 @@ int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T 
 template <typename T, int DMAX>
 int launch_static_adj_nt(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                          int64_t B, int M, int N, int D, T *out, hipStream_t s) {
-    if (N <= 80) return launch_static_adj_d<T, DMAX, 64>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
-    return launch_static_adj_d<T, DMAX, 128>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    if constexpr (DMAX >= 24) {     // 17..32 dims: the y points of a pair through LDS, shared by four rows' waves (k_static_rbf_adj_tiled)
+        if (kind == 1 && N <= ADJT_NMAX) {
+            const int rgs = (M + ADJT_NW - 1) / ADJT_NW;
+            const int64_t blk = A * rgs;
+            if (blk > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            const size_t lds = sizeof(double) * 2 * (size_t)N * (DMAX + 1);
+            auto kern = k_static_rbf_adj_tiled<T, DMAX>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            SK_LAUNCH(kern, dim3((unsigned)blk), dim3(64 * ADJT_NW), lds, s, X, Y, W, ldw, scale, B, M, N, D, 1.0 / param, rgs, out);
+            return check_launch();
+        }
+        return launch_static_adj_d<T, DMAX, 128>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    } else {
+        if (N <= 80) return launch_static_adj_d<T, DMAX, 64>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+        return launch_static_adj_d<T, DMAX, 128>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    }
 }
 
 template <typename T, int DMAX>
@@ -672,6 +773,7 @@ int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const 
     if (D <= 4) return launch_static_adj_nt<T, 4>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     if (D <= 8) return launch_static_adj_nt<T, 8>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     if (D <= 16) return launch_static_adj_nt<T, 16>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+    if (D <= 24) return launch_static_adj_nt<T, 24>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);   // (lead-lag of 8..11 dims + time)
     if (D <= 32) return launch_static_adj_nt<T, 32>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     return SK_ERR_UNSUPPORTED;
 }

@@ -145,6 +145,11 @@ def gated(g, be):
         sk.compute_kernel(Xg, walk(g, Pn, M, 4, f64)).sum().backward()
         del Xg
         torch.cuda.empty_cache()
+    # paths of 25..32 dims with a gradient (the static adjoint's 32-dim instances; the sweep above has 20 dims: the 24-dim ones)
+    for dt, (M, N) in itertools.product((f64, f32), ((40, 50), (30, 140))):
+        sk = sigkernel_amd.SigKernel(RBF(0.9), 1)
+        Xg = walk(g, 3, M, 30, dt).requires_grad_(True)
+        sk.compute_Gram(Xg, walk(g, 4, N, 30, dt)).sum().backward()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
     # and more; its in-LDS band boundary (two bands, 126..157-point second paths)
     for kname, d, (M, N) in itertools.product(("linear", "rbf"), (0, 1, 2), ((65, 130), (129, 140), (129, 200), (100, 140))):
