@@ -762,6 +762,7 @@ int launch_static_increments(int kind, double param, const T *X, const T *Y, int
     if (D <= 4) return launch_static_d<T, 4>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);
     if (D <= 8) return launch_static_d<T, 8>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);
     if (D <= 16) return launch_static_d<T, 16>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);
+    if (D <= 24) return launch_static_d<T, 24>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);   // (lead-lag of 8..11 dims + time: 17..23)
     if (D <= 32) return launch_static_d<T, 32>(kind, param, X, Y, A, B, M, N, D, inc, ld, s);
     return SK_ERR_UNSUPPORTED;   // wide paths: the caller uses the generic static kernel + sk_increments
 }

@@ -146,8 +146,8 @@ def gated(g, be):
         del Xg
         torch.cuda.empty_cache()
     # paths of 25..32 dims with a gradient (the static adjoint's 32-dim instances; the sweep above has 20 dims: the 24-dim ones)
-    for dt, (M, N) in itertools.product((f64, f32), ((40, 50), (30, 140))):
-        sk = sigkernel_amd.SigKernel(RBF(0.9), 1)
+    for kname, dt, (M, N) in itertools.product(("rbf", "linear"), (f64, f32), ((40, 50), (30, 140))):
+        sk = sigkernel_amd.SigKernel(RBF(0.9) if kname == "rbf" else LIN(), 1)
         Xg = walk(g, 3, M, 30, dt).requires_grad_(True)
         sk.compute_Gram(Xg, walk(g, 4, N, 30, dt)).sum().backward()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
