@@ -163,9 +163,12 @@ __device__ __forceinline__ void lds_read_pair_start<2, 2>(d2_t (&x)[2], d2_t (&c
 
 // YS: 0 = first-argument sums; 1 = both (the triangular K_XX; dims <= 4); 2 = the SECOND-argument sums only (route FUSED_SWAP: all the
 // swapped call needs -- no first-argument accumulators, no second read of the y points; the only second-argument form of dims 5..8)
-template <int DY, int RC, bool FULLWAVE, int ND, int YS>
+// PAIRED: a paired batch (B == 0) with SEVERAL pairs per lane group (sk_wave_adj_fused.hip): a lane stores and clears its sums when a pair
+// of its run is complete -- at the FIRST step of the next one, whose c2 terms still belong to the pair before
+template <int DY, int RC, bool FULLWAVE, int ND, int YS, bool PAIRED = false>
 __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) void k_adj_fused_rbf(const AdjRbfParams prm) {
     constexpr bool YSIDE = YS != 0;
+    static_assert(!PAIRED || YS == 0, "several pairs per lane group: first-argument sums only");
     static_assert(YS != 1 || ND == 4, "both sets of sums fit for paths of dim <= 4 only");
     constexpr int CW = 2;
     constexpr int R = RC << DY, S = CW << DY, r = 1 << DY;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     // c2 -- at the first step of a pair the c2 terms still belong to the pair before.  The weights themselves stay unscaled (the
     // second-argument sums are weighted by the caller) and are SELECTED to zero outside the group's pairs.
     double sx = 0.0, sx_d = 0.0;
-    int valid = 0;
+    int valid = 0, valid_d = 0;      // (valid_d, PAIRED: whether the pair BEFORE the one being swept is one of the group's)
     d2_t car[YSIDE ? NCAR : 1];    // YSIDE: S0 / S1[0..ND) of node columns (c1, c2), summed over the node rows of the lanes above
 #pragma unroll
     for (int i = 0; i < (YSIDE ? NCAR : 1); ++i) car[i] = d2_t{0.0, 0.0};
@@ -596,6 +599,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             asm volatile("" ::: "memory");
             lds_read_ydims<ND>(yv, ya + (unsigned)(ypar << 7), ya + (unsigned)((ypar ^ 1) << 7));
         }
+        double cbA[PAIRED ? RC + 1 : 1], cbB[PAIRED ? RC + 1 : 1];     // PAIRED: V G of the node rows r_k (k < RC) and of the bottom lane's node row 0 at columns c1, c2
 #pragma unroll
         for (int k = 0; k < RC; ++k) {
             const double u0 = k == 0 ? wup0[0] : wk[(k + RC - 1) % RC][0];     // cells of coarse row p_k + 1
@@ -606,7 +610,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double V1 = ((wk[k][0] + u1) - wk[k][1]) - u0;
             const double V2 = ((wk[k][1] + u2) - wkP[k]) - u1;
             const double cb1 = V1 * g1, cb2 = V2 * g2;
-            if constexpr (!YONLY) {
+            if constexpr (PAIRED) { cbA[k] = cb1; cbB[k] = cb2; }
+            if constexpr (!YONLY && !PAIRED) {
                 const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
                 cs[k] += cv1 + cv2;
 #pragma unroll
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
             const double V1 = wk[RC - 1][1] - wk[RC - 1][0];
             const double V2 = wkP[RC - 1] - wk[RC - 1][1];
             const double cb1 = V1 * Gown[RC - 1][1], cb2 = V2 * GownP[RC - 1];
-            if constexpr (!YONLY) {
+            if constexpr (PAIRED) { cbA[RC] = cb1; cbB[RC] = cb2; }
+            if constexpr (!YONLY && !PAIRED) {
                 const double cv1 = cb1 * sx, cv2 = cb2 * sx_d;
                 if (is_bot) {
                     asm volatile("");
@@ -662,6 +668,53 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
                 }
             }
         }
+        // -- PAIRED: the first-argument sums, weighted by the upstream gradient of the pair a column belongs to (c2 at a pair's first step: the
+        //    pair before -- which that step completes, stores and clears)
+        if constexpr (PAIRED) {
+            auto add = [&](double w1, double w2) __attribute__((always_inline)) {
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    const double cv1 = cbA[k] * w1, cv2 = cbB[k] * w2;
+                    cs[k] += cv1 + cv2;
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) accd[k][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[k][j]));
+                }
+                if (is_bot) {
+                    asm volatile("");
+                    const double cv1 = cbA[RC] * w1, cv2 = cbB[RC] * w2;
+                    cs[RC] += cv1 + cv2;
+#pragma unroll
+                    for (int j = 0; j < ND; ++j) accd[RC][j] = fma(cv1, yv[j][1], fma(cv2, yP[j], accd[RC][j]));
+                }
+            };
+            {
+                if (u == 0) {
+                    asm volatile("");
+                    add(0.0, sx_d);       // the c2 terms complete the pair before: out it goes (slot = pair), the sums start over
+                    if (valid_d) {
+                        double *base = prm.Gpart + (pair0 + ps - 1) * (int64_t)(Mcp + 1) * OUTW;
+#pragma unroll
+                        for (int k = 0; k <= RC; ++k) {
+                            if (k == RC && !is_bot) break;
+                            const int row = k == RC ? 0 : Mcp - lam * RC - k;
+                            double *dst = base + (int64_t)row * OUTW;
+                            *reinterpret_cast<d2_t *>(dst) = d2_t{cs[k], 0.0};
+#pragma unroll
+                            for (int j = 0; j < ND; j += 2) *reinterpret_cast<d2_t *>(dst + 2 + j) = d2_t{accd[k][j], accd[k][j + 1]};
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k <= RC; ++k) {
+                        cs[k] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < ND; ++j) accd[k][j] = 0.0;
+                    }
+                    add(sx, 0.0);
+                } else {
+                    add(sx, sx_d);
+                }
+            }
+        }
         // -- histories for the next macro-step (and for the lane below, which reads lastOwn / lastW at its top)
         wupP = wup0[0];
         GabvP = Gabv[0];
@@ -674,6 +727,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         lastOwn[0] = Gown[RC - 1][0]; lastOwn[1] = Gown[RC - 1][1];
         lastW[0] = wk[RC - 1][0]; lastW[1] = wk[RC - 1][1];
         sx_d = sx;
+        if constexpr (PAIRED) valid_d = valid;
 
         // -- self-check on the last flipped unit (see sk_wave_adj.hip)
         if (u == NUp - 1 && prm.err && valid) {
@@ -697,7 +751,7 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
         atomicMax(reinterpret_cast<unsigned long long *>(prm.err + chk_pair), (unsigned long long)__double_as_longlong(chk_val));
 
     // ---- the group's partial sums: Gpart[group][node row][OUTW], node row r_k = Mcp - lam RC - k; node row 0 from the bottom lane
-    if constexpr (!YONLY) {
+    if constexpr (!YONLY && !PAIRED) {
         if (pair0 < prm.P) {
             double *base = prm.Gpart + gslot * (int64_t)(Mcp + 1) * OUTW;
 #pragma unroll
@@ -714,9 +768,9 @@ __global__ __launch_bounds__(4 * WAVE) __attribute__((amdgpu_waves_per_eu(2))) v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DY, int RC, bool FULLWAVE, int ND, int YS>
+template <int DY, int RC, bool FULLWAVE, int ND, int YS, bool PAIRED = false>
 int launch_adjr(const AdjRbfParams &prm, size_t lds_block, hipStream_t s) {
-    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YS>;
+    auto kern = k_adj_fused_rbf<DY, RC, FULLWAVE, ND, YS, PAIRED>;
     if (lds_block > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_block);
     SK_LAUNCH(kern, dim3(wave_group_blocks(prm.wg)), dim3(WAVE * prm.wg.wpb), lds_block, s, prm);
@@ -774,6 +828,13 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     const int64_t max_groups = (int64_t)n_cu * wpc * G;
     // pairs per lane group: see pick_chunk (paired batches: every pair has its own x, one pair per lane group)
     int64_t PPG = pick_chunk(A, B, max_groups);
+    // paired batches of more pairs than resident lane groups (dims <= 4): several consecutive pairs per lane group (PAIRED)
+    int64_t ppp = 1;
+    if (B <= 0 && ys == 0 && ND == 4) {
+        ppp = g.P / max_groups;
+        ppp = ppp < 1 ? 1 : (ppp > 64 ? 64 : ppp);
+        PPG = ppp;
+    }
     if (force_nch > 0) PPG = (B + force_nch - 1) / force_nch;
     else if (rows_per_launch) {
         // Shares by wave age rank (ChunkSplit) need a launch that fills the chip exactly, with the chunks of an a a multiple of
@@ -797,14 +858,14 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         }
     }
     if (PPG > 0x3fffffff / NUp || g.P >= 0x7ff00000LL) return SK_ERR_UNSUPPORTED;   // (pair indices are divided in 32 bits inside the kernel)
-    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : g.P;
+    const int64_t groups = B > 0 ? A * chunks_of(B, PPG) : (g.P + ppp - 1) / ppp;
     const int OUTW = ND + 2;
     if (ppg_out) *ppg_out = (int)PPG;
     if (rows_out) *rows_out = L * RC + 1;
     if (outw_out) *outw_out = OUTW;
     if (ycols_out) *ycols_out = 2 * NUp;
     if (!gpart && !ypart) return SK_OK;
-    if (gpart && gpart_doubles < (size_t)groups * (L * RC + 1) * OUTW) return SK_ERR_WORKSPACE;
+    if (gpart && gpart_doubles < (size_t)(B > 0 ? groups : g.P) * (L * RC + 1) * OUTW) return SK_ERR_WORKSPACE;   // (paired: a slot per pair)
     const int64_t waves = (groups + G - 1) / G;
 
     AdjRbfParams prm;
@@ -816,11 +877,16 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
     prm.n_steps = (int)(PPG * NUp + (L - 1)) + 1;    // + 1: node column 0 of the last pair completes one step later
     prm.wg = wave_group(lds_bytes, waves, knobs().adjr_wpb);
     prm.cs = chunk_split(A, B, PPG, max_groups, G, prm.wg.wpb, n_cu, knobs().adjr_rank_w);
+    prm.cs.ppp = (int)ppp;
     const size_t lds_block = wave_group_lds(prm.wg);
     const bool full = logL == 6;
     int rc;
     const bool yonly = ys == 2;
-    if (DY == 0) {
+    if (ppp > 1) {
+        if (DY == 0) rc = full ? launch_adjr<0, 2, true, 4, 0, true>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 0, true>(prm, lds_block, s);
+        else if (DY == 1) rc = full ? launch_adjr<1, 2, true, 4, 0, true>(prm, lds_block, s) : launch_adjr<1, 2, false, 4, 0, true>(prm, lds_block, s);
+        else rc = full ? launch_adjr<2, 1, true, 4, 0, true>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, 0, true>(prm, lds_block, s);
+    } else if (DY == 0) {
         if (yonly && ND == 8) rc = full ? launch_adjr<0, 2, true, 8, 2>(prm, lds_block, s) : launch_adjr<0, 2, false, 8, 2>(prm, lds_block, s);
         else if (yonly) rc = full ? launch_adjr<0, 2, true, 4, 2>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 2>(prm, lds_block, s);
         else if (ypart) rc = full ? launch_adjr<0, 2, true, 4, 1>(prm, lds_block, s) : launch_adjr<0, 2, false, 4, 1>(prm, lds_block, s);
@@ -839,8 +905,11 @@ int launch_adj_fused_rbf_rows(const double *Xr, const double *Yt, int64_t A, int
         rc = full ? launch_adjr<2, 1, true, 4, 0>(prm, lds_block, s) : launch_adjr<2, 1, false, 4, 0>(prm, lds_block, s);
     }
     if (rc != SK_OK || !rescue || !rescue_ws) return rc;
+    ChunkSplit rcs = prm.cs;      // (paired: every pair has its slot whatever the lane groups swept -- the rescue walks pairs)
+    rcs.ppp = 1;
+    if (B <= 0) rcs.size[0] = 1;
     return launch_fused_rescue(1, Xr, Yt, scale_orig, err, rescue->tol, gpart, ypart, A, B, Mrows, Ncp, D, g, L * RC + 1, OUTW, 2 * NUp, inv_sigma,
-                               prm.cs, groups, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
+                               rcs, B > 0 ? groups : g.P, rescue_ws, rescue_ws_bytes, s, 8, nullptr, 0, rescue->kfinal);
 }
 }  // namespace
 

@@ -301,11 +301,11 @@ def test_baseline_kernels_keep_their_waves_per_simd():
     need = {"k_fwd_fused<double, 1, false, false, false, 0, 8, 4>": 2,          # C3 (headline)
             "k_fwd_fused<double, 1, false, false, false, 1, 4, 4>": 2,          # C2
             "k_fwd_fused<double, 1, false, false, true, 1, 4, 4>": 2,           # the training-sized steps' forward
-            "k_adj_fused_rbf<1, 2, false, 4, 0>": 2,                        # ... and adjoint
+            "k_adj_fused_rbf<1, 2, false, 4, 0, false>": 2,                        # ... and adjoint
             "k_fwd_fused<double, 2, false, false, true, 1, 4, 2>": 3,           # C4: forward with edges
             "k_fwd_fused<double, 2, false, true, false, 1, 4, 0>": 3,           # C4: K_YY
-            "k_adj_fused_rbf<2, 1, true, 4, 0>": 2,                         # C4: adjoint of K_XY
-            "k_adj_fused_rbf<2, 1, true, 4, 1>": 2,                          # C4: triangle of K_XX with second-argument sums
+            "k_adj_fused_rbf<2, 1, true, 4, 0, false>": 2,                         # C4: adjoint of K_XY
+            "k_adj_fused_rbf<2, 1, true, 4, 1, false>": 2,                          # C4: triangle of K_XX with second-argument sums
             "k_fwd_fused_mb<float, 2, true, 1, 16, false, 1, false>": 2}        # C5
     for name, waves in need.items():
         assert name in vgpr, name

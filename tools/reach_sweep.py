@@ -139,8 +139,8 @@ def gated(g, be):
         sk.compute_Gram(Xg, walk(g, 7, N, D, f64)).sum().backward()
     # paired batches of more pairs than resident lane groups, with a gradient: several pairs per lane group in the linear one-band
     # adjoint (PAIRED), on the full wave and on fewer lanes
-    for d, M, Pn in ((0, 128, 5000), (0, 40, 9000), (1, 128, 5000), (1, 40, 9000), (2, 64, 5000), (2, 30, 9000)):
-        sk = sigkernel_amd.SigKernel(LIN(), d)
+    for kname, (d, M, Pn) in itertools.product(("linear", "rbf"), ((0, 128, 5000), (0, 40, 9000), (1, 128, 5000), (1, 40, 9000), (2, 64, 5000), (2, 30, 9000))):
+        sk = sigkernel_amd.SigKernel(LIN() if kname == "linear" else RBF(0.9), d)
         Xg = walk(g, Pn, M, 4, f64).requires_grad_(True)
         sk.compute_kernel(Xg, walk(g, Pn, M, 4, f64)).sum().backward()
         del Xg
