@@ -40,21 +40,41 @@ __global__ __launch_bounds__(SK_TPB) void k_static_linear(const T *__restrict__ 
         for (int k = 0; k < DMAX; ++k)
             dy[c][k] = (k < D && q < Nc) ? s2 * ((double)y[(int64_t)(q + 1) * D + k] - (double)y[(int64_t)q * D + k]) : 0.0;
     }
-    for (int i = 0; i < Mc; ++i) {
-        double acc[LIN_CPT];
+    {
+        // the row differences of x through LDS -- lane = row forms its DMAX differences once per tile of 64 rows, every row of
+        // the sweep reads them back with DMAX / 2 broadcast ds_read_b128.  (As 2 D scalar loads per row they put a scalar-cache round trip
+        // on every row's critical path: 256 x 256 pairs of 64 points, dim 32: 3.7 ms, dim 8: 0.75; now 1.1 / 0.39 -- dim <= 8 at the
+        // speed the increments can be written; profiles/r06_wide_dims.txt.)
+        __shared__ __attribute__((aligned(16))) double xl[SK_TPB * DMAX];
+        for (int i0 = 0; i0 < Mc; i0 += SK_TPB) {
+            __syncthreads();
+            {
+                const int ir = min(i0 + (int)threadIdx.x, Mc - 1);
 #pragma unroll
-        for (int c = 0; c < LIN_CPT; ++c) acc[c] = 0.0;
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k)
-            if (k < D) {
-                const double dx = (double)x[(int64_t)(i + 1) * D + k] - (double)x[(int64_t)i * D + k];
-#pragma unroll
-                for (int c = 0; c < LIN_CPT; ++c) acc[c] = fma(dx, dy[c][k], acc[c]);
+                for (int k = 0; k < DMAX; k += 2) {
+                    const double d0 = k < D ? (double)x[(int64_t)(ir + 1) * D + k] - (double)x[(int64_t)ir * D + k] : 0.0;
+                    const double d1 = k + 1 < D ? (double)x[(int64_t)(ir + 1) * D + k + 1] - (double)x[(int64_t)ir * D + k + 1] : 0.0;
+                    *reinterpret_cast<double2 *>(&xl[threadIdx.x * DMAX + k]) = double2{d0, d1};
+                }
             }
+            __syncthreads();
+            const int rows = min(SK_TPB, Mc - i0);
+            for (int r = 0; r < rows; ++r) {
+                double acc[LIN_CPT];
 #pragma unroll
-        for (int c = 0; c < LIN_CPT; ++c) {
-            const int q = c0 + c * SK_TPB + threadIdx.x;
-            if (q < ld) o[(int64_t)i * ld + q] = (T)acc[c];   // columns >= Nc: dy == 0 -> the zero padding
+                for (int c = 0; c < LIN_CPT; ++c) acc[c] = 0.0;
+#pragma unroll
+                for (int k = 0; k < DMAX; k += 2) {
+                    const double2 dx = *reinterpret_cast<const double2 *>(&xl[r * DMAX + k]);   // the same address in every lane: a broadcast
+#pragma unroll
+                    for (int c = 0; c < LIN_CPT; ++c) acc[c] = fma(dx.y, dy[c][k + 1], fma(dx.x, dy[c][k], acc[c]));
+                }
+#pragma unroll
+                for (int c = 0; c < LIN_CPT; ++c) {
+                    const int q = c0 + c * SK_TPB + threadIdx.x;
+                    if (q < ld) o[(int64_t)(i0 + r) * ld + q] = (T)acc[c];
+                }
+            }
         }
     }
 }
