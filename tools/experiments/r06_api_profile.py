@@ -37,5 +37,20 @@ elif case == "deriv":
 elif case == "swap_bwd":
     sk = sigkernel_amd.SigKernel(LIN(), 1); X, Y = walk(128, 512, 8), walk(128, 64, 8)
     def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "lin_dim20":
+    sk = sigkernel_amd.SigKernel(LIN(), 1); X, Y = walk(256, 64, 20), walk(256, 64, 20)
+    def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "rbf_dim12":
+    sk = sigkernel_amd.SigKernel(RBF(1.0), 1); X, Y = walk(256, 64, 12), walk(256, 64, 12)
+    def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "generic":
+    class Poly:
+        def Gram_matrix(self, X, Y): return (1.0 + torch.einsum("amd,bnd->abmn", X, Y)) ** 2
+        def batch_kernel(self, X, Y): return (1.0 + torch.einsum("amd,and->amn", X, Y)) ** 2
+    sk = sigkernel_amd.SigKernel(Poly(), 1); X, Y = walk(128, 64, 5), walk(128, 64, 5)
+    def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "rbf_d3":
+    sk = sigkernel_amd.SigKernel(RBF(1.0), 3); X, Y = walk(128, 64, 3), walk(128, 64, 3)
+    def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
 for _ in range(8): step()
 torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # (GPU box) rocprofv3 kernel summaries of a handful of public calls -> gpurun_out/r06_api_profile.txt
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/r06_api_profile.txt; : > $OUT; cd /tmp
-for c in gram_bwd_128 gram_bwd_1024_lin sym_bwd_1024 mmd_512 gram_bwd_f32 stream_dim20 mb_bwd_300 deriv swap_bwd; do
+for c in ${@:-gram_bwd_128 gram_bwd_1024_lin sym_bwd_1024 mmd_512 gram_bwd_f32 stream_dim20 mb_bwd_300 deriv swap_bwd lin_dim20 rbf_dim12 generic rbf_d3}; do
   rm -rf /tmp/apiprof; rocprofv3 --kernel-trace --stats -f csv -d /tmp/apiprof -o p -- python $R/tools/experiments/r06_api_profile.py $c > /dev/null 2>&1
   echo "== $c (8 steps)" >> $OUT
   python - >> $OUT <<PY
