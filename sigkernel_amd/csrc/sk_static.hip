@@ -181,7 +181,11 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
         // the x rows of this block, lanes = rows: they serve the extra node column, and (narrow paths) every row of the
         // sweep below reads its x through v_readlane from here -- a scalar load per row and dimension would put one
         // scalar-cache round trip on the critical path of every iteration
-        constexpr bool XREG = DMAX <= 8 || (NV == 1 && DMAX <= 32);
+        // (9..32 dims, plain increments: through LDS instead -- lane = row writes its DMAX values once per tile, every row of the sweep is
+        // DMAX / 2 broadcast ds_read_b128, issued ONE ROW AHEAD of its use: the kernel is 89 % VALU-busy and 64 v_readlane per row were a
+        // third of its vector instructions, profiles/r06_wide_dims.txt)
+        constexpr bool XREG = DMAX <= 8, XLDS = NV == 1 && DMAX > 8;
+        __shared__ __attribute__((aligned(16))) double xl[XLDS ? SK_TPB * DMAX : 2];
         double xr[NV][XREG ? DMAX : 1], xsq[NV];   // xsq: |x_row|^2, computed once per row here instead of once per node
         TA E[NV];
         {
@@ -195,23 +199,47 @@ __global__ __launch_bounds__(SK_TPB) void k_static_nodes(const T *__restrict__ X
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) xr[v][k] = xv[k];
                 }
+                if constexpr (XLDS) {
+                    __syncthreads();      // (the rows of the tile before have been swept)
+#pragma unroll
+                    for (int k = 0; k < DMAX; k += 2) *reinterpret_cast<double2 *>(&xl[lane * DMAX + k]) = double2{xv[k], xv[k + 1]};
+                    __syncthreads();
+                }
                 xsq[v] = sqnorm<DMAX>(xv);
                 E[v] = (TA)static_node<DMAX, KIND, NV == 1>(xv, xsq[v], ye, yse, inv_sigma);
             }
         }
         const int rows = min(SK_TPB, M - i0);
+        double xnext[XLDS ? DMAX : 1];      // XLDS: the x of the row after the one being evaluated, already on its way from LDS
+        if constexpr (XLDS) {
+#pragma unroll
+            for (int k = 0; k < DMAX; k += 2) {
+                const double2 t2 = *reinterpret_cast<const double2 *>(&xl[k]);
+                xnext[k] = t2.x; xnext[k + 1] = t2.y;
+            }
+        }
         for (int r = 0; r < rows; ++r) {
             const int i = i0 + r;
             TA g[CPT][NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 double xv[DMAX];
+                if constexpr (XLDS) {
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) xv[k] = xnext[k];
+                    const int rn = min(r + 1, SK_TPB - 1);
+#pragma unroll
+                    for (int k = 0; k < DMAX; k += 2) {      // the same address in every lane: a broadcast
+                        const double2 t2 = *reinterpret_cast<const double2 *>(&xl[rn * DMAX + k]);
+                        xnext[k] = t2.x; xnext[k + 1] = t2.y;
+                    }
+                }
 #pragma unroll
                 for (int k = 0; k < DMAX; ++k) {
                     if constexpr (XREG) xv[k] = readlane_f64(xr[v][k], r);                       // wave-uniform
-                    else xv[k] = (double)xs[v][(int64_t)i * D + min(k, D - 1)];   // unconditional (mergeable) scalar loads
+                    else if constexpr (!XLDS) xv[k] = (double)xs[v][(int64_t)i * D + min(k, D - 1)];   // unconditional (mergeable) scalar loads
                 }
-                if constexpr (!XREG) {
+                if constexpr (!XREG && !XLDS) {
 #pragma unroll
                     for (int k = 0; k < DMAX; ++k) xv[k] = k < D ? xv[k] : 0.0;
                 }
