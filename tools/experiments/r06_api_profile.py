@@ -52,5 +52,17 @@ elif case == "generic":
 elif case == "rbf_d3":
     sk = sigkernel_amd.SigKernel(RBF(1.0), 3); X, Y = walk(128, 64, 3), walk(128, 64, 3)
     def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "c5_grad":
+    sk = sigkernel_amd.SigKernel(RBF(1.0), 2); X, Y = walk(256, 512, 16, f32), walk(256, 512, 16, f32)
+    def step(): Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+elif case == "sym_wide":
+    sk = sigkernel_amd.SigKernel(RBF(1.0), 1); X = walk(512, 64, 20)
+    def step(): sk.compute_Gram(X, X, sym=True)
+elif case == "deriv_generic":
+    class Poly:
+        def Gram_matrix(self, X, Y): return (1.0 + torch.einsum("amd,bnd->abmn", X, Y)) ** 2
+        def batch_kernel(self, X, Y): return (1.0 + torch.einsum("amd,and->amn", X, Y)) ** 2
+    sk = sigkernel_amd.SigKernel(Poly(), 1); X, Y = walk(128, 64, 5), walk(128, 64, 5); G = torch.randn(128, 64, 5, generator=g, dtype=torch.float64).cuda()
+    def step(): sk.compute_kernel_and_derivatives_Gram(X, Y, G)
 for _ in range(8): step()
 torch.cuda.synchronize()
