@@ -89,6 +89,11 @@ const CostEntry COSTS[] = {
      "the square / the merged block K(X, [X; Y]): 128 x 128 pairs of 64 points take 0.4 ms in one launch, 0.8 ms in 8 blocks; merged loss "
      "15.1 vs 15.5 ms composed at 512 x 512 (4e9 cells, r04_merged_loss), C4 (2.7e11) 349 ms composed"},
     {"sym_min_rows", 32, "least rows per block of the triangular adjoint: 64 paths of length 700 in 8 blocks of 8 rows: backward 60 -> 74 ms"},
+    {"sym_stream_min_paths", 224,
+     "compute_Gram(X, X, sym=True) without a gradient on the STREAMING route (wide paths, dyadic >= 3, user-defined kernels): paths from "
+     "which the blocked triangle replaces the one block of all pairs whatever the grid -- the node evaluation and the increments are most of a "
+     "pair's cost there (r06_sym_stream, rbf dim 20, 64 points, d = 1: 192 paths 0.91x, 256 paths 1.52 -> 1.09 ms, 512 paths 5.76 -> 3.48; "
+     "rbf dim 3 d = 3: 192 paths 1.15x, 256 paths 0.84x)"},
     {"paired_merge_cells", 2e9,
      "grid cells of a paired batch below which compute_distance solves k(X, X) and k(X, Y) as ONE batch of 2n pairs (launch- and fill-bound there)"},
     {"mmd_streams_max_pairs", 16384,

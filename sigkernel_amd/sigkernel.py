@@ -399,6 +399,7 @@ class _SigKernel(torch.autograd.Function):
 _SYM_TILES = None              # "sym_tiles": row tiles of the symmetric shortcut: work = (T + 1) / (2 T) of the full Gram
 _SYM_MIN_CELLS = None          # "sym_min_cells": below this the extra launches cost more than the saved solves
 _SYM_MIN_ROWS = None           # "sym_min_rows": rows per block of the triangular adjoint
+_SYM_STREAM_MIN_PATHS = None   # "sym_stream_min_paths": the streaming route's symmetric forward takes the blocked triangle from this many paths
 _KEEP_EDGES_FRACTION = None    # "keep_edges_fraction": of the transient budget, what may stay allocated between forward and backward
 _PAIRED_MERGE_CELLS = None     # "paired_merge_cells"
 _MMD_STREAMS_MAX_PAIRS = None  # "mmd_streams_max_pairs"
@@ -496,6 +497,11 @@ def _gram_symmetric(be, static_kernel, Xd, dyadic_order, naive, workspace_bytes,
     # length 64 take 0.4 ms in one launch, 0.8 ms in blocks)
     tiles = int(_cost("sym_tiles"))
     T = tiles if (A >= 8 * tiles and cells >= _cost("sym_min_cells")) else 1
+    if T == 1 and keep_blocks is None and A >= _cost("sym_stream_min_paths") and _SYM_MIN_CELLS is None and \
+            _route(be, OP_FORWARD, static_kernel, Xd, Xd, dyadic_order, naive, True) == STREAM:
+        # the streaming route (wide paths, dyadic >= 3, user-defined kernels): the static kernel and the increments are most of a pair's
+        # cost, the blocked triangle pays from ~200 paths on whatever the grid (profiles/r06_sym_stream.txt)
+        T = tiles
     if T > 1 and A >= 64 * T and keep_blocks is not None:
         T *= 2        # big batches with the fused adjoint: 16 row blocks solve 53 % of the square instead of 56 % (C4: -1 %)
     if keep_blocks is not None and T > 1:

@@ -659,6 +659,33 @@ def test_big_paired_batches_sweep_several_pairs_per_lane_group(kind, D, d, P, M,
         assert rel_err(res[0][1][p], want[0]) <= (1e-6 if (p == wild and kind == "rbf") else 2 * be.ADJ_RESIDUAL_TOL), p
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,D,d", [("rbf", 20, 1), ("linear", 12, 1), ("rbf", 3, 3)])
+def test_symmetric_forward_on_the_streaming_route_takes_the_blocked_triangle(kind, D, d, monkeypatch):
+    """compute_Gram(X, X, sym=True) without a gradient on the streaming route (wide paths, dyadic 3): from sym_stream_min_paths paths on
+    only the blocks on and above the diagonal are solved (the node evaluation and the increments are most of a pair's cost there) --
+    exactly symmetric, equal to the full computation."""
+    gen = torch.Generator().manual_seed(D + d)
+    k = sigkernel_amd.RBFKernel(0.9) if kind == "rbf" else sigkernel_amd.LinearKernel()
+    sk = sigkernel_amd.SigKernel(k, d)
+    A = int(_lib.cost("sym_stream_min_paths")) + 3
+    X = walk(gen, A, 24, D).to(DEV)
+    from sigkernel_amd import sigkernel as S
+    calls = []
+    orig = S._gram_block
+    monkeypatch.setattr(S, "_gram_block", lambda *a, **kw: (calls.append(a[2].shape[0]), orig(*a, **kw))[1])
+    K = sk.compute_Gram(X, X, sym=True)
+    assert len(calls) == int(_lib.cost("sym_tiles")) and sum(calls) == A, calls        # row blocks, not one block
+    monkeypatch.setattr(S, "_gram_block", orig)
+    K2 = sk.compute_Gram(X, X, sym=False)
+    assert torch.equal(K, K.t()) and rel_err(K.cpu().numpy(), K2.cpu().numpy()) <= 1e-12
+    # fewer paths: one block of all pairs
+    calls.clear()
+    monkeypatch.setattr(S, "_gram_block", lambda *a, **kw: (calls.append(a[2].shape[0]), orig(*a, **kw))[1])
+    sk.compute_Gram(X[:100], X[:100], sym=True)
+    assert calls == [100], calls
+
+
 def _mb_split_knob(on):
     os.environ["SK_FUSEDMB_SPLIT"] = "1" if on else "0"
     _lib.load().sk_reload_knobs()
