@@ -93,6 +93,16 @@ S._PAIRED_MERGE_CELLS = None
 report("paired_merge_cells", "rbf dim 4 d=1, compute_distance + backward, %d pairs of 64 points (just below the limit)" % n,
        "one batch of 2n pairs", ta, "three paired batches", tb, "a")
 
+# --- sym_stream_min_paths: the symmetric forward on the streaming route (rbf dim 20), one block against the blocked triangle at the threshold
+A = int(_lib.cost("sym_stream_min_paths"))
+X = walk(A, 64, 20)
+sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(1.0), 1)
+def fa(): S._SYM_STREAM_MIN_PATHS = 0; sk.compute_Gram(X, X, sym=True)
+def fb(): S._SYM_STREAM_MIN_PATHS = 1e9; sk.compute_Gram(X, X, sym=True)
+ta, tb = ab(fa, fb, n=10)
+S._SYM_STREAM_MIN_PATHS = None
+report("sym_stream_min_paths", "rbf dim 20 d=1, compute_Gram(X, X, sym=True), %d paths of 64 points (streaming route)" % A, "blocked triangle", ta, "one block, all pairs", tb, "a")
+
 # --- age-rank shares of mid-size no-queue launches, and bands on several waves (library knobs)
 lib = _lib.load()
 def knob(name, v):
