@@ -155,9 +155,10 @@ int sk_static_increments_f32(int kind, double param, const float *X, const float
  * `grad_output * grad_points` reduction over the second batch index (:343, :410-416) for these two static kernels.
  *   W [P,M-1,ldw]; scale [P] = upstream gradient per pair (NULL = 1); pairs as in sk_static_increments_*.
  *   kind 1 (rbf):    out = dL/dX [A,M,D].
- *   kind 0 (linear): SK_ERR_UNSUPPORTED -- T[a][p] = sum_b scale_ab sum_q W[a,b,p,q] (y[b,q+1]-y[b,q]) runs from pre-differenced paths in
- *                    sk_linear_adjoint_* (dim <= 8) and is a plain batched GEMM beyond; the generic kernel that served it here was
- *                    reached by no route (removed in round 6). */
+ *   kind 0 (linear): out = T [A,M-1,D], T[a][p] = sum_b scale_ab sum_q W[a,b,p,q] (y[b,q+1]-y[b,q]) (the caller differences it along
+ *                    the path and applies scale^2), for 9 <= D <= 32 and N <= 128 (k_static_linear_adj_tiled: W read once, y_b through
+ *                    LDS).  SK_ERR_UNSUPPORTED otherwise: dim <= 8 runs from pre-differenced paths in sk_linear_adjoint_*, wider or
+ *                    longer paths as a plain batched GEMM in the caller.  X and param are not read. */
 int sk_static_adjoint_f64(int kind, double param, const double *X, const double *Y, const double *W, int64_t ldw,
                           const double *scale, int64_t A, int64_t B, int M, int N, int D, double *out, void *stream);
 int sk_static_adjoint_f32(int kind, double param, const float *X, const float *Y, const float *W, int64_t ldw,

@@ -995,9 +995,14 @@ class HipBackend:
                     fl = getattr(load(), "sk_linear_adjoint_" + _suffix(X))
                     _check(fl(_ptr(dYt), ldy, _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M - 1, N - 1, D, _ptr(T), _stream(X)),
                            "sk_linear_adjoint")
+                elif D <= 32 and N <= 128:
+                    # 9..32 dims: k_static_linear_adj_tiled reads W once, y_b differenced into LDS per pair (sk_static.hip)
+                    T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
+                    _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(T),
+                              _stream(X)), "sk_static_adjoint")
                 else:
-                    # wide paths: T[a] = sum_b scale[a, b] W[a, b] (Mc x Nc) @ dY[b] (Nc x D) IS a batched matrix product -- a plain
-                    # library GEMM (rocBLAS under torch.matmul), 3-10x faster than sk_static_adjoint's generic contraction here
+                    # wider or longer paths: T[a] = sum_b scale[a, b] W[a, b] (Mc x Nc) @ dY[b] (Nc x D) IS a batched matrix product --
+                    # a plain library GEMM (rocBLAS under torch.matmul)
                     # (256 x 256 pairs of 100 points: dim 12 / 20 / 32 7.2 / 24.4 / 42.9 -> 2.3 / 2.5 / 4.9 ms, equal to 1e-15)
                     dY = Y[:, 1:] - Y[:, :-1]
                     Wv = W[..., :N - 1]

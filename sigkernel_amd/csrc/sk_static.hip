@@ -695,12 +695,160 @@ __global__ __launch_bounds__(64 * ADJT_NW) void k_static_rbf_adj_tiled(const T *
     }
 }
 
+// LINEAR static kernel, paths of 9..32 dims: T[a][m][k] = sum_b s_ab sum_n W[a, b][m][n] (y_b[n + 1][k] - y_b[n][k]) -- until round 6 a batched
+// library GEMM per column block of Y plus three elementwise passes over its (A, b, Mc, D) products (0.9 + 0.9 ms of a 5.3 ms gradient step at
+// 256 x 256 pairs of 64 points and 20 dims, profiles/r06_api_profile.txt).  Here every element of W is read ONCE and nothing else touches
+// HBM: a block owns ADJT_NW * RM rows of W[a, .] (RM per wave, a lane per POINT n of y_b, coefficient W[m][n - 1] - W[m][n] -- the
+// neighbour's value by DPP), its 256 threads copy y_b to LDS (rows of DMAX + 2 doubles, read two at a time) and each value read from there feeds RM
+// accumulators.  Pairs go in CHUNKS of PB: a pair is ~0.15 us of arithmetic per wave against ~2 us for a load from HBM, and with the
+// barriers a block has nothing else to hide its loads behind -- so the whole NEXT chunk's W values and y points are loaded into registers
+// before this chunk's arithmetic and consumed after it (one pair ahead: 2.0 ms at 256 x 256 pairs of 64 points and 20 dims, bound by
+// that latency; the GEMM route it replaces 1.8).
+__device__ __forceinline__ double lane_shr1(double v, double lane0) {      // lane l <- lane l - 1; lane 0 <- its own `lane0`
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(lane0), hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63_of(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+template <typename T, int DMAX, int RM, int NP, int PB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_static_linear_adj_tiled(const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
+                                                                          const T *__restrict__ scale, int64_t B, int M, int N, int D,
+                                                                          int row_groups, T *__restrict__ Tout) {
+    constexpr int DS = DMAX + 2;      // 16-byte rows for ds_read_b128: 2 DS = 4 (mod 8) dwords, the 16 lanes of a read group on 16 different bank quads
+    constexpr int SREG = NP * 64 * DMAX / (64 * NW);         // values of one y_b a thread stages, at most (N <= 64 NP)
+    extern __shared__ __attribute__((aligned(16))) double ysh[];      // [PB][N][DS], columns D..DMAX-1 zero
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t a = blockIdx.x / row_groups;
+    const int wv_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = ((int)(blockIdx.x % row_groups) * NW + wv_id) * RM;      // this wave's first row of W (>= Mc: it only keeps the barriers)
+    const bool rows_ok = m0 < Mc;
+    double acc[RM][DMAX];
+#pragma unroll
+    for (int j = 0; j < RM; ++j)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) acc[j][k] = 0.0;
+    for (int i = threadIdx.x; i < PB * N * DS; i += 64 * NW) ysh[i] = 0.0;
+    const int64_t nb = B > 0 ? B : 1;
+    const int nd = N * D;
+    int soff[SREG];      // where this thread's r-th value of a y_b goes in its LDS image (-1: none)
+#pragma unroll
+    for (int r = 0; r < SREG; ++r) {
+        const int i = threadIdx.x + r * 64 * NW, n = i / D;
+        soff[r] = i < nd ? n * DS + (i - n * D) : -1;
+    }
+    // the NEXT chunk of PB pairs, in registers while this one is worked on: its points of y (this thread's share), its W values
+    // W[m0 + j][lane + 64 pp] -- raw: nothing may wait for these loads before the arithmetic below
+    T yq[PB][SREG], wq[PB][NP][RM];
+    auto loads = [&](int64_t b0) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int64_t bb = b0 + u;
+            if (bb >= nb) break;
+            const T *y = Y + (B > 0 ? bb : a) * (int64_t)N * D;
+#pragma unroll
+            for (int r = 0; r < SREG; ++r) yq[u][r] = y[min((int)threadIdx.x + r * 64 * NW, nd - 1)];
+            if (rows_ok) {
+                const int64_t p = B > 0 ? a * B + bb : a;
+                const T *w = W + p * (int64_t)Mc * ldw;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int n = lane + 64 * pp;
+#pragma unroll
+                    for (int j = 0; j < RM; ++j)      // (rows past Mc: never stored; columns past Nc: masked where the value is used --
+                        wq[u][pp][j] = w[(int64_t)min(m0 + j, Mc - 1) * ldw + min(n, Nc - 1)];      // nothing here may wait for a load)
+                }
+            }
+        }
+    };
+    loads(0);
+    for (int64_t b0 = 0; b0 < nb; b0 += PB) {
+        __syncthreads();      // every wave is done with the previous chunk's points (the first time: the zero fill above)
+        double wc[PB][NP][RM], sc[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (b0 + u >= nb) break;
+#pragma unroll
+            for (int r = 0; r < SREG; ++r)
+                if (soff[r] >= 0) ysh[u * N * DS + soff[r]] = (double)yq[u][r];
+            sc[u] = scale ? (double)scale[B > 0 ? a * B + b0 + u : a] : 1.0;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                for (int j = 0; j < RM; ++j) wc[u][pp][j] = lane + 64 * pp < Nc ? (double)wq[u][pp][j] : 0.0;
+        }
+        __syncthreads();
+        if (b0 + PB < nb) loads(b0 + PB);
+        if (rows_ok) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (b0 + u >= nb) break;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    if (64 * pp >= N) break;
+                    double c[RM];
+#pragma unroll
+                    for (int j = 0; j < RM; ++j) {
+                        const double left = lane_shr1(wc[u][pp][j], pp ? lane63_of(wc[u][pp ? pp - 1 : 0][j]) : 0.0);
+                        c[j] = sc[u] * (left - wc[u][pp][j]);      // 0 from point N on
+                    }
+                    const double *yr = ysh + u * N * DS + min(lane + 64 * pp, N - 1) * DS;
+#pragma unroll
+                    for (int k = 0; k < DMAX; k += 2) {
+                        const double2 yk = *reinterpret_cast<const double2 *>(yr + k);
+#pragma unroll
+                        for (int j = 0; j < RM; ++j) {
+                            acc[j][k] = fma(c[j], yk.x, acc[j][k]);
+                            acc[j][k + 1] = fma(c[j], yk.y, acc[j][k + 1]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RM; ++j)
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            double v = acc[j][k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && k < D && m0 + j < Mc) Tout[(a * Mc + m0 + j) * (int64_t)D + k] = (T)v;
+        }
+}
+
+template <typename T, int DMAX, int NP, int NW>
+int launch_static_linear_adj_tiled_np(const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B, int M, int N, int D, T *out,
+                                      hipStream_t s) {
+    // RM rows per wave and PB pairs per chunk: what the registers hold beside the RM * DMAX sums -- 16 dims fit 128 registers (two blocks
+    // per CU) with PB = 2, and that beats longer chunks (0.61 ms against 0.75 at 256 x 256 pairs of 64 points, profiles/r06_lin_adj.txt);
+    // beyond, one block per CU whatever PB is
+    constexpr int RM = 2;
+    constexpr int PB = DMAX <= 16 ? 2 : DMAX <= 24 ? 4 / NP : 2 / NP;
+    const int rgs = (M - 1 + NW * RM - 1) / (NW * RM);
+    const int64_t blk = A * rgs;
+    if (blk > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(double) * PB * (size_t)N * (DMAX + 2);
+    auto kern = k_static_linear_adj_tiled<T, DMAX, RM, NP, PB, NW>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SK_LAUNCH(kern, dim3((unsigned)blk), dim3(64 * NW), lds, s, Y, W, ldw, scale, B, M, N, D, rgs, out);
+    return check_launch();
+}
+template <typename T, int DMAX>
+int launch_static_linear_adj_tiled(const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B, int M, int N, int D, T *out,
+                                   hipStream_t s) {
+    if (N > ADJT_NMAX) return SK_ERR_UNSUPPORTED;      // (the caller's batched GEMM)
+    if (N <= 64) return launch_static_linear_adj_tiled_np<T, DMAX, 1, 8>(Y, W, ldw, scale, A, B, M, N, D, out, s);
+    return launch_static_linear_adj_tiled_np<T, DMAX, 2, 8>(Y, W, ldw, scale, A, B, M, N, D, out, s);
+}
+
 template <typename T, int DMAX, int NT>
 int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
-    // (kind 0, the LINEAR static kernel, has no kernel here any more: its contraction T[a] = sum_b W[a, b] dY[b] runs from pre-differenced,
-    // dimension-major paths in sk_linear_adjoint_* for dim <= 8, and is a plain batched GEMM beyond -- the generic form that lived here
-    // was reached by no route of the host layer, round 6)
+    // (kind 0, the LINEAR static kernel: its contraction T[a] = sum_b W[a, b] dY[b] runs from pre-differenced, dimension-major paths in
+    // sk_linear_adjoint_* for dim <= 8 and in k_static_linear_adj_tiled for 9..32 dims, see launch_static_adjoint)
     if (kind == 0) {
         return SK_ERR_UNSUPPORTED;
     } else {
@@ -819,6 +967,13 @@ int launch_static_increments(int kind, double param, const T *X, const T *Y, int
 template <typename T>
 int launch_static_adjoint(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                           int64_t B, int M, int N, int D, T *out, hipStream_t s) {
+    if (kind == 0) {
+        if (D <= 8) return SK_ERR_UNSUPPORTED;      // sk_linear_adjoint_*
+        if (D <= 16) return launch_static_linear_adj_tiled<T, 16>(Y, W, ldw, scale, A, B, M, N, D, out, s);
+        if (D <= 24) return launch_static_linear_adj_tiled<T, 24>(Y, W, ldw, scale, A, B, M, N, D, out, s);
+        if (D <= 32) return launch_static_linear_adj_tiled<T, 32>(Y, W, ldw, scale, A, B, M, N, D, out, s);
+        return SK_ERR_UNSUPPORTED;
+    }
     if (D <= 4) return launch_static_adj_nt<T, 4>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     if (D <= 8) return launch_static_adj_nt<T, 8>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     if (D <= 16) return launch_static_adj_nt<T, 16>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);

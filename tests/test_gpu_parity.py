@@ -451,7 +451,9 @@ def test_fused_static_increments_match_the_generic_route(be, kind, A, B, M, N, D
 
 
 @pytest.mark.parametrize("kind", ["linear", "rbf"])
-@pytest.mark.parametrize("A,B,M,N,D", [(3, 4, 10, 20, 2), (2, 3, 128, 128, 8), (5, 2, 64, 64, 4), (2, 2, 70, 131, 17), (1, 1, 2, 2, 1)])
+@pytest.mark.parametrize("A,B,M,N,D", [(3, 4, 10, 20, 2), (2, 3, 128, 128, 8), (5, 2, 64, 64, 4), (2, 2, 70, 131, 17), (1, 1, 2, 2, 1),
+                                       # 9..32 dims, at most 128 points of y: the tiled contractions (rows per block 16 / 8; both column passes)
+                                       (3, 5, 70, 128, 17), (4, 3, 9, 66, 9), (2, 3, 40, 30, 32), (3, 2, 21, 2, 24), (2, 4, 2, 65, 12)])
 def test_fused_static_adjoint_matches_autograd_through_the_static_kernel(be, kind, A, B, M, N, D):
     gen = torch.Generator().manual_seed(7 + A * 100 + M + N + D)
     X = (walk(gen, A, M, D) * 3).to(DEV)
@@ -470,6 +472,31 @@ def test_fused_static_adjoint_matches_autograd_through_the_static_kernel(be, kin
             param = (1.0 if gram else scale) if kind == "linear" else scale
             got = be.static_adjoint(code, param, Xt, Yt, W, go, gram)
             assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
+
+
+@pytest.mark.parametrize("A,B,M,N,D", [(3, 5, 40, 128, 17), (4, 3, 9, 64, 9), (2, 3, 40, 30, 32), (5, 4, 33, 100, 30), (2, 6, 18, 65, 16)])
+def test_linear_static_adjoint_of_wide_paths_in_fp32_and_against_the_batched_product(be, A, B, M, N, D):
+    """sk_static_adjoint_* kind 0 (k_static_linear_adj_tiled, 9..32 dims): against the batched matrix product it replaced, written out in
+    torch fp64 -- the fp64 entry to rounding, the fp32 one to fp32 rounding of its inputs; all pairs and paired."""
+    gen = torch.Generator().manual_seed(11 + A + M + N + D)
+    X, Y = walk(gen, A, M, D).to(DEV), (walk(gen, B, N, D) * 2).to(DEV)
+    for gram in (True, False):
+        Xt, Yt = (X, Y) if gram else (X[:min(A, B)].contiguous(), Y[:min(A, B)].contiguous())
+        shape = (Xt.shape[0], Yt.shape[0], M - 1, N - 1) if gram else (Xt.shape[0], M - 1, N - 1)
+        W = padded(np.random.default_rng(5).normal(size=shape))
+        go = torch.randn(shape[:-2], generator=gen, dtype=torch.float64).to(DEV)
+        dY = Yt[:, 1:] - Yt[:, :-1]
+        T = (torch.matmul(W, dY) * go[..., None, None]).sum(1) if gram else torch.matmul(W, dY) * go[:, None, None]
+        want = torch.zeros_like(Xt)
+        want[:, 1:] += T
+        want[:, :-1] -= T
+        want *= 0.7 ** 2
+        got = be.static_adjoint(0, 0.7, Xt, Yt, W, go, gram)
+        assert rel_err(got.cpu().numpy(), want.cpu().numpy()) <= 1e-12
+        W32 = padded(W.cpu().numpy().astype(np.float32))
+        got32 = be.static_adjoint(0, 0.7, Xt.float(), Yt.float(), W32, go.float(), gram)
+        assert got32.dtype == torch.float32 and rel_err(got32.double().cpu().numpy(), want.cpu().numpy()) <= 2e-6
+        assert be.static_adjoint(0, 0.7, Xt, Yt, W, None, gram).shape == Xt.shape      # (no upstream gradient: scale 1)
 
 
 @pytest.mark.parametrize("kind", ["linear", "rbf"])

@@ -12,7 +12,7 @@ def t(f, n=4, reps=5):
         for _ in range(n): r = f()
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / n * 1e3)
     return sorted(ts)[reps // 2], r
-for kind in ("rbf", "linear"):
+for kind in (os.environ.get("KINDS") or "rbf,linear").split(","):
     for D, dt in ((12, torch.float64), (20, torch.float64), (32, torch.float64), (20, torch.float32), (9, torch.float64)):
         k = sigkernel_amd.RBFKernel(1.0) if kind == "rbf" else sigkernel_amd.LinearKernel()
         sk = sigkernel_amd.SigKernel(k, 1)
