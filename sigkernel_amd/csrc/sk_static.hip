@@ -608,97 +608,12 @@ __global__ __launch_bounds__(NT *NW) void k_rbf_adj2(const T *__restrict__ X, co
     }
 }
 
-// The same for paths of 17..32 dims (one node row per wave: RM = 1 there), with the y points of a pair shared by the FOUR waves of a block
-// through LDS: in k_static_rbf_adj every (a, row) block streams all of Y from L2 -- 43 GB per launch at 256 x 256 pairs of 64 points and
-// 20 dims, 7.3 ms, 54 % of that gradient step (profiles/r06_api_profile.txt); holding the kernel to two waves per SIMD made it slower: it is
-// bound by that traffic.  Here a block owns four consecutive node rows of x_a; per pair its 256 threads copy y_b to LDS once (coalesced,
-// double-buffered, one barrier per pair) and every wave reads its column's point from there -- rows of DMAX + 1 doubles, so the 64 lanes
-// of a wave fall on different banks.  The arithmetic per (pair, node) is that of k_static_rbf_adj, operand for operand.
-constexpr int ADJT_NW = 4;
-constexpr int ADJT_NMAX = 128;
-template <typename T, int DMAX>
-__global__ __launch_bounds__(64 * ADJT_NW) void k_static_rbf_adj_tiled(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
-                                                                       const T *__restrict__ scale, int64_t B, int M, int N, int D, double inv_sigma,
-                                                                       int row_groups, T *__restrict__ gX) {
-    constexpr int DS = DMAX + 1;
-    extern __shared__ __attribute__((aligned(16))) double ysh[];      // [2][N][DS]
-    const int Mc = M - 1, Nc = N - 1;
-    const int64_t a = blockIdx.x / row_groups;
-    const int wv_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = (int)(blockIdx.x % row_groups) * ADJT_NW + wv_id;      // this wave's node row (>= M: it only keeps the barriers)
-    const bool row_ok = m < M;
-    const int mr = min(m, M - 1);
-    double xm[DMAX], acc[DMAX], xs = 0.0;
-    {
-        const T *x = X + (a * M + mr) * (int64_t)D;
-#pragma unroll
-        for (int k = 0; k < DMAX; ++k) {
-            xm[k] = k < D ? (double)x[k] : 0.0;
-            xs = fma(xm[k], xm[k], xs);
-            acc[k] = 0.0;
-        }
-    }
-    const int64_t nb = B > 0 ? B : 1;
-    const int nd = N * D;
-    auto stage = [&](int64_t bb, int buf) {      // y_bb -> LDS buffer `buf` (all threads of the block)
-        const int64_t b = B > 0 ? bb : a;
-        const T *y = Y + b * (int64_t)N * D;
-        double *dst = ysh + (size_t)buf * N * DS;
-        for (int i = threadIdx.x; i < nd; i += 64 * ADJT_NW) {
-            const int n = i / D, k = i - n * D;
-            dst[n * DS + k] = (double)y[i];
-        }
-    };
-    stage(0, 0);
-    __syncthreads();
-    for (int64_t bb = 0; bb < nb; ++bb) {
-        if (bb + 1 < nb) stage(bb + 1, (int)((bb + 1) & 1));
-        const int64_t p = B > 0 ? a * B + bb : a;
-        const double sc = scale ? (double)scale[p] : 1.0;
-        const T *w = W + p * (int64_t)Mc * ldw;
-        const double *yb = ysh + (size_t)(bb & 1) * N * DS;
-        if (row_ok)
-            for (int n = lane; n < N; n += 64) {
-                const int nl = max(n - 1, 0), nr = min(n, Nc - 1);
-                const bool lf = n >= 1, rt = n < Nc;
-                double t[2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {      // W rows m - 1 + r (zero outside the matrix)
-                    const int wr = m - 1 + r;
-                    const bool ok = wr >= 0 && wr < Mc;
-                    const int64_t ro = (int64_t)min(max(wr, 0), Mc - 1) * ldw;
-                    const double wl = (double)w[ro + nl], wr_ = (double)w[ro + nr];
-                    t[r] = ((ok && rt) ? wr_ : 0.0) - ((ok && lf) ? wl : 0.0);
-                }
-                double ys = 0.0, xy = 0.0, dk[DMAX];
-#pragma unroll
-                for (int k = 0; k < DMAX; ++k) {
-                    const double yk = k < D ? yb[n * DS + k] : 0.0;
-                    ys = fma(yk, yk, ys);
-                    dk[k] = yk - xm[k];
-                    xy = fma(xm[k], yk, xy);
-                }
-                const double g = exp_nonpos(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
-                const double c = sc * (t[1] - t[0]) * g;
-#pragma unroll
-                for (int k = 0; k < DMAX; ++k) acc[k] = fma(c, dk[k], acc[k]);
-            }
-        __syncthreads();
-    }
-    // sum c (x_m - y) = - sum c d  (d = y - x_m): the lanes' sums added up, dL/dx = (-2 / sigma) of it
-#pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        double v = -acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && k < D && row_ok) gX[(a * M + m) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
-    }
-}
+constexpr int ADJT_NMAX = 128;      // second paths the tiled adjoints below stage whole in LDS
 
 // LINEAR static kernel, paths of 9..32 dims: T[a][m][k] = sum_b s_ab sum_n W[a, b][m][n] (y_b[n + 1][k] - y_b[n][k]) -- until round 6 a batched
 // library GEMM per column block of Y plus three elementwise passes over its (A, b, Mc, D) products (0.9 + 0.9 ms of a 5.3 ms gradient step at
 // 256 x 256 pairs of 64 points and 20 dims, profiles/r06_api_profile.txt).  Here every element of W is read ONCE and nothing else touches
-// HBM: a block owns ADJT_NW * RM rows of W[a, .] (RM per wave, a lane per POINT n of y_b, coefficient W[m][n - 1] - W[m][n] -- the
+// HBM: a block owns NW * RM rows of W[a, .] (RM per wave, a lane per POINT n of y_b, coefficient W[m][n - 1] - W[m][n] -- the
 // neighbour's value by DPP), its 256 threads copy y_b to LDS (rows of DMAX + 2 doubles, read two at a time) and each value read from there feeds RM
 // accumulators.  Pairs go in CHUNKS of PB: a pair is ~0.15 us of arithmetic per wave against ~2 us for a load from HBM, and with the
 // barriers a block has nothing else to hide its loads behind -- so the whole NEXT chunk's W values and y points are loaded into registers
@@ -844,6 +759,145 @@ int launch_static_linear_adj_tiled(const T *Y, const T *W, int64_t ldw, const T 
     return launch_static_linear_adj_tiled_np<T, DMAX, 2, 8>(Y, W, ldw, scale, A, B, M, N, D, out, s);
 }
 
+// k_static_rbf_adj for paths of 17..32 dims (one node row per wave there), with the y points of a pair shared by the EIGHT waves of a block
+// through LDS: in k_static_rbf_adj every (a, row) block streams all of Y from L2 -- 43 GB per launch at 256 x 256 pairs of 64 points and
+// 20 dims, 7.3 ms, 54 % of that gradient step (profiles/r06_api_profile.txt).  The linear kernel's schedule (above): pairs in chunks of PB
+// whose W values (rows m - 1 and m, raw) and y points are loaded a chunk ahead -- pair by pair with a barrier each, loads waited for where
+// they were issued, the first tiled form took 4.5 ms there, this one 2.4 --, the left neighbour's W by DPP instead of a second load, y_b
+// in 16-byte rows read twice (once for the exponent, once for the sums: the differences y - x_m are not kept, which is what lets the
+// queue into the registers).  Operand for operand the arithmetic of k_static_rbf_adj: bit-identical results.
+template <typename T, int DMAX, int NP, int PB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_static_rbf_adj_tiled(const T *__restrict__ X, const T *__restrict__ Y, const T *__restrict__ W, int64_t ldw,
+                                                                    const T *__restrict__ scale, int64_t B, int M, int N, int D, double inv_sigma,
+                                                                    int row_groups, T *__restrict__ gX) {
+    constexpr int DS = DMAX + 2;
+    constexpr int SREG = NP * 64 * DMAX / (64 * NW);
+    extern __shared__ __attribute__((aligned(16))) double ysh[];      // [PB][N][DS], columns D..DMAX-1 zero
+    const int Mc = M - 1, Nc = N - 1;
+    const int64_t a = blockIdx.x / row_groups;
+    const int wv_id = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = (int)(blockIdx.x % row_groups) * NW + wv_id;      // this wave's node row (>= M: it only keeps the barriers)
+    const bool row_ok = m < M;
+    const int mr = min(m, M - 1);
+    const bool ok0 = m - 1 >= 0 && m - 1 < Mc, ok1 = m < Mc;      // W rows m - 1, m inside the matrix
+    const int64_t ro0 = (int64_t)min(max(m - 1, 0), Mc - 1) * ldw, ro1 = (int64_t)min(max(m, 0), Mc - 1) * ldw;
+    double xm[DMAX], acc[DMAX], xs = 0.0;
+    {
+        const T *x = X + (a * M + mr) * (int64_t)D;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            xm[k] = k < D ? (double)x[k] : 0.0;
+            xs = fma(xm[k], xm[k], xs);
+            acc[k] = 0.0;
+        }
+    }
+    for (int i = threadIdx.x; i < PB * N * DS; i += 64 * NW) ysh[i] = 0.0;
+    const int64_t nb = B > 0 ? B : 1;
+    const int nd = N * D;
+    int soff[SREG];
+#pragma unroll
+    for (int r = 0; r < SREG; ++r) {
+        const int i = threadIdx.x + r * 64 * NW, n = i / D;
+        soff[r] = i < nd ? n * DS + (i - n * D) : -1;
+    }
+    T yq[PB][SREG], wq[PB][NP][2];
+    auto loads = [&](int64_t b0) {      // (nothing here may wait for a load: the values are used a chunk later)
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int64_t bb = b0 + u;
+            if (bb >= nb) break;
+            const T *y = Y + (B > 0 ? bb : a) * (int64_t)N * D;
+#pragma unroll
+            for (int r = 0; r < SREG; ++r) yq[u][r] = y[min((int)threadIdx.x + r * 64 * NW, nd - 1)];
+            if (row_ok) {
+                const T *w = W + (B > 0 ? a * B + bb : a) * (int64_t)Mc * ldw;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int nc = min(lane + 64 * pp, Nc - 1);
+                    wq[u][pp][0] = w[ro0 + nc];
+                    wq[u][pp][1] = w[ro1 + nc];
+                }
+            }
+        }
+    };
+    loads(0);
+    for (int64_t b0 = 0; b0 < nb; b0 += PB) {
+        __syncthreads();
+        double wc[PB][NP][2], sc[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (b0 + u >= nb) break;
+#pragma unroll
+            for (int r = 0; r < SREG; ++r)
+                if (soff[r] >= 0) ysh[u * N * DS + soff[r]] = (double)yq[u][r];
+            sc[u] = scale ? (double)scale[B > 0 ? a * B + b0 + u : a] : 1.0;
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const bool rt = lane + 64 * pp < Nc;
+                wc[u][pp][0] = (ok0 && rt) ? (double)wq[u][pp][0] : 0.0;
+                wc[u][pp][1] = (ok1 && rt) ? (double)wq[u][pp][1] : 0.0;
+            }
+        }
+        __syncthreads();
+        if (b0 + PB < nb) loads(b0 + PB);
+        if (row_ok) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (b0 + u >= nb) break;
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) {
+                    if (64 * pp >= N) break;
+                    double t[2];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)      // t_r = W[r][n] - W[r][n - 1], zero outside the matrix
+                        t[r] = wc[u][pp][r] - lane_shr1(wc[u][pp][r], pp ? lane63_of(wc[u][pp ? pp - 1 : 0][r]) : 0.0);
+                    const double *yr = ysh + u * N * DS + min(lane + 64 * pp, N - 1) * DS;
+                    double ys = 0.0, xy = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DMAX; k += 2) {
+                        const double2 yk = *reinterpret_cast<const double2 *>(yr + k);
+                        ys = fma(yk.x, yk.x, ys);
+                        xy = fma(xm[k], yk.x, xy);
+                        ys = fma(yk.y, yk.y, ys);
+                        xy = fma(xm[k + 1], yk.y, xy);
+                    }
+                    const double g = exp_nonpos(-(fma(-2.0, xy, xs + ys)) * inv_sigma);
+                    const double c = sc[u] * (t[1] - t[0]) * g;
+                    asm volatile("" ::: "memory");      // (read y_b[n] again: held across the exponential it costs DMAX registers)
+#pragma unroll
+                    for (int k = 0; k < DMAX; k += 2) {
+                        const double2 yk = *reinterpret_cast<const double2 *>(yr + k);
+                        acc[k] = fma(c, yk.x - xm[k], acc[k]);
+                        acc[k + 1] = fma(c, yk.y - xm[k + 1], acc[k + 1]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        double v = -acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && k < D && row_ok) gX[(a * M + m) * (int64_t)D + k] = (T)(-2.0 * inv_sigma * v);
+    }
+}
+
+template <typename T, int DMAX, int NP>
+int launch_static_rbf_adj_tiled(double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A, int64_t B, int M,
+                                  int N, int D, T *out, hipStream_t s) {
+    constexpr int NW = 8;
+    constexpr int PB = DMAX > 24 && NP > 1 ? 1 : 2;
+    const int rgs = (M + NW - 1) / NW;
+    const int64_t blk = A * rgs;
+    if (blk > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(double) * PB * (size_t)N * (DMAX + 2);
+    auto kern = k_static_rbf_adj_tiled<T, DMAX, NP, PB, NW>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    SK_LAUNCH(kern, dim3((unsigned)blk), dim3(64 * NW), lds, s, X, Y, W, ldw, scale, B, M, N, D, 1.0 / param, rgs, out);
+    return check_launch();
+}
+
 template <typename T, int DMAX, int NT>
 int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                         int64_t B, int M, int N, int D, T *out, hipStream_t s) {
@@ -865,16 +919,10 @@ int launch_static_adj_d(int kind, double param, const T *X, const T *Y, const T 
 template <typename T, int DMAX>
 int launch_static_adj_nt(int kind, double param, const T *X, const T *Y, const T *W, int64_t ldw, const T *scale, int64_t A,
                          int64_t B, int M, int N, int D, T *out, hipStream_t s) {
-    if constexpr (DMAX >= 24) {     // 17..32 dims: the y points of a pair through LDS, shared by four rows' waves (k_static_rbf_adj_tiled)
-        if (kind == 1 && N <= ADJT_NMAX) {
-            const int rgs = (M + ADJT_NW - 1) / ADJT_NW;
-            const int64_t blk = A * rgs;
-            if (blk > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-            const size_t lds = sizeof(double) * 2 * (size_t)N * (DMAX + 1);
-            auto kern = k_static_rbf_adj_tiled<T, DMAX>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            SK_LAUNCH(kern, dim3((unsigned)blk), dim3(64 * ADJT_NW), lds, s, X, Y, W, ldw, scale, B, M, N, D, 1.0 / param, rgs, out);
-            return check_launch();
+    if constexpr (DMAX >= 24) {     // 17..32 dims: the y points of a pair through LDS, shared by eight rows' waves (k_static_rbf_adj_tiled;
+        if (kind == 1 && N <= ADJT_NMAX) {      // at 16 dims it is no faster than two rows per thread: 1.87 / 1.66 against 1.80 ms, r06_lin_adj.txt)
+            if (N <= 64) return launch_static_rbf_adj_tiled<T, DMAX, 1>(param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
+            return launch_static_rbf_adj_tiled<T, DMAX, 2>(param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
         }
         return launch_static_adj_d<T, DMAX, 128>(kind, param, X, Y, W, ldw, scale, A, B, M, N, D, out, s);
     } else {

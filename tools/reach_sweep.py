@@ -150,10 +150,10 @@ def gated(g, be):
         sk = sigkernel_amd.SigKernel(RBF(0.9) if kname == "rbf" else LIN(), 1)
         Xg = walk(g, 3, M, 30, dt).requires_grad_(True)
         sk.compute_Gram(Xg, walk(g, 4, N, 30, dt)).sum().backward()
-    # LinearKernel on paths of 9..32 dims with a gradient: the tiled contraction of the static adjoint (16 / 24 / 32 dims, second paths of
+    # paths of 9..32 dims with a gradient: the tiled static adjoints (LinearKernel 16 / 24 / 32 dims, RBFKernel 24 / 32; second paths of
     # <= 64 and of 65..128 points)
-    for D, dt, N in itertools.product((12, 20, 30), (f64, f32), (50, 100)):
-        sk = sigkernel_amd.SigKernel(LIN(), 1)
+    for kname, D, dt, N in itertools.product(("linear", "rbf"), (12, 20, 30), (f64, f32), (50, 100)):
+        sk = sigkernel_amd.SigKernel(LIN() if kname == "linear" else RBF(0.9), 1)
         Xg = walk(g, 3, 40, D, dt).requires_grad_(True)
         sk.compute_Gram(Xg, walk(g, 4, N, D, dt)).sum().backward()
     # the fused derivative solver on first paths of 64 k + 1 points (bands that need no shifted lanes) against second paths of 126 points
