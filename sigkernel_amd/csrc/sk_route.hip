@@ -99,6 +99,10 @@ const CostEntry COSTS[] = {
     {"mmd_streams_max_pairs", 16384,
      "pairs per Gram matrix up to which a CAPTURED composed compute_mmd forks its three matrices onto three streams (replays 10-15 % faster at 16..64 paths)"},
     {"keep_edges_fraction", 0.5, "share of the transient budget the edges kept between forward and backward may take"},
+    {"keep_increments_fraction", 0.125,
+     "share of the transient budget the STREAMING route's increments of a one-tile Gram block may keep between forward and backward (beside the edges): "
+     "backward then skips the second evaluation of the node kernel -- r06_keep_inc, 256 x 256 pairs of 64 points, forward + backward: rbf dim 20 "
+     "5.96 -> 5.02 ms, linear dim 20 3.89 -> 3.23; 2.1 GB held there, 6 GB at most under the default budget"},
     {"loss_launch_free_bytes", 268435456.0,
      "bytes the one-launch loss route (sk_solve_fwd_loss_f64: values, weights, pair table and the rectangle's edges, allocated in one piece and held until "
      "backward) may take without asking the device for its free memory -- hipMemGetInfo costs 20-30 us, a tenth of a 32 + 32-path step; above it the "

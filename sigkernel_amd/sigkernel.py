@@ -188,10 +188,14 @@ def _tile_gradient(be, static_kernel, Xt, Yt, go, dyadic, naive, gram, edges=Non
             # from the up-cast paths, adjoint, chain rule -- instead of fp32 increments up-cast in 4 GB chunks (round 2: 3x slower)
             g = _tile_gradient(be, static_kernel, Xt.double(), Yt.double(), go.double(), dyadic, naive, gram)
             return g.to(Xt.dtype)
-        inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
+        inc = getattr(edges, "_sk_increments", None) if edges is not None else None      # (what _gram_block kept with the edges)
+        if inc is None or inc.shape[:-2] != ((Xt.shape[0], Yt.shape[0]) if gram else (Xt.shape[0],)) or inc.dtype != Xt.dtype:
+            inc = be.static_increments(fused[0], fused[1], Xt, Yt, gram)
         if inc is not None:
             _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
             del inc
+            if getattr(edges, "_sk_increments", None) is not None:
+                edges._sk_increments = None      # (freed before the chain rule allocates)
             return be.static_adjoint(fused[0], fused[1], Xt, Yt, W, go, gram)
     Xg = Xt.clone().requires_grad_(True)
     with torch.enable_grad():
@@ -401,6 +405,7 @@ _SYM_MIN_CELLS = None          # "sym_min_cells": below this the extra launches 
 _SYM_MIN_ROWS = None           # "sym_min_rows": rows per block of the triangular adjoint
 _SYM_STREAM_MIN_PATHS = None   # "sym_stream_min_paths": the streaming route's symmetric forward takes the blocked triangle from this many paths
 _KEEP_EDGES_FRACTION = None    # "keep_edges_fraction": of the transient budget, what may stay allocated between forward and backward
+_KEEP_INCREMENTS_FRACTION = None   # "keep_increments_fraction": ... and the streaming route's increments of a one-tile block beside them
 _PAIRED_MERGE_CELLS = None     # "paired_merge_cells"
 _MMD_STREAMS_MAX_PAIRS = None  # "mmd_streams_max_pairs"
 
@@ -467,10 +472,16 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
         budget = _budget(Xd.device, workspace_bytes)
     # transient bytes per Gram row: G_static + inc_c on the generic route, inc_c alone on the fused one
     per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
-    for a0, a1 in _tiles(A, per_row, budget):
+    tiles = _tiles(A, per_row, budget)
+    for a0, a1 in tiles:
         inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
         if keep is not None:
             K[a0:a1], edges = be.solve_fwd_keep_edges(inc, dyadic_order, naive)  # :378 / :395, + the edges for backward
+            if edges is not None and fused and len(tiles) == 1 and \
+                    inc.numel() * inc.element_size() <= _cost("keep_increments_fraction") * budget:
+                # one tile of moderate size: its increments ride along with the edges, and backward does not evaluate the static
+                # kernel a second time (a quarter of a gradient step on wide paths, profiles/r06_keep_inc.txt)
+                edges._sk_increments = inc
             keep.append((a0, a1, edges))
         else:
             K[a0:a1] = be.solve_fwd(inc, dyadic_order, naive)                    # :378 / :395

@@ -660,6 +660,38 @@ def test_big_paired_batches_sweep_several_pairs_per_lane_group(kind, D, d, P, M,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["rbf", "linear"])
+def test_streaming_gradient_reuses_the_increments_its_forward_kept(kind, monkeypatch):
+    """A one-tile Gram block on the streaming route with a gradient pending keeps its increments beside the edges (cost entry
+    keep_increments_fraction of the budget): backward evaluates the static kernel ONCE less and returns the same bits; with the entry
+    at 0, or a budget the increments do not fit, they are formed again."""
+    from sigkernel_amd import _lib, sigkernel
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(123)
+    X, Y = walk(gen, 6, 40, 20).to(DEV), walk(gen, 5, 50, 20).to(DEV)
+    sk = sigkernel_amd.SigKernel(sigkernel_amd.RBFKernel(0.9) if kind == "rbf" else sigkernel_amd.LinearKernel(), 1)
+    calls = []
+    orig = type(be).static_increments
+    monkeypatch.setattr(type(be), "static_increments", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+
+    def step():
+        del calls[:]
+        Xg = X.clone().requires_grad_(True)
+        sk.compute_Gram(Xg, Y).sum().backward()
+        return Xg.grad, len(calls)
+    g_kept, n_kept = step()
+    monkeypatch.setattr(sigkernel, "_KEEP_INCREMENTS_FRACTION", 0.0)
+    g_again, n_again = step()
+    assert (n_kept, n_again) == (1, 2) and torch.equal(g_kept, g_again)
+    monkeypatch.setattr(sigkernel, "_KEEP_INCREMENTS_FRACTION", None)
+    sk_small = sigkernel_amd.SigKernel(sk.static_kernel, 1, workspace_bytes=6 * 5 * 39 * 64 * 8 * 4)      # (the increments: more than an eighth of it)
+    Xg = X.clone().requires_grad_(True)
+    del calls[:]
+    sk_small.compute_Gram(Xg, Y).sum().backward()
+    assert len(calls) >= 2 and torch.allclose(Xg.grad, g_kept, rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,D,d", [("rbf", 20, 1), ("linear", 12, 1), ("rbf", 3, 3)])
 def test_symmetric_forward_on_the_streaming_route_takes_the_blocked_triangle(kind, D, d, monkeypatch):
     """compute_Gram(X, X, sym=True) without a gradient on the streaming route (wide paths, dyadic 3): from sym_stream_min_paths paths on

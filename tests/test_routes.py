@@ -129,12 +129,12 @@ def test_cost_rules_live_in_one_table():
     from sigkernel_amd import _lib, sigkernel
     table = _lib.costs()
     for name in ("mb_min_eff", "stream_one_strip_cells", "mb_min_eff_rbf16_forward", "sym_tiles", "sym_min_cells", "sym_min_rows", "paired_merge_cells",
-                 "mmd_streams_max_pairs", "keep_edges_fraction", "fused_mid_min_pairs_per_rank", "mb_split_max_resident_share",
+                 "mmd_streams_max_pairs", "keep_edges_fraction", "keep_increments_fraction", "fused_mid_min_pairs_per_rank", "mb_split_max_resident_share",
                  "fused_static_share_linear", "fused_static_share_rbf"):
         value, note = table[name]
         assert value > 0 and len(note) > 40, name
     assert 0 < table["fused_static_share_rbf"][0] <= table["fused_static_share_linear"][0] < 100      # per cent of the equal share
-    for attr in ("_SYM_TILES", "_SYM_MIN_CELLS", "_SYM_MIN_ROWS", "_PAIRED_MERGE_CELLS", "_MMD_STREAMS_MAX_PAIRS", "_KEEP_EDGES_FRACTION"):
+    for attr in ("_SYM_TILES", "_SYM_MIN_CELLS", "_SYM_MIN_ROWS", "_PAIRED_MERGE_CELLS", "_MMD_STREAMS_MAX_PAIRS", "_KEEP_EDGES_FRACTION", "_KEEP_INCREMENTS_FRACTION"):
         assert getattr(sigkernel, attr) is None and sigkernel._cost(attr[1:].lower()) == table[attr[1:].lower()][0]
     src = open(sigkernel.__file__).read()
     assert not re.search(r"^_[A-Z_]+ = [0-9][0-9e.* ]*(#|$)", src.replace("_DEFAULT_WORKSPACE = 48 << 30", "").replace("_MAX_LAUNCH_PAIRS = 1 << 30", ""), re.M)

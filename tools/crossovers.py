@@ -103,6 +103,19 @@ ta, tb = ab(fa, fb, n=10)
 S._SYM_STREAM_MIN_PATHS = None
 report("sym_stream_min_paths", "rbf dim 20 d=1, compute_Gram(X, X, sym=True), %d paths of 64 points (streaming route)" % A, "blocked triangle", ta, "one block, all pairs", tb, "a")
 
+# --- keep_increments_fraction: a one-tile Gram block on the streaming route, forward + backward, with the forward's increments kept or formed again
+for kname, k in (("rbf", sigkernel_amd.RBFKernel(1.0)), ("linear", sigkernel_amd.LinearKernel())):
+    X, Y = walk(256, 64, 20), walk(256, 64, 20)
+    sk = sigkernel_amd.SigKernel(k, 1)
+    def stepg():
+        Xg = X.clone().requires_grad_(True); sk.compute_Gram(Xg, Y).sum().backward()
+    def fa(): S._KEEP_INCREMENTS_FRACTION = None; stepg()
+    def fb(): S._KEEP_INCREMENTS_FRACTION = 0.0; stepg()
+    ta, tb = ab(fa, fb, n=6)
+    S._KEEP_INCREMENTS_FRACTION = None
+    report("keep_increments_fraction", "%s dim 20 d=1, compute_Gram + backward, 256 x 256 pairs of 64 points (2.1 GB of increments)" % kname,
+           "increments kept", ta, "formed again in backward", tb, "a")
+
 # --- age-rank shares of mid-size no-queue launches, and bands on several waves (library knobs)
 lib = _lib.load()
 def knob(name, v):
