@@ -19,9 +19,10 @@ namespace {
 
 constexpr int SK_TPB = 64;   // one wavefront; lane t owns node column c0 + t, outputs for t < 63
 
-constexpr int LIN_CPT = 2;   // output columns per lane (amortises the row differences of x, which are wave-uniform)
+// (LIN_CPT: output columns per lane -- 2 amortise the row differences of x, which are wave-uniform; 1 for second paths of <= 65 points, whose
+// second column would be all padding: half of the arithmetic of a 64-point path, 0.74 -> 0.5 ms per 256 x 256 pairs at 20 dims)
 
-template <typename T, int DMAX>
+template <typename T, int DMAX, int LIN_CPT>
 __global__ __launch_bounds__(SK_TPB) void k_static_linear(const T *__restrict__ X, const T *__restrict__ Y, int64_t B,
                                                           int M, int N, int D, double s2, T *__restrict__ inc,
                                                           int64_t ld, int col_tiles) {
@@ -74,6 +75,92 @@ __global__ __launch_bounds__(SK_TPB) void k_static_linear(const T *__restrict__ 
                     const int q = c0 + c * SK_TPB + threadIdx.x;
                     if (q < ld) o[(int64_t)(i0 + r) * ld + q] = (T)acc[c];
                 }
+            }
+        }
+    }
+}
+
+// The same on the matrix cores for paths of 9..32 dims: inc = s^2 dX dY^T IS a matrix product, and beyond 8 dims the kernel above is bound by
+// its DMAX / 2 broadcast LDS reads per row (0.63 / 0.78 / 1.11 ms per 256 x 256 pairs of 64 points at 12 / 20 / 32 dims, against 0.39 for the
+// 2.1 GB to be written).  One wave per 64 x 64 tile of a pair's increments; v_mfma_f64_16x16x4_f64 takes one double of A = dX (row lane & 15,
+// any dim the lanes of a quarter wave agree on) and of B = s^2 dY (the same with columns) per lane, gathered straight from the paths (10 KB each, in L1 / L2),
+// and leaves C[row (lane >> 4) + 4 r][col lane & 15] in register r -- sixteen consecutive doubles of a row per quarter wave, whole 128-byte
+// lines.  fp64 MFMA issues at the VALU's rate on this part (64 cycles per 1024 FMAs): what is saved is the LDS traffic and the
+// instruction count, not arithmetic time.  Sums of four dims at a time inside the instruction: equal to the kernel above to rounding, not bits.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct Pair2;      // two consecutive path values, at the paths' own alignment
+template <> struct Pair2<double> { typedef double2 __attribute__((aligned(8))) type; };
+template <> struct Pair2<float> { typedef float2 __attribute__((aligned(4))) type; };
+// v[k0], v[k0 + 1] of (row r1) - (row r0), zero from dim D on: one vector load per row where both dims exist
+template <typename T>
+__device__ __forceinline__ void diff_pair(const T *r1, const T *r0, int k0, int D, double &o0, double &o1) {
+    typedef typename Pair2<T>::type P2;
+    if (k0 + 1 < D) {
+        const P2 u = *reinterpret_cast<const P2 *>(r1 + k0), v = *reinterpret_cast<const P2 *>(r0 + k0);
+        o0 = (double)u.x - (double)v.x;
+        o1 = (double)u.y - (double)v.y;
+    } else {
+        const int kc = min(k0, D - 1);
+        o0 = k0 < D ? (double)r1[kc] - (double)r0[kc] : 0.0;
+        o1 = 0.0;
+    }
+}
+template <typename T, int DMAX>
+__global__ __launch_bounds__(64) void k_static_linear_mfma(const T *__restrict__ X, const T *__restrict__ Y, int64_t B, int M, int N, int D,
+                                                           double s2, T *__restrict__ inc, int64_t ld, int row_tiles, int col_tiles) {
+    constexpr int KS = DMAX / 4;      // MFMA steps; step ks takes dim (lane >> 4) KS + ks from each lane: a lane's dims are consecutive in memory
+    const int Mc = M - 1, Nc = N - 1;
+    int64_t blk = blockIdx.x;
+    const int ct = (int)(blk % col_tiles);
+    blk /= col_tiles;
+    const int rt = (int)(blk % row_tiles);
+    const int64_t p = blk / row_tiles;
+    const int64_t a = B > 0 ? p / B : p, b = B > 0 ? p % B : p;
+    const T *x = X + a * (int64_t)M * D;
+    const T *y = Y + b * (int64_t)N * D;
+    T *o = inc + p * (int64_t)Mc * ld;
+    const int li = threadIdx.x & 15, lk = threadIdx.x >> 4, kb = lk * KS;
+    double bf[4][KS];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int q = ct * 64 + nt * 16 + li, qc = min(q, Nc - 1);
+        const T *y0 = y + (int64_t)qc * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            double v0, v1;
+            diff_pair<T>(y0 + D, y0, kb + ks, D, v0, v1);
+            bf[nt][ks] = q < Nc ? s2 * v0 : 0.0;
+            bf[nt][ks + 1] = q < Nc ? s2 * v1 : 0.0;
+        }
+    }
+#pragma unroll 1
+    for (int mt = 0; mt < 4; ++mt) {
+        const int p0 = rt * 64 + mt * 16;
+        if (p0 >= Mc) break;
+        const int pr = p0 + li;
+        const T *x0 = x + (int64_t)min(pr, Mc - 1) * D;
+        double af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            double v0, v1;
+            diff_pair<T>(x0 + D, x0, kb + ks, D, v0, v1);
+            af[ks] = pr < Mc ? v0 : 0.0;
+            af[ks + 1] = pr < Mc ? v1 : 0.0;
+        }
+        d4_t acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[nt][ks], acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int col = ct * 64 + nt * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = p0 + lk + 4 * r;
+                if (row < Mc && col < ld) o[(int64_t)row * ld + col] = (T)acc[nt][r];
             }
         }
     }
@@ -936,11 +1023,21 @@ int launch_static_d(int kind, double param, const T *X, const T *Y, int64_t A, i
                     int64_t ld, hipStream_t s) {
     const int64_t P = B > 0 ? A * B : A;
     if (kind == 0) {
-        const int col_tiles = (int)((ld + SK_TPB * LIN_CPT - 1) / (SK_TPB * LIN_CPT));
-        const int64_t blocks = P * col_tiles;
-        if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
-        SK_LAUNCH((k_static_linear<T, DMAX>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
-                           param * param, inc, ld, col_tiles);
+        if constexpr (DMAX >= 16) {
+            const int rts = (M - 1 + 63) / 64, cts = (int)((ld + 63) / 64);
+            const int64_t blocks = P * rts * cts;
+            if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            SK_LAUNCH((k_static_linear_mfma<T, DMAX>), dim3((unsigned)blocks), dim3(64), 0, s, X, Y, B, M, N, D, param * param, inc, ld, rts, cts);
+        } else if (ld <= SK_TPB) {
+            if (P > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            SK_LAUNCH((k_static_linear<T, DMAX, 1>), dim3((unsigned)P), dim3(SK_TPB), 0, s, X, Y, B, M, N, D, param * param, inc, ld, 1);
+        } else {
+            const int col_tiles = (int)((ld + SK_TPB * 2 - 1) / (SK_TPB * 2));
+            const int64_t blocks = P * col_tiles;
+            if (blocks > 0x7fffffffLL) return SK_ERR_UNSUPPORTED;
+            SK_LAUNCH((k_static_linear<T, DMAX, 2>), dim3((unsigned)blocks), dim3(SK_TPB), 0, s, X, Y, B, M, N, D,
+                               param * param, inc, ld, col_tiles);
+        }
     } else {
         const T z = (T)0;
         if (ld <= SK_TPB) {

@@ -148,13 +148,16 @@ def _fused_forward(be, static_kernel, Xd, Yd, dyadic, naive, gram, keep_edges=Fa
     return (res, None) if keep_edges else res
 
 
-def _increments(be, static_kernel, Xd, Yd, gram):
+def _increments(be, static_kernel, Xd, Yd, gram, from_kernel=None):
     """Coarse increments of the static Gram for a tile: fused kernel when available, else the reference's route
-    (static kernel in torch -> 4-corner difference, sigkernel.py:216-217 / :362-363)."""
+    (static kernel in torch -> 4-corner difference, sigkernel.py:216-217 / :362-363).  from_kernel (a list): receives True when the
+    fused static kernel formed them (what _tile_gradient's Linear / RBF branch would form again)."""
     fused = _fused_static(static_kernel, gram)
     if fused is not None and hasattr(be, "static_increments"):
         inc = be.static_increments(fused[0], fused[1], Xd.contiguous(), Yd.contiguous(), gram)
         if inc is not None:
+            if from_kernel is not None:
+                from_kernel.append(True)
             return inc
     G = (static_kernel.Gram_matrix(Xd, Yd) if gram else static_kernel.batch_kernel(Xd, Yd)).contiguous()
     return be.increments(G)
@@ -474,10 +477,11 @@ def _gram_block(be, static_kernel, Xd, Yd, dyadic_order, naive, workspace_bytes,
     per_row = (rows_factor or (1 if fused else 2)) * B * M * N * Xd.element_size()
     tiles = _tiles(A, per_row, budget)
     for a0, a1 in tiles:
-        inc = _increments(be, static_kernel, Xd[a0:a1], Yd, gram=True)           # sigkernel.py:362-363 (:364 by index)
+        by_kernel = []
+        inc = _increments(be, static_kernel, Xd[a0:a1], Yd, True, by_kernel)     # sigkernel.py:362-363 (:364 by index)
         if keep is not None:
             K[a0:a1], edges = be.solve_fwd_keep_edges(inc, dyadic_order, naive)  # :378 / :395, + the edges for backward
-            if edges is not None and fused and len(tiles) == 1 and \
+            if edges is not None and by_kernel and len(tiles) == 1 and \
                     inc.numel() * inc.element_size() <= _cost("keep_increments_fraction") * budget:
                 # one tile of moderate size: its increments ride along with the edges, and backward does not evaluate the static
                 # kernel a second time (a quarter of a gradient step on wide paths, profiles/r06_keep_inc.txt)

@@ -280,7 +280,7 @@ def test_kernel_variants_stay_within_their_budget():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variants.py")], capture_output=True, text=True)
     built = set(ln.split("\t")[-1] for ln in r.stdout.splitlines()[1:] if ln.strip())
     n = len(built)
-    assert 0 < n <= 530, n
+    assert 0 < n <= 540, n
     listed = set(r["mangled"] for r in rows)
     assert built == listed, "instances of the build without a row in %s (run tools/reach_sweep.py on a GPU box and regenerate it): %s; rows without an instance: %s" % (
         os.path.basename(VARIANTS_TABLE), sorted(built - listed)[:5], sorted(listed - built)[:5])

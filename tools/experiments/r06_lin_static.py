@@ -14,7 +14,7 @@ def t(f, n=5, reps=5):
         for _ in range(n): r = f()
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / n * 1e3)
     return sorted(ts)[reps // 2], r
-for D in (2, 4, 8):
+for D in (2, 4, 8, 12, 20, 32):
     X, Y = walk(256, 64, D), walk(256, 64, D)
     ms, inc = t(lambda: be.static_increments(0, 1.0, X, Y, True))
     print("linear static increments dim %d: %.3f ms checksum %.12g" % (D, ms, float(inc.sum())), flush=True)
