@@ -3,7 +3,7 @@
 
 Every case draws a static kernel (LinearKernel with a scale, RBFKernel with a sigma, or a user-defined duck-typed kernel that takes
 the generic route), a dyadic order 0..4, either stencil, fp64 or fp32, batch sizes 1..24, path lengths 2..90 (one case in three with
-equal lengths: the merged loss route; one in seven 100..420 points: several bands per pair), path dimension 1..20, the default transient budget or a tiny one (every call tiles over rows), the default routes or memory-first
+equal lengths: the merged loss route; one in seven 100..420 points: several bands per pair), path dimension 1..20 (one case in four 17..36), the default transient budget or a tiny one (every call tiles over rows), the default routes or memory-first
 (routes.no_stream), and checks against the oracle's closed forms
   compute_kernel        values + gradient under random weights            (_SigKernel, sigkernel.py:201-343)
   compute_Gram          values (sym or not) + gradient, 2x rule            (_SigKernelGram, :347-416; prep_backward :419-502)
@@ -69,7 +69,7 @@ def draw(rng):
     c["A"], c["B"] = int(rng.integers(1, 25)), int(rng.integers(1, 25))
     c["M"] = int(rng.integers(2, 91))
     c["N"] = c["M"] if rng.integers(0, 3) == 0 else int(rng.integers(2, 91))
-    c["D"] = int(rng.integers(1, 21))
+    c["D"] = int(rng.integers(1, 21)) if rng.integers(0, 4) else int(rng.integers(17, 37))      # (one in four: 17..36 dims, the widest static kernels and beyond)
     if rng.integers(0, 7) == 0:    # long paths: several bands per pair (the multi-band kernels), few of them
         c["M"], c["N"] = int(rng.integers(100, 420)), int(rng.integers(100, 420))
         c["A"], c["B"] = min(c["A"], 4), min(c["B"], 4)
@@ -192,13 +192,20 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     fails = 0
+    import time
+    t0, slow = time.time(), float(os.environ.get("FUZZ_SLOW", "0") or 0)      # FUZZ_SLOW=s: name the cases that take longer than s seconds
     for i in range(n):
         c = draw(rng)
+        t1 = time.time()
+        if slow:
+            print("case %d %s" % (i, c), file=sys.stderr, flush=True)
         try:
             bad = run_case(c, rng)
         except Exception:      # noqa: BLE001
             bad = [("exception", 1.0, 0.0)]
             traceback.print_exc()
+        if slow and time.time() - t1 > slow:
+            print("SLOW case %d: %.1f s (%.1f s so far) %s" % (i, time.time() - t1, time.time() - t0, c), flush=True)
         if bad:
             fails += 1
             print("FAIL case %d %s: %s" % (i, c, "; ".join("%s %.2e > %.0e" % b for b in bad)), flush=True)
