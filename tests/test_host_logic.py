@@ -313,3 +313,50 @@ def test_failed_fused_adjoint_falls_back_tiled_by_the_unfused_budget():
     assert fake.fused_calls >= 1 and fake.got_kfinal               # tried (in its own, larger tiles), declined -> fallback
     assert fake.tile_rows and max(fake.tile_rows) <= 2 and sum(fake.tile_rows) == A, fake.tile_rows
     assert rel_err(Xg.grad.numpy(), c["grad_w"]) <= grad_tol("gram_c3mini_lin_d1", "grad_w")
+
+
+@pytest.mark.parametrize("kind", ["linear", "rbf"])
+def test_streaming_backward_reuses_the_increments_the_forward_kept(kind, monkeypatch):
+    """sigkernel._gram_block / _tile_gradient: a one-tile Gram block on the streaming route with a gradient pending keeps the increments its
+    fused static kernel formed, beside the edges, when they fit keep_increments_fraction of the budget -- backward then does not form them
+    again; several tiles, a fraction of 0, or increments the torch route formed (no kernel for them) and they are formed again.  Same
+    gradient every way, equal to the golden one."""
+    from sigkernel_amd import _lib, sigkernel as skmod
+    from fake_backend import OracleBackend
+    name = "gram_c3mini_lin_d1" if kind == "linear" else "gram_c2mini_rbf_d1"
+    c = golden(name)
+    X, Y, w = (torch.from_numpy(c[k]) for k in ("X", "Y", "w"))
+    A, M, B, N = X.shape[0], X.shape[1], Y.shape[0], Y.shape[1]
+    k = sigkernel_amd.LinearKernel() if kind == "linear" else sigkernel_amd.RBFKernel(float(c["param"]))
+
+    calls = []
+
+    class Counting(OracleBackend):
+        def static_increments(self, *a, **kw):
+            calls.append(1)
+            return OracleBackend.static_increments(self, *a, **kw)
+
+    def step(workspace=None, be=None):
+        del calls[:]
+        prev = _lib.set_backend(be or Counting())
+        try:
+            Xg = X.clone().requires_grad_(True)
+            (sigkernel_amd.SigKernel(k, int(c["dyadic"]), workspace_bytes=workspace).compute_Gram(Xg, Y) * w).sum().backward()
+        finally:
+            _lib.set_backend(prev)
+        return Xg.grad, len(calls)
+    g_kept, n_kept = step()
+    assert n_kept == 1 and rel_err(g_kept.numpy(), c["grad_w"]) <= grad_tol(name, "grad_w")
+    monkeypatch.setattr(skmod, "_KEEP_INCREMENTS_FRACTION", 0.0)
+    g0, n0 = step()
+    assert n0 == 2 and torch.equal(g0, g_kept)
+    monkeypatch.setattr(skmod, "_KEEP_INCREMENTS_FRACTION", None)
+    g_tiles, n_tiles = step(workspace=3 * B * M * N * 8 * 2)      # two rows per tile: nothing kept across tiles
+    assert n_tiles >= 2 * ((A + 1) // 2) and torch.allclose(g_tiles, g_kept, rtol=1e-12, atol=1e-300)
+
+    class NoKernel(Counting):      # (a path dimension the static kernels do not cover: increments by the torch route, never kept)
+        def static_increments(self, *a, **kw):
+            calls.append(1)
+            return None
+    g_nk, n_nk = step(be=NoKernel())
+    assert n_nk >= 2 and torch.allclose(g_nk, g_kept, rtol=1e-12, atol=1e-300)
