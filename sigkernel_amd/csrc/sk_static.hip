@@ -705,7 +705,9 @@ constexpr int ADJT_NMAX = 128;      // second paths the tiled adjoints below sta
 // accumulators.  Pairs go in CHUNKS of PB: a pair is ~0.15 us of arithmetic per wave against ~2 us for a load from HBM, and with the
 // barriers a block has nothing else to hide its loads behind -- so the whole NEXT chunk's W values and y points are loaded into registers
 // before this chunk's arithmetic and consumed after it (one pair ahead: 2.0 ms at 256 x 256 pairs of 64 points and 20 dims, bound by
-// that latency; the GEMM route it replaces 1.8).
+// that latency; the GEMM route it replaces 1.8).  (Rounding: sum_n (W[n - 1] - W[n]) y[n] loses digits against the GEMM's sum_n W[n] dy[n] in
+// proportion to |y| / |dy| -- 1e-12 relative for a path 1e4 increments away from the origin; centring y_b at its first point would undo
+// that at the price of the 16-dim instance's 128 registers, 0.61 -> 0.75 ms: not done.)
 __device__ __forceinline__ double lane_shr1(double v, double lane0) {      // lane l <- lane l - 1; lane 0 <- its own `lane0`
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(__double2loint(lane0), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
