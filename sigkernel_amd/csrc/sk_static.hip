@@ -10,6 +10,11 @@
 //   rbf    : G[p][q] = exp(-(|x_p|^2 + |y_q|^2 - 2<x_p,y_q>)/sigma), inc = ((G11 + G00) - G10) - G01
 // The linear form is algebraically the 4-corner difference of <x_p, y_q>; it is evaluated as a product of
 // differences (no cancellation), so it agrees with the reference to rounding (1e-16 absolute), not bit for bit.
+//
+// Kernels: k_static_linear (dim <= 8, VALU) and k_static_linear_mfma (9..32 dims, v_mfma_f64_16x16x4_f64); k_static_nodes (rbf, and the three
+// node arrays of the directional derivative); their adjoints k_static_rbf_adj (dim <= 16, or second paths of more than 128 points),
+// k_static_rbf_adj_tiled (17..32 dims) and k_static_linear_adj_tiled (9..32 dims) -- y_b through LDS, pairs loaded a chunk ahead --,
+// k_linear_adj_dyt (dim <= 8, pre-differenced dimension-major y), and the second-argument forms k_linear_adj2 / k_rbf_adj2.
 #include <type_traits>
 
 #include "sk_internal.h"
@@ -701,7 +706,7 @@ constexpr int ADJT_NMAX = 128;      // second paths the tiled adjoints below sta
 // library GEMM per column block of Y plus three elementwise passes over its (A, b, Mc, D) products (0.9 + 0.9 ms of a 5.3 ms gradient step at
 // 256 x 256 pairs of 64 points and 20 dims, profiles/r06_api_profile.txt).  Here every element of W is read ONCE and nothing else touches
 // HBM: a block owns NW * RM rows of W[a, .] (RM per wave, a lane per POINT n of y_b, coefficient W[m][n - 1] - W[m][n] -- the
-// neighbour's value by DPP), its 256 threads copy y_b to LDS (rows of DMAX + 2 doubles, read two at a time) and each value read from there feeds RM
+// neighbour's value by DPP), its 64 NW threads copy y_b to LDS (rows of DMAX + 2 doubles, read two at a time) and each value read from there feeds RM
 // accumulators.  Pairs go in CHUNKS of PB: a pair is ~0.15 us of arithmetic per wave against ~2 us for a load from HBM, and with the
 // barriers a block has nothing else to hide its loads behind -- so the whole NEXT chunk's W values and y points are loaded into registers
 // before this chunk's arithmetic and consumed after it (one pair ahead: 2.0 ms at 256 x 256 pairs of 64 points and 20 dims, bound by
