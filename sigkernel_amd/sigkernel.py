@@ -631,9 +631,13 @@ def _sym_unfused_gradient(be, kind, param, Xd, go, dyadic, naive, sym_blocks, bu
         per_row = 3 * Xc.shape[0] * M * N * Xd.element_size()
         for a0, a1, edges in _edge_tiles(kept, r1 - r0, per_row, budget):
             Xt = Xr[a0:a1].contiguous()
-            inc = be.static_increments(kind, param, Xt, Xc, True)
+            inc = getattr(edges, "_sk_increments", None) if edges is not None else None      # (what _gram_block kept with the edges)
+            if inc is None or inc.shape[:-2] != (Xt.shape[0], Xc.shape[0]) or inc.dtype != Xt.dtype:
+                inc = be.static_increments(kind, param, Xt, Xc, True)
             _, W = be.solve_adj(inc, dyadic, naive, edges=edges) if edges is not None else be.solve_adj(inc, dyadic, naive)
             del inc
+            if getattr(edges, "_sk_increments", None) is not None:
+                edges._sk_increments = None
             grad_X[r0 + a0:r0 + a1] += be.static_adjoint(kind, param, Xt, Xc, W, go_blk[a0:a1].contiguous(), True)
             if r1 < A:
                 g2 = be.static_adjoint2(kind, param, Xt, Xc, W, go_t[a0:a1].contiguous(), r1 - r0)

@@ -354,6 +354,28 @@ def test_streaming_backward_reuses_the_increments_the_forward_kept(kind, monkeyp
     g_tiles, n_tiles = step(workspace=3 * B * M * N * 8 * 2)      # two rows per tile: nothing kept across tiles
     assert n_tiles >= 2 * ((A + 1) // 2) and torch.allclose(g_tiles, g_kept, rtol=1e-12, atol=1e-300)
 
+    # the symmetric Gram's row blocks (triangle + second-argument sums) reuse theirs the same way
+    monkeypatch.setattr(skmod, "_SYM_TILES", 2)
+    monkeypatch.setattr(skmod, "_SYM_MIN_CELLS", 0.0)
+    monkeypatch.setattr(skmod, "_SYM_MIN_ROWS", 1)
+    gen = torch.Generator().manual_seed(5)
+    X16 = torch.cat([X, X + 0.01 * torch.randn(X.shape, generator=gen, dtype=X.dtype), X.flip(1), 0.5 * X])[:16].contiguous()
+
+    def sym_step():
+        del calls[:]
+        prev = _lib.set_backend(Counting())
+        try:
+            Xg = X16.clone().requires_grad_(True)
+            sigkernel_amd.SigKernel(k, int(c["dyadic"])).compute_Gram(Xg, Xg, sym=True).sum().backward()
+        finally:
+            _lib.set_backend(prev)
+        return Xg.grad, len(calls)
+    gs_kept, ns_kept = sym_step()
+    monkeypatch.setattr(skmod, "_KEEP_INCREMENTS_FRACTION", 0.0)
+    gs0, ns0 = sym_step()
+    monkeypatch.setattr(skmod, "_KEEP_INCREMENTS_FRACTION", None)
+    assert ns_kept == 2 and ns0 == 4 and torch.equal(gs_kept, gs0), (ns_kept, ns0)
+
     class NoKernel(Counting):      # (a path dimension the static kernels do not cover: increments by the torch route, never kept)
         def static_increments(self, *a, **kw):
             calls.append(1)
