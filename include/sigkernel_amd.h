@@ -141,7 +141,8 @@ int sk_increments_f32(const float *G, int64_t P, int M, int N, float *inc_c, int
  * replaces static_kernel.Gram_matrix(X, Y) / batch_kernel(X, Y) (static_kernels.py:24,33,56,73) followed by the
  * 4-corner difference (sigkernel.py:216-217, :362-363) -- G_static is never materialised.
  *   kind 0: linear, inc = param^2 <dx_p, dy_q>  (param = 1 reproduces Gram_matrix, which ignores `scale`;
- *           param = scale reproduces batch_kernel)
+ *           param = scale reproduces batch_kernel).  9 <= D <= 32: on v_mfma_f64_16x16x4_f64, dims summed four at a time --
+ *           equal to the D <= 8 form's left-to-right sum to rounding
  *   kind 1: rbf,    G = exp(-|x_p - y_q|^2 / param) (param = sigma), inc = ((G11 + G00) - G10) - G01
  *   X [A,M,D], Y [B,N,D] dense; B > 0: Gram, pair (a,b) at a*B+b; B == 0: paired, pair a = (x_a, y_a), Y [A,N,D].
  *   inc_c [P,M-1,ld] with zero-filled padding columns.  D <= 32 (else SK_ERR_UNSUPPORTED: use the generic path). */
