@@ -86,9 +86,21 @@ def readme_case():
 # ---------------------------------------------------------------------------
 # 3. Gram forward + adjoint on reduced C2/C3/C4-like inputs
 # ---------------------------------------------------------------------------
-def gram_cases():
-    gen = torch.Generator().manual_seed(0)
-    cases = [
+WIDE_CASES = [      # paths of 9..32 dims (lead-lag + time: the streaming route's static kernels); their own seed, added in round 6
+    ("wide_rbf_d1", "rbf", 1.0, 1, 3, 4, 10, 70, 20, 0),
+    ("wide_lin_d1", "linear", 0.0, 1, 3, 3, 12, 12, 30, 0),
+    ("wide_lin_d0", "linear", 0.0, 0, 4, 3, 9, 40, 12, 0),
+    ("wide_rbf_d2", "rbf", 2.0, 2, 3, 3, 8, 8, 17, 0),
+]
+
+
+def gram_wide_cases():
+    gram_cases(WIDE_CASES, seed=606)
+
+
+def gram_cases(cases=None, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    cases = cases or [
         # name, kernel, param, dyadic, A, B, M, N, D, naive
         ("c2mini_rbf_d1", "rbf", 1.0, 1, 6, 6, 16, 16, 3, 0),
         ("c3mini_lin_d1", "linear", 0.0, 1, 5, 7, 24, 24, 8, 0),
@@ -242,8 +254,8 @@ def derivative_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["solver", "readme", "gram", "kat", "wrappers", "derivatives"]
-    table = dict(solver=solver_cases, readme=readme_case, gram=gram_cases, kat=kat_case, wrappers=wrappers_case,
+    which = sys.argv[1:] or ["solver", "readme", "gram", "gram_wide", "kat", "wrappers", "derivatives"]
+    table = dict(solver=solver_cases, readme=readme_case, gram=gram_cases, gram_wide=gram_wide_cases, kat=kat_case, wrappers=wrappers_case,
                  derivatives=derivative_cases)
     for w in which:
         table[w]()
