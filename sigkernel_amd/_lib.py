@@ -996,7 +996,7 @@ class HipBackend:
                     _check(fl(_ptr(dYt), ldy, _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M - 1, N - 1, D, _ptr(T), _stream(X)),
                            "sk_linear_adjoint")
                 elif D <= 32 and N <= 128:
-                    # 9..32 dims: k_static_linear_adj_tiled reads W once, y_b differenced into LDS per pair (sk_static.hip)
+                    # 9..32 dims: k_static_linear_adj_tiled reads W once, y_b through LDS, pairs loaded a chunk ahead (sk_static.hip)
                     T = torch.empty(A, M - 1, D, dtype=X.dtype, device=X.device)
                     _check(fn(0, float(param), _ptr(X), _ptr(Y), _ptr(W), ldw, _ptr(scale), A, B if gram else 0, M, N, D, _ptr(T),
                               _stream(X)), "sk_static_adjoint")
